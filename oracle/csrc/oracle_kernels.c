@@ -1,0 +1,141 @@
+/*
+ * oracle/csrc/oracle_kernels.c -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * Plain-C twins of the heavy ReFeX loops, single thread, used (a) as the checker for large
+ * parity cases where the numpy loops of oracle/refex.py would take minutes and (b) as the
+ * "port" CPU baseline timed by bench.py.  Each function restates the reference lines cited;
+ * tests/test_oracle_refex.py checks them against oracle/refex.py and the golden vectors.
+ *
+ *   gcc -O2 -shared -fPIC -o oracle/liboracle.so oracle/csrc/oracle_kernels.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* graphrole/features/extract.py:98-119 -- sum and mean of neighbour rows, CSR order.
+ * X, S, M row-major n x f. */
+void orc_aggregate(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
+                   const double *X, double *S, double *M)
+{
+    for (int64_t v = 0; v < n; ++v) {
+        double *s = S + v * f, *m = M + v * f;
+        for (int c = 0; c < f; ++c) s[c] = 0.0;
+        int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        for (int64_t k = b; k < e; ++k) {
+            const double *x = X + (int64_t)col[k] * f;
+            for (int c = 0; c < f; ++c) s[c] += x[c];
+        }
+        double cnt = (double)(e - b);
+        for (int c = 0; c < f; ++c) m[c] = (e > b) ? s[c] / cnt : 0.0;
+    }
+}
+
+/* graphrole/graph/interface/networkx.py:48-63 -- weighted row sums; the undirected degree adds
+ * the self-loop weight once more (networkx counts a self-loop twice). */
+void orc_rowsum(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *w,
+                int add_self_loop, double *out)
+{
+    for (int64_t v = 0; v < n; ++v) {
+        double s = 0.0;
+        for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) {
+            double x = w ? w[k] : 1.0;
+            s += x;
+            if (add_self_loop && col[k] == v) s += x;
+        }
+        out[v] = s;
+    }
+}
+
+/* graphrole/graph/interface/networkx.py:71-83,115-123 -- ego-net internal / boundary weight.
+ * ego(v) = {v} U row(v).  Rows of the ego members are walked in ascending member order and
+ * CSR order inside a row. */
+int orc_egonet(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *w,
+               int directed, double *internal, double *external)
+{
+    int64_t *mark = (int64_t *)calloc((size_t)n, sizeof(int64_t));
+    if (!mark) return -1;
+    for (int64_t v = 0; v < n; ++v) {
+        int64_t stamp = v + 1;
+        mark[v] = stamp;
+        for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) mark[col[k]] = stamp;
+        double ins = 0.0, ext = 0.0;
+        int v_done = 0;
+        /* members in ascending order: merge v into the sorted row */
+        int64_t k = row_ptr[v], e = row_ptr[v + 1];
+        for (;;) {
+            int64_t a;
+            if (!v_done && (k >= e || v <= col[k])) {
+                a = v; v_done = 1;
+                if (k < e && col[k] == v) ++k;
+            } else if (k < e) {
+                a = col[k++];
+            } else break;
+            for (int64_t j = row_ptr[a]; j < row_ptr[a + 1]; ++j) {
+                int64_t b = col[j];
+                double x = w ? w[j] : 1.0;
+                if (mark[b] == stamp) { if (directed || b >= a) ins += x; }
+                else ext += x;
+            }
+        }
+        internal[v] = ins;
+        external[v] = ext;
+    }
+    free(mark);
+    return 0;
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* graphrole/features/prune.py:13-56 -- vertical logarithmic binning.  Returns the number of
+ * bins, or -1 on allocation failure / bad frac. */
+int64_t orc_vertical_log_binning(int64_t n, const double *arr, double frac, int32_t *out)
+{
+    if (!(frac > 0.0 && frac < 1.0)) return -1;
+    if (n == 0) return 0;
+    double *s = (double *)malloc((size_t)n * sizeof(double));
+    if (!s) return -1;
+    memcpy(s, arr, (size_t)n * sizeof(double));
+    qsort(s, (size_t)n, sizeof(double), cmp_double);
+    double thr[128];
+    int64_t nb = 0, done = 0;
+    while (done < n && nb < 128) {
+        int64_t size = (int64_t)(frac * (double)(n - done));
+        if (size < 1) size = 1;
+        int64_t pos = done + size - 1;               /* first unique with cumcount >= done+size */
+        double hi = s[pos];
+        while (pos + 1 < n && s[pos + 1] == hi) ++pos;   /* extend to the end of the tie run */
+        thr[nb++] = hi;
+        done = pos + 1;
+    }
+    free(s);
+    for (int64_t i = 0; i < n; ++i) {
+        double x = arr[i];
+        int64_t lo = 0, hi = nb;                     /* first threshold >= x  == bin index */
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (thr[mid] < x) lo = mid + 1; else hi = mid; }
+        out[i] = (int32_t)lo;
+    }
+    return nb;
+}
+
+/* graphrole/features/prune.py:108 -- pdist(binned.T, 'chebychev').  B column-major F x n. */
+void orc_chebyshev(int64_t n, int F, const int32_t *B, int64_t *D)
+{
+    for (int p = 0; p < F; ++p) {
+        D[p * F + p] = 0;
+        for (int q = p + 1; q < F; ++q) {
+            const int32_t *bp = B + (int64_t)p * n, *bq = B + (int64_t)q * n;
+            int64_t mx = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                int64_t d = (int64_t)bp[i] - (int64_t)bq[i];
+                if (d < 0) d = -d;
+                if (d > mx) mx = d;
+            }
+            D[p * F + q] = D[q * F + p] = mx;
+        }
+    }
+}

@@ -1,0 +1,430 @@
+"""
+oracle/refex.py -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Numpy restatement of the ReFeX half of the GraphRole hot path.  Citations are
+``/root/reference/<file>:<line>``.  Parity: pinned by tests/test_oracle_refex.py against the
+reference's own known-answer tables and against golden vectors produced by the reference
+(tools/make_golden.py).
+
+Conventions:
+  * rows  = node labels sorted ascending            (graph/interface/base.py:24-25)
+  * neighbours of v = out-adjacency *set* of v, self-loop included, unweighted in the recursion
+                                                     (graph/interface/networkx.py:42-46)
+  * every feature value is carried as float64; integer-valued gen-0 columns of unweighted graphs
+    are cast to int64 only when a DataFrame is produced.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from numbers import Number
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------
+# graph container
+# --------------------------------------------------------------------------------------
+@dataclass
+class OracleGraph:
+    """CSR of the out-adjacency with rows in sorted-label order."""
+    labels: list
+    row_ptr: np.ndarray            # int64 [n+1]
+    col: np.ndarray                # int32 [nnz], ascending inside each row
+    w: Optional[np.ndarray]        # float64 [nnz] or None (implicit weight 1)
+    directed: bool
+    num_edges: int                 # G.number_of_edges()
+    # transpose (in-adjacency) -- only needed for directed in_degree
+    t_row_ptr: Optional[np.ndarray] = None
+    t_col: Optional[np.ndarray] = None
+    t_w: Optional[np.ndarray] = None
+    attrs: Dict[str, np.ndarray] = field(default_factory=dict)   # 'attribute_<name>' -> float64[n]
+
+    @property
+    def n(self) -> int:
+        return len(self.row_ptr) - 1
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def row(self, v: int) -> np.ndarray:
+        return self.col[self.row_ptr[v]:self.row_ptr[v + 1]]
+
+    def row_w(self, v: int) -> np.ndarray:
+        s, e = self.row_ptr[v], self.row_ptr[v + 1]
+        if self.w is None:
+            return np.ones(e - s, dtype=np.float64)
+        return self.w[s:e]
+
+
+def _csr_from_coo(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarray]):
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(row_ptr, src + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    return row_ptr, dst.astype(np.int32), (None if w is None else w[order].astype(np.float64))
+
+
+def graph_from_arrays(n: int, src, dst, w=None, directed: bool = False, labels=None) -> OracleGraph:
+    """
+    Build from unique edge arrays (row indices already refer to sorted labels).
+    Undirected input lists every edge once (either orientation); self-loops allowed.
+    """
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    w = None if w is None else np.asarray(w, dtype=np.float64)
+    m = len(src)
+    if directed:
+        row_ptr, col, ww = _csr_from_coo(n, src, dst, w)
+        t_row_ptr, t_col, t_w = _csr_from_coo(n, dst, src, w)
+    else:
+        loop = src == dst
+        s2 = np.concatenate([src, dst[~loop]])
+        d2 = np.concatenate([dst, src[~loop]])
+        w2 = None if w is None else np.concatenate([w, w[~loop]])
+        row_ptr, col, ww = _csr_from_coo(n, s2, d2, w2)
+        t_row_ptr = t_col = t_w = None
+    return OracleGraph(labels=list(range(n)) if labels is None else list(labels),
+                       row_ptr=row_ptr, col=col, w=ww, directed=directed, num_edges=m,
+                       t_row_ptr=t_row_ptr, t_col=t_col, t_w=t_w)
+
+
+def graph_from_networkx(G, attributes: bool = False, attributes_include: Sequence[str] = (),
+                        attributes_exclude: Sequence[str] = ()) -> OracleGraph:
+    """
+    networkx (Di)Graph -> OracleGraph.  Follows NetworkxInterface: get_nodes / get_neighbors
+    (graph/interface/networkx.py:36-46), edge weight default 1 (:115-123), attribute selection
+    (:87-113, base.py:28-48).
+    """
+    labels = sorted(G.nodes)
+    index = {lab: i for i, lab in enumerate(labels)}
+    directed = G.is_directed()
+    weighted = any('weight' in d for _, _, d in G.edges(data=True))
+    src, dst, ww = [], [], []
+    for u, v, d in G.edges(data=True):
+        src.append(index[u])
+        dst.append(index[v])
+        ww.append(d.get('weight', 1))
+    g = graph_from_arrays(len(labels), src, dst, ww if weighted else None, directed, labels)
+    g.num_edges = G.number_of_edges()
+    if attributes:
+        g.attrs = _attribute_columns(G, labels, attributes_include, attributes_exclude)
+    return g
+
+
+def _attribute_columns(G, labels, include, exclude) -> Dict[str, np.ndarray]:
+    """networkx.py:87-113: numeric attrs only, missing -> 0, exclude beats include."""
+    exclude = set(exclude)
+    cols: Dict[str, Dict] = {}
+    if include:
+        for name in include:
+            if name in exclude:
+                continue
+            cols['attribute_' + name] = {
+                node: a.get(name, 0) for node, a in G.nodes(data=True)
+                if isinstance(a.get(name, 0), Number)
+            }
+    else:
+        for node, a in G.nodes(data=True):
+            for name, val in a.items():
+                if name in exclude or not isinstance(val, Number):
+                    continue
+                cols.setdefault('attribute_' + name, {})[node] = val
+    return {k: np.array([float(d.get(lab, 0)) for lab in labels]) for k, d in cols.items()}
+
+
+# --------------------------------------------------------------------------------------
+# generation 0: local + ego-net features
+# --------------------------------------------------------------------------------------
+def local_features(g: OracleGraph) -> Dict[str, np.ndarray]:
+    """
+    graph/interface/networkx.py:48-69.  Undirected: weighted degree, a self-loop counts twice
+    (networkx convention).  Directed: in/out/total weighted degree.
+    """
+    n = g.n
+    rowsum = np.array([g.row_w(v).sum() for v in range(n)], dtype=np.float64)
+    if g.directed:
+        indeg = np.zeros(n)
+        for v in range(n):
+            s, e = g.t_row_ptr[v], g.t_row_ptr[v + 1]
+            indeg[v] = (e - s) if g.t_w is None else g.t_w[s:e].sum()
+        out = {'in_degree': indeg, 'out_degree': rowsum, 'total_degree': rowsum + indeg}
+    else:
+        loopw = np.zeros(n)
+        for v in range(n):
+            r = g.row(v)
+            hit = np.nonzero(r == v)[0]
+            if len(hit):
+                loopw[v] = g.row_w(v)[hit[0]]
+        out = {'degree': rowsum + loopw}
+    out.update(g.attrs)
+    return out
+
+
+def egonet_features(g: OracleGraph) -> Dict[str, np.ndarray]:
+    """
+    graph/interface/networkx.py:71-83,115-123.  ego(v) = {v} U nbrs(v).
+    internal = sum of w over edges with both ends in ego (undirected: each edge once, self-loops
+    once; directed: every arc).  external = sum of w over edge_boundary(G, ego): arcs/edges
+    leaving the ego set.
+    """
+    n = g.n
+    internal = np.zeros(n)
+    external = np.zeros(n)
+    for v in range(n):
+        ego = np.union1d(g.row(v), [v])
+        ins = 0.0
+        ext = 0.0
+        for a in ego:
+            r = g.row(int(a))
+            wr = g.row_w(int(a))
+            inside = np.isin(r, ego, assume_unique=True)
+            if g.directed:
+                ins += wr[inside].sum()
+            else:
+                ins += wr[inside & (r >= a)].sum()
+            ext += wr[~inside].sum()
+        internal[v] = ins
+        external[v] = ext
+    return {'internal_edges': internal, 'external_edges': external}
+
+
+def local_features_c(g: OracleGraph) -> Dict[str, np.ndarray]:
+    """local_features through the plain-C twins (oracle/csrc/oracle_kernels.c)."""
+    from . import ckernels
+    if g.directed:
+        outd = ckernels.rowsum(g.row_ptr, g.col, g.w, False)
+        ind = ckernels.rowsum(g.t_row_ptr, g.t_col, g.t_w, False)
+        out = {'in_degree': ind, 'out_degree': outd, 'total_degree': outd + ind}
+    else:
+        out = {'degree': ckernels.rowsum(g.row_ptr, g.col, g.w, True)}
+    out.update(g.attrs)
+    return out
+
+
+def egonet_features_c(g: OracleGraph) -> Dict[str, np.ndarray]:
+    from . import ckernels
+    i, e = ckernels.egonet(g.row_ptr, g.col, g.w, g.directed)
+    return {'internal_edges': i, 'external_edges': e}
+
+
+def neighborhood_features(g: OracleGraph, fast: bool = False) -> Tuple[List[str], np.ndarray]:
+    """graph/interface/base.py:18-26: concat([local, ego], axis=1)."""
+    loc = local_features_c(g) if fast else local_features(g)
+    ego = egonet_features_c(g) if fast else egonet_features(g)
+    names = list(loc) + list(ego)
+    X = np.column_stack([loc[k] for k in loc] + [ego[k] for k in ego])
+    return names, X
+
+
+# --------------------------------------------------------------------------------------
+# recursion: neighbour aggregation
+# --------------------------------------------------------------------------------------
+def aggregate(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """
+    features/extract.py:98-119.  For every node v and column c:
+        sum[v,c]  = sum_{u in nbrs(v)} X[u,c]
+        mean[v,c] = sum[v,c] / |nbrs(v)|          (0 when v has no neighbours, :113 fillna)
+    Summation is sequential in CSR (ascending neighbour index) order.
+    """
+    n, f = X.shape
+    s = np.zeros((n, f))
+    m = np.zeros((n, f))
+    for v in range(n):
+        nb = g.row(v)
+        if len(nb):
+            acc = np.zeros(f)
+            for u in nb:
+                acc = acc + X[u]
+            s[v] = acc
+            m[v] = acc / len(nb)
+    return s, m
+
+
+def aggregate_fast(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Same values up to fp64 re-association; scipy CSR @ dense.  Used for large parity cases."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(g.nnz), g.col, g.row_ptr), shape=(g.n, g.n))
+    s = A @ X
+    deg = np.diff(g.row_ptr).astype(np.float64)
+    m = np.divide(s, deg[:, None], out=np.zeros_like(s), where=deg[:, None] > 0)
+    return s, m
+
+
+# --------------------------------------------------------------------------------------
+# pruning
+# --------------------------------------------------------------------------------------
+def vertical_log_binning(arr, frac: float = 0.5) -> np.ndarray:
+    """
+    features/prune.py:13-56.  Sorted uniques + cumulative counts; repeatedly take
+    max(int(frac * unbinned), 1) more values, extend to the end of the tie run, label that
+    half-open value interval (bin_min, bin_max] with the running bin index.
+    """
+    if not 0 < frac < 1:
+        raise ValueError('must specify frac in interval (0, 1)')
+    arr = np.asarray(arr)
+    n = len(arr)
+    binned = np.zeros(n, dtype=np.int64)
+    if n == 0:
+        return binned
+    uniq, counts = np.unique(arr, return_counts=True)
+    cum = np.cumsum(counts)
+    done = 0
+    lo = -np.inf
+    b = 0
+    while done < n:
+        size = max(int(frac * (n - done)), 1)
+        j = int(np.searchsorted(cum, done + size, side='left'))
+        hi = uniq[j]
+        binned[(arr > lo) & (arr <= hi)] = b
+        done = int(cum[j])
+        lo = hi
+        b += 1
+    return binned
+
+
+def chebyshev_matrix(B: np.ndarray) -> np.ndarray:
+    """features/prune.py:108: max_i |B[i,p] - B[i,q]| for every column pair (int64 F x F)."""
+    F = B.shape[1]
+    D = np.zeros((F, F), dtype=np.int64)
+    Bi = B.astype(np.int64)
+    for p in range(F):
+        for q in range(p + 1, F):
+            d = int(np.abs(Bi[:, p] - Bi[:, q]).max()) if B.shape[0] else 0
+            D[p, q] = D[q, p] = d
+    return D
+
+
+def connected_components(edges: Sequence[Tuple]) -> List[Set]:
+    """graph/graph.py:18-57: components over nodes that appear in at least one edge."""
+    adj: Dict = {}
+    for a, b in edges:
+        adj.setdefault(a, set()).add(b)
+        adj.setdefault(b, set()).add(a)
+    seen: Set = set()
+    comps = []
+    for start in adj:
+        if start in seen:
+            continue
+        comp = set()
+        stack = [start]
+        while stack:
+            x = stack.pop()
+            if x in comp:
+                continue
+            comp.add(x)
+            stack.extend(adj[x] - comp)
+        seen |= comp
+        comps.append(comp)
+    return comps
+
+
+def group_features(names: Sequence[str], D: np.ndarray, thresh: int) -> List[Set[str]]:
+    """features/prune.py:94-116: edge (p,q) iff D[p,q] <= thresh; connected components."""
+    F = len(names)
+    edges = [(names[p], names[q]) for p in range(F) for q in range(p + 1, F) if D[p, q] <= thresh]
+    return connected_components(edges)
+
+
+def oldest_feature(group: Set[str], generation_names: Dict[int, Sequence[str]]) -> str:
+    """features/prune.py:118-139: earliest recorded generation, ties -> smallest name."""
+    for gen in range(len(generation_names)):
+        cur = group.intersection(generation_names[gen])
+        if cur:
+            return min(cur)
+    return min(group)
+
+
+def prune_features(names: Sequence[str], D: np.ndarray, thresh: int,
+                   generation_names: Dict[int, Sequence[str]]) -> Set[str]:
+    """features/prune.py:76-92: per component keep the oldest member, drop the rest."""
+    drop: Set[str] = set()
+    for group in group_features(names, D, thresh):
+        if len(group) == 1:
+            continue
+        drop |= group - {oldest_feature(group, generation_names)}
+    return drop
+
+
+# --------------------------------------------------------------------------------------
+# driver
+# --------------------------------------------------------------------------------------
+@dataclass
+class GenerationTrace:
+    generation: int
+    candidates: List[str]          # new columns offered this generation, in offered order
+    working_before: List[str]      # pruner input columns (old working set + candidates)
+    dropped: List[str]             # sorted
+    retained: List[str]            # recorded for this generation (order as the reference records)
+    working_after: List[str]
+
+
+@dataclass
+class RefexResult:
+    labels: list
+    columns: List[str]             # final column order (latest generation first)
+    values: np.ndarray             # n x len(columns) float64
+    generation_count: int
+    trace: List[GenerationTrace]
+    gen0_is_int: bool
+
+
+def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = False,
+                     gen0: Optional[Tuple[List[str], np.ndarray]] = None,
+                     aggs: Sequence[str] = ('sum', 'mean')) -> RefexResult:
+    """
+    features/extract.py:65-142.  ``fast=True`` swaps the numpy loops for the plain-C twins.  Working set = dict name -> column; ``final[g]`` = names recorded
+    at generation g (their values are frozen copies).
+    """
+    if fast:
+        from . import ckernels
+        agg_fn = lambda gg, X: ckernels.aggregate(gg.row_ptr, gg.col, X)
+        bin_fn = ckernels.vertical_log_binning
+        cheb_fn = lambda B: ckernels.chebyshev(B.T)
+    else:
+        agg_fn, bin_fn, cheb_fn = aggregate, vertical_log_binning, chebyshev_matrix
+    names0, X0 = gen0 if gen0 is not None else neighborhood_features(g, fast)
+    work: Dict[str, np.ndarray] = {}
+    final_names: Dict[int, List[str]] = {}
+    final_vals: Dict[str, np.ndarray] = {}
+    trace: List[GenerationTrace] = []
+
+    def update(gen: int, cand_names: List[str], cand_vals: np.ndarray, thresh: int):
+        before = list(work)                      # extract.py:128-133 concat keeps old then new
+        for j, nm in enumerate(cand_names):
+            work[nm] = cand_vals[:, j]
+        cols = list(work)
+        B = np.column_stack([bin_fn(work[c]) for c in cols]) if cols else np.zeros((g.n, 0))
+        D = cheb_fn(B)
+        drop = prune_features(cols, D, thresh, final_names)          # prune.py:76
+        for nm in drop:
+            del work[nm]                                              # extract.py:137
+        # extract.py:140 Index.difference: name-sorted iff something was dropped (pandas 2.x)
+        kept = [c for c in cand_names if c not in drop]
+        retained = sorted(kept) if drop else kept
+        final_names[gen] = retained
+        for nm in retained:
+            final_vals[nm] = work[nm].copy()
+        trace.append(GenerationTrace(gen, list(cand_names), before + list(cand_names),
+                                     sorted(drop), list(retained), list(work)))
+
+    update(0, names0, X0, 0)
+    generation_count = 0
+    for gen in range(1, max_generations):                             # extract.py:77
+        generation_count = gen
+        prev = final_names[gen - 1]
+        Xp = np.column_stack([work[c] for c in prev]) if prev else np.zeros((g.n, 0))
+        s, m = agg_fn(g, Xp)
+        blocks = {'sum': s, 'mean': m}
+        cand_names = [f'{c}({a})' for a in aggs for c in prev]        # extract.py:152-162
+        cand_vals = np.column_stack([blocks[a] for a in aggs]) if prev else np.zeros((g.n, 0))
+        update(gen, cand_names, cand_vals, gen)
+        if not final_names[gen]:                                      # extract.py:86-87
+            break
+    columns: List[str] = []
+    for gen in sorted(final_names, reverse=True):                     # extract.py:95 ChainMap order
+        columns.extend(final_names[gen])
+    values = np.column_stack([final_vals[c] for c in columns]) if columns else np.zeros((g.n, 0))
+    return RefexResult(g.labels, columns, values, generation_count, trace, g.w is None)
