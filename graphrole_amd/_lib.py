@@ -1,0 +1,110 @@
+"""
+ctypes binding of libgrx.so (the C ABI declared in include/grx.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.  PyTorch is imported first so that libgrx.so resolves ``libamdhip64.so.7``
+to the HIP runtime PyTorch already loaded (one runtime per process); PyTorch itself is only
+plumbing here (device memory, streams, torch.distributed).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgrx.so')
+
+
+class GrxError(RuntimeError):
+    """A libgrx.so call returned a non-zero status."""
+
+
+class GrxInvalid(GrxError, ValueError):
+    """GRX_ERR_INVALID: the reference raises ValueError for the same condition."""
+
+
+_lib = None
+
+# name -> (restype, argtypes); every entry mirrors include/grx.h
+_SIGNATURES = {
+    'grx_version': (c_int, []),
+    'grx_last_error': (c_char_p, []),
+    'grx_device_info': (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),
+    'grx_dev_malloc': (c_int, [POINTER(c_void_p), c_size_t]),
+    'grx_dev_free': (c_int, [c_void_p]),
+    'grx_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_memset': (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    'grx_stream_sync': (c_int, [c_void_p]),
+    'grx_event_create': (c_int, [POINTER(c_void_p)]),
+    'grx_event_destroy': (c_int, [c_void_p]),
+    'grx_event_record': (c_int, [c_void_p, c_void_p]),
+    'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'grx_row_sums': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_void_p]),
+    'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'grx_aggregate': (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
+                              c_void_p, c_int64, c_int, c_void_p]),
+    'grx_log_bin_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'grx_vertical_log_bin': (c_int, [c_int64, c_int, c_void_p, c_int64, c_double, c_void_p, c_int64, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    'grx_sort_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'grx_sort_columns': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    'grx_chebyshev': (c_int, [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_gather_columns': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    'grx_gram_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'grx_gram': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                         c_size_t, c_void_p]),
+    'grx_project_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'grx_project': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64,
+                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nndsvd_apply': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double,
+                                 c_double, c_void_p]),
+    'grx_nmf_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'grx_nmf_w_pass': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_h_update': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_nmf_residual': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load() -> ctypes.CDLL:
+    """Load libgrx.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GrxError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C graphrole_amd/csrc`.  graphrole_amd has no CPU fallback.')
+    import torch  # noqa: F401  -- loads the HIP runtime libgrx.so links against
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the .so disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = '') -> None:
+    if status == 0:
+        return
+    msg = load().grx_last_error().decode('utf-8', 'replace')
+    text = f'{what}: {msg}' if what else msg
+    if status == -1:
+        raise GrxInvalid(text)
+    raise GrxError(f'[status {status}] {text}')
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    fn = getattr(load(), name)
+    check(fn(*args), name)

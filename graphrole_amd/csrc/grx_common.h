@@ -1,0 +1,47 @@
+// grx_common.h -- internal helpers shared by the libgrx.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "grx.h"
+
+void grx_set_error(const char *fmt, ...);
+
+#define GRX_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            grx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return GRX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define GRX_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            grx_set_error(__VA_ARGS__);                                                       \
+            return GRX_ERR_INVALID;                                                           \
+        }                                                                                     \
+    } while (0)
+
+#define GRX_LAUNCH_CHECK() GRX_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t grx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int GRX_WAVE = 64;       // CDNA4 wavefront
+constexpr int GRX_NUM_CU = 256;    // MI355X
+
+static inline int64_t grx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t grx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Fixed-shape butterfly: every lane ends with the same total, the addition tree depends only
+// on WIDTH, so results are bitwise reproducible.
+template <int WIDTH>
+__device__ __forceinline__ double grx_group_sum(double v)
+{
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WIDTH);
+    return v;
+}

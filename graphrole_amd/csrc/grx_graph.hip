@@ -1,0 +1,431 @@
+// grx_graph.hip -- generation-0 features and the ReFeX neighbour aggregation on a CSR graph.
+//
+// Kernels (all HBM/L2-gather bound; no MFMA -- this is integer-indexed fp64 streaming work):
+//   row_sums_kernel        weighted degree            networkx.py:48-63
+//   egonet_kernel          ego-net internal/external  networkx.py:71-83,115-123
+//   pack_rows_kernel       column-major -> row-major gather source
+//   aggregate_kernel       sum / mean over neighbours  features/extract.py:98-119
+//   aggregate_hub_kernel   same, one workgroup per high-degree row
+//
+// Determinism: every reduction is "per-lane sequential in CSR order, then a fixed butterfly /
+// fixed-order LDS sum", so the addition tree of a row depends only on its degree and the launch
+// geometry chosen from the graph's average degree.
+#include "grx_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+// position of key in the ascending slice col[b,e), or -1
+__device__ __forceinline__ int64_t find_in_row(const int32_t *__restrict__ col, int64_t b,
+                                               int64_t e, int32_t key)
+{
+    while (b < e) {
+        int64_t mid = (b + e) >> 1;
+        int32_t c = col[mid];
+        if (c < key) b = mid + 1;
+        else if (c > key) e = mid;
+        else return mid;
+    }
+    return -1;
+}
+
+// first position in col[b,e) with col[pos] >= key
+__device__ __forceinline__ int64_t lower_bound_row(const int32_t *__restrict__ col, int64_t b,
+                                                   int64_t e, int32_t key)
+{
+    while (b < e) {
+        int64_t mid = (b + e) >> 1;
+        if (col[mid] < key) b = mid + 1;
+        else e = mid;
+    }
+    return b;
+}
+
+__device__ __forceinline__ int ilog2_i64(int64_t x) { return 63 - __clzll((unsigned long long)(x | 1)); }
+
+// ---------------------------------------------------------------------------------------
+// weighted row sums
+// ---------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict__ row_ptr,
+                                                       const int32_t *__restrict__ col,
+                                                       const double *__restrict__ w, int add_loop,
+                                                       int64_t row_begin, int64_t row_end,
+                                                       double *__restrict__ out)
+{
+    const int lane = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        double s = 0.0, loop = 0.0;
+        for (int64_t k = b + lane; k < e; k += G) {
+            const double x = w ? w[k] : 1.0;
+            s += x;
+            if (add_loop && col[k] == v) loop = x;
+        }
+        s = grx_group_sum<G>(s);
+        loop = grx_group_sum<G>(loop);
+        if (lane == 0) out[v] = s + loop;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ego-net features
+// ---------------------------------------------------------------------------------------
+// One node per TPN threads.  Each lane owns ego members m = lane, lane+TPN, ... and for member a
+// picks the cheaper of
+//   S1: walk row(a), test membership of each entry in ego(v)        cost deg(a) * log deg(v)
+//   S2: walk ego(v), look each member up in row(a)                   cost deg(v) * log deg(a)
+// S2 obtains the boundary weight of a as rowsum(a) - matched weight; when every entry of row(a)
+// matched, the boundary contribution is exactly 0 (no cancellation residue).
+template <int TPN>
+__global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ w, const double *__restrict__ rowsum, int directed,
+    int64_t row_begin, int64_t row_end, int64_t deg_lo, int64_t deg_hi,
+    double *__restrict__ internal, double *__restrict__ external)
+{
+    constexpr int BLOCK = (TPN == 64) ? 256 : TPN;
+    constexpr int NODES_PER_BLOCK = BLOCK / TPN;
+    constexpr int WAVES = TPN / 64;
+    __shared__ double red[2][WAVES > 1 ? WAVES : 1];
+    const int lane = threadIdx.x % TPN;
+    const int64_t slot = (int64_t)blockIdx.x * NODES_PER_BLOCK + threadIdx.x / TPN;
+    const int64_t nslots = (int64_t)gridDim.x * NODES_PER_BLOCK;
+
+    for (int64_t v = row_begin + slot; v < row_end; v += nslots) {
+        const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
+        const int64_t dv = ve - vb;
+        if (dv < deg_lo || dv >= deg_hi) continue;          // uniform over the TPN threads
+        const bool v_in_row = find_in_row(col, vb, ve, (int32_t)v) >= 0;
+        const int64_t members = dv + (v_in_row ? 0 : 1);
+        const int lg_dv = ilog2_i64(members) + 2;
+        double ins = 0.0, ext = 0.0;
+        for (int64_t m = lane; m < members; m += TPN) {
+            const int64_t a = (m < dv) ? (int64_t)col[vb + m] : v;
+            const int64_t ab = row_ptr[a], ae = row_ptr[a + 1];
+            const int64_t da = ae - ab;
+            if (da * lg_dv <= members * (int64_t)(ilog2_i64(da) + 2)) {
+                for (int64_t j = ab; j < ae; ++j) {
+                    const int32_t b = col[j];
+                    const double x = w ? w[j] : 1.0;
+                    const bool inside = (b == (int32_t)v) || find_in_row(col, vb, ve, b) >= 0;
+                    if (inside) {
+                        if (directed || b >= a) ins += x;
+                    } else {
+                        ext += x;
+                    }
+                }
+            } else {
+                int64_t matched = 0;
+                double in_all = 0.0;
+                int64_t lo = ab;
+                // look one ego member up in the not-yet-passed tail of row(a)
+                auto probe = [&](int32_t b) {
+                    const int64_t pos = lower_bound_row(col, lo, ae, b);
+                    if (pos < ae && col[pos] == b) {
+                        const double x = w ? w[pos] : 1.0;
+                        ++matched;
+                        in_all += x;
+                        if (directed || b >= a) ins += x;
+                        lo = pos + 1;
+                    } else {
+                        lo = pos;
+                    }
+                };
+                bool v_pending = !v_in_row;                  // v merged at its sorted position
+                for (int64_t t = 0; t < dv && lo < ae; ++t) {
+                    const int32_t b = col[vb + t];
+                    if (v_pending && (int32_t)v < b) {
+                        probe((int32_t)v);
+                        v_pending = false;
+                        if (lo >= ae) break;
+                    }
+                    probe(b);
+                }
+                if (v_pending && lo < ae) probe((int32_t)v);
+                if (matched != da) ext += (w ? rowsum[a] : (double)da) - in_all;
+            }
+        }
+        ins = grx_group_sum<64>(ins);
+        ext = grx_group_sum<64>(ext);
+        if constexpr (WAVES > 1) {
+            const int wv = threadIdx.x / 64;
+            if ((threadIdx.x & 63) == 0) { red[0][wv] = ins; red[1][wv] = ext; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double si = 0.0, se = 0.0;
+                for (int i = 0; i < WAVES; ++i) { si += red[0][i]; se += red[1][i]; }
+                internal[v] = si;
+                external[v] = se;
+            }
+            __syncthreads();
+        } else {
+            if (lane == 0) { internal[v] = ins; external[v] = ext; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// pack: column-major columns -> row-major n x ldr (zero padded)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ldr,
+                                                        const double *const *__restrict__ cols,
+                                                        double *__restrict__ rows)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double *dst = rows + i * ldr;
+        for (int c = 0; c < f; ++c) dst[c] = cols[c][i];
+        for (int c = f; c < ldr; ++c) dst[c] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// neighbour aggregation
+// ---------------------------------------------------------------------------------------
+// G lanes cooperate on one output row; lane l gathers neighbours l, l+G, ... (two per trip for
+// memory-level parallelism) as FP/2 16-byte loads each, accumulates FP fp64 partials, then a
+// fixed G-wide butterfly produces the row sum.  Rows with degree > hub_deg are left to
+// aggregate_hub_kernel.
+template <int FP, int G>
+__global__ __launch_bounds__(256) void aggregate_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ rows, int ldr, int f, int64_t row_begin, int64_t row_end,
+    int64_t hub_deg, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+{
+    const int lane = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        const int64_t d = e - b;
+        if (d > hub_deg) continue;
+        double acc[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) acc[c] = 0.0;
+        int64_t k = b + lane;
+        for (; k + G < e; k += 2 * G) {
+            const int64_t u0 = col[k], u1 = col[k + G];
+            const double2 *p0 = reinterpret_cast<const double2 *>(rows + u0 * ldr);
+            const double2 *p1 = reinterpret_cast<const double2 *>(rows + u1 * ldr);
+            double2 x0[FP / 2], x1[FP / 2];
+#pragma unroll
+            for (int c = 0; c < FP / 2; ++c) { x0[c] = p0[c]; x1[c] = p1[c]; }
+#pragma unroll
+            for (int c = 0; c < FP / 2; ++c) {
+                acc[2 * c] += x0[c].x; acc[2 * c + 1] += x0[c].y;
+            }
+#pragma unroll
+            for (int c = 0; c < FP / 2; ++c) {
+                acc[2 * c] += x1[c].x; acc[2 * c + 1] += x1[c].y;
+            }
+        }
+        if (k < e) {
+            const int64_t u0 = col[k];
+            const double2 *p0 = reinterpret_cast<const double2 *>(rows + u0 * ldr);
+#pragma unroll
+            for (int c = 0; c < FP / 2; ++c) {
+                const double2 x = p0[c];
+                acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<G>(acc[c]);
+        if (lane == 0) {
+            const double inv_cnt = (double)d;
+#pragma unroll
+            for (int c = 0; c < FP; ++c) {
+                if (c < f) {
+                    if (out_sum) out_sum[(int64_t)c * ld + v] = acc[c];
+                    if (out_mean) out_mean[(int64_t)c * ld + v] = (d > 0) ? acc[c] / inv_cnt : 0.0;
+                }
+            }
+        }
+    }
+}
+
+template <int FP>
+__global__ __launch_bounds__(256) void aggregate_hub_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ rows, int ldr, int f, int64_t row_begin, int64_t row_end,
+    int64_t hub_deg, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+{
+    __shared__ double red[4][FP];
+    __shared__ int hub_list[256];
+    __shared__ int hub_cnt;
+    for (int64_t v0 = row_begin + (int64_t)blockIdx.x * 256; v0 < row_end;
+         v0 += (int64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) hub_cnt = 0;
+        __syncthreads();
+        const int64_t mine = v0 + threadIdx.x;
+        if (mine < row_end && (row_ptr[mine + 1] - row_ptr[mine]) > hub_deg) {
+            const int slot = atomicAdd(&hub_cnt, 1);
+            hub_list[slot] = threadIdx.x;
+        }
+        __syncthreads();
+        const int cnt = hub_cnt;
+        for (int h = 0; h < cnt; ++h) {
+            const int64_t v = v0 + hub_list[h];
+            const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+            double acc[FP];
+#pragma unroll
+            for (int c = 0; c < FP; ++c) acc[c] = 0.0;
+            for (int64_t k = b + threadIdx.x; k < e; k += 256) {
+                const int64_t u = col[k];
+                const double2 *p = reinterpret_cast<const double2 *>(rows + u * ldr);
+#pragma unroll
+                for (int c = 0; c < FP / 2; ++c) {
+                    const double2 x = p[c];
+                    acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<64>(acc[c]);
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int c = 0; c < FP; ++c) red[threadIdx.x >> 6][c] = acc[c];
+            }
+            __syncthreads();
+            if (threadIdx.x < f) {
+                const int c = threadIdx.x;
+                const double s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+                if (out_sum) out_sum[(int64_t)c * ld + v] = s;
+                if (out_mean) out_mean[(int64_t)c * ld + v] = s / (double)(e - b);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int FP>
+int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const double *rows,
+                     int ldr, int f, int64_t rb, int64_t re, int64_t hub_deg, double *s,
+                     double *m, int64_t ld, hipStream_t st)
+{
+    const int64_t nrows = re - rb;
+    const int64_t want = grx_ceil_div(nrows * G, 256);
+    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    switch (G) {
+    case 4:  aggregate_kernel<FP, 4><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+    case 8:  aggregate_kernel<FP, 8><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+    case 16: aggregate_kernel<FP, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+    default: aggregate_kernel<FP, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+    }
+    GRX_LAUNCH_CHECK();
+    const int64_t hub_blocks = grx_ceil_div(nrows, 256);
+    const int hgrid = (int)(hub_blocks > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : hub_blocks);
+    aggregate_hub_kernel<FP><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, const double *d_w,
+                 int add_self_loop, int64_t row_begin, int64_t row_end, double *d_out, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
+                "grx_row_sums: bad row range [%lld,%lld) for n=%lld", (long long)row_begin,
+                (long long)row_end, (long long)n);
+    if (row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_out, "grx_row_sums: NULL pointer");
+    const int64_t nrows = row_end - row_begin;
+    const int64_t want = grx_ceil_div(nrows * 8, 256);
+    const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    row_sums_kernel<8><<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, add_self_loop,
+                                                            row_begin, row_end, d_out);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
+                        const double *d_w, const double *d_rowsum, int directed,
+                        int64_t row_begin, int64_t row_end, double *d_internal,
+                        double *d_external, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
+                "grx_egonet_features: bad row range");
+    if (row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_internal && d_external, "grx_egonet_features: NULL pointer");
+    GRX_REQUIRE(d_w == nullptr || d_rowsum != nullptr,
+                "grx_egonet_features: weighted graphs need d_rowsum (grx_row_sums, add_self_loop=0)");
+    const int64_t nrows = row_end - row_begin;
+    constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup above this
+    {
+        const int64_t want = grx_ceil_div(nrows, 4);
+        const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+        egonet_kernel<64><<<grid, 256, 0, grx_stream(stream)>>>(
+            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, 0, HUB, d_internal,
+            d_external);
+        GRX_LAUNCH_CHECK();
+    }
+    {
+        const int grid = (int)(nrows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : nrows);
+        egonet_kernel<512><<<grid, 512, 0, grx_stream(stream)>>>(
+            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, HUB,
+            (int64_t)1 << 62, d_internal, d_external);
+        GRX_LAUNCH_CHECK();
+    }
+    return GRX_OK;
+}
+
+int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
+                  void *stream)
+{
+    GRX_REQUIRE(n >= 0 && f >= 0 && ldr >= f, "grx_pack_rows: bad shape n=%lld f=%d ldr=%d",
+                (long long)n, f, ldr);
+    if (n == 0 || ldr == 0) return GRX_OK;
+    GRX_REQUIRE(d_col_ptrs && d_rows, "grx_pack_rows: NULL pointer");
+    const int64_t want = grx_ceil_div(n, 256);
+    const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, f, ldr, d_col_ptrs, d_rows);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                  const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
+                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
+                "grx_aggregate: bad row range");
+    GRX_REQUIRE(f >= 0 && ldr >= f && (ldr % 2) == 0, "grx_aggregate: ldr=%d must be even and >= f=%d", ldr, f);
+    if (row_end == row_begin || f == 0) return GRX_OK;
+    GRX_REQUIRE(f <= 64, "grx_aggregate: f=%d > 64 (split the columns)", f);
+    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate: NULL pointer");
+    GRX_REQUIRE(ld >= n, "grx_aggregate: ld < n");
+    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, "grx_aggregate: d_rows must be 16-byte aligned");
+    int G = lanes_per_row;
+    if (G != 4 && G != 8 && G != 16 && G != 32) G = 8;
+    const int64_t hub_deg = (int64_t)G * 32;
+    hipStream_t st = grx_stream(stream);
+    // columns are processed in chunks of at most 16 (accumulators stay in registers)
+    for (int c0 = 0; c0 < f; c0 += 16) {
+        const int fc = (f - c0 < 16) ? (f - c0) : 16;
+        const int fp = (fc + 1) & ~1;
+        const double *rows = d_rows + c0;
+        double *s = d_sum ? d_sum + (int64_t)c0 * ld : nullptr;
+        double *m = d_mean ? d_mean + (int64_t)c0 * ld : nullptr;
+        int rc;
+        switch (fp) {
+        case 2:  rc = launch_aggregate<2>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 4:  rc = launch_aggregate<4>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 6:  rc = launch_aggregate<6>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 8:  rc = launch_aggregate<8>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 10: rc = launch_aggregate<10>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 12: rc = launch_aggregate<12>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 14: rc = launch_aggregate<14>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        default: rc = launch_aggregate<16>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        }
+        if (rc != GRX_OK) return rc;
+    }
+    return GRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,661 @@
+// grx_nmf.hip -- RolX NMF: NNDSVDa building blocks and the multiplicative-update loop.
+//
+// Reference call site: graphrole/roles/factor.py:19,24 -> sklearn NMF(solver='mu',
+// init='nndsvda') (sklearn/decomposition/_nmf.py).  Shapes: X is N x F with N up to millions
+// and F <= ~100, rank r <= 16: every pass below streams X (and W) once from HBM and is bound by
+// HBM bandwidth (2-3 flop/byte, far under the fp64 ridge), so the arithmetic is plain fp64 FMA
+// on LDS-staged row tiles; the reduction over the N axis is a fixed-order tree (per-workgroup
+// partials, then a fixed-order sum) -- bitwise reproducible, no floating-point atomics.
+//
+//   gather_columns_kernel   column pointers -> contiguous F x ld
+//   gram_kernel             G = (X T)^T (X T)                 (init: orthogonal factorisation)
+//   project_kernel          U = X Z + per-column statistics   (init: singular vectors, svd_flip,
+//                                                              NNDSVD +/- norms)
+//   nndsvd_apply_kernel     _nmf.py:324-359 elementwise part
+//   nmf_w_pass_kernel       W <- W*(XH^T)/(W HH^T) fused with A = W^T X, B = W^T W partials
+//   nmf_h_update_kernel     H <- H*A/(B H)
+//   nmf_residual_kernel     ||X - WH||_F^2
+#include "grx_common.h"
+
+namespace {
+
+constexpr double NMF_EPSILON = 1.1920928955078125e-07;   // np.finfo(np.float32).eps, _nmf.py:39
+constexpr int MAX_R = GRX_MAX_ROLES;                      // 16
+constexpr int MAX_F = 120;                                // LDS budget of the tiled kernels
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_columns_kernel(int64_t n, int F,
+                                                             const double *const *__restrict__ ptrs,
+                                                             double *__restrict__ out, int64_t ld)
+{
+    const double *src = ptrs[blockIdx.y];
+    double *dst = out + (size_t)blockIdx.y * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+// sum partial[b*P + p] over b in fixed order
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
+                                                             int nblocks, int P,
+                                                             double *__restrict__ out)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * P + p];
+    out[p] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gram of the (optionally transformed) rows
+// ---------------------------------------------------------------------------------------
+constexpr int GR_TR = 64;
+constexpr int GR_LD = GR_TR + 1;
+constexpr int GR_YSLOTS = (MAX_F + 3) / 4;                          // 30
+constexpr int GR_PSLOTS = (MAX_F * (MAX_F + 1) / 2 + 255) / 256;    // 29
+
+template <bool HAS_T>
+__global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t row_end, int F, int k,
+                                                   const double *__restrict__ X, int64_t ldx,
+                                                   const double *__restrict__ T,
+                                                   double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double *sY = gsm;                                  // k * GR_LD
+    __shared__ double xred[4];
+    const int t = threadIdx.x, i = t & 63, g = t >> 6;
+    const int npairs = k * (k + 1) / 2;
+    int pq[GR_PSLOTS];
+    double acc[GR_PSLOTS];
+#pragma unroll
+    for (int s = 0; s < GR_PSLOTS; ++s) {
+        const int id = t + 256 * s;
+        acc[s] = 0.0;
+        pq[s] = -1;
+        if (id < npairs) {
+            // id = b(b+1)/2 + a with a <= b
+            int b = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+            while (b * (b + 1) / 2 > id) --b;
+            while ((b + 1) * (b + 2) / 2 <= id) ++b;
+            pq[s] = ((id - b * (b + 1) / 2) << 8) | b;
+        }
+    }
+    double xsum = 0.0;
+    for (int64_t r0 = row_begin + (int64_t)blockIdx.x * GR_TR; r0 < row_end;
+         r0 += (int64_t)gridDim.x * GR_TR) {
+        const bool live = (r0 + i) < row_end;
+        __syncthreads();
+        if (HAS_T) {
+            double y[GR_YSLOTS];
+#pragma unroll
+            for (int s = 0; s < GR_YSLOTS; ++s) y[s] = 0.0;
+            for (int c = 0; c < F; ++c) {
+                const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
+                const double *Tc = T + (size_t)c * k;
+#pragma unroll
+                for (int s = 0; s < GR_YSLOTS; ++s) {
+                    const int j = g + 4 * s;
+                    if (j < k) y[s] += x * Tc[j];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GR_YSLOTS; ++s) {
+                const int j = g + 4 * s;
+                if (j < k) sY[j * GR_LD + i] = y[s];
+            }
+        } else {
+            for (int c = g; c < F; c += 4) {
+                const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
+                sY[c * GR_LD + i] = x;
+                xsum += x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GR_PSLOTS; ++s) {
+            if (pq[s] >= 0) {
+                const double *a = sY + (pq[s] >> 8) * GR_LD;
+                const double *b = sY + (pq[s] & 0xFF) * GR_LD;
+                double v = acc[s];
+#pragma unroll 8
+                for (int ii = 0; ii < GR_TR; ++ii) v += a[ii] * b[ii];
+                acc[s] = v;
+            }
+        }
+    }
+    double *out = partial + (size_t)blockIdx.x * (npairs + 1);
+#pragma unroll
+    for (int s = 0; s < GR_PSLOTS; ++s) {
+        const int id = t + 256 * s;
+        if (id < npairs) out[id] = acc[s];
+    }
+    xsum = grx_group_sum<64>(xsum);
+    if (i == 0) xred[g] = xsum;
+    __syncthreads();
+    if (t == 0) out[npairs] = ((xred[0] + xred[1]) + xred[2]) + xred[3];
+}
+
+// partial [nblocks][npairs+1] -> out: full symmetric k x k, then the X sum
+__global__ __launch_bounds__(64) void gram_finalize_kernel(const double *__restrict__ partial,
+                                                           int nblocks, int k,
+                                                           double *__restrict__ out)
+{
+    const int npairs = k * (k + 1) / 2;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx > k * k) return;
+    int id;
+    if (idx == k * k) {
+        id = npairs;
+    } else {
+        const int a = idx / k, b = idx % k;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        id = hi * (hi + 1) / 2 + lo;
+    }
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (npairs + 1) + id];
+    out[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// U = X Z with per-column statistics
+// ---------------------------------------------------------------------------------------
+struct ColStat { double maxabs; double signed_val; double idx; double sq_pos; double sq_neg; };
+
+__global__ __launch_bounds__(256) void project_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                      const double *__restrict__ X, int64_t ldx,
+                                                      const double *__restrict__ Z,
+                                                      double *__restrict__ U, int64_t ldu,
+                                                      double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    double *sZ = psm;                                  // F * r
+    double *sred = sZ + F * r;                         // 4 waves * r * 5
+    for (int idx = threadIdx.x; idx < F * r; idx += 256) sZ[idx] = Z[idx];
+    __syncthreads();
+    double mx[MAX_R], sv[MAX_R], ix[MAX_R], sp[MAX_R], sn[MAX_R];
+#pragma unroll
+    for (int j = 0; j < MAX_R; ++j) { mx[j] = -1.0; sv[j] = 0.0; ix[j] = 0.0; sp[j] = 0.0; sn[j] = 0.0; }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
+        double u[MAX_R];
+#pragma unroll
+        for (int j = 0; j < MAX_R; ++j) u[j] = 0.0;
+        for (int c = 0; c < F; ++c) {
+            const double x = X[(size_t)c * ldx + i];
+#pragma unroll
+            for (int j = 0; j < MAX_R; ++j)
+                if (j < r) u[j] += x * sZ[c * r + j];
+        }
+#pragma unroll
+        for (int j = 0; j < MAX_R; ++j) {
+            if (j < r) {
+                U[(size_t)j * ldu + i] = u[j];
+                const double a = fabs(u[j]);
+                if (a > mx[j]) { mx[j] = a; sv[j] = u[j]; ix[j] = (double)i; }   // i ascending per thread
+                if (u[j] > 0.0) sp[j] += u[j] * u[j]; else sn[j] += u[j] * u[j];
+            }
+        }
+    }
+    // wave reduce (max-abs with smallest index on ties; sums by fixed butterfly)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < MAX_R; ++j) {
+        if (j < r) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double om = __shfl_xor(mx[j], off, 64);
+                const double os = __shfl_xor(sv[j], off, 64);
+                const double oi = __shfl_xor(ix[j], off, 64);
+                if (om > mx[j] || (om == mx[j] && oi < ix[j])) { mx[j] = om; sv[j] = os; ix[j] = oi; }
+            }
+            sp[j] = grx_group_sum<64>(sp[j]);
+            sn[j] = grx_group_sum<64>(sn[j]);
+            if (lane == 0) {
+                double *o = sred + ((size_t)wave * r + j) * 5;
+                o[0] = mx[j]; o[1] = sv[j]; o[2] = ix[j]; o[3] = sp[j]; o[4] = sn[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < r) {
+        const int j = threadIdx.x;
+        double bm = -1.0, bs = 0.0, bi = 0.0, p = 0.0, q = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            const double *o = sred + ((size_t)w * r + j) * 5;
+            if (o[0] > bm || (o[0] == bm && o[2] < bi)) { bm = o[0]; bs = o[1]; bi = o[2]; }
+            p += o[3]; q += o[4];
+        }
+        double *o = partial + ((size_t)blockIdx.x * r + j) * 5;
+        o[0] = bm; o[1] = bs; o[2] = bi; o[3] = p; o[4] = q;
+    }
+}
+
+// stats out: [r][4] = signed value of the max-|.| entry, its row index, sum sq pos, sum sq neg
+__global__ __launch_bounds__(64) void project_finalize_kernel(const double *__restrict__ partial,
+                                                              int nblocks, int r,
+                                                              double *__restrict__ stats)
+{
+    const int j = threadIdx.x;
+    if (j >= r) return;
+    double bm = -1.0, bs = 0.0, bi = 0.0, p = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        const double *o = partial + ((size_t)b * r + j) * 5;
+        if (o[0] > bm || (o[0] == bm && o[2] < bi)) { bm = o[0]; bs = o[1]; bi = o[2]; }
+        p += o[3]; q += o[4];
+    }
+    stats[j * 4 + 0] = bs; stats[j * 4 + 1] = bi; stats[j * 4 + 2] = p; stats[j * 4 + 3] = q;
+}
+
+struct NndsvdArgs { double sign[MAX_R]; double scale[MAX_R]; };
+
+__global__ __launch_bounds__(256) void nndsvd_apply_kernel(int64_t row_begin, int64_t row_end, int r,
+                                                           double *__restrict__ U, int64_t ldu,
+                                                           NndsvdArgs a, double eps, double fill)
+{
+    const int j = blockIdx.y;
+    const double sg = a.sign[j], sc = a.scale[j];
+    double *u = U + (size_t)j * ldu;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
+        const double x = u[i];
+        double v = (sg == 0.0) ? fabs(x) : fmax(sg * x, 0.0);
+        v *= sc;
+        u[i] = (v < eps) ? fill : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// multiplicative update, W side (fused with the H-side reductions)
+// ---------------------------------------------------------------------------------------
+constexpr int MU_PSLOTS = (MAX_R * MAX_F + MAX_R * MAX_R + 255) / 256;      // 9
+
+static inline size_t mu_lds_doubles(int F, int r, int TR)
+{
+    return (size_t)(F + 2 * r) * (TR + 1) + (size_t)r * F + (size_t)r * r;
+}
+
+template <int TR>
+__global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                         const double *__restrict__ X, int64_t ldx,
+                                                         double *__restrict__ W, int64_t ldw,
+                                                         const double *__restrict__ H,
+                                                         double *__restrict__ partial)
+{
+    constexpr int LD = TR + 1;
+    constexpr int PARTS = 256 / TR;
+    extern __shared__ __attribute__((aligned(16))) double msm[];
+    double *sX = msm;                    // F * LD
+    double *sWo = sX + F * LD;           // r * LD   old W tile
+    double *sW = sWo + r * LD;           // r * LD   new W tile
+    double *sH = sW + r * LD;            // r * F
+    double *sHH = sH + r * F;            // r * r
+    const int t = threadIdx.x;
+    for (int idx = t; idx < r * F; idx += 256) sH[idx] = H[idx];
+    __syncthreads();
+    for (int idx = t; idx < r * r; idx += 256) {
+        const int k = idx / r, l = idx % r;
+        double s = 0.0;
+        for (int c = 0; c < F; ++c) s += sH[k * F + c] * sH[l * F + c];
+        sHH[idx] = s;
+    }
+    const int nA = r * F, P = nA + r * r;
+    const int ngrp = (P <= 256) ? (256 / P) : 1;
+    const int grp = (P <= 256) ? (t / P) : 0;
+    const bool acc_active = (P > 256) || (grp < ngrp);
+    double acc[MU_PSLOTS];
+#pragma unroll
+    for (int s = 0; s < MU_PSLOTS; ++s) acc[s] = 0.0;
+
+    for (int64_t r0 = row_begin + (int64_t)blockIdx.x * TR; r0 < row_end; r0 += (int64_t)gridDim.x * TR) {
+        const int rows = (int)((row_end - r0 < TR) ? (row_end - r0) : TR);
+        __syncthreads();
+        for (int idx = t; idx < F * TR; idx += 256) {
+            const int c = idx / TR, i = idx % TR;
+            sX[c * LD + i] = (i < rows) ? X[(size_t)c * ldx + r0 + i] : 0.0;
+        }
+        for (int idx = t; idx < r * TR; idx += 256) {
+            const int k = idx / TR, i = idx % TR;
+            sWo[k * LD + i] = (i < rows) ? W[(size_t)k * ldw + r0 + i] : 0.0;
+        }
+        __syncthreads();
+        {
+            const int i = t % TR, g = t / TR;
+            for (int k = g; k < r; k += PARTS) {
+                double numer = 0.0, denom = 0.0;
+                for (int c = 0; c < F; ++c) numer += sX[c * LD + i] * sH[k * F + c];
+                for (int l = 0; l < r; ++l) denom += sWo[l * LD + i] * sHH[l * r + k];
+                if (denom == 0.0) denom = NMF_EPSILON;
+                const double wk = (i < rows) ? sWo[k * LD + i] * (numer / denom) : 0.0;
+                sW[k * LD + i] = wk;
+                if (i < rows) W[(size_t)k * ldw + r0 + i] = wk;
+            }
+        }
+        __syncthreads();
+        if (acc_active) {
+#pragma unroll
+            for (int s = 0; s < MU_PSLOTS; ++s) {
+                const int pid = (P <= 256) ? (t % P) : (t + 256 * s);
+                if ((P <= 256) ? (s == 0) : (pid < P)) {
+                    const double *a, *b;
+                    if (pid < nA) { a = sW + (pid / F) * LD; b = sX + (pid % F) * LD; }
+                    else { const int q = pid - nA; a = sW + (q / r) * LD; b = sW + (q % r) * LD; }
+                    double v = acc[s];
+                    for (int i = grp; i < TR; i += ngrp) v += a[i] * b[i];
+                    acc[s] = v;
+                }
+            }
+        }
+    }
+    double *out = partial + (size_t)blockIdx.x * P;
+    if (P <= 256) {
+        __syncthreads();
+        double *red = sX;                               // ngrp * P <= 256 doubles
+        if (acc_active) red[grp * P + (t % P)] = acc[0];
+        __syncthreads();
+        if (t < P) {
+            double s = 0.0;
+            for (int gI = 0; gI < ngrp; ++gI) s += red[gI * P + t];
+            out[t] = s;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < MU_PSLOTS; ++s) {
+            const int pid = t + 256 * s;
+            if (pid < P) out[pid] = acc[s];
+        }
+    }
+}
+
+// H <- H * (A / (B H)), one workgroup
+__global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, double *__restrict__ H,
+                                                           const double *__restrict__ AB)
+{
+    extern __shared__ __attribute__((aligned(16))) double hsm[];
+    double *sA = hsm;                 // r*F
+    double *sB = sA + r * F;          // r*r
+    double *sH = sB + r * r;          // r*F
+    for (int idx = threadIdx.x; idx < r * F; idx += 256) { sA[idx] = AB[idx]; sH[idx] = H[idx]; }
+    for (int idx = threadIdx.x; idx < r * r; idx += 256) sB[idx] = AB[r * F + idx];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < r * F; idx += 256) {
+        const int k = idx / F, c = idx % F;
+        double denom = 0.0;
+        for (int l = 0; l < r; ++l) denom += sB[k * r + l] * sH[l * F + c];
+        if (denom == 0.0) denom = NMF_EPSILON;
+        H[idx] = sH[idx] * (sA[idx] / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                           const double *__restrict__ X, int64_t ldx,
+                                                           const double *__restrict__ W, int64_t ldw,
+                                                           const double *__restrict__ H,
+                                                           double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double rsm[];
+    double *sH = rsm;                 // r*F
+    __shared__ double wred[4];
+    for (int idx = threadIdx.x; idx < r * F; idx += 256) sH[idx] = H[idx];
+    __syncthreads();
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
+        double w[MAX_R];
+#pragma unroll
+        for (int k = 0; k < MAX_R; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
+        for (int c = 0; c < F; ++c) {
+            double wh = 0.0;
+#pragma unroll
+            for (int k = 0; k < MAX_R; ++k)
+                if (k < r) wh += w[k] * sH[k * F + c];
+            const double d = X[(size_t)c * ldx + i] - wh;
+            s += d * d;
+        }
+    }
+    s = grx_group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+}
+
+int pick_tr(int F, int r)
+{
+    const int cand[4] = {256, 128, 64, 32};
+    for (int i = 0; i < 4; ++i)
+        if (mu_lds_doubles(F, r, cand[i]) * 8 <= 64 * 1024) return cand[i];
+    return 0;
+}
+
+int mu_grid(int64_t nrows, int TR)
+{
+    const int64_t tiles = grx_ceil_div(nrows, TR);
+    return (int)(tiles > GRX_NUM_CU * 2 ? GRX_NUM_CU * 2 : (tiles < 1 ? 1 : tiles));
+}
+
+constexpr int RES_GRID = GRX_NUM_CU * 4;
+
+int check_nmf_shape(const char *who, int F, int r)
+{
+    if (F < 1 || r < 1 || F > MAX_F || r > MAX_R || pick_tr(F, r) == 0) {
+        grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d)", who, F, r, MAX_F, MAX_R);
+        return GRX_ERR_UNSUPPORTED;
+    }
+    return GRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double *d_out, int64_t ld,
+                       void *stream)
+{
+    GRX_REQUIRE(n >= 0 && F >= 0 && ld >= n, "grx_gather_columns: bad shape");
+    if (n == 0 || F == 0) return GRX_OK;
+    GRX_REQUIRE(d_col_ptrs && d_out, "grx_gather_columns: NULL pointer");
+    const int64_t want = grx_ceil_div(n, 256 * 4);
+    const dim3 grid((unsigned)(want > 1024 ? 1024 : want), F);
+    gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, F, d_col_ptrs, d_out, ld);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+static int gram_grid(int64_t nrows)
+{
+    const int64_t tiles = grx_ceil_div(nrows, GR_TR);
+    return (int)(tiles > GRX_NUM_CU * 2 ? GRX_NUM_CU * 2 : (tiles < 1 ? 1 : tiles));
+}
+
+size_t grx_gram_workspace_bytes(int64_t n, int k)
+{
+    if (k < 1) k = 1;
+    const size_t npairs = (size_t)k * (k + 1) / 2 + 1;
+    return grx_align_up((size_t)gram_grid(n) * npairs * 8, 256) + grx_align_up((size_t)MAX_F * MAX_F * 8, 256);
+}
+
+int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
+             const double *h_T, int k, double *d_out, void *d_workspace, size_t workspace_bytes,
+             void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n,
+                "grx_gram: bad row range");
+    if (F < 1 || F > MAX_F || k < 1 || k > MAX_F) {
+        grx_set_error("grx_gram: F=%d k=%d outside [1,%d]", F, k, MAX_F);
+        return GRX_ERR_UNSUPPORTED;
+    }
+    GRX_REQUIRE(h_T != nullptr || k == F, "grx_gram: identity transform needs k == F");
+    GRX_REQUIRE(d_X && d_out && d_workspace, "grx_gram: NULL pointer");
+    if (workspace_bytes < grx_gram_workspace_bytes(n, k)) {
+        grx_set_error("grx_gram: workspace %zu < %zu", workspace_bytes, grx_gram_workspace_bytes(n, k));
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    const int grid = gram_grid(row_end - row_begin);
+    const size_t npairs = (size_t)k * (k + 1) / 2;
+    char *ws = reinterpret_cast<char *>(d_workspace);
+    double *partial = reinterpret_cast<double *>(ws);
+    double *dT = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_grid(n) * (npairs + 1) * 8, 256));
+    const size_t lds = (size_t)k * GR_LD * 8;
+    if (h_T) {
+        GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
+        gram_kernel<true><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+    } else {
+        gram_kernel<false><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial);
+    }
+    GRX_LAUNCH_CHECK();
+    gram_finalize_kernel<<<(k * k + 1 + 63) / 64, 64, 0, st>>>(partial, grid, k, d_out);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+constexpr int PROJ_GRID = GRX_NUM_CU * 4;
+
+size_t grx_project_workspace_bytes(int64_t n, int r)
+{
+    (void)n;
+    if (r < 1) r = 1;
+    return grx_align_up((size_t)PROJ_GRID * r * 5 * 8, 256) + grx_align_up((size_t)MAX_F * MAX_R * 8, 256);
+}
+
+int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
+                const double *h_Z, int r, double *d_U, int64_t ldu, double *d_stats,
+                void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldu >= n,
+                "grx_project: bad row range");
+    int rc = check_nmf_shape("grx_project", F, r);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(d_X && h_Z && d_U && d_stats && d_workspace, "grx_project: NULL pointer");
+    if (workspace_bytes < grx_project_workspace_bytes(n, r)) {
+        grx_set_error("grx_project: workspace too small");
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    char *ws = reinterpret_cast<char *>(d_workspace);
+    double *partial = reinterpret_cast<double *>(ws);
+    double *dZ = reinterpret_cast<double *>(ws + grx_align_up((size_t)PROJ_GRID * r * 5 * 8, 256));
+    GRX_CHECK_HIP(hipMemcpyAsync(dZ, h_Z, (size_t)F * r * 8, hipMemcpyHostToDevice, st));
+    const int64_t want = grx_ceil_div(row_end - row_begin, 256);
+    const int grid = (int)(want > PROJ_GRID ? PROJ_GRID : (want < 1 ? 1 : want));
+    const size_t lds = ((size_t)F * r + 4 * (size_t)r * 5) * 8;
+    project_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
+    GRX_LAUNCH_CHECK();
+    project_finalize_kernel<<<1, 64, 0, st>>>(partial, grid, r, d_stats);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_nndsvd_apply(int64_t n, int r, double *d_U, int64_t ldu, int64_t row_begin, int64_t row_end,
+                     const double *h_sign, const double *h_scale, double eps, double fill, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldu >= n,
+                "grx_nndsvd_apply: bad row range");
+    GRX_REQUIRE(r >= 1 && r <= MAX_R, "grx_nndsvd_apply: r=%d outside [1,%d]", r, MAX_R);
+    GRX_REQUIRE(d_U && h_sign && h_scale, "grx_nndsvd_apply: NULL pointer");
+    if (row_end == row_begin) return GRX_OK;
+    NndsvdArgs a;
+    for (int j = 0; j < MAX_R; ++j) { a.sign[j] = j < r ? h_sign[j] : 0.0; a.scale[j] = j < r ? h_scale[j] : 0.0; }
+    const int64_t want = grx_ceil_div(row_end - row_begin, 256 * 4);
+    const dim3 grid((unsigned)(want > 1024 ? 1024 : want), r);
+    nndsvd_apply_kernel<<<grid, 256, 0, grx_stream(stream)>>>(row_begin, row_end, r, d_U, ldu, a, eps, fill);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+size_t grx_nmf_workspace_bytes(int64_t n, int F, int r)
+{
+    (void)n;
+    if (F < 1) F = 1;
+    if (r < 1) r = 1;
+    const size_t P = (size_t)r * F + (size_t)r * r;
+    const size_t a = grx_align_up((size_t)GRX_NUM_CU * 2 * P * 8, 256);
+    const size_t b = grx_align_up((size_t)RES_GRID * 8, 256);
+    return a + b;
+}
+
+int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                   int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
+                   void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldw >= n,
+                "grx_nmf_w_pass: bad row range");
+    int rc = check_nmf_shape("grx_nmf_w_pass", F, r);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(d_X && d_W && d_H && d_AB && d_workspace, "grx_nmf_w_pass: NULL pointer");
+    if (workspace_bytes < grx_nmf_workspace_bytes(n, F, r)) {
+        grx_set_error("grx_nmf_w_pass: workspace too small");
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    const int TR = pick_tr(F, r);
+    const int grid = mu_grid(row_end - row_begin, TR);
+    const size_t lds = mu_lds_doubles(F, r, TR) * 8;
+    double *partial = reinterpret_cast<double *>(d_workspace);
+    const int P = r * F + r * r;
+    switch (TR) {
+    case 256: nmf_w_pass_kernel<256><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+    case 128: nmf_w_pass_kernel<128><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+    case 64:  nmf_w_pass_kernel<64><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+    default:  nmf_w_pass_kernel<32><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+    }
+    GRX_LAUNCH_CHECK();
+    reduce_partials_kernel<<<(P + 63) / 64, 64, 0, st>>>(partial, grid, P, d_AB);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream)
+{
+    int rc = check_nmf_shape("grx_nmf_h_update", F, r);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(d_H && d_AB, "grx_nmf_h_update: NULL pointer");
+    const size_t lds = (2 * (size_t)r * F + (size_t)r * r) * 8;
+    nmf_h_update_kernel<<<1, 256, lds, grx_stream(stream)>>>(F, r, d_H, d_AB);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *d_W,
+                     int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H, double *d_out,
+                     void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldw >= n,
+                "grx_nmf_residual: bad row range");
+    int rc = check_nmf_shape("grx_nmf_residual", F, r);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(d_X && d_W && d_H && d_out && d_workspace, "grx_nmf_residual: NULL pointer");
+    if (workspace_bytes < grx_nmf_workspace_bytes(n, F, r)) {
+        grx_set_error("grx_nmf_residual: workspace too small");
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    const size_t P = (size_t)r * F + (size_t)r * r;
+    double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(d_workspace) +
+                                                 grx_align_up((size_t)GRX_NUM_CU * 2 * P * 8, 256));
+    const int64_t want = grx_ceil_div(row_end - row_begin, 256);
+    const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
+    nmf_residual_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
+                                                             d_H, partial);
+    GRX_LAUNCH_CHECK();
+    reduce_partials_kernel<<<1, 64, 0, st>>>(partial, grid, 1, d_out);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                    double *d_H, double *d_AB, double *d_err, int iters, void *d_workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(iters >= 0, "grx_nmf_iterate: iters < 0");
+    for (int it = 0; it < iters; ++it) {
+        int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream);
+        if (rc != GRX_OK) return rc;
+        rc = grx_nmf_h_update(F, r, d_H, d_AB, stream);
+        if (rc != GRX_OK) return rc;
+    }
+    if (d_err)
+        return grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err, d_workspace, workspace_bytes, stream);
+    return GRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// grx_prune.hip -- vertical logarithmic binning and pairwise Chebyshev distance.
+//
+// graphrole/features/prune.py:13-56 needs, per column, the sorted values (np.unique + cumsum),
+// a short walk that picks the bin thresholds, and a relabelling pass.  On the GPU:
+//   1. batched LSD radix sort of the fp64 columns (8 passes x 8 bits, keys only)
+//        tile_count_kernel -> scan_kernel -> scatter_kernel        (HBM bound, wave ballots)
+//   2. bin_threshold_kernel : one wavefront per column walks the sorted column; the end of a
+//        tie run is found with a 64-ary ballot search                (latency bound, tiny)
+//   3. bin_assign_kernel    : each value -> lower_bound over <=128 thresholds held in LDS
+//   4. chebyshev_kernel     : max_i |bin_p[i]-bin_q[i]| for column pairs, LDS-tiled rows,
+//        integer atomicMax into the F x F matrix (prune.py:108)
+// All integer work: results are bit-exact functions of the input columns.
+#include "grx_common.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;     // 4096 keys per workgroup
+constexpr int RADIX = 256;
+
+__device__ __forceinline__ uint64_t f64_to_key(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return b ^ ((b >> 63) ? 0xFFFFFFFFFFFFFFFFull : 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double key_to_f64(uint64_t k)
+{
+    const uint64_t b = k ^ ((k >> 63) ? 0x8000000000000000ull : 0xFFFFFFFFFFFFFFFFull);
+    return __longlong_as_double((long long)b);
+}
+
+// Load the ITEMS keys of this thread.  Wave w of the tile owns the contiguous slice
+// [w*64*ITEMS, (w+1)*64*ITEMS); item i of lane l is element i*64 + l of that slice, so
+// (wave, item, lane) order == memory order (needed for LSD stability) and loads coalesce.
+template <bool FROM_F64>
+__device__ __forceinline__ void load_keys(const void *__restrict__ src, int64_t n, int64_t tile_base,
+                                          uint64_t (&keys)[SORT_ITEMS], uint32_t &valid_mask)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = tile_base + (int64_t)wave * 64 * SORT_ITEMS + lane;
+    valid_mask = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * 64;
+        if (idx < n) {
+            valid_mask |= 1u << i;
+            if (FROM_F64) keys[i] = f64_to_key(reinterpret_cast<const double *>(src)[idx]);
+            else keys[i] = reinterpret_cast<const uint64_t *>(src)[idx];
+        } else {
+            keys[i] = 0xFFFFFFFFFFFFFFFFull;
+        }
+    }
+}
+
+// hist layout per column: [RADIX][ntiles] (digit-major) so one flat exclusive scan yields the
+// global output offset of (digit, tile).
+template <bool FROM_F64>
+__global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
+    const void *__restrict__ src, int64_t src_ld, int64_t n, int shift, int ntiles,
+    uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t cnt[RADIX];
+    const int col = blockIdx.y, tile = blockIdx.x;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const char *csrc = reinterpret_cast<const char *>(src) + (size_t)col * src_ld * 8;
+    uint64_t keys[SORT_ITEMS];
+    uint32_t vm;
+    load_keys<FROM_F64>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i)
+        if (vm & (1u << i)) atomicAdd(&cnt[(keys[i] >> shift) & 0xFF], 1u);
+    __syncthreads();
+    hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
+}
+
+// One workgroup per column: in-place exclusive scan of RADIX*ntiles counters.
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t *__restrict__ hist, int64_t len)
+{
+    __shared__ uint32_t wave_tot[16];
+    uint32_t *h = hist + (size_t)blockIdx.x * len;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = (len + 1023) / 1024;
+    const int64_t b = (int64_t)threadIdx.x * per;
+    const int64_t e = (b + per < len) ? (b + per) : len;
+    uint32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += h[i];
+    // inclusive scan of s across the workgroup
+    uint32_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 16; ++i) { const uint32_t t = wave_tot[i]; wave_tot[i] = run; run += t; }
+    }
+    __syncthreads();
+    uint32_t run = wave_tot[wave] + inc - s;       // exclusive prefix of this thread's slice
+    for (int64_t i = b; i < e; ++i) { const uint32_t t = h[i]; h[i] = run; run += t; }
+}
+
+template <bool FROM_F64, bool TO_F64>
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
+    const void *__restrict__ src, int64_t src_ld, void *__restrict__ dst, int64_t dst_ld, int64_t n,
+    int shift, int ntiles, const uint32_t *__restrict__ offsets)
+{
+    __shared__ uint32_t cnt[4][RADIX];
+    const int col = blockIdx.y, tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const char *csrc = reinterpret_cast<const char *>(src) + (size_t)col * src_ld * 8;
+    uint64_t keys[SORT_ITEMS];
+    uint32_t vm;
+    load_keys<FROM_F64>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t rank[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool valid = (vm >> i) & 1u;
+        const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (d >> bit) & 1u;
+            const uint64_t m = __ballot(set);
+            peers &= set ? m : ~m;
+        }
+        uint32_t r = 0;
+        if (valid) {
+            const uint32_t before = cnt[wave][d];
+            const uint32_t in_group = (uint32_t)__popcll(peers & lt_mask);
+            r = before + in_group;
+            __builtin_amdgcn_wave_barrier();
+            if (in_group == 0) cnt[wave][d] = before + (uint32_t)__popcll(peers);
+        }
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = r;
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+        const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile];
+        cnt[0][d] = g;
+        cnt[1][d] = g + c0;
+        cnt[2][d] = g + c0 + c1;
+        cnt[3][d] = g + c0 + c1 + c2;
+    }
+    __syncthreads();
+    char *cdst = reinterpret_cast<char *>(dst) + (size_t)col * dst_ld * 8;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        if ((vm >> i) & 1u) {
+            const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
+            const uint32_t pos = cnt[wave][d] + rank[i];
+            if (TO_F64) reinterpret_cast<double *>(cdst)[pos] = key_to_f64(keys[i]);
+            else reinterpret_cast<uint64_t *>(cdst)[pos] = keys[i];
+        }
+    }
+}
+
+// One wavefront per column.  prune.py:33-54: repeat { size = max(int(frac*unbinned),1);
+// hi = value at sorted position done+size-1; extend to the end of hi's tie run }.
+__global__ __launch_bounds__(64) void bin_threshold_kernel(const double *__restrict__ sorted,
+                                                           int64_t ld, int64_t n, double frac,
+                                                           double *__restrict__ thr,
+                                                           int32_t *__restrict__ nbins)
+{
+    const double *s = sorted + (size_t)blockIdx.x * ld;
+    double *t = thr + (size_t)blockIdx.x * GRX_MAX_BINS;
+    const int lane = threadIdx.x;
+    int64_t done = 0;
+    int nb = 0;
+    while (done < n && nb < GRX_MAX_BINS) {
+        int64_t size = (int64_t)(frac * (double)(n - done));
+        if (size < 1) size = 1;
+        const int64_t pos = done + size - 1;
+        const double hi = s[pos];
+        int64_t L = pos + 1, R = n;
+        while (L < R) {
+            const int64_t len = R - L;
+            const int64_t step = (len + 63) >> 6;
+            const int64_t idx = L + (int64_t)lane * step;
+            const bool eq = (idx < R) && (s[idx] == hi);
+            const int c = __popcll(__ballot(eq));
+            if (c == 0) {
+                R = L;
+            } else {
+                const int64_t nL = L + (int64_t)(c - 1) * step + 1;
+                const int64_t cap = L + (int64_t)c * step;
+                R = (cap < R) ? cap : R;
+                L = nL;
+            }
+        }
+        if (lane == 0) t[nb] = hi;
+        ++nb;
+        done = L;
+    }
+    if (lane == 0) nbins[blockIdx.x] = nb;
+}
+
+__global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restrict__ cols, int64_t ld,
+                                                         int64_t n, const double *__restrict__ thr,
+                                                         const int32_t *__restrict__ nbins,
+                                                         uint8_t *__restrict__ bins, int64_t ld_bins)
+{
+    __shared__ double t[GRX_MAX_BINS];
+    const int col = blockIdx.y;
+    const int nb = nbins[col];
+    if (threadIdx.x < GRX_MAX_BINS)
+        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0.0;
+    __syncthreads();
+    const double *x = cols + (size_t)col * ld;
+    uint8_t *o = bins + (size_t)col * ld_bins;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = x[i];
+        int lo = 0, hi = nb;                 // first threshold >= v
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        o[i] = (uint8_t)lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Chebyshev distance between binned columns
+// ---------------------------------------------------------------------------------------
+constexpr int CH_ROWS = 512;                 // rows per LDS tile
+constexpr int CH_STRIDE = CH_ROWS + 4;       // +4 bytes: column p starts on bank p (mod 32)
+constexpr int CH_MAX_F = 120;               // F * CH_STRIDE <= 64 KiB of LDS
+
+__global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
+                                                        int first_new,
+                                                        const uint8_t *const *__restrict__ ptrs,
+                                                        int32_t *__restrict__ dist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *tile = smem;                                   // F * CH_STRIDE
+    const int q0 = first_new > 1 ? first_new : 1;
+    // pairs (p,q), q in [q0,F), p in [0,q): id = tri(q) - tri(q0) + p, tri(q) = q(q-1)/2
+    const int tri0 = q0 * (q0 - 1) / 2;
+    const int npairs = F * (F - 1) / 2 - tri0;
+    constexpr int MAX_OWN = (CH_MAX_F * (CH_MAX_F - 1) / 2 + 255) / 256;   // 28
+    int own_pq[MAX_OWN], own_max[MAX_OWN];
+#pragma unroll
+    for (int k = 0; k < MAX_OWN; ++k) {
+        const int id = threadIdx.x + 256 * k;
+        own_max[k] = 0;
+        own_pq[k] = -1;
+        if (id < npairs) {
+            const int target = id + tri0;
+            int q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)target)) * 0.5f);
+            while (q * (q - 1) / 2 > target) --q;
+            while ((q + 1) * q / 2 <= target) ++q;
+            own_pq[k] = ((target - q * (q - 1) / 2) << 8) | q;
+        }
+    }
+    for (int64_t r0 = row_begin + (int64_t)blockIdx.x * CH_ROWS; r0 < row_end;
+         r0 += (int64_t)gridDim.x * CH_ROWS) {
+        const int rows = (int)((row_end - r0 < CH_ROWS) ? (row_end - r0) : CH_ROWS);
+        __syncthreads();
+        for (int c = 0; c < F; ++c) {
+            const uint8_t *src = ptrs[c] + r0;
+            for (int i = threadIdx.x; i < CH_ROWS; i += 256)
+                tile[c * CH_STRIDE + i] = (i < rows) ? src[i] : 0;
+        }
+        // rows beyond `rows` are zero in every column -> contribute distance 0
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAX_OWN; ++k) {
+            if (own_pq[k] >= 0) {
+                const uint32_t *a = reinterpret_cast<const uint32_t *>(tile + (own_pq[k] >> 8) * CH_STRIDE);
+                const uint32_t *b = reinterpret_cast<const uint32_t *>(tile + (own_pq[k] & 0xFF) * CH_STRIDE);
+                int mx = own_max[k];
+                for (int i = 0; i < CH_ROWS / 4; ++i) {
+                    const uint32_t x = a[i], y = b[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xa = (x >> (8 * j)) & 0xFF, yb = (y >> (8 * j)) & 0xFF;
+                        const int d = xa > yb ? xa - yb : yb - xa;
+                        mx = d > mx ? d : mx;
+                    }
+                }
+                own_max[k] = mx;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_OWN; ++k) {
+        if (own_pq[k] >= 0) {
+            const int p = own_pq[k] >> 8, q = own_pq[k] & 0xFF;
+            atomicMax(&dist[p * F + q], own_max[k]);
+            atomicMax(&dist[q * F + p], own_max[k]);
+        }
+    }
+}
+
+struct SortPlan {
+    int ntiles;
+    size_t keys_bytes;      // one key buffer: ncols * n * 8
+    size_t hist_bytes;      // ncols * RADIX * ntiles * 4
+};
+
+SortPlan make_plan(int64_t n, int ncols)
+{
+    SortPlan p;
+    p.ntiles = (int)grx_ceil_div(n, SORT_TILE);
+    p.keys_bytes = grx_align_up((size_t)ncols * (size_t)n * 8, 256);
+    p.hist_bytes = grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256);
+    return p;
+}
+
+// sort ncols columns; keysA/hist are scratch; result (fp64 ascending) in out (column stride out_ld)
+int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
+                 uint64_t *keysA, uint32_t *hist, hipStream_t st)
+{
+    const SortPlan p = make_plan(n, ncols);
+    const dim3 grid(p.ntiles, ncols);
+    const int64_t scan_len = (int64_t)RADIX * p.ntiles;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        // ping-pong: pass 0 cols->A, odd A->out, even out->A; pass 7 writes fp64 into out
+        const void *src;
+        int64_t sld;
+        void *dst;
+        int64_t dld;
+        if (pass == 0) { src = cols; sld = ld; }
+        else if (pass & 1) { src = keysA; sld = n; }
+        else { src = out; sld = out_ld; }
+        if (pass & 1) { dst = out; dld = out_ld; }
+        else { dst = keysA; dld = n; }
+        if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+        else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+        GRX_LAUNCH_CHECK();
+        scan_kernel<<<ncols, 1024, 0, st>>>(hist, scan_len);
+        GRX_LAUNCH_CHECK();
+        if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+        else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+        else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+        GRX_LAUNCH_CHECK();
+    }
+    return GRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t grx_sort_workspace_bytes(int64_t n, int ncols)
+{
+    if (n <= 0 || ncols <= 0) return 256;
+    const SortPlan p = make_plan(n, ncols);
+    return p.keys_bytes + p.hist_bytes;
+}
+
+size_t grx_log_bin_workspace_bytes(int64_t n, int ncols)
+{
+    if (n <= 0 || ncols <= 0) return 256;
+    const SortPlan p = make_plan(n, ncols);
+    // keysA + sorted + hist + thresholds + nbins
+    return 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
+           grx_align_up((size_t)ncols * 4, 256);
+}
+
+int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, double *d_sorted,
+                     int64_t ld_sorted, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && ncols >= 0 && ld >= n && ld_sorted >= n, "grx_sort_columns: bad shape");
+    GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_sort_columns: n must be < 2^31");
+    if (n == 0 || ncols == 0) return GRX_OK;
+    GRX_REQUIRE(d_cols && d_sorted && d_workspace, "grx_sort_columns: NULL pointer");
+    if (workspace_bytes < grx_sort_workspace_bytes(n, ncols)) {
+        grx_set_error("grx_sort_columns: workspace %zu < %zu", workspace_bytes, grx_sort_workspace_bytes(n, ncols));
+        return GRX_ERR_WORKSPACE;
+    }
+    const SortPlan p = make_plan(n, ncols);
+    char *ws = reinterpret_cast<char *>(d_workspace);
+    return sort_columns(n, ncols, d_cols, ld, d_sorted, ld_sorted, reinterpret_cast<uint64_t *>(ws),
+                        reinterpret_cast<uint32_t *>(ws + p.keys_bytes), grx_stream(stream));
+}
+
+int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, double frac,
+                         uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(frac > 0.0 && frac < 1.0, "must specify frac in interval (0, 1)");
+    GRX_REQUIRE(n >= 0 && ncols >= 0 && ld >= n && ld_bins >= n, "grx_vertical_log_bin: bad shape");
+    GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_vertical_log_bin: n must be < 2^31");
+    if (n == 0 || ncols == 0) return GRX_OK;
+    GRX_REQUIRE(d_cols && d_bins && d_workspace, "grx_vertical_log_bin: NULL pointer");
+    if (workspace_bytes < grx_log_bin_workspace_bytes(n, ncols)) {
+        grx_set_error("grx_vertical_log_bin: workspace %zu < %zu", workspace_bytes, grx_log_bin_workspace_bytes(n, ncols));
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    const SortPlan p = make_plan(n, ncols);
+    char *ws = reinterpret_cast<char *>(d_workspace);
+    uint64_t *keysA = reinterpret_cast<uint64_t *>(ws);
+    double *sorted = reinterpret_cast<double *>(ws + p.keys_bytes);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 2 * p.keys_bytes);
+    double *thr = reinterpret_cast<double *>(ws + 2 * p.keys_bytes + p.hist_bytes);
+    int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
+                                                 grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
+    int rc = sort_columns(n, ncols, d_cols, ld, sorted, n, keysA, hist, st);
+    if (rc != GRX_OK) return rc;
+    bin_threshold_kernel<<<ncols, 64, 0, st>>>(sorted, n, n, frac, thr, nb_ws);
+    GRX_LAUNCH_CHECK();
+    const int64_t want = grx_ceil_div(n, 256 * 4);
+    const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
+    bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins);
+    GRX_LAUNCH_CHECK();
+    if (d_nbins)
+        GRX_CHECK_HIP(hipMemcpyAsync(d_nbins, nb_ws, (size_t)ncols * 4, hipMemcpyDeviceToDevice, st));
+    return GRX_OK;
+}
+
+int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
+                  const uint8_t *const *d_bin_ptrs, int32_t *d_dist, void *stream)
+{
+    GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end, "grx_chebyshev: bad row range");
+    GRX_REQUIRE(F >= 0 && first_new >= 0, "grx_chebyshev: bad F/first_new");
+    if (F > CH_MAX_F) {
+        grx_set_error("grx_chebyshev: F=%d > %d", F, CH_MAX_F);
+        return GRX_ERR_UNSUPPORTED;
+    }
+    if (F < 2 || first_new >= F || row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_bin_ptrs && d_dist, "grx_chebyshev: NULL pointer");
+    const int64_t tiles = grx_ceil_div(row_end - row_begin, CH_ROWS);
+    const int grid = (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : tiles);
+    const size_t lds = (size_t)F * CH_STRIDE;
+    chebyshev_kernel<<<grid, 256, lds, grx_stream(stream)>>>(row_begin, row_end, F, first_new,
+                                                            d_bin_ptrs, d_dist);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+}  // extern "C"

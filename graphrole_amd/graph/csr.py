@@ -1,0 +1,83 @@
+"""
+CSRGraph -- array-native graph input for graphs that are too large to hold as networkx objects
+(BASELINE configs 3-5: 1 M - 5 M nodes, 10 M - 100 M edges).  It is a *new* adapter key of the
+reference's plug-in seam (graphrole/graph/interface/__init__.py:12-17): the extractor accepts it
+wherever a networkx graph is accepted.
+
+Host-side ingest: edge arrays -> CSR of the out-adjacency with rows in sorted-label
+order and ascending column indices (+ the transposed CSR for directed graphs, used for the
+weighted in-degree).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+
+def _csr_from_coo(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarray]):
+    order = np.lexsort((dst, src))
+    src_sorted = src[order]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src_sorted, minlength=n), out=row_ptr[1:])
+    col = dst[order].astype(np.int32)
+    return row_ptr, col, (None if w is None else np.ascontiguousarray(w[order], dtype=np.float64))
+
+
+class CSRGraph:
+    """
+    :param n: number of nodes (row i <-> labels[i]; labels default to 0..n-1 and must be sorted)
+    :param src, dst: unique edges as row indices; an undirected edge is listed once
+    :param weights: optional fp64 edge weights (None = every edge has the implicit weight 1)
+    :param directed: arcs src -> dst when True
+    :param attributes: optional {name: array of n numbers} numeric node attributes
+    """
+
+    def __init__(self, n: int, src, dst, weights=None, directed: bool = False,
+                 labels: Optional[Sequence] = None, attributes: Optional[Dict[str, np.ndarray]] = None,
+                 validate: bool = True) -> None:
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        if src.shape != dst.shape or src.ndim != 1:
+            raise ValueError('src and dst must be 1-d arrays of equal length')
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if w is not None and w.shape != src.shape:
+            raise ValueError('weights must match the edge arrays')
+        if n >= 2 ** 31:
+            raise ValueError('CSRGraph supports fewer than 2^31 nodes (int32 column indices)')
+        if validate and len(src):
+            if src.min() < 0 or dst.min() < 0 or src.max() >= n or dst.max() >= n:
+                raise ValueError('edge endpoint outside [0, n)')
+            a, b = (src, dst) if directed else (np.minimum(src, dst), np.maximum(src, dst))
+            if len(np.unique(a * n + b)) != len(src):
+                raise ValueError('duplicate edges: merge parallel edges before building a CSRGraph')
+        self.n = int(n)
+        self.directed = bool(directed)
+        self.weighted = w is not None
+        self.num_edges = int(len(src))
+        self.labels = list(range(n)) if labels is None else list(labels)
+        if len(self.labels) != n:
+            raise ValueError('labels must have n entries')
+        if directed:
+            self.row_ptr, self.col, self.w = _csr_from_coo(n, src, dst, w)
+            self.t_row_ptr, self.t_col, self.t_w = _csr_from_coo(n, dst, src, w)
+        else:
+            off = src != dst
+            s2 = np.concatenate([src, dst[off]])
+            d2 = np.concatenate([dst, src[off]])
+            w2 = None if w is None else np.concatenate([w, w[off]])
+            self.row_ptr, self.col, self.w = _csr_from_coo(n, s2, d2, w2)
+            self.t_row_ptr = self.t_col = self.t_w = None
+        self.attributes: Dict[str, np.ndarray] = {}
+        for name, values in (attributes or {}).items():
+            values = np.asarray(values)
+            if values.shape != (n,):
+                raise ValueError(f'attribute {name!r} must have shape ({n},)')
+            self.attributes[name] = values
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def neighbors(self, row: int) -> np.ndarray:
+        return self.col[self.row_ptr[row]:self.row_ptr[row + 1]]

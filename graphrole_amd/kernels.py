@@ -1,0 +1,246 @@
+"""
+Thin Python wrappers over the libgrx.so C ABI (include/grx.h) for torch-held device memory.
+
+torch is plumbing only: tensors provide HBM allocations (caching allocator) and the current
+HIP stream; every computation below is a hand-written HIP kernel in graphrole_amd/csrc.
+There is no CPU path in this module -- it raises when no GPU / no libgrx.so is present.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+c_void_p = ctypes.c_void_p
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _hptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.GrxError('graphrole_amd needs a HIP device (torch.cuda.is_available() is False); '
+                            'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def ptr_array(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Device array of device pointers (the `const T* const*` arguments of the ABI)."""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=device())
+
+
+class DeviceCSR:
+    """CSR adjacency resident in HBM (row_ptr int64[n+1], col int32[nnz], optional w fp64[nnz])."""
+
+    def __init__(self, row_ptr: np.ndarray, col: np.ndarray, w: Optional[np.ndarray] = None):
+        dev = device()
+        self.n = int(len(row_ptr) - 1)
+        self.nnz = int(row_ptr[-1]) if len(row_ptr) else 0
+        self.row_ptr = torch.from_numpy(np.ascontiguousarray(row_ptr, dtype=np.int64)).to(dev)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        self.col = torch.from_numpy(col if len(col) else np.zeros(1, np.int32)).to(dev)
+        self.w = None
+        if w is not None:
+            w = np.ascontiguousarray(w, dtype=np.float64)
+            self.w = torch.from_numpy(w if len(w) else np.zeros(1)).to(dev)
+        avg = self.nnz / max(self.n, 1)
+        # lanes that cooperate on one row in grx_aggregate: ~half the mean degree, power of two
+        self.lanes_per_row = 4 if avg < 12 else 8 if avg < 24 else 16 if avg < 48 else 32
+
+
+def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: Optional[int] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    row_end = csr.n if row_end is None else row_end
+    if out is None:
+        out = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    _lib.call('grx_row_sums', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), int(add_self_loop),
+              row_begin, row_end, _ptr(out), _stream())
+    return out
+
+
+def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tensor] = None,
+                    row_begin: int = 0, row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    row_end = csr.n if row_end is None else row_end
+    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    if csr.w is not None and rowsum is None:
+        rowsum = row_sums(csr, False)
+    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
+              int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _stream())
+    return internal, external
+
+
+def pack_rows(cols: Sequence[torch.Tensor], n: int) -> Tuple[torch.Tensor, int]:
+    """Column tensors -> row-major [n, ldr] gather source (ldr = f rounded up to even)."""
+    f = len(cols)
+    ldr = max(2, (f + 1) & ~1)
+    rows = torch.empty((max(n, 1), ldr), dtype=torch.float64, device=device())
+    if f and n:
+        ptrs = ptr_array(cols)
+        _lib.call('grx_pack_rows', n, f, _ptr(ptrs), _ptr(rows), ldr, _stream())
+    return rows, ldr
+
+
+def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
+              row_end: Optional[int] = None, want_sum: bool = True, want_mean: bool = True,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """
+    Returns a [2f, n] block: rows 0..f-1 = neighbour sums, rows f..2f-1 = neighbour means
+    (features/extract.py:152-162 orders all sums before all means).
+    """
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    if out is None:
+        out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+    if f == 0:
+        return out
+    for c0 in range(0, f, 64):
+        fc = min(64, f - c0)
+        s_ptr = c_void_p(out.data_ptr() + c0 * n * 8) if want_sum else None
+        m_ptr = c_void_p(out.data_ptr() + (f + c0) * n * 8) if want_mean else None
+        r_ptr = c_void_p(rows.data_ptr() + c0 * 8)
+        _lib.call('grx_aggregate', n, _ptr(csr.row_ptr), _ptr(csr.col), fc, r_ptr, ldr, row_begin, row_end,
+                  s_ptr, m_ptr, n, csr.lanes_per_row, _stream())
+    return out
+
+
+def sort_columns(block: torch.Tensor) -> torch.Tensor:
+    """Ascending sort of every row of a [ncols, n] fp64 block (each row is one feature column)."""
+    ncols, n = block.shape
+    out = torch.empty_like(block)
+    if ncols == 0 or n == 0:
+        return out
+    ws_bytes = _lib.load().grx_sort_workspace_bytes(n, ncols)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_sort_columns', n, ncols, _ptr(block), block.stride(0), _ptr(out), out.stride(0), _ptr(ws),
+              ws_bytes, _stream())
+    return out
+
+
+def vertical_log_bin(block: torch.Tensor, frac: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Bin every row of a [ncols, n] fp64 block -> (uint8 [ncols, n], int32 [ncols] bin counts)."""
+    ncols, n = block.shape
+    bins = torch.zeros((ncols, max(n, 1)), dtype=torch.uint8, device=device())[:, :n]
+    nbins = torch.zeros(max(ncols, 1), dtype=torch.int32, device=device())
+    lib = _lib.load()
+    ws_bytes = lib.grx_log_bin_workspace_bytes(n, ncols)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_vertical_log_bin', n, ncols, _ptr(block), block.stride(0) if ncols else n, float(frac),
+              _ptr(bins), bins.stride(0) if ncols else max(n, 1), _ptr(nbins), _ptr(ws), ws_bytes, _stream())
+    return bins, nbins[:ncols]
+
+
+def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_begin: int = 0,
+              row_end: Optional[int] = None) -> torch.Tensor:
+    """int32 [F, F] pairwise max |bin difference| over rows [row_begin,row_end)."""
+    F = len(bin_cols)
+    row_end = n if row_end is None else row_end
+    dist = torch.zeros((F, F), dtype=torch.int32, device=device())
+    if F >= 2 and row_end > row_begin:
+        ptrs = ptr_array(bin_cols)
+        _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, _ptr(ptrs), _ptr(dist), _stream())
+    return dist
+
+
+# ------------------------------------------------------------------------------- NMF
+def gather_columns(cols: Sequence[torch.Tensor], n: int) -> torch.Tensor:
+    F = len(cols)
+    out = torch.empty((F, max(n, 1)), dtype=torch.float64, device=device())
+    if F and n:
+        ptrs = ptr_array(cols)
+        _lib.call('grx_gather_columns', n, F, _ptr(ptrs), _ptr(out), out.stride(0), _stream())
+    return out
+
+
+def gram(X: torch.Tensor, n: int, T: Optional[np.ndarray] = None, row_begin: int = 0,
+         row_end: Optional[int] = None) -> Tuple[np.ndarray, float]:
+    """(X T)^T (X T) as a host k x k array plus sum(X) (valid when T is None)."""
+    F = X.shape[0]
+    row_end = n if row_end is None else row_end
+    k = F if T is None else T.shape[1]
+    if T is not None:
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        assert T.shape[0] == F
+    lib = _lib.load()
+    ws_bytes = lib.grx_gram_workspace_bytes(n, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    out = torch.empty(k * k + 1, dtype=torch.float64, device=device())
+    _lib.call('grx_gram', n, F, _ptr(X), X.stride(0), row_begin, row_end, _hptr(T), k, _ptr(out), _ptr(ws),
+              ws_bytes, _stream())
+    host = out.cpu().numpy()
+    return host[:k * k].reshape(k, k).copy(), float(host[k * k])
+
+
+def project(X: torch.Tensor, n: int, Z: np.ndarray, row_begin: int = 0,
+            row_end: Optional[int] = None, out: Optional[torch.Tensor] = None):
+    """U = X Z (feature-major [r, ld]) and host stats [r,4] (see grx.h)."""
+    F = X.shape[0]
+    row_end = n if row_end is None else row_end
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    r = Z.shape[1]
+    if out is None:
+        out = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+    lib = _lib.load()
+    ws_bytes = lib.grx_project_workspace_bytes(n, r)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    stats = torch.empty(r * 4, dtype=torch.float64, device=device())
+    _lib.call('grx_project', n, F, _ptr(X), X.stride(0), row_begin, row_end, _hptr(Z), r, _ptr(out),
+              out.stride(0), _ptr(stats), _ptr(ws), ws_bytes, _stream())
+    return out, stats.cpu().numpy().reshape(r, 4)
+
+
+def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, eps: float, fill: float,
+                 row_begin: int = 0, row_end: Optional[int] = None) -> None:
+    row_end = n if row_end is None else row_end
+    sign = np.ascontiguousarray(sign, dtype=np.float64)
+    scale = np.ascontiguousarray(scale, dtype=np.float64)
+    _lib.call('grx_nndsvd_apply', n, U.shape[0], _ptr(U), U.stride(0), row_begin, row_end, _hptr(sign),
+              _hptr(scale), float(eps), float(fill), _stream())
+
+
+class NmfState:
+    """Device buffers of one multiplicative-update run (X, W feature-major; H r x F)."""
+
+    def __init__(self, X: torch.Tensor, n: int, W: torch.Tensor, H: np.ndarray):
+        self.X, self.n, self.W = X, n, W
+        self.F, self.r = X.shape[0], W.shape[0]
+        dev = device()
+        self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)
+        self.AB = torch.zeros(self.r * self.F + self.r * self.r, dtype=torch.float64, device=dev)
+        self.err = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.ws_bytes = _lib.load().grx_nmf_workspace_bytes(n, self.F, self.r)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+
+    def w_pass(self, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        row_end = self.n if row_end is None else row_end
+        _lib.call('grx_nmf_w_pass', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
+                  self.W.stride(0), row_begin, row_end, _ptr(self.H), _ptr(self.AB), _ptr(self.ws),
+                  self.ws_bytes, _stream())
+
+    def h_update(self) -> None:
+        _lib.call('grx_nmf_h_update', self.F, self.r, _ptr(self.H), _ptr(self.AB), _stream())
+
+    def residual_sq(self, row_begin: int = 0, row_end: Optional[int] = None) -> torch.Tensor:
+        row_end = self.n if row_end is None else row_end
+        _lib.call('grx_nmf_residual', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
+                  self.W.stride(0), row_begin, row_end, _ptr(self.H), _ptr(self.err), _ptr(self.ws),
+                  self.ws_bytes, _stream())
+        return self.err
+
+    def iterate(self, iters: int, with_residual: bool = True) -> None:
+        _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
+                  self.W.stride(0), _ptr(self.H), _ptr(self.AB), _ptr(self.err) if with_residual else None,
+                  int(iters), _ptr(self.ws), self.ws_bytes, _stream())

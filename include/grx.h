@@ -1,0 +1,221 @@
+/*
+ * grx.h -- C ABI of libgrx.so, the MI355X (gfx950) ReFeX / RolX hot-path library.
+ *
+ * The reference (dkaslovsky/GraphRole) is pure Python and has no FFI of its own; the seam this
+ * library sits under is the pair of public classes and the graph-adapter ABC
+ * (SURVEY.md section 8b).  Every entry point below names the reference lines it replaces.
+ * graphrole_amd/ binds these symbols with ctypes; INTEGRATION.md shows the stub a GraphRole
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every function returns 0 on success and a
+ *     negative grx_status otherwise; grx_last_error() returns a thread-local message.
+ *   - Pointers named d_* are DEVICE pointers (hipMalloc'ed by the caller, by PyTorch's caching
+ *     allocator, or by grx_dev_malloc).  h_* are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *     stream-ordered; nothing here synchronises unless the name says so.
+ *   - Feature columns are column-major: one contiguous fp64 array of n values per column.
+ *     "rows" buffers are row-major n x f (the gather source of the aggregation kernel).
+ *   - Graph = CSR of the out-adjacency, rows in sorted-label order, column indices ascending in
+ *     each row, int64 row_ptr[n+1], int32 col[nnz], optional fp64 w[nnz] (NULL = weight 1).
+ *   - Node-range sharding: kernels that produce one value per node take [row_begin,row_end)
+ *     and touch only those output rows, so a rank computes its own slice of a replicated graph.
+ */
+#ifndef GRX_H
+#define GRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRX_VERSION 100          /* 0.1.0 */
+#define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
+#define GRX_MAX_ROLES 16         /* NMF rank limit of the device kernels */
+#define GRX_MAX_NMF_FEATURES 120 /* NMF feature-count limit of the device kernels */
+
+typedef enum {
+    GRX_OK = 0,
+    GRX_ERR_INVALID = -1,        /* bad argument */
+    GRX_ERR_HIP = -2,            /* HIP runtime error (message has hipGetErrorString) */
+    GRX_ERR_WORKSPACE = -3,      /* workspace too small */
+    GRX_ERR_UNSUPPORTED = -4     /* shape outside the compiled limits */
+} grx_status;
+
+/* ------------------------------------------------------------------ runtime helpers ---- */
+int grx_version(void);
+const char *grx_last_error(void);
+/* Device properties: CU count, wavefront size, gcn arch name (buf may be NULL). */
+int grx_device_info(int *cu_count, int *wave_size, char *arch_buf, size_t arch_buf_len);
+/* For callers without their own allocator (numpy-only hosts). */
+int grx_dev_malloc(void **d_out, size_t bytes);
+int grx_dev_free(void *d_ptr);
+int grx_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int grx_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int grx_memset(void *d_dst, int value, size_t bytes, void *stream);
+int grx_stream_sync(void *stream);
+/* Stream-ordered event timing helpers (bench.py measures kernels on the launch stream). */
+int grx_event_create(void **event_out);
+int grx_event_destroy(void *event);
+int grx_event_record(void *event, void *stream);
+int grx_event_elapsed_ms(void *start, void *stop, float *ms_out);   /* synchronises on stop */
+
+/* ------------------------------------------------------------------ generation 0 -------- */
+/*
+ * Weighted row sums of a CSR.  Replaces NetworkxInterface._get_local_features
+ * (graphrole/graph/interface/networkx.py:48-63): out-degree / undirected degree from the CSR,
+ * in-degree from the transposed CSR.  add_self_loop != 0 adds the diagonal entry a second time
+ * (networkx counts an undirected self-loop twice).  Deterministic summation order.
+ */
+int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, const double *d_w,
+                 int add_self_loop, int64_t row_begin, int64_t row_end, double *d_out,
+                 void *stream);
+
+/*
+ * Ego-net features.  Replaces NetworkxInterface._get_egonet_features + _get_edge_sum
+ * (graphrole/graph/interface/networkx.py:71-83,115-123).  ego(v) = {v} U row(v);
+ * internal[v] = weight of edges with both ends in ego(v) (undirected: each edge and self-loop
+ * once; directed: every arc); external[v] = weight of edges leaving ego(v).
+ * d_rowsum: plain weighted row sums of the same CSR (grx_row_sums with add_self_loop = 0, all n
+ * rows); required when d_w != NULL, ignored otherwise.
+ */
+int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
+                        const double *d_w, const double *d_rowsum, int directed,
+                        int64_t row_begin, int64_t row_end, double *d_internal,
+                        double *d_external, void *stream);
+
+/* ------------------------------------------------------------------ recursion ----------- */
+/*
+ * Pack f feature columns into the row-major gather source of grx_aggregate.
+ * d_col_ptrs: DEVICE array of f device pointers (each an fp64 column of n values).
+ * d_rows: n x ldr row-major, ldr >= f; columns f..ldr-1 are zero-filled.  grx_aggregate wants
+ * ldr even (16-byte aligned rows).
+ */
+int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
+                  void *stream);
+
+/*
+ * ReFeX neighbour aggregation.  Replaces RecursiveFeatureExtractor._get_next_features
+ * (graphrole/features/extract.py:98-119):
+ *     sum[c][v]  = sum_{u in row(v)} rows[u][c]
+ *     mean[c][v] = sum[c][v] / |row(v)|      (0 when row(v) is empty)
+ * d_rows: n x ldr row-major, ldr even, 16-byte aligned (all n rows are needed: neighbours may
+ * live on any rank's slice).
+ * d_sum / d_mean: column-major, column c at d_sum + c*ld (ld >= n); only rows
+ * [row_begin,row_end) are written.  Either output may be NULL.  f <= 64.
+ * lanes_per_row in {4,8,16,32}: lanes that cooperate on one row (pick ~ half the average
+ * degree; anything else selects 8).  Per-row summation order is a fixed function of the row's
+ * degree and lanes_per_row, so equal input columns give bitwise-equal output columns and
+ * repeated runs are bitwise reproducible.
+ */
+int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                  const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
+                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row, void *stream);
+
+/* ------------------------------------------------------------------ pruning ------------- */
+/*
+ * Vertical logarithmic binning of ncols columns.  Replaces vertical_log_binning
+ * (graphrole/features/prune.py:13-56) as FeaturePruner._group_features applies it (:105).
+ * d_cols: column j at d_cols + j*ld.  d_bins: uint8 bin ids, column j at d_bins + j*ld_bins.
+ * d_nbins: int32[ncols] number of bins used per column (may be NULL).
+ * Workspace: grx_log_bin_workspace_bytes(n, ncols) bytes.
+ * 0 < frac < 1 (the reference raises ValueError otherwise -> GRX_ERR_INVALID).
+ */
+size_t grx_log_bin_workspace_bytes(int64_t n, int ncols);
+int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, double frac,
+                         uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Batched ascending sort of fp64 columns (the first stage of the binning; exposed for tests).
+ * Workspace: grx_sort_workspace_bytes(n, ncols). */
+size_t grx_sort_workspace_bytes(int64_t n, int ncols);
+int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, double *d_sorted,
+                     int64_t ld_sorted, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Pairwise Chebyshev distance between binned columns.  Replaces
+ * pdist(binned.T, metric='chebychev') (graphrole/features/prune.py:108).
+ * d_bin_ptrs: DEVICE array of F device pointers to uint8 columns.  Only rows
+ * [row_begin,row_end) are scanned (multi-GPU: all-reduce(MAX) the result).  d_dist: int32
+ * F x F, must be zero-filled by the caller; pairs (p,q) with q >= first_new are computed
+ * (first_new = 0: all pairs), the matrix is written symmetrically.  F <= 120.
+ */
+int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
+                  const uint8_t *const *d_bin_ptrs, int32_t *d_dist, void *stream);
+
+/* ------------------------------------------------------------------ RolX NMF ------------ */
+/*
+ * All NMF matrices are "feature-major": X is F x ldx (row c = feature column c, n valid
+ * entries), W is r x ldw.  H is r x F row-major, HHt is r x r.  Rows [row_begin,row_end) of
+ * the node axis are processed (multi-GPU: partial results are summed by the caller).
+ */
+
+/* Copy F columns given by a DEVICE pointer array into a contiguous F x ld matrix. */
+int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double *d_out,
+                       int64_t ld, void *stream);
+
+/*
+ * G = (X T)^T (X T), T = h_T (host, F x k row-major; NULL = identity, k = F), k <= 128.
+ * Also returns sum of all entries of X in d_out[k*k] (for X.mean()).  d_out: fp64 [k*k + 1].
+ * Used for the rank-revealing orthogonal factorisation behind the NNDSVDa initialisation that
+ * sklearn's NMF(init='nndsvda') performs (sklearn/decomposition/_nmf.py:316-359,
+ * sklearn/utils/extmath.py:531-604) at graphrole/roles/factor.py:19.
+ */
+size_t grx_gram_workspace_bytes(int64_t n, int k);
+int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
+             const double *h_T, int k, double *d_out, void *d_workspace, size_t workspace_bytes,
+             void *stream);
+
+/*
+ * U = X Z (Z = h_Z host, F x r row-major) written feature-major to d_U (r x ldu), plus per
+ * column j statistics in d_stats (fp64 [r*4]): {max|U_j| entry with its sign, index of it,
+ * sum of squares of positive part, sum of squares of negative part}.
+ */
+size_t grx_project_workspace_bytes(int64_t n, int r);
+int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin,
+                int64_t row_end, const double *h_Z, int r, double *d_U, int64_t ldu,
+                double *d_stats, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * NNDSVDa column transform (sklearn/decomposition/_nmf.py:324-359), in place on d_U:
+ *   W[j][i] = scale[j] * max(sign[j] * U[j][i], 0)   (column 0: scale*|U|),
+ *   values < eps -> 0 -> fill.   h_sign: +1/-1 per column (0 = take |.|).
+ */
+int grx_nndsvd_apply(int64_t n, int r, double *d_U, int64_t ldu, int64_t row_begin,
+                     int64_t row_end, const double *h_sign, const double *h_scale, double eps,
+                     double fill, void *stream);
+
+/*
+ * Multiplicative-update state.  Replaces the loop body of sklearn's
+ * _fit_multiplicative_update (sklearn/decomposition/_nmf.py:831-868) reached from
+ * graphrole/roles/factor.py:24:
+ *     W <- W * (X H^T) / (W (H H^T));   H <- H * (W^T X) / ((W^T W) H);   zero denominators
+ *     are replaced by float32 eps (_nmf.py:39,632,720).
+ * grx_nmf_w_pass   : updates W rows [row_begin,row_end) in place and writes this rank's
+ *                    partial sums  d_AB = [ W'^T X (r x F) | W'^T W' (r x r) ].
+ * grx_nmf_h_update : H <- H * A / (B H) from the (all-reduced) d_AB.
+ * grx_nmf_residual : d_out[0] = sum_i ||x_i - w_i H||^2 over the row range
+ *                    (_beta_divergence, _nmf.py:120-133, before the square root).
+ */
+size_t grx_nmf_workspace_bytes(int64_t n, int F, int r);
+int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
+                   int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H,
+                   double *d_AB, void *d_workspace, size_t workspace_bytes, void *stream);
+int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream);
+int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *d_W,
+                     int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H,
+                     double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+/*
+ * Enqueue `iters` full single-GPU iterations (w_pass + h_update each) followed by one residual
+ * evaluation into d_err[0]; no host synchronisation.  This is the unit bench.py times.
+ */
+int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
+                    int64_t ldw, double *d_H, double *d_AB, double *d_err, int iters,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRX_H */

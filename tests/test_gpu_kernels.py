@@ -1,0 +1,411 @@
+"""
+-m gpu: kernel-level parity of the HIP path (through the libgrx.so C ABI) against the oracle and
+the golden vectors produced by the reference.  Integer / index results are compared bit-exactly;
+fp64 sums within RTOL (re-association of fp64 additions only -- stated in DESIGN.md).
+"""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def K():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from graphrole_amd import kernels
+    return kernels
+
+
+def _oracle_graph(n, src, dst, w, directed):
+    from oracle import refex
+    return refex.graph_from_arrays(n, src, dst, w, directed)
+
+
+def _dev_csr(K, og, transpose=False):
+    if transpose:
+        return K.DeviceCSR(og.t_row_ptr, og.t_col, og.t_w)
+    return K.DeviceCSR(og.row_ptr, og.col, og.w)
+
+
+GRAPHS = [
+    dict(n=50, m=120, seed=1, directed=False, weighted=False, self_loops=0),
+    dict(n=300, m=2000, seed=2, directed=False, weighted=True, self_loops=5),
+    dict(n=300, m=2500, seed=3, directed=True, weighted=True, self_loops=4),
+    dict(n=1000, m=3000, seed=4, directed=True, weighted=False, self_loops=3),
+    dict(n=5000, m=60000, seed=5, directed=False, weighted=False, self_loops=10),
+]
+
+
+@pytest.mark.parametrize('spec', GRAPHS)
+def test_row_sums_and_egonet_vs_oracle(K, spec):
+    from oracle import refex
+    src, dst, w = util.random_graph(**spec)
+    og = _oracle_graph(spec['n'], src, dst, w, spec['directed'])
+    csr = _dev_csr(K, og)
+    loc = refex.local_features_c(og)
+    ego = refex.egonet_features_c(og)
+    if spec['directed']:
+        out = K.row_sums(csr, False).cpu().numpy()
+        ind = K.row_sums(_dev_csr(K, og, True), False).cpu().numpy()
+        np.testing.assert_allclose(out, loc['out_degree'], rtol=RTOL)
+        np.testing.assert_allclose(ind, loc['in_degree'], rtol=RTOL)
+    else:
+        deg = K.row_sums(csr, True).cpu().numpy()
+        np.testing.assert_allclose(deg, loc['degree'], rtol=RTOL)
+    internal, external = K.egonet_features(csr, spec['directed'])
+    np.testing.assert_allclose(internal.cpu().numpy(), ego['internal_edges'], rtol=RTOL, atol=0)
+    got_ext = external.cpu().numpy()
+    np.testing.assert_allclose(got_ext, ego['external_edges'], rtol=1e-11, atol=0)
+    # exact zeros stay exact zeros (boundary-free ego-nets)
+    assert np.array_equal(got_ext == 0, ego['external_edges'] == 0)
+    if not spec['weighted']:
+        assert np.array_equal(internal.cpu().numpy(), ego['internal_edges'])
+        assert np.array_equal(got_ext, ego['external_edges'])
+
+
+def test_egonet_hub_rows_powerlaw(K):
+    """Power-law graph: rows above the hub threshold go through the workgroup-per-node kernel."""
+    from oracle import refex
+    n, m = 30000, 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=0)
+    og = _oracle_graph(n, src, dst, None, False)
+    assert np.diff(og.row_ptr).max() > 600
+    csr = _dev_csr(K, og)
+    ego = refex.egonet_features_c(og)
+    internal, external = K.egonet_features(csr, False)
+    assert np.array_equal(internal.cpu().numpy(), ego['internal_edges'])
+    assert np.array_equal(external.cpu().numpy(), ego['external_edges'])
+    # node-range slices reproduce the full result
+    i2, e2 = K.egonet_features(csr, False, row_begin=1000, row_end=17000)
+    assert np.array_equal(i2.cpu().numpy()[1000:17000], ego['internal_edges'][1000:17000])
+    assert np.all(i2.cpu().numpy()[:1000] == 0) and np.all(e2.cpu().numpy()[17000:] == 0)
+
+
+@pytest.mark.parametrize('name', ['karate', 'karate_weighted', 'dw200_attrs', 'loops_dangling150', 'directed120',
+                                  'iface7', 'iface7_dw', 'path4', 'er2000', 'ba2000'])
+def test_gen0_vs_reference_golden(K, name):
+    g = util.load_refex(name)
+    og = util.oracle_graph_from_golden(g)
+    names = g.js('gen0_names')
+    vals = g['gen0_values']
+    csr = _dev_csr(K, og)
+    got = {}
+    if og.directed:
+        got['out_degree'] = K.row_sums(csr, False).cpu().numpy()
+        got['in_degree'] = K.row_sums(_dev_csr(K, og, True), False).cpu().numpy()
+        got['total_degree'] = got['out_degree'] + got['in_degree']
+    else:
+        got['degree'] = K.row_sums(csr, True).cpu().numpy()
+    i, e = K.egonet_features(csr, og.directed)
+    got['internal_edges'], got['external_edges'] = i.cpu().numpy(), e.cpu().numpy()
+    for j, nm in enumerate(names):
+        if nm.startswith('attribute_'):
+            continue
+        np.testing.assert_allclose(got[nm], vals[:, j], rtol=1e-12, atol=0, err_msg=f'{name}:{nm}')
+        assert np.array_equal(got[nm] == 0, vals[:, j] == 0), f'{name}:{nm} zero pattern'
+
+
+@pytest.mark.parametrize('f', [1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 26, 40])
+def test_aggregate_vs_oracle(K, f):
+    import torch
+    from oracle import ckernels
+    n, m = 20000, 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=f)
+    og = _oracle_graph(n, src, dst, None, False)
+    # a few dangling nodes at the end
+    og.row_ptr = np.concatenate([og.row_ptr, np.full(7, og.row_ptr[-1])])
+    n2 = og.n
+    X = np.abs(np.random.default_rng(f).standard_normal((n2, f))) * 10.0 ** np.arange(f).clip(0, 6)
+    S, M = ckernels.aggregate(og.row_ptr, og.col, X)
+    csr = _dev_csr(K, og)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
+    assert np.array_equal(rows.cpu().numpy()[:, :f], X)
+    blk = K.aggregate(csr, rows, f, ldr)
+    got = blk.cpu().numpy()
+    np.testing.assert_allclose(got[:f].T, S, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(got[f:].T, M, rtol=RTOL, atol=0)
+    assert np.all(got[:, n:] == 0)                              # dangling rows: sum 0, mean 0 (not NaN)
+    # bitwise reproducible
+    blk2 = K.aggregate(csr, rows, f, ldr)
+    assert torch.equal(blk, blk2)
+    # row-range slices agree bitwise with the full run
+    blk3 = K.aggregate(csr, rows, f, ldr, row_begin=123, row_end=15001)
+    assert torch.equal(blk3[:, 123:15001], blk[:, 123:15001])
+    assert float(blk3[:, :123].abs().sum()) == 0.0
+
+
+def test_aggregate_equal_columns_give_equal_outputs(K):
+    """Pruning relies on it: identical input columns -> bitwise identical aggregated columns."""
+    import torch
+    n, m = 10000, 8
+    src, dst, _ = util.powerlaw_graph(n, m, seed=3)
+    og = _oracle_graph(n, src, dst, None, False)
+    csr = _dev_csr(K, og)
+    base = torch.rand(n, dtype=torch.float64, device='cuda') * 3.7
+    other = torch.rand(n, dtype=torch.float64, device='cuda')
+    rows, ldr = K.pack_rows([base, other, base.clone(), other, base], n)
+    blk = K.aggregate(csr, rows, 5, ldr)
+    for a, b in [(0, 2), (0, 4), (1, 3), (5, 7), (5, 9), (6, 8)]:
+        assert torch.equal(blk[a], blk[b])
+
+
+def test_aggregate_integer_columns_exact(K):
+    import torch
+    from oracle import ckernels
+    src, dst, w = util.random_graph(3000, 40000, seed=9)
+    og = _oracle_graph(3000, src, dst, None, False)
+    csr = _dev_csr(K, og)
+    X = np.random.default_rng(1).integers(0, 1000, size=(3000, 3)).astype(np.float64)
+    S, M = ckernels.aggregate(og.row_ptr, og.col, X)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(3)], 3000)
+    got = K.aggregate(csr, rows, 3, ldr).cpu().numpy()
+    assert np.array_equal(got[:3].T, S)          # integer sums are exact in any order
+    assert np.array_equal(got[3:].T, M)          # and so are their IEEE quotients
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 4095, 4096, 4097, 100003, 1 << 20])
+def test_sort_columns_exact(K, n):
+    import torch
+    rng = np.random.default_rng(n)
+    cols = [
+        rng.standard_normal(n) * 1e3,
+        rng.integers(-5, 6, size=n).astype(np.float64),
+        np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-300, 300, size=n),
+        np.where(rng.random(n) < 0.3, 0.0, rng.random(n)),
+    ]
+    cols[3][::7] = -0.0
+    if n > 10:
+        cols[2][3] = np.inf
+        cols[2][5] = -np.inf
+        cols[0][1] = 5e-324
+    block = torch.from_numpy(np.stack(cols)).cuda()
+    got = K.sort_columns(block).cpu().numpy()
+    for j, c in enumerate(cols):
+        exp = np.sort(c)
+        assert np.array_equal(got[j], exp), f'col {j}'
+
+
+REFERENCE_BINNING_TABLE = [   # /root/reference/tests/test_features/test_prune.py:17-85
+    ([0], 0.5, [0]),
+    ([1], 0.5, [0]),
+    ([1, 1], 0.5, [0, 0]),
+    ([1, 2], 0.5, [0, 1]),
+    ([1, 2, 1], 0.5, [0, 1, 0]),
+    ([1, 2, 2], 0.5, [0, 1, 1]),
+    ([-1, 0, 0], 0.5, [0, 1, 1]),
+    ([1, 2, 3, 4], 0.5, [0, 0, 1, 2]),
+    ([1, 2, 3, 4, 5], 0.5, [0, 0, 1, 2, 3]),
+    ([1, 2, 3, 4, 5, 6], 0.5, [0, 0, 0, 1, 2, 3]),
+    (list(range(10)), 0.5, [0, 0, 0, 0, 0, 1, 1, 2, 3, 4]),
+    ([-x for x in range(10)], 0.5, [0, 0, 0, 0, 0, 1, 1, 2, 3, 4][::-1]),
+    ([-0.1 * x for x in range(10)], 0.5, [0, 0, 0, 0, 0, 1, 1, 2, 3, 4][::-1]),
+    (list(range(10)), 0.1, list(range(10))),
+    (list(range(10)), 0.25, [0, 0, 1, 1, 2, 3, 4, 5, 6, 7]),
+]
+
+
+def test_log_bin_reference_known_answers(K):
+    import torch
+    for arr, frac, expected in REFERENCE_BINNING_TABLE:
+        block = torch.tensor([arr], dtype=torch.float64, device='cuda')
+        bins, nb = K.vertical_log_bin(block, frac)
+        assert bins.cpu().numpy()[0].tolist() == expected, (arr, frac)
+        assert int(nb[0]) == max(expected) + 1
+    # empty input -> empty output (test_prune.py:18-21)
+    bins, _ = K.vertical_log_bin(torch.zeros((1, 0), dtype=torch.float64, device='cuda'))
+    assert bins.shape == (1, 0)
+
+
+def test_log_bin_bad_frac_raises_value_error(K):
+    import torch
+    block = torch.ones((1, 4), dtype=torch.float64, device='cuda')
+    for frac in (0.0, 1.0, -0.5, 1.5):
+        with pytest.raises(ValueError, match='frac'):        # prune.py:20-21
+            K.vertical_log_bin(block, frac)
+
+
+@pytest.mark.parametrize('name', ['karate', 'er300', 'ba300', 'dw200_attrs', 'er2000', 'ba2000', 'directed120'])
+def test_log_bin_and_chebyshev_vs_reference_golden(K, name):
+    """Bins / distances of the reference's own pruner inputs, bit-exact."""
+    import torch
+    g = util.load_refex(name)
+    n = int(g['n'])
+    for gen in range(int(g['n_generations_recorded'])):
+        names = g.js(f'g{gen}_working_before')
+        exp_bins = g[f'g{gen}_binned']
+        # rebuild the pruner input columns: previous working set + this generation's candidates
+        cols = _working_columns(g, gen)
+        block = torch.from_numpy(np.ascontiguousarray(np.stack([cols[nm] for nm in names]))).cuda()
+        bins, nb = K.vertical_log_bin(block)
+        got = bins.cpu().numpy().T
+        assert np.array_equal(got, exp_bins), f'{name} gen {gen}'
+        D = K.chebyshev([bins[j] for j in range(len(names))], n).cpu().numpy()
+        assert np.array_equal(D, g[f'g{gen}_cheb']), f'{name} gen {gen}'
+
+
+def _working_columns(g, gen):
+    """name -> reference values for every column that is in the pruner input of `gen`."""
+    cols = {}
+    for gg in range(gen + 1):
+        names = g.js(f'g{gg}_cand_names')
+        vals = g[f'g{gg}_cand_values']
+        for j, nm in enumerate(names):
+            cols[nm] = vals[:, j]
+    return cols
+
+
+@pytest.mark.parametrize('n', [1000, 123457, 1 << 20])
+def test_log_bin_vs_oracle_random(K, n):
+    import torch
+    from oracle import ckernels
+    rng = np.random.default_rng(n)
+    cols = [
+        rng.pareto(1.5, n).round(2),                                   # heavy ties + heavy tail
+        rng.integers(0, 30, n).astype(np.float64),                      # few distinct values
+        rng.standard_normal(n),                                         # all distinct
+        np.zeros(n),                                                    # constant
+        np.where(rng.random(n) < 0.9, 0.0, rng.random(n)),              # mostly zeros
+        np.arange(n, dtype=np.float64)[::-1].copy(),
+    ]
+    block = torch.from_numpy(np.stack(cols)).cuda()
+    bins, nb = K.vertical_log_bin(block)
+    got = bins.cpu().numpy()
+    for j, c in enumerate(cols):
+        exp = ckernels.vertical_log_binning(c)
+        assert np.array_equal(got[j], exp), f'col {j}'
+        assert int(nb[j]) == exp.max() + 1
+    D = K.chebyshev([bins[j] for j in range(len(cols))], n).cpu().numpy()
+    exp_D = ckernels.chebyshev(np.stack([ckernels.vertical_log_binning(c) for c in cols]))
+    assert np.array_equal(D, exp_D)
+    # only pairs that involve the last two ("new") columns
+    D2 = K.chebyshev([bins[j] for j in range(len(cols))], n, first_new=4).cpu().numpy()
+    mask = np.zeros_like(exp_D, dtype=bool)
+    mask[:, 4:] = True
+    mask[4:, :] = True
+    np.fill_diagonal(mask, False)
+    assert np.array_equal(D2[mask], exp_D[mask]) and np.all(D2[~mask] == 0)
+    # row-range partial maxima combine by elementwise max (multi-GPU all-reduce MAX)
+    h = n // 3
+    Da = K.chebyshev([bins[j] for j in range(len(cols))], n, row_begin=0, row_end=h).cpu().numpy()
+    Db = K.chebyshev([bins[j] for j in range(len(cols))], n, row_begin=h, row_end=n).cpu().numpy()
+    assert np.array_equal(np.maximum(Da, Db), exp_D)
+
+
+def test_chebyshev_many_columns(K):
+    import torch
+    rng = np.random.default_rng(0)
+    n, F = 5000, 70
+    B = rng.integers(0, 25, size=(F, n)).astype(np.uint8)
+    Bd = torch.from_numpy(B).cuda()
+    D = K.chebyshev([Bd[j] for j in range(F)], n).cpu().numpy()
+    exp = np.abs(B[:, None, :].astype(np.int32) - B[None, :, :].astype(np.int32)).max(axis=2)
+    assert np.array_equal(D, exp)
+
+
+# ------------------------------------------------------------------------------------- NMF
+@pytest.mark.parametrize('shape', [(1000, 7, 4), (50000, 12, 6), (3000, 40, 6), (2000, 64, 8), (700, 100, 16),
+                                   (100, 3, 2)])
+def test_nmf_building_blocks_vs_numpy(K, shape):
+    import torch
+    from oracle import rolx
+    n, F, r = shape
+    rng = np.random.default_rng(n + F)
+    X = np.abs(rng.standard_normal((n, F))) * np.linspace(1, 50, F)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    # gram, identity and transformed
+    G, xsum = K.gram(Xd, n)
+    np.testing.assert_allclose(G, X.T @ X, rtol=1e-12)
+    np.testing.assert_allclose(xsum, X.sum(), rtol=1e-12)
+    k = max(1, F - 2)
+    T = rng.standard_normal((F, k))
+    G2, _ = K.gram(Xd, n, T)
+    Y = X @ T
+    np.testing.assert_allclose(G2, Y.T @ Y, rtol=1e-10, atol=1e-10 * np.abs(Y.T @ Y).max())
+    # row-range partials add up
+    Ga, sa = K.gram(Xd, n, None, 0, n // 2)
+    Gb, sb = K.gram(Xd, n, None, n // 2, n)
+    np.testing.assert_allclose(Ga + Gb, X.T @ X, rtol=1e-12)
+    # project + stats
+    Z = rng.standard_normal((F, r))
+    U, stats = K.project(Xd, n, Z)
+    Ue = X @ Z
+    np.testing.assert_allclose(U.cpu().numpy()[:, :n].T, Ue, rtol=1e-11, atol=1e-11 * np.abs(Ue).max())
+    Ug = U.cpu().numpy()[:, :n].T
+    idx = np.argmax(np.abs(Ug), axis=0)
+    assert np.array_equal(stats[:, 1].astype(np.int64), idx)
+    assert np.array_equal(stats[:, 0], Ug[idx, np.arange(r)])
+    np.testing.assert_allclose(stats[:, 2], (np.maximum(Ug, 0) ** 2).sum(axis=0), rtol=1e-12)
+    np.testing.assert_allclose(stats[:, 3], (np.minimum(Ug, 0) ** 2).sum(axis=0), rtol=1e-12)
+    # one multiplicative update against the numpy restatement of sklearn's update
+    W0 = np.abs(rng.standard_normal((n, r))) + 0.1
+    H0 = np.abs(rng.standard_normal((r, F))) + 0.1
+    W0[::17, 1 % r] = 0.0
+    W0[::29, :] = 0.0                                         # all-zero rows: zero denominators -> EPSILON
+    Wd = torch.from_numpy(np.ascontiguousarray(W0.T)).cuda()
+    st = K.NmfState(Xd, n, Wd, H0)
+    st.w_pass()
+    W1 = W0 * ((X @ H0.T) / np.where(W0 @ (H0 @ H0.T) == 0, rolx.EPSILON, W0 @ (H0 @ H0.T)))
+    np.testing.assert_allclose(st.W.cpu().numpy().T, W1, rtol=1e-12, atol=0)
+    AB = st.AB.cpu().numpy()
+    np.testing.assert_allclose(AB[:r * F].reshape(r, F), W1.T @ X, rtol=1e-12)
+    np.testing.assert_allclose(AB[r * F:].reshape(r, r), W1.T @ W1, rtol=1e-12)
+    st.h_update()
+    den = (W1.T @ W1) @ H0
+    H1 = H0 * ((W1.T @ X) / np.where(den == 0, rolx.EPSILON, den))
+    np.testing.assert_allclose(st.H.cpu().numpy(), H1, rtol=1e-12)
+    err = float(st.residual_sq().cpu()[0])
+    np.testing.assert_allclose(err, ((X - W1 @ H1) ** 2).sum(), rtol=1e-11)
+
+
+def test_nmf_iterate_matches_oracle_loop(K):
+    import torch
+    from oracle import rolx
+    rng = np.random.default_rng(5)
+    n, F, r = 20000, 10, 6
+    X = np.abs(rng.standard_normal((n, F))) * np.linspace(1, 20, F)
+    W0 = np.abs(rng.standard_normal((n, r))) + 0.05
+    H0 = np.abs(rng.standard_normal((r, F))) + 0.05
+    We, He, _ = rolx.mu_iterations(X, W0, H0, tol=0.0, max_iter=20)
+    st = K.NmfState(torch.from_numpy(np.ascontiguousarray(X.T)).cuda(), n,
+                    torch.from_numpy(np.ascontiguousarray(W0.T)).cuda(), H0)
+    st.iterate(20)
+    np.testing.assert_allclose(st.W.cpu().numpy().T, We, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(st.H.cpu().numpy(), He, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.sqrt(float(st.err.cpu()[0])), rolx.frobenius_error(X, We, He), rtol=1e-9)
+    # bitwise reproducible
+    st2 = K.NmfState(torch.from_numpy(np.ascontiguousarray(X.T)).cuda(), n,
+                     torch.from_numpy(np.ascontiguousarray(W0.T)).cuda(), H0)
+    st2.iterate(20)
+    assert torch.equal(st.W, st2.W) and torch.equal(st.H, st2.H)
+
+
+def test_nndsvd_apply(K):
+    import torch
+    rng = np.random.default_rng(2)
+    n, r = 5000, 5
+    U = rng.standard_normal((r, n)) * 1e-3
+    Ud = torch.from_numpy(U.copy()).cuda()
+    sign = np.array([0.0, 1.0, -1.0, 1.0, -1.0])
+    scale = np.array([2.0, 3.0, 0.5, 1e-4, 7.0])
+    K.nndsvd_apply(Ud, n, sign, scale, 1e-6, 0.123)
+    exp = np.empty_like(U)
+    for j in range(r):
+        v = np.abs(U[j]) if sign[j] == 0 else np.maximum(sign[j] * U[j], 0)
+        v = v * scale[j]
+        exp[j] = np.where(v < 1e-6, 0.123, v)
+    assert np.array_equal(Ud.cpu().numpy(), exp)
+
+
+def test_unsupported_shapes_fail_loudly(K):
+    import torch
+    from graphrole_amd._lib import GrxError
+    X = torch.zeros((130, 10), dtype=torch.float64, device='cuda')
+    with pytest.raises(GrxError):
+        K.gram(X, 10)

@@ -1,0 +1,89 @@
+"""Shared helpers for the tests: golden-fixture loading and synthetic graphs."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'loops_dangling150',
+               'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000']
+NMF_CASES = ['rand20x30_r3', 'rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'karate_r4', 'er2000_r6',
+             'ba2000_r6', 'dw200_r5']
+
+
+class Golden:
+    def __init__(self, path):
+        self.z = np.load(path, allow_pickle=False)
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def js(self, k):
+        return json.loads(str(self.z[k + '_json']))
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+
+def load_refex(name):
+    return Golden(os.path.join(GOLDEN, f'refex_{name}.npz'))
+
+
+def load_nmf(name):
+    return Golden(os.path.join(GOLDEN, f'nmf_{name}.npz'))
+
+
+def oracle_graph_from_golden(g):
+    from oracle import refex
+    w = g['w'] if len(g['w']) else None
+    og = refex.graph_from_arrays(int(g['n']), g['src'], g['dst'], w, bool(g['directed']), g.js('labels'))
+    og.num_edges = int(g['num_edges'])
+    return og
+
+
+def random_graph(n, m, seed, directed=False, weighted=False, self_loops=0):
+    """Unique random edges (each undirected edge listed once)."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, size=3 * m)
+    dst = rng.integers(0, n, size=3 * m)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    if not directed:
+        lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+        src, dst = lo, hi
+    key = src.astype(np.int64) * n + dst
+    _, idx = np.unique(key, return_index=True)
+    idx = np.sort(idx)[:m]
+    src, dst = src[idx], dst[idx]
+    if self_loops:
+        loops = rng.choice(n, size=self_loops, replace=False)
+        src = np.concatenate([src, loops])
+        dst = np.concatenate([dst, loops])
+    w = rng.uniform(0.1, 5.0, size=len(src)) if weighted else None
+    return src, dst, w
+
+
+def powerlaw_graph(n, m, seed):
+    """Barabasi-Albert style preferential attachment (repeated-nodes method), undirected, unique edges."""
+    rng = np.random.default_rng(seed)
+    src = np.empty((n - m) * m, dtype=np.int64)
+    dst = np.empty((n - m) * m, dtype=np.int64)
+    repeated = np.empty(2 * (n - m) * m + m, dtype=np.int64)
+    repeated[:m] = np.arange(m)
+    fill = m
+    pos = 0
+    targets = np.arange(m)
+    for v in range(m, n):
+        src[pos:pos + m] = v
+        dst[pos:pos + m] = targets
+        pos += m
+        repeated[fill:fill + m] = targets
+        repeated[fill + m:fill + 2 * m] = v
+        fill += 2 * m
+        chosen = set()
+        while len(chosen) < m:
+            chosen.update(repeated[rng.integers(0, fill, size=m - len(chosen))].tolist())
+        targets = np.fromiter(chosen, dtype=np.int64, count=m)
+    return src, dst, None
