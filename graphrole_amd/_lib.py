@@ -42,6 +42,7 @@ _SIGNATURES = {
     'grx_event_record': (c_int, [c_void_p, c_void_p]),
     'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     'grx_row_sums': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    'grx_add_columns': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p]),
     'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),

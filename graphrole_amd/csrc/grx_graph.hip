@@ -184,6 +184,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ld
     }
 }
 
+__global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const double *__restrict__ a,
+                                                          const double *__restrict__ b,
+                                                          double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // neighbour aggregation
 // ---------------------------------------------------------------------------------------
@@ -340,6 +348,17 @@ int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, cons
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
     row_sums_kernel<8><<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, add_self_loop,
                                                             row_begin, row_end, d_out);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_out, void *stream)
+{
+    GRX_REQUIRE(n >= 0, "grx_add_columns: n < 0");
+    if (n == 0) return GRX_OK;
+    GRX_REQUIRE(d_a && d_b && d_out, "grx_add_columns: NULL pointer");
+    const int64_t want = grx_ceil_div(n, 256 * 4);
+    add_columns_kernel<<<(int)(want > 2048 ? 2048 : want), 256, 0, grx_stream(stream)>>>(n, d_a, d_b, d_out);
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

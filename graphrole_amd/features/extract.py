@@ -1,0 +1,330 @@
+"""
+ReFeX recursive feature extraction on MI355X (reference: graphrole/features/extract.py).
+
+Same public surface as the reference's ``RecursiveFeatureExtractor`` -- constructor signature,
+``extract_features()``, ``generation_count``, error types, column names / order, row order,
+dtypes, memoisation -- but all features live as fp64 columns in HBM from generation 0 until the
+final DataFrame is assembled: one device column per feature, never a dict of dicts.
+
+Per generation (device kernels in graphrole_amd/csrc, host decisions in features/prune.py):
+    pack retained columns -> grx_aggregate (sum, mean over neighbours) -> grx_vertical_log_bin of
+    the new columns (bins of older columns are cached: re-binning is result-identical,
+    prune.py:101-104) -> grx_chebyshev -> tiny host step: feature-graph components, drop list.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+
+from graphrole_amd.features.prune import FeaturePruner
+from graphrole_amd.graph import interface
+from graphrole_amd.types import DataFrameDict, DataFrameLike
+
+_SUPPORTED_AGGS = ('sum', 'mean')
+
+
+def _agg_name(agg) -> str:
+    """'sum' / np.sum / pd.DataFrame.sum -> 'sum' (the name pandas puts in the result index)."""
+    if isinstance(agg, str):
+        return agg
+    name = getattr(agg, '__name__', None)
+    if name is None:
+        raise TypeError(f'cannot interpret aggregation {agg!r}')
+    return name
+
+
+class RecursiveFeatureExtractor:
+
+    """ Compute recursive features for nodes of a graph """
+
+    supported_graph_libs = interface.get_supported_graph_libraries()
+
+    default_aggs = [
+        pd.DataFrame.sum,
+        pd.DataFrame.mean,
+    ]
+
+    def __init__(
+        self,
+        G,
+        max_generations: int = 10,
+        aggs: Optional[List] = None,
+        **kwargs
+    ) -> None:
+        """
+        :param G: graph object from a supported graph package (networkx, graphrole_amd.CSRGraph)
+        :param max_generations: maximum levels of recursion
+        :param aggs: optional list of aggregations for each recursive generation
+          ('sum' / 'mean' in any spelling pandas accepts; others raise NotImplementedError)
+        :kwargs: attributes / attributes_include / attributes_exclude for the graph interface;
+          distributed=True|ProcessGroup shards node ranges over the ranks of torch.distributed
+        """
+        distributed = kwargs.pop('distributed', None)
+        graph_class = interface.get_interface(G)
+        if graph_class is None:
+            raise TypeError(f'Input graph G must be from one of the following '
+                            f'supported libraries: {self.supported_graph_libs}')
+
+        graph = graph_class(G, **kwargs)
+        if graph.get_num_edges() == 0:
+            raise ValueError('Input graph G must contain at least one edge')
+
+        self.graph = graph
+        self.max_generations = max_generations
+        self.aggs = aggs if aggs else self.default_aggs
+        self._distributed = distributed
+
+        # current generation
+        self.generation_count = 0
+        # distance threshold for grouping binned features; equals generation_count
+        self._feature_group_thresh = 0
+
+        # device feature store --------------------------------------------------------
+        self._work: 'OrderedDict[str, object]' = OrderedDict()     # working set: name -> fp64 column
+        self._work_bins: Dict[str, object] = {}                    # name -> uint8 binned column
+        self._dtypes: Dict[str, np.dtype] = {}                     # pandas dtype of each column
+        self._final_names: Dict[int, List[str]] = {}               # generation -> recorded names
+        self._final_cols: Dict[str, object] = {}                   # recorded name -> fp64 column
+        self._plan = None
+        self._plan_ready = False
+        #: per-generation statistics (candidates, retained, widths) for benchmarks
+        self.stats: List[Dict] = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _K(self):
+        return self.graph._K()
+
+    def _labels(self) -> list:
+        return self.graph.to_csr().labels
+
+    def _n(self) -> int:
+        return self.graph.to_csr().n
+
+    def _shard(self):
+        if not self._plan_ready:
+            from graphrole_amd.parallel import maybe_plan
+            self._plan = maybe_plan(self.graph.to_csr().row_ptr, self._distributed)
+            self.graph._shard_plan = self._plan
+            self._plan_ready = True
+        return self._plan
+
+    def _agg_names(self) -> List[str]:
+        names = [_agg_name(a) for a in self.aggs]
+        bad = [a for a in names if a not in _SUPPORTED_AGGS]
+        if bad:
+            raise NotImplementedError(
+                f'aggregations {bad} have no device kernel (supported: {list(_SUPPORTED_AGGS)}); '
+                f'graphrole_amd has no CPU fallback')
+        return names
+
+    # ------------------------------------------------------------------ public API
+    def extract_features(self) -> DataFrameLike:
+        """
+        Perform recursive feature extraction to return DataFrame of features
+        """
+        # return already calculated features if stored in state (extract.py:70-71)
+        if self._final_names:
+            return self._finalize_features()
+        self._agg_names()
+        self._shard()
+
+        # generation 0: neighbourhood (local + ego-net) features
+        names, cols, dtypes = self.graph.neighborhood_feature_columns()
+        self._update_columns(names, cols, dtypes)
+
+        for generation in range(1, self.max_generations):
+
+            self.generation_count = generation
+            self._feature_group_thresh = generation
+
+            names, cols, dtypes, block = self._next_feature_columns()
+            self._update_columns(names, cols, dtypes, block)
+
+            # stop if an iteration results in no features retained
+            if not self._final_names[generation]:
+                break
+
+        return self._finalize_features()
+
+    # ------------------------------------------------------------------ engine
+    def _next_feature_columns(self):
+        """Candidate columns of the current generation: every aggregation of every column
+        retained in the previous generation (extract.py:98-119,152-162)."""
+        K = self._K()
+        plan = self._shard()
+        n = self._n()
+        prev = list(self._final_names[self.generation_count - 1])
+        aggs = self._agg_names()
+        f = len(prev)
+        if f == 0:
+            return [], [], [], None
+        _, dev_graph, _ = self.graph._device_graph()
+        rows, ldr = K.pack_rows([self._work[c] for c in prev], n)
+        rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
+        block = K.aggregate(dev_graph, rows, f, ldr, rb, re,
+                            want_sum='sum' in aggs, want_mean='mean' in aggs)
+        offset = {'sum': 0, 'mean': f}
+        picked = [offset[a] + j for a in aggs for j in range(f)]
+        # the requested rows of the block, in candidate order (all sums, then all means, :158-162)
+        sub = block if picked == list(range(2 * f)) else block[picked].contiguous()
+        if plan is not None:
+            plan.all_gather_block(sub)            # the one exchange of this generation
+        cols = [sub[j] for j in range(len(picked))]
+        names = [f'{c}({a})' for a in aggs for c in prev]
+        return names, cols, [np.dtype('float64')] * len(names), sub
+
+    def _update_columns(self, names: Sequence[str], cols: Sequence, dtypes: Sequence[np.dtype],
+                        block=None) -> None:
+        """Add candidate columns, prune across the whole working set, record what this
+        generation retains (extract.py:121-142)."""
+        K = self._K()
+        plan = self._shard()
+        n = self._n()
+        names = list(names)
+        for nm, col, dt in zip(names, cols, dtypes):
+            self._work[nm] = col
+            self._dtypes[nm] = dt
+        # bin the columns that have no cached bins yet
+        fresh = [nm for nm in self._work if nm not in self._work_bins]
+        if fresh:
+            if block is None or fresh != names:
+                block = self._as_block([self._work[nm] for nm in fresh], n)
+            if plan is None:
+                bins, _ = K.vertical_log_bin(block)
+            else:
+                bins = K.zeros((len(fresh), max(n, 1)), dtype=self._uint8())[:, :n]
+                mine = slice(plan.rank, len(fresh), plan.world)
+                if len(range(len(fresh))[mine]):
+                    K.vertical_log_bin(block[mine], out=bins[mine])
+                plan.all_reduce_max_(bins)
+            for j, nm in enumerate(fresh):
+                self._work_bins[nm] = bins[j]
+        work_names = list(self._work)
+        rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
+        dist = K.chebyshev([self._work_bins[nm] for nm in work_names], n, 0, rb, re)
+        if plan is not None:
+            plan.all_reduce_max_(dist)
+        dist_host = K.to_host(dist)
+        # host: feature graph -> groups -> drop list (a few dozen nodes)
+        pruner = FeaturePruner(self._final_names, self._feature_group_thresh)
+        features_to_drop = pruner.prune_from_distances(work_names, dist_host)
+        dropped = set(features_to_drop)
+        for nm in dropped:
+            del self._work[nm]
+            del self._work_bins[nm]
+        # extract.py:140 Index.difference: name-sorted iff the drop list is non-empty (pandas 2)
+        kept = list(dict.fromkeys(nm for nm in names if nm not in dropped))
+        retained = sorted(kept) if dropped else kept
+        self._final_names[self.generation_count] = retained
+        for nm in retained:
+            self._final_cols[nm] = self._work[nm]
+        self.stats.append(dict(generation=self.generation_count, candidates=len(names),
+                               working=len(work_names), dropped=len(dropped), retained=len(retained)))
+
+    def _uint8(self):
+        import torch
+        return torch.uint8
+
+    def _as_block(self, cols: Sequence, n: int):
+        """[len(cols), n] contiguous fp64 block assembled by grx_gather_columns."""
+        K = self._K()
+        return K.gather_columns(list(cols), n)[:, :n] if n else K.zeros((len(cols), 0))
+
+    def _finalize_features(self) -> DataFrameLike:
+        """DataFrame of every recorded feature, latest generation first (extract.py:91-96)."""
+        K = self._K()
+        columns: List[str] = []
+        for gen in sorted(self._final_names, reverse=True):
+            columns.extend(nm for nm in self._final_names[gen] if nm not in columns)
+        data = {nm: K.to_host(self._final_cols[nm]).astype(self._dtypes.get(nm, np.dtype('float64')))
+                for nm in columns}
+        return pd.DataFrame(data, index=pd.Index(self._labels()), columns=columns)
+
+    # ------------------------------------------------------------------ reference-compatible internals
+    # The reference's tests drive these private members with DataFrames / dicts of dicts
+    # (tests/test_features/test_extract.py:87-214).  They are thin views over the device store.
+    @property
+    def _features(self) -> pd.DataFrame:
+        K = self._K()
+        data = {nm: K.to_host(col).astype(self._dtypes.get(nm, np.dtype('float64')))
+                for nm, col in self._work.items()}
+        if not data:
+            return pd.DataFrame()
+        return pd.DataFrame(data, index=pd.Index(self._labels()), columns=list(data))
+
+    @_features.setter
+    def _features(self, frame: pd.DataFrame) -> None:
+        self._work.clear()
+        self._work_bins.clear()
+        for nm, col, dt in zip(*self._columns_from_frame(frame)):
+            self._work[nm] = col
+            self._dtypes[nm] = dt
+
+    @property
+    def _final_features(self) -> Dict[int, DataFrameDict]:
+        K = self._K()
+        labels = self._labels()
+        out: Dict[int, DataFrameDict] = {}
+        for gen, names in self._final_names.items():
+            frame = pd.DataFrame(
+                {nm: K.to_host(self._final_cols[nm]).astype(self._dtypes.get(nm, np.dtype('float64')))
+                 for nm in names}, index=pd.Index(labels), columns=list(names))
+            out[gen] = frame.to_dict()
+        return out
+
+    @_final_features.setter
+    def _final_features(self, value: Dict[int, DataFrameDict]) -> None:
+        self._final_names = {}
+        self._final_cols = {}
+        for gen, table in value.items():
+            frame = pd.DataFrame(table)
+            names, cols, dtypes = self._columns_from_frame(frame)
+            self._final_names[gen] = list(names)
+            for nm, col, dt in zip(names, cols, dtypes):
+                # share the working-set column when it is the same feature
+                self._final_cols[nm] = self._work.get(nm, col)
+                self._dtypes.setdefault(nm, dt)
+
+    def _columns_from_frame(self, frame: pd.DataFrame):
+        K = self._K()
+        frame = frame.reindex(self._labels()).fillna(0)     # nodes missing from the frame -> 0 (:132)
+        names = [str(c) if not isinstance(c, str) else c for c in frame.columns]
+        cols = [K.to_device(frame[c].to_numpy(dtype=np.float64)) for c in frame.columns]
+        dtypes = [frame[c].dtype if frame[c].dtype.kind in 'iu' else np.dtype('float64') for c in frame.columns]
+        return names, cols, dtypes
+
+    def _get_next_features(self) -> DataFrameLike:
+        """Next level of recursive features as a DataFrame (extract.py:98-119)."""
+        self._shard()
+        names, cols, _, _ = self._next_feature_columns()
+        K = self._K()
+        data = {nm: K.to_host(c) for nm, c in zip(names, cols)}
+        return pd.DataFrame(data, index=pd.Index(self._labels()), columns=names)
+
+    def _update(self, features: DataFrameLike) -> None:
+        """Add candidate features given as a DataFrame and prune (extract.py:121-142)."""
+        self._shard()
+        names, cols, dtypes = self._columns_from_frame(as_frame(features))
+        self._update_columns(names, cols, dtypes)
+
+    @staticmethod
+    def _aggregated_df_to_dict(agg_df: DataFrameLike) -> Dict[str, float]:
+        """{'<feature>(<agg>)': value} from the result of DataFrame.agg (extract.py:144-163);
+        kept for API compatibility -- the device path names its columns directly."""
+        if isinstance(agg_df, pd.Series):
+            agg_df = agg_df.to_frame().T
+        flat: Dict[str, float] = {}
+        for agg, row in agg_df.to_dict(orient='index').items():
+            for feature, value in row.items():
+                flat[f'{feature}({agg})'] = value
+        return flat
+
+
+# Helper functions
+
+def as_frame(df_like: DataFrameLike) -> pd.DataFrame:
+    """pd.Series -> one-column DataFrame; DataFrames pass through (extract.py:168-177)."""
+    return df_like.to_frame() if isinstance(df_like, pd.Series) else df_like

@@ -28,7 +28,8 @@ class CSRGraph:
     """
     :param n: number of nodes (row i <-> labels[i]; labels default to 0..n-1 and must be sorted)
     :param src, dst: unique edges as row indices; an undirected edge is listed once
-    :param weights: optional fp64 edge weights (None = every edge has the implicit weight 1)
+    :param weights: optional edge weights (None = every edge has the implicit weight 1); an
+      integer-typed array keeps the degree / ego-net columns int64 like networkx does
     :param directed: arcs src -> dst when True
     :param attributes: optional {name: array of n numbers} numeric node attributes
     """
@@ -40,6 +41,8 @@ class CSRGraph:
         dst = np.ascontiguousarray(dst, dtype=np.int64)
         if src.shape != dst.shape or src.ndim != 1:
             raise ValueError('src and dst must be 1-d arrays of equal length')
+        # integer-typed weights keep generation-0 features integer (networkx sums Python ints)
+        self.integral = weights is None or np.asarray(weights).dtype.kind in 'iub'
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
         if w is not None and w.shape != src.shape:
             raise ValueError('weights must match the edge arrays')

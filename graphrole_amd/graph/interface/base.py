@@ -1,0 +1,164 @@
+"""
+Graph adapters: the plug-in seam of the reference (graphrole/graph/interface/base.py:9-83).
+
+``BaseGraphInterface`` keeps the reference's five abstract methods and the concrete
+``get_neighborhood_features``.  New here: every adapter exposes its graph in bulk through
+``to_csr()`` so the engine never calls ``get_neighbors`` node by node, and the generation-0
+features are computed by HIP kernels (grx_row_sums / grx_egonet_features) on the CSR in HBM.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+
+from graphrole_amd.graph.csr import CSRGraph
+from graphrole_amd.types import Node
+
+
+class BaseGraphInterface(ABC):
+
+    # prefix of feature names derived from node attributes (base.py:16)
+    attribute_feature_prefix = 'attribute'
+
+    # ------------------------------------------------------------------ reference API
+    def get_neighborhood_features(self) -> pd.DataFrame:
+        """Generation-0 block = local features then ego-net features, rows sorted by node
+        (base.py:18-26)."""
+        local = self._get_local_features()
+        ego = self._get_egonet_features()
+        return pd.concat([local, ego], axis=1, sort=True).sort_index()
+
+    def _set_attribute_kwargs(self, **kwargs) -> None:
+        """attributes / attributes_include / attributes_exclude (base.py:28-39)."""
+        self._attrs: bool = kwargs.get('attributes', False)
+        self._attrs_include: List[str] = kwargs.get('attributes_include', [])
+        self._attrs_exclude: List[str] = kwargs.get('attributes_exclude', [])
+
+    @classmethod
+    def _attribute_feature_name(cls, attr_name: str) -> str:
+        return f'{cls.attribute_feature_prefix}_{attr_name}'
+
+    @abstractmethod
+    def get_num_edges(self) -> int:
+        """Number of edges of the wrapped graph."""
+
+    @abstractmethod
+    def get_nodes(self) -> Iterable[Node]:
+        """Iterable over node labels."""
+
+    @abstractmethod
+    def get_neighbors(self, node: Node) -> Iterable[Node]:
+        """Out-neighbours of one node."""
+
+    @abstractmethod
+    def _get_local_features(self) -> pd.DataFrame:
+        """Degree (and optional attribute) features, one row per node."""
+
+    @abstractmethod
+    def _get_egonet_features(self) -> pd.DataFrame:
+        """internal_edges / external_edges of every node's 1-hop ego-net."""
+
+    # ------------------------------------------------------------------ engine API (new)
+    @abstractmethod
+    def to_csr(self) -> CSRGraph:
+        """The whole graph as a host CSR (rows = sorted labels)."""
+
+
+class DeviceGraphInterface(BaseGraphInterface):
+    """
+    Shared implementation of the generation-0 features on the GPU.  Subclasses provide
+    ``to_csr()`` and ``_attribute_frame()``; everything numerical happens in libgrx.so.
+    """
+
+    def _K(self):
+        from graphrole_amd import backend
+        return backend.get()
+
+    # -- device state -----------------------------------------------------------------
+    def _device_graph(self):
+        if getattr(self, '_dev', None) is None:
+            K = self._K()
+            host = self.to_csr()
+            out = K.DeviceCSR(host.row_ptr, host.col, host.w)
+            tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
+            self._dev = (host, out, tr)
+        return self._dev
+
+    def _row_range(self) -> Tuple[int, int]:
+        """Rows this rank computes (whole graph unless a ShardPlan was attached)."""
+        plan = getattr(self, '_shard_plan', None)
+        host = self._device_graph()[0]
+        return (0, host.n) if plan is None else (plan.row_begin, plan.row_end)
+
+    def _finish_columns(self, cols):
+        """Exchange row slices between ranks (no-op on a single GPU)."""
+        plan = getattr(self, '_shard_plan', None)
+        if plan is None:
+            return cols
+        return plan.all_gather_columns(cols)
+
+    def local_feature_columns(self) -> Tuple[List[str], list, List[np.dtype]]:
+        """
+        Device columns of networkx.py:48-63: weighted ``degree`` (self-loop twice) or
+        ``in_degree, out_degree, total_degree``; then the attribute columns.
+        Returns (names, device columns, pandas dtypes of the reference's frame).
+        """
+        K = self._K()
+        host, out, tr = self._device_graph()
+        rb, re = self._row_range()
+        int_dtype = np.dtype('int64') if host.integral else np.dtype('float64')
+        if host.directed:
+            outd = K.row_sums(out, False, rb, re)
+            ind = K.row_sums(tr, False, rb, re)
+            outd, ind = self._finish_columns([outd, ind])
+            names = ['in_degree', 'out_degree', 'total_degree']
+            cols = [ind, outd, K.add_columns(outd, ind)]
+        else:
+            deg, = self._finish_columns([K.row_sums(out, True, rb, re)])
+            names, cols = ['degree'], [deg]
+        dtypes = [int_dtype] * len(names)
+        attr = self._attribute_frame() if self._attrs else None
+        if attr is not None and attr.shape[1]:
+            attr = attr.reindex(host.labels).fillna(0)
+            for name in attr.columns:
+                values = attr[name].to_numpy()
+                names.append(name)
+                dtypes.append(values.dtype if values.dtype.kind in 'iu' else np.dtype('float64'))
+                cols.append(K.to_device(values.astype(np.float64)))
+        return names, cols, dtypes
+
+    def egonet_feature_columns(self) -> Tuple[List[str], list, List[np.dtype]]:
+        """Device columns of networkx.py:71-83."""
+        K = self._K()
+        host, out, _ = self._device_graph()
+        rb, re = self._row_range()
+        rowsum = K.row_sums(out, False) if host.weighted else None
+        internal, external = K.egonet_features(out, host.directed, rowsum, rb, re)
+        internal, external = self._finish_columns([internal, external])
+        dt = np.dtype('int64') if host.integral else np.dtype('float64')
+        return ['internal_edges', 'external_edges'], [internal, external], [dt, dt]
+
+    def neighborhood_feature_columns(self):
+        n1, c1, d1 = self.local_feature_columns()
+        n2, c2, d2 = self.egonet_feature_columns()
+        return n1 + n2, c1 + c2, d1 + d2
+
+    def _frame(self, names, cols, dtypes) -> pd.DataFrame:
+        K = self._K()
+        host = self._device_graph()[0]
+        data = {nm: K.to_host(c).astype(dt) for nm, c, dt in zip(names, cols, dtypes)}
+        return pd.DataFrame(data, index=pd.Index(host.labels), columns=names)
+
+    # -- reference API on top ------------------------------------------------------------
+    def _get_local_features(self) -> pd.DataFrame:
+        return self._frame(*self.local_feature_columns())
+
+    def _get_egonet_features(self) -> pd.DataFrame:
+        return self._frame(*self.egonet_feature_columns())
+
+    def _attribute_frame(self) -> Optional[pd.DataFrame]:
+        """Numeric node attributes as a frame indexed by node label (columns already prefixed)."""
+        return None

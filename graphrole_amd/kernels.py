@@ -37,6 +37,22 @@ def device() -> torch.device:
     return torch.device('cuda', torch.cuda.current_device())
 
 
+def to_device(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device())
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy()
+
+
+def empty(shape, dtype=torch.float64) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=device())
+
+
+def zeros(shape, dtype=torch.float64) -> torch.Tensor:
+    return torch.zeros(shape, dtype=dtype, device=device())
+
+
 def ptr_array(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
     """Device array of device pointers (the `const T* const*` arguments of the ABI)."""
     return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=device())
@@ -68,6 +84,12 @@ def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: O
         out = torch.zeros(csr.n, dtype=torch.float64, device=device())
     _lib.call('grx_row_sums', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), int(add_self_loop),
               row_begin, row_end, _ptr(out), _stream())
+    return out
+
+
+def add_columns(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    _lib.call('grx_add_columns', a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream())
     return out
 
 
@@ -130,10 +152,13 @@ def sort_columns(block: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vertical_log_bin(block: torch.Tensor, frac: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Bin every row of a [ncols, n] fp64 block -> (uint8 [ncols, n], int32 [ncols] bin counts)."""
+def vertical_log_bin(block: torch.Tensor, frac: float = 0.5,
+                     out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Bin every row of a [ncols, n] fp64 block -> (uint8 [ncols, n], int32 [ncols] bin counts).
+    `block` (and `out`) may be row-strided views (e.g. every P-th column of a candidate block)."""
     ncols, n = block.shape
-    bins = torch.zeros((ncols, max(n, 1)), dtype=torch.uint8, device=device())[:, :n]
+    assert n <= 1 or block.stride(1) == 1
+    bins = out if out is not None else torch.zeros((ncols, max(n, 1)), dtype=torch.uint8, device=device())[:, :n]
     nbins = torch.zeros(max(ncols, 1), dtype=torch.int32, device=device())
     lib = _lib.load()
     ws_bytes = lib.grx_log_bin_workspace_bytes(n, ncols)

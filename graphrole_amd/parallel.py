@@ -1,0 +1,99 @@
+"""
+Node-range sharding across GPUs (one process per GPU, torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" in the CPU tests).  The reference has no distributed code at all
+ -- this is new.
+
+Scheme:
+  * the CSR is replicated; rank p computes rows [bounds[p], bounds[p+1]) of every per-node
+    kernel (ego-net, aggregation, NMF row passes).  Bounds balance nnz + n, not n.
+  * ONE exchange per ReFeX generation: all-gather of the rank-local slices of the candidate
+    block, after which every rank holds all columns.
+  * pruning: rank p bins candidate columns p, p+P, ... (whole columns), the uint8 bins are
+    combined by all-reduce(MAX) (non-owned columns are zero); each rank scans its own row range
+    for the Chebyshev matrix, combined by all-reduce(MAX) of the F x F int32 matrix.  All ranks
+    then take identical decisions.
+  * NMF: W rows sharded, H replicated; one all-reduce(SUM) of [W^T X | W^T W] per iteration and
+    of the residual at convergence checks.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class ShardPlan:
+
+    def __init__(self, row_ptr: np.ndarray, group=None) -> None:
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError('ShardPlan needs an initialised torch.distributed process group')
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        n = len(row_ptr) - 1
+        self.n = n
+        work = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n + 1, dtype=np.int64)
+        total = int(work[-1]) if n else 0
+        cuts = [0]
+        for p in range(1, self.world):
+            cuts.append(int(np.searchsorted(work, total * p / self.world, side='left')))
+        cuts.append(n)
+        self.bounds = np.maximum.accumulate(np.array(cuts, dtype=np.int64))
+        self.row_begin = int(self.bounds[self.rank])
+        self.row_end = int(self.bounds[self.rank + 1])
+        self.max_rows = int(np.diff(self.bounds).max()) if n else 0
+
+    # ------------------------------------------------------------------ collectives
+    def all_gather_block(self, block: torch.Tensor) -> torch.Tensor:
+        """block [ncols, n] with only this rank's row slice valid -> every slice valid, in place."""
+        if self.world == 1:
+            return block
+        ncols = block.shape[0]
+        if ncols == 0 or self.n == 0:
+            return block
+        send = torch.zeros((ncols, self.max_rows), dtype=block.dtype, device=block.device)
+        send[:, :self.row_end - self.row_begin] = block[:, self.row_begin:self.row_end]
+        recv = torch.empty((self.world, ncols, self.max_rows), dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for p in range(self.world):
+            b, e = int(self.bounds[p]), int(self.bounds[p + 1])
+            if p != self.rank and e > b:
+                block[:, b:e] = recv[p, :, :e - b]
+        return block
+
+    def all_gather_columns(self, cols: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """Same for a list of separate [n] columns."""
+        if self.world == 1 or not cols:
+            return list(cols)
+        block = torch.stack(list(cols))
+        self.all_gather_block(block)
+        return [block[j] for j in range(len(cols))]
+
+    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1 and t.numel():
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1 and t.numel():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def maybe_plan(row_ptr: np.ndarray, distributed) -> Optional[ShardPlan]:
+    """
+    distributed: None/False -> single GPU; True -> default process group (if initialised with
+    world size > 1); a ProcessGroup -> that group.
+    """
+    if not distributed:
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        if distributed is True:
+            return None
+        raise RuntimeError('distributed= was given but torch.distributed is not initialised')
+    group = None if distributed is True else distributed
+    if dist.get_world_size(group) == 1:
+        return None
+    return ShardPlan(row_ptr, group)

@@ -1,0 +1,119 @@
+"""
+RolX role extraction (reference: graphrole/roles/extract.py).  Same class, constructor,
+properties and error behaviour as the reference's ``RoleExtractor``; the NMF runs on the GPU
+(roles/factor.py), quantisation and MDL model selection follow the reference on the host.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+
+from graphrole_amd.roles.description_length import get_description_length_costs
+from graphrole_amd.roles.factor import encode, get_nmf_decomposition
+from graphrole_amd.types import DataFrameLike, FactorTuple, Node
+
+
+class RoleExtractor:
+
+    """ Assign node roles based on input features """
+
+    N_ROLE_RANGE = (2, 8)
+    N_BIT_RANGE = (1, 8)
+
+    def __init__(
+        self,
+        n_roles: Optional[int] = None,
+        n_role_range: Optional[Tuple[int, int]] = None,
+        n_bit_range: Optional[Tuple[int, int]] = None,
+    ) -> None:
+        """
+        :param n_roles: optional number of roles to select; default uses MDL model selection
+        :param n_role_range: optional tuple for (min, max) roles for model selection grid search
+        :param n_bit_range: optional tuple for (min, max) bits for model selection grid search
+        """
+        self.n_roles = n_roles
+
+        self.min_roles, self.max_roles = n_role_range if n_role_range else self.N_ROLE_RANGE
+        self.min_bits, self.max_bits = n_bit_range if n_bit_range else self.N_BIT_RANGE
+
+        self.node_role_factor: Optional[pd.DataFrame] = None
+        self.role_feature_factor: Optional[pd.DataFrame] = None
+
+    @property
+    def roles(self) -> Optional[Dict[Node, float]]:
+        """node -> label of its dominant role (first maximum wins), None before fitting (:38-47)"""
+        if self.node_role_factor is None:
+            return None
+        return self.node_role_factor.idxmax(axis=1).to_dict()
+
+    @property
+    def role_percentage(self) -> Optional[DataFrameLike]:
+        """row-normalised node-role factor, None before fitting (:49-57)"""
+        if self.node_role_factor is None:
+            return None
+        totals = self.node_role_factor.sum(axis=1)
+        return self.node_role_factor.div(totals, axis=0)
+
+    def extract_role_factors(self, features: pd.DataFrame) -> None:
+        """
+        Extract role factors from a node feature DataFrame and store them as
+        ``node_role_factor`` (nodes x roles) and ``role_feature_factor`` (roles x features)
+        """
+        if self.n_roles:
+            # the two factors hold n_roles * (n_nodes + n_features) values; encode them with
+            # about log2(n_roles * min(shape)) bits (:69-72)
+            n_bits = int(np.log2(self.n_roles * min(features.shape)))
+            node_role, role_feature = self._get_encoded_role_factors(features, self.n_roles, n_bits)
+        else:
+            node_role, role_feature = self._select_model(features)
+
+        role_labels = [f'role_{i}' for i in range(node_role.shape[1])]
+        self.node_role_factor = pd.DataFrame(node_role, index=features.index, columns=role_labels)
+        self.role_feature_factor = pd.DataFrame(role_feature, index=role_labels, columns=features.columns)
+
+    def explain(self):
+        raise NotImplementedError('Role explanation ("sense making") is not yet implemented.')
+
+    def _select_model(self, features: pd.DataFrame) -> FactorTuple:
+        """
+        Grid search over (n_roles, n_bits) scored by minimum description length (:98-142).
+        Like the reference, the NMF is recomputed for every cell, so numpy's global RNG is
+        consumed in the same order (one Gaussian test matrix per cell).
+        """
+        bit_stop = self.max_bits + 1
+        role_stop = min(min(features.shape), self.max_roles) + 1
+        encoding_costs = np.full((role_stop, bit_stop), np.nan)
+        error_costs = np.full((role_stop, bit_stop), np.nan)
+        factors = defaultdict(dict)
+
+        for roles in range(self.min_roles, role_stop):
+            for bits in range(self.min_bits, bit_stop):
+                try:
+                    model = self._get_encoded_role_factors(features, roles, bits)
+                    encoding_cost, error_cost = get_description_length_costs(features, model)
+                except ValueError:
+                    # more bins requested than there are factor entries to quantise
+                    continue
+                encoding_costs[roles, bits] = encoding_cost
+                error_costs[roles, bits] = error_cost
+                factors[roles][bits] = model
+
+        costs = self._rescale_costs(encoding_costs) + self._rescale_costs(error_costs)
+        best_roles, best_bits = np.argwhere(costs == np.nanmin(costs))[0]
+        return factors[best_roles][best_bits]
+
+    @staticmethod
+    def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int) -> FactorTuple:
+        """NMF of the feature matrix with both factors quantised to 2**n_bits levels (:144-161)"""
+        n_bins = int(2 ** n_bits)
+        G, F = get_nmf_decomposition(features.values, n_roles)
+        return encode(G, n_bins), encode(F, n_bins)
+
+    @staticmethod
+    def _rescale_costs(costs: np.ndarray) -> np.ndarray:
+        """row-wise L2 normalisation that ignores NaN cells (:163-173)"""
+        norms = np.sqrt(np.nansum(np.square(costs), axis=1))
+        return costs / norms.reshape(costs.shape[0], 1)

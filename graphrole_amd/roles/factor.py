@@ -1,0 +1,264 @@
+"""
+RolX factorisation (reference: graphrole/roles/factor.py).
+
+``get_nmf_decomposition`` reproduces ``sklearn.decomposition.NMF(n_components=r, solver='mu',
+init='nndsvda')`` (factor.py:19) with every O(N) pass on the GPU:
+
+  init  (sklearn _nmf.py:316-359, extmath.py:531-604)
+        X = Q M with Q orthonormal is obtained from two Gram passes (grx_gram): the first gives a
+        whitening transform T1 from eigh(X^T X), the second re-orthogonalises (CholeskyQR2-style),
+        M = pinv(T) is formed from the factors (no inversion).  Because Q has orthonormal columns,
+        sklearn's randomised range finder on X maps to the same algorithm on the small matrix M
+        (same Gaussian test matrix, drawn from numpy's global RNG exactly as sklearn does), so the
+        singular triplets agree to rounding.  U = X Z, the svd_flip signs and the +/- part norms of
+        NNDSVD come from one projection pass (grx_project); the element-wise NNDSVDa transform is
+        grx_nndsvd_apply.  All k x F algebra (k, F <= ~100) is numpy on the host.
+  loop  (_nmf.py:815-885)  grx_nmf_iterate: fused W-update + W^T X / W^T W reduction pass,
+        H-update kernel, residual pass every 10 iterations; the host only reads one scalar per
+        convergence check.
+
+``encode`` (1-D Lloyd-Max quantiser = sklearn KMeans, factor.py:29-49) stays the reference's own
+host call in this round: SURVEY.md section 8(f) rank 1 lists it as the next row to move.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional, Tuple
+
+import numpy as np
+from scipy import linalg
+
+from graphrole_amd.types import FactorTuple
+
+NMF_TOL = 1e-4          # sklearn NMF defaults (_nmf.py:1538-1553)
+NMF_MAX_ITER = 200
+NNDSVD_EPS = 1e-6
+
+
+def _kernels():
+    from graphrole_amd import backend
+    return backend.get()
+
+
+# ------------------------------------------------------------------------------------------
+# small-space algebra of the initialisation (host, k x F matrices)
+# ------------------------------------------------------------------------------------------
+def _range_finder_svd(M: np.ndarray, r: int, omega: np.ndarray, shape: Tuple[int, int]):
+    """
+    sklearn's randomized_svd (extmath.py:531-604, n_oversamples=10, n_iter='auto',
+    normalizer 'auto' = LU) applied to the k x F matrix M that stands for X = Q M.
+    Returns (Us [k x r], S [r], Vt [r x F]) with X ~= (Q Us) diag(S) Vt, before svd_flip.
+    """
+    n_iter = 7 if r < 0.1 * min(shape) else 4                    # extmath.py:557-560
+
+    def lu_norm(a):
+        return linalg.lu(a, permute_l=True, check_finite=False)[0]
+
+    Qs = omega
+    for _ in range(n_iter):                                        # extmath.py:349-351
+        Qs = lu_norm(M @ Qs)
+        Qs = lu_norm(M.T @ Qs)
+    Qs, _ = linalg.qr(M @ Qs, mode='economic', check_finite=False)
+    B = Qs.T @ M
+    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver='gesdd')
+    Us = Qs @ Uhat
+    k = Us.shape[1]
+    if k < r:                                                       # rank(X) < r: pad with zeros
+        Us = np.hstack([Us, np.zeros((Us.shape[0], r - k))])
+        s = np.concatenate([s, np.zeros(r - k)])
+        Vt = np.vstack([Vt, np.zeros((r - k, Vt.shape[1]))])
+    return Us[:, :r], s[:r], Vt[:r]
+
+
+def _nndsvd_plan(S, Vt, stats):
+    """
+    Column choices of NNDSVD (_nmf.py:324-352) from per-column statistics of the raw U = X Z:
+    stats[j] = (signed max-|.| entry, row, sum sq of positive part, sum sq of negative part).
+    Returns (sign[r], scale[r]) for grx_nndsvd_apply and the H matrix before thresholding.
+    """
+    r, F = Vt.shape
+    flip = np.sign(stats[:, 0])                                     # svd_flip, u-based (extmath.py:935-943)
+    flip[flip == 0] = 1.0
+    sign = np.zeros(r)
+    scale = np.zeros(r)
+    H = np.zeros((r, F))
+    scale[0] = np.sqrt(S[0])
+    H[0] = np.sqrt(S[0]) * np.abs(Vt[0])
+    for j in range(1, r):
+        y = Vt[j] * flip[j]
+        # positive / negative part norms of x = flip * u
+        x_p_nrm = np.sqrt(stats[j, 2] if flip[j] > 0 else stats[j, 3])
+        x_n_nrm = np.sqrt(stats[j, 3] if flip[j] > 0 else stats[j, 2])
+        y_p, y_n = np.maximum(y, 0), np.abs(np.minimum(y, 0))
+        y_p_nrm, y_n_nrm = linalg.norm(y_p), linalg.norm(y_n)
+        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+        with np.errstate(invalid='ignore', divide='ignore'):
+            if m_p > m_n:
+                x_nrm, v, sigma, part = x_p_nrm, y_p / y_p_nrm, m_p, 1.0
+            else:
+                x_nrm, v, sigma, part = x_n_nrm, y_n / y_n_nrm, m_n, -1.0
+        lbd = np.sqrt(S[j] * sigma)
+        if not np.isfinite(lbd) or x_nrm == 0:
+            sign[j], scale[j] = 1.0, 0.0                             # degenerate component -> all fill
+            continue
+        sign[j] = flip[j] * part                                     # W_j = lbd * max(sign*u, 0) / x_nrm
+        scale[j] = lbd / x_nrm
+        H[j] = lbd * v
+    return sign, scale, H
+
+
+def _host_init(X: np.ndarray, r: int, omega: np.ndarray):
+    """N < F (fewer nodes than features): every matrix is small, the whole initialisation is the
+    k x F algebra above with Q = I."""
+    n, F = X.shape
+    Us, S, Vt = _range_finder_svd(X.T, r, omega, X.shape)           # transposed branch of sklearn
+    # X^T ~= Us S Vt  ->  X ~= Vt^T S Us^T ; sklearn flips on the rows of its "Vt" = our Us^T
+    U, V = Vt.T, Us.T
+    idx = np.argmax(np.abs(U), axis=0)
+    flip = np.sign(U[idx, np.arange(r)])
+    flip[flip == 0] = 1.0
+    stats = np.stack([U[idx, np.arange(r)], idx.astype(float), (np.maximum(U, 0) ** 2).sum(0),
+                      (np.minimum(U, 0) ** 2).sum(0)], axis=1)
+    sign, scale, H = _nndsvd_plan(S, V, stats)
+    W = np.empty_like(U)
+    for j in range(r):
+        col = np.abs(U[:, j]) if sign[j] == 0 else np.maximum(sign[j] * U[:, j], 0)
+        W[:, j] = col * scale[j]
+    return W, H
+
+
+def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray):
+    """
+    NNDSVDa start (W0 on the device, feature-major r x ld; H0 on the host) for the feature-major
+    device matrix Xd [F, ld] with n valid rows.  N >= F.
+    """
+    K = _kernels()
+    F = Xd.shape[0]
+    G1, xsum = K.gram(Xd, n)
+    x_mean = xsum / (n * F)
+    lam, V1 = linalg.eigh(G1)
+    floor = max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
+    keep = lam > floor
+    if not keep.any():
+        raise ValueError('NMF initialisation: the feature matrix is numerically zero')
+    T1 = V1[:, keep] / np.sqrt(lam[keep])
+    G2, _ = K.gram(Xd, n, T1)
+    lam2, V2 = linalg.eigh(G2)
+    T = (T1 @ V2) / np.sqrt(lam2)                                    # X T = Q, orthonormal columns
+    M = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)   # Q^T X
+    Us, S, Vt = _range_finder_svd(M, r, omega, (n, F))
+    Z = T @ Us                                                       # U = X Z
+    U, stats = K.project(Xd, n, Z)
+    sign, scale, H = _nndsvd_plan(S, Vt, stats)
+    K.nndsvd_apply(U, n, sign, scale, NNDSVD_EPS, x_mean)            # W[W < eps] = 0; W[W == 0] = mean
+    H[H < NNDSVD_EPS] = 0
+    H[H == 0] = x_mean
+    return U, H
+
+
+def draw_omega(shape: Tuple[int, int], n_roles: int) -> np.ndarray:
+    """Gaussian test matrix exactly as sklearn draws it: global numpy RNG (random_state=None,
+    factor.py:19), shape (min(N, F), r + 10) (extmath.py:297, 565-569)."""
+    n, F = shape
+    return np.random.normal(size=(n if n < F else F, n_roles + 10))
+
+
+def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=None):
+    """
+    sklearn's _fit_multiplicative_update driver (_nmf.py:815-885): iterations are enqueued ten
+    at a time (grx_nmf_iterate); the host reads ||X - WH||_F once per block and applies the
+    reference's stopping rule (prev_err - err) / err_init < tol.
+    With a ShardPlan the per-iteration partial sums are all-reduced across ranks.
+    """
+    K = _kernels()
+
+    def residual_norm():
+        if plan is None:
+            return float(np.sqrt(K.to_host(state.err)[0]))
+        plan.all_reduce_sum_(state.err)
+        return float(np.sqrt(K.to_host(state.err)[0]))
+
+    rb, re = (0, state.n) if plan is None else (plan.row_begin, plan.row_end)
+    state.residual_sq(rb, re)
+    err_init = residual_norm()                                        # _nmf.py:826
+    prev = err_init
+    n_iter = 0
+    while n_iter < max_iter:
+        step = min(10, max_iter - n_iter)
+        check = tol > 0 and (n_iter + step) % 10 == 0
+        if plan is None:
+            state.iterate(step, with_residual=check)
+        else:
+            for _ in range(step):
+                state.w_pass(rb, re)
+                plan.all_reduce_sum_(state.AB)
+                state.h_update()
+            if check:
+                state.residual_sq(rb, re)
+        n_iter += step
+        if check:                                                     # _nmf.py:872-885
+            err = residual_norm()
+            if (prev - err) / err_init < tol:
+                break
+            prev = err
+    return state, n_iter
+
+
+def nmf_device(Xd, n: int, n_roles: int, omega: np.ndarray,
+               tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER):
+    """NNDSVDa + multiplicative updates on a device matrix; returns (NmfState, n_iter)."""
+    K = _kernels()
+    W0, H0 = nndsvda_init_device(Xd, n, n_roles, omega)
+    return run_mu_loop(K.NmfState(Xd, n, W0, H0), tol, max_iter)
+
+
+def get_nmf_decomposition(X: np.ndarray, n_roles: int) -> FactorTuple:
+    """
+    Compute NMF decomposition
+    :param X: matrix to factor (n_nodes x n_features, non-negative)
+    :param n_roles: rank of decomposition
+    """
+    G, F, _ = nmf_with_info(X, n_roles)
+    return G, F
+
+
+def nmf_with_info(X: np.ndarray, n_roles: int):
+    """(G, F, n_iter); G = W (n x r), F = H (r x n_features)."""
+    K = _kernels()
+    X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError('X must be 2-dimensional')
+    if (X < 0).any():
+        raise ValueError('Negative values in data passed to NMF (input X)')        # _nmf.py:283
+    n, F = X.shape
+    if n_roles > min(n, F):
+        raise ValueError("init = 'nndsvda' can only be used when n_components <= min(n_samples, n_features)")
+    omega = draw_omega(X.shape, n_roles)
+    Xd = K.to_device(np.ascontiguousarray(X.T))
+    if n < F:
+        W0h, H0 = _host_init(X, n_roles, omega)
+        W0h[W0h < NNDSVD_EPS] = 0
+        H0[H0 < NNDSVD_EPS] = 0
+        W0h[W0h == 0] = X.mean()
+        H0[H0 == 0] = X.mean()
+        state = K.NmfState(Xd, n, K.to_device(np.ascontiguousarray(W0h.T)), H0)
+        state, n_iter = run_mu_loop(state)
+    else:
+        state, n_iter = nmf_device(Xd, n, n_roles, omega)
+    return K.to_host(state.W)[:, :n].T.copy(), K.to_host(state.H).copy(), n_iter
+
+
+def encode(X: np.ndarray, n_bins: int) -> np.ndarray:
+    """
+    Encode (quantize) a matrix X using a specified number of bins: 1-D Lloyd-Max quantiser =
+    k-means on the flattened entries, random_state=1 (factor.py:29-49).  Host sklearn call, as in
+    the reference (next-row item, see module docstring).
+    """
+    from sklearn.cluster import KMeans
+    data = X.reshape(X.size, 1)
+    quantizer = KMeans(n_clusters=n_bins, random_state=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        quantizer.fit(data)
+    centres = quantizer.cluster_centers_
+    return centres[quantizer.labels_].reshape(X.shape)

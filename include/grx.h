@@ -73,6 +73,9 @@ int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, cons
                  int add_self_loop, int64_t row_begin, int64_t row_end, double *d_out,
                  void *stream);
 
+/* out[i] = a[i] + b[i]  (total_degree = in_degree + out_degree, networkx.py:57). */
+int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_out, void *stream);
+
 /*
  * Ego-net features.  Replaces NetworkxInterface._get_egonet_features + _get_edge_sum
  * (graphrole/graph/interface/networkx.py:71-83,115-123).  ego(v) = {v} U row(v);

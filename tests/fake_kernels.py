@@ -1,0 +1,201 @@
+"""
+CPU test double of graphrole_amd.kernels (same function signatures, torch CPU tensors), built on
+oracle/.  Used ONLY by the `-m "not gpu"` tests to exercise the host logic (drop-in classes,
+pruning decisions, naming, sharding over gloo) in a container without a GPU.  Never shipped,
+never measured.
+"""
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from oracle import ckernels, rolx
+
+
+def device():
+    return torch.device('cpu')
+
+
+def to_device(a):
+    return torch.from_numpy(np.ascontiguousarray(a).copy())
+
+
+def to_host(t):
+    return t.detach().cpu().numpy()
+
+
+def empty(shape, dtype=torch.float64):
+    return torch.empty(shape, dtype=dtype)
+
+
+def zeros(shape, dtype=torch.float64):
+    return torch.zeros(shape, dtype=dtype)
+
+
+class DeviceCSR:
+    def __init__(self, row_ptr, col, w=None):
+        self.n = len(row_ptr) - 1
+        self.nnz = int(row_ptr[-1])
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        self.lanes_per_row = 8
+
+
+def row_sums(csr, add_self_loop, row_begin=0, row_end=None, out=None):
+    row_end = csr.n if row_end is None else row_end
+    full = ckernels.rowsum(csr.row_ptr, csr.col, csr.w, add_self_loop)
+    res = torch.zeros(csr.n, dtype=torch.float64) if out is None else out
+    res[row_begin:row_end] = torch.from_numpy(full[row_begin:row_end])
+    return res
+
+
+def add_columns(a, b):
+    return a + b
+
+
+def egonet_features(csr, directed, rowsum=None, row_begin=0, row_end=None):
+    row_end = csr.n if row_end is None else row_end
+    i, e = ckernels.egonet(csr.row_ptr, csr.col, csr.w, directed)
+    internal = torch.zeros(csr.n, dtype=torch.float64)
+    external = torch.zeros(csr.n, dtype=torch.float64)
+    internal[row_begin:row_end] = torch.from_numpy(i[row_begin:row_end])
+    external[row_begin:row_end] = torch.from_numpy(e[row_begin:row_end])
+    return internal, external
+
+
+def pack_rows(cols, n):
+    f = len(cols)
+    ldr = max(2, (f + 1) & ~1)
+    rows = torch.zeros((max(n, 1), ldr), dtype=torch.float64)
+    for c, col in enumerate(cols):
+        rows[:n, c] = col[:n]
+    return rows, ldr
+
+
+def aggregate(csr, rows, f, ldr, row_begin=0, row_end=None, want_sum=True, want_mean=True, out=None):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    res = torch.zeros((2 * f, n), dtype=torch.float64) if out is None else out
+    if f == 0:
+        return res
+    S, M = ckernels.aggregate(csr.row_ptr, csr.col, np.ascontiguousarray(rows.numpy()[:n, :f]))
+    if want_sum:
+        res[:f, row_begin:row_end] = torch.from_numpy(S.T[:, row_begin:row_end].copy())
+    if want_mean:
+        res[f:, row_begin:row_end] = torch.from_numpy(M.T[:, row_begin:row_end].copy())
+    return res
+
+
+def sort_columns(block):
+    return torch.from_numpy(np.sort(block.numpy(), axis=1))
+
+
+def vertical_log_bin(block, frac=0.5, out=None):
+    ncols, n = block.shape
+    bins = out if out is not None else torch.zeros((ncols, n), dtype=torch.uint8)
+    nb = torch.zeros(ncols, dtype=torch.int32)
+    if not 0 < frac < 1:
+        raise ValueError('must specify frac in interval (0, 1)')
+    for j in range(ncols):
+        b = ckernels.vertical_log_binning(np.ascontiguousarray(block[j].numpy()), frac)
+        bins[j] = torch.from_numpy(b.astype(np.uint8))
+        nb[j] = int(b.max()) + 1 if n else 0
+    return bins, nb
+
+
+def chebyshev(bin_cols, n, first_new=0, row_begin=0, row_end=None):
+    F = len(bin_cols)
+    row_end = n if row_end is None else row_end
+    D = torch.zeros((F, F), dtype=torch.int32)
+    if F >= 2 and row_end > row_begin:
+        B = np.stack([c.numpy()[row_begin:row_end].astype(np.int32) for c in bin_cols])
+        full = ckernels.chebyshev(B)
+        mask = np.zeros((F, F), dtype=bool)
+        mask[:, first_new:] = True
+        mask[first_new:, :] = True
+        D = torch.from_numpy(np.where(mask, full, 0).astype(np.int32))
+    return D
+
+
+def gather_columns(cols, n):
+    F = len(cols)
+    out = torch.zeros((F, max(n, 1)), dtype=torch.float64)
+    for j, c in enumerate(cols):
+        out[j, :n] = c[:n]
+    return out
+
+
+def gram(X, n, T=None, row_begin=0, row_end=None):
+    row_end = n if row_end is None else row_end
+    A = X.numpy()[:, row_begin:row_end].T
+    Y = A if T is None else A @ T
+    return Y.T @ Y, float(A.sum())
+
+
+def project(X, n, Z, row_begin=0, row_end=None, out=None):
+    row_end = n if row_end is None else row_end
+    A = X.numpy()[:, :n].T
+    U = A @ Z
+    r = Z.shape[1]
+    res = torch.zeros((r, X.shape[1]), dtype=torch.float64) if out is None else out
+    res[:, row_begin:row_end] = torch.from_numpy(U.T[:, row_begin:row_end].copy())
+    Us = U[row_begin:row_end]
+    idx = np.argmax(np.abs(Us), axis=0)
+    stats = np.stack([Us[idx, np.arange(r)], (idx + row_begin).astype(float),
+                      (np.maximum(Us, 0) ** 2).sum(0), (np.minimum(Us, 0) ** 2).sum(0)], axis=1)
+    return res, stats
+
+
+def nndsvd_apply(U, n, sign, scale, eps, fill, row_begin=0, row_end=None):
+    row_end = n if row_end is None else row_end
+    u = U.numpy()
+    for j in range(u.shape[0]):
+        x = u[j, row_begin:row_end]
+        v = np.abs(x) if sign[j] == 0 else np.maximum(sign[j] * x, 0)
+        v = v * scale[j]
+        u[j, row_begin:row_end] = np.where(v < eps, fill, v)
+
+
+class NmfState:
+    def __init__(self, X, n, W, H):
+        self.X, self.n, self.W = X, n, W
+        self.F, self.r = X.shape[0], W.shape[0]
+        self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64).copy())
+        self.AB = torch.zeros(self.r * self.F + self.r * self.r, dtype=torch.float64)
+        self.err = torch.zeros(1, dtype=torch.float64)
+
+    def w_pass(self, row_begin=0, row_end=None):
+        row_end = self.n if row_end is None else row_end
+        X = self.X.numpy()[:, row_begin:row_end].T
+        W = self.W.numpy()[:, row_begin:row_end].T
+        H = self.H.numpy()
+        den = W @ (H @ H.T)
+        den[den == 0] = rolx.EPSILON
+        W1 = W * ((X @ H.T) / den)
+        self.W.numpy()[:, row_begin:row_end] = W1.T
+        self.AB[:self.r * self.F] = torch.from_numpy((W1.T @ X).ravel())
+        self.AB[self.r * self.F:] = torch.from_numpy((W1.T @ W1).ravel())
+
+    def h_update(self):
+        A = self.AB.numpy()[:self.r * self.F].reshape(self.r, self.F)
+        B = self.AB.numpy()[self.r * self.F:].reshape(self.r, self.r)
+        H = self.H.numpy()
+        den = B @ H
+        den[den == 0] = rolx.EPSILON
+        H *= A / den
+
+    def residual_sq(self, row_begin=0, row_end=None):
+        row_end = self.n if row_end is None else row_end
+        X = self.X.numpy()[:, row_begin:row_end].T
+        W = self.W.numpy()[:, row_begin:row_end].T
+        R = X - W @ self.H.numpy()
+        self.err[0] = float((R * R).sum())
+        return self.err
+
+    def iterate(self, iters, with_residual=True):
+        for _ in range(iters):
+            self.w_pass()
+            self.h_update()
+        if with_residual:
+            self.residual_sq()

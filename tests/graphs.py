@@ -1,0 +1,92 @@
+"""
+Deterministic networkx graph builders shared by tools/make_golden.py (which runs the reference on
+them) and the tests (which run graphrole_amd on them).  No reference code involved.
+"""
+import networkx as nx
+import numpy as np
+
+
+def er(n, m, seed):
+    return nx.gnm_random_graph(n, m, seed=seed), {}
+
+
+def ba(n, m, seed):
+    return nx.barabasi_albert_graph(n, m, seed=seed), {}
+
+
+def directed_weighted_attrs(n=200, m=900, seed=3):
+    G = nx.gnm_random_graph(n, m, seed=seed, directed=True)
+    rng = np.random.default_rng(seed)
+    for u, v in G.edges:
+        G[u][v]['weight'] = float(rng.uniform(0.1, 5.0))
+    G.add_edge(5, 5, weight=2.5)
+    G.add_edge(7, 7, weight=1.25)
+    for node in G.nodes:
+        G.nodes[node]['a_uniform'] = float(rng.random())
+        G.nodes[node]['a_poisson'] = int(rng.poisson(3))
+        G.nodes[node]['a_text'] = 'not numeric'
+        if node % 3 == 0:
+            G.nodes[node]['a_sparse'] = float(rng.exponential(1.0))
+    return G, {'attributes': True}
+
+
+def loops_dangling(seed=4):
+    G = nx.gnm_random_graph(150, 400, seed=seed)
+    G.add_edge(3, 3)
+    G.add_edge(9, 9)
+    G.add_nodes_from([1000, 1001])
+    return G, {}
+
+
+def directed_unweighted(seed=6):
+    G = nx.gnm_random_graph(120, 500, seed=seed, directed=True)
+    G.add_edge(2, 2)
+    return G, {}
+
+
+def path4():
+    return nx.Graph([('a', 'b'), ('a', 'c'), ('c', 'd')]), {}
+
+
+IFACE7_EDGES = [(0, 1), (0, 2), (0, 3), (3, 6), (4, 5), (4, 6), (5, 6)]
+IFACE7_WEIGHTS = [2, 1.5, 3, 0.25, 0.75, 2.5, 1]
+IFACE7_ATTRS = {
+    0: {'attr1': 1.00, 'attr2': 0.00},
+    1: {'attr2': 1.00},
+    2: {'attr2': 2.00},
+    3: {'attr2': 3.00},
+    4: {'attr2': 4.00},
+    5: {'attr2': 5.00},
+    6: {'attr2': 6.00},
+}
+
+
+def iface7():
+    return nx.Graph(IFACE7_EDGES), {}
+
+
+def iface7_directed_weighted():
+    G = nx.DiGraph()
+    for e, w in zip(IFACE7_EDGES, IFACE7_WEIGHTS):
+        G.add_edge(*e, weight=w)
+    return G, {}
+
+
+def iface7_attrs():
+    G = nx.Graph(IFACE7_EDGES)
+    nx.set_node_attributes(G, IFACE7_ATTRS)
+    return G
+
+
+BUILDERS = {
+    'er300': lambda: er(300, 1500, 1),
+    'ba300': lambda: ba(300, 3, 2),
+    'dw200_attrs': directed_weighted_attrs,
+    'loops_dangling150': loops_dangling,
+    'directed120': directed_unweighted,
+    'path4': path4,
+    'iface7': iface7,
+    'iface7_dw': iface7_directed_weighted,
+    'er2000': lambda: er(2000, 20000, 0),
+    'ba2000': lambda: ba(2000, 10, 0),
+}

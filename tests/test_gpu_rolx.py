@@ -1,0 +1,219 @@
+"""
+-m gpu: parity of the RolX half (graphrole_amd.roles, HIP NMF) with the reference's
+``get_nmf_decomposition`` (sklearn NMF(solver='mu', init='nndsvda')) through golden factors the
+reference produced with a fixed numpy seed (tests/golden/nmf_*.npz), plus the reference's own
+unit tests for roles (tests/test_roles/*) restated against the drop-in classes.
+
+Tolerance: factors within 1e-8 relative (max-norm per factor), equal
+iteration count.  The reference's tests pin only shapes / non-negativity / unique counts.
+"""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+FACTOR_RTOL = 1e-8
+
+
+def _relmax(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize('name', util.NMF_CASES)
+def test_nmf_matches_reference_golden(name):
+    from graphrole_amd.roles import factor
+    g = util.load_nmf(name)
+    X, r, seed = g['X'], int(g['r']), int(g['seed'])
+    np.random.seed(seed)
+    G, F, n_iter = factor.nmf_with_info(X, r)
+    assert G.shape == g['W'].shape and F.shape == g['H'].shape
+    assert n_iter == int(g['n_iter'])
+    assert (G >= 0).all() and (F >= 0).all()
+    assert _relmax(G, g['W']) < FACTOR_RTOL, _relmax(G, g['W'])
+    assert _relmax(F, g['H']) < FACTOR_RTOL, _relmax(F, g['H'])
+
+
+@pytest.mark.parametrize('name', ['rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'er2000_r6', 'dw200_r5'])
+def test_nndsvda_init_matches_reference_golden(name):
+    from graphrole_amd import kernels as K
+    from graphrole_amd.roles import factor
+    g = util.load_nmf(name)
+    X, r = g['X'], int(g['r'])
+    n = X.shape[0]
+    Xd = K.to_device(np.ascontiguousarray(X.T))
+    W0, H0 = factor.nndsvda_init_device(Xd, n, r, g['omega'])
+    assert _relmax(K.to_host(W0)[:, :n].T, g['W0']) < 1e-9
+    assert _relmax(H0, g['H0']) < 1e-9
+
+
+def test_nmf_consumes_global_rng_like_sklearn():
+    """random_state=None in the reference (factor.py:19): one normal(size=(min(N,F), r+10)) draw."""
+    from graphrole_amd.roles import factor
+    X = np.abs(np.random.RandomState(3).randn(200, 9))
+    np.random.seed(42)
+    factor.get_nmf_decomposition(X, 3)
+    after = np.random.rand()
+    np.random.seed(42)
+    np.random.normal(size=(9, 13))
+    assert after == np.random.rand()
+
+
+def test_nmf_rejects_negative_input():
+    from graphrole_amd.roles import factor
+    with pytest.raises(ValueError, match='Negative'):
+        factor.get_nmf_decomposition(np.array([[1.0, -1.0], [2.0, 3.0]]), 1)
+
+
+def test_nmf_rank_deficient_features():
+    """total_degree = in_degree + out_degree is an exact linear dependency (directed graphs)."""
+    from graphrole_amd.roles import factor
+    from oracle import rolx
+    rng = np.random.RandomState(0)
+    a, b = np.abs(rng.randn(3000)), np.abs(rng.randn(3000))
+    X = np.column_stack([a, b, a + b, np.abs(rng.randn(3000, 4))])
+    np.random.seed(1)
+    G, F, n_iter = factor.nmf_with_info(X, 4)
+    np.random.seed(1)
+    We, He, it = rolx.nmf(X, 4)
+    assert n_iter == it
+    assert _relmax(G, We) < FACTOR_RTOL and _relmax(F, He) < FACTOR_RTOL
+
+
+class TestFactorLikeReference:
+    """tests/test_roles/test_factor.py of the reference."""
+
+    def test_get_nmf_decomposition_shapes(self):
+        from graphrole_amd.roles import factor
+        np.random.seed(0)
+        X = np.random.rand(20, 30)
+        for n_roles in range(2, 8):
+            G, F = factor.get_nmf_decomposition(X, n_roles)
+            assert G.shape == (20, n_roles) and F.shape == (n_roles, 30)
+            assert (G >= 0).all() and (F >= 0).all()
+
+    def test_encode(self):
+        from graphrole_amd.roles import factor
+        np.random.seed(0)
+        X = np.random.rand(20, 30)
+        for n_bins in range(1, 8):
+            assert len(np.unique(factor.encode(X, n_bins))) <= n_bins
+
+
+class TestDescriptionLengthLikeReference:
+    """tests/test_roles/test_description_length.py of the reference (host arithmetic)."""
+
+    def test_costs(self):
+        from graphrole_amd.roles import description_length as dl
+        G = np.array([[1, 2, 3], [1, 2, 4]])
+        F = np.array([[1, 2, 3], [4, 5, 5]])
+        assert dl.get_encoding_cost((G, F)) == 3 * (G.size + F.size)
+        np.random.seed(0)
+        X = np.random.rand(20, 30)
+        assert dl.get_error_cost(X, abs(X - np.random.randn(*X.shape))) > 0
+        assert dl.get_error_cost(X, X) == 0
+        assert len(dl.get_description_length_costs(X, (np.random.rand(20, 4), np.random.rand(4, 30)))) == 2
+
+
+class TestRoleExtractorLikeReference:
+    """tests/test_roles/test_extract.py of the reference."""
+
+    def setup_method(self):
+        np.random.seed(0)
+        self.n_nodes, self.n_features = 20, 30
+        names = [f'feature{i + 1}' for i in range(self.n_features)]
+        self.features = pd.DataFrame(np.random.rand(self.n_nodes, self.n_features), columns=names,
+                                     index=range(self.n_nodes))
+
+    def test_init(self):
+        from graphrole_amd import RoleExtractor
+        re_ = RoleExtractor()
+        assert re_.n_roles is None
+        assert (re_.min_roles, re_.max_roles) == RoleExtractor.N_ROLE_RANGE == (2, 8)
+        assert (re_.min_bits, re_.max_bits) == RoleExtractor.N_BIT_RANGE == (1, 8)
+        assert RoleExtractor(n_roles=5).n_roles == 5
+        re_ = RoleExtractor(n_role_range=(3, 5), n_bit_range=(2, 6))
+        assert (re_.min_roles, re_.max_roles, re_.min_bits, re_.max_bits) == (3, 5, 2, 6)
+
+    def test_extract_role_factors(self):
+        from graphrole_amd import RoleExtractor
+        for n_roles in range(2, 6):
+            re_ = RoleExtractor(n_roles=n_roles)
+            re_.extract_role_factors(self.features)
+            roles = {f'role_{i}' for i in range(n_roles)}
+            assert re_.node_role_factor.shape == (self.n_nodes, n_roles)
+            assert re_.role_feature_factor.shape == (n_roles, self.n_features)
+            assert set(re_.node_role_factor.index) == set(self.features.index)
+            assert set(re_.node_role_factor.columns) == roles
+            assert set(re_.role_feature_factor.index) == roles
+            assert set(re_.role_feature_factor.columns) == set(self.features.columns)
+
+    def test_roles_and_percentage(self):
+        from graphrole_amd import RoleExtractor
+        re_ = RoleExtractor()
+        assert re_.roles is None and re_.role_percentage is None
+        re_ = RoleExtractor(n_roles=3)
+        re_.extract_role_factors(self.features)
+        names = {f'role_{i}' for i in range(3)}
+        assert set(re_.roles.keys()) == set(self.features.index)
+        assert set(re_.roles.values()) <= names
+        pct = re_.role_percentage
+        assert set(pct.columns) == names
+        assert np.allclose(pct.sum(axis=1).values, 1.0)
+
+    def test_explain(self):
+        from graphrole_amd import RoleExtractor
+        with pytest.raises(NotImplementedError):
+            RoleExtractor().explain()
+
+    def test_select_model_picks_two_roles(self):
+        from graphrole_amd import RoleExtractor
+        re_ = RoleExtractor(n_role_range=(2, 5), n_bit_range=(2, 5))
+        G, F = re_._select_model(self.features)
+        assert G.shape[1] == F.shape[0] == 2                  # test_extract.py:81-88
+
+    def test_get_encoded_role_factors(self):
+        from graphrole_amd import RoleExtractor
+        re_ = RoleExtractor()
+        min_shape = min(self.features.shape)
+        for n_roles in range(2, 4):
+            for n_bits in range(1, 6):
+                if 2 ** n_bits <= n_roles * min_shape:
+                    G, F = re_._get_encoded_role_factors(self.features, n_roles, n_bits)
+                    assert G.shape == (self.n_nodes, n_roles) and F.shape == (n_roles, self.n_features)
+                    assert len(np.unique(G)) <= 2 ** n_bits and len(np.unique(F)) <= 2 ** n_bits
+                else:
+                    with pytest.raises(ValueError):
+                        re_._get_encoded_role_factors(self.features, n_roles, n_bits)
+
+    def test_rescale_costs(self):
+        from graphrole_amd import RoleExtractor
+        costs = np.full((3, 3), np.nan)
+        costs[1, 1] = 0.37
+        costs[2, :] = [0.1, 0.5, 0.9]
+        out = RoleExtractor._rescale_costs(costs)
+        assert np.isnan(out[0]).all()
+        assert np.isnan(out[1, 0]) and np.isnan(out[1, 2]) and out[1, 1] == pytest.approx(1.0)
+        assert np.linalg.norm(out[2]) == pytest.approx(1.0)
+
+
+def test_end_to_end_karate_roles():
+    """BASELINE config 1 plumbing: karate club, ReFeX then RolX with MDL model selection."""
+    import networkx as nx
+    from graphrole_amd import RecursiveFeatureExtractor, RoleExtractor
+    g = util.load_refex('karate')
+    labels = g.js('labels')
+    G = nx.Graph()
+    G.add_nodes_from(labels)
+    G.add_edges_from((labels[s], labels[d]) for s, d in zip(g['src'], g['dst']))
+    features = RecursiveFeatureExtractor(G).extract_features()
+    assert features.shape == (34, 7)
+    np.random.seed(0)
+    re_ = RoleExtractor(n_roles=None)
+    re_.extract_role_factors(features)
+    k = re_.node_role_factor.shape[1]
+    assert 2 <= k <= 7
+    assert set(re_.roles.keys()) == set(labels)
+    assert np.allclose(re_.role_percentage.sum(axis=1).values, 1.0)

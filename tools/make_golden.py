@@ -46,79 +46,20 @@ AGGS = ['sum', 'mean']
 
 
 # --------------------------------------------------------------------------- graphs
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import graphs as G_                              # noqa: E402
+
+
 def g_karate(weighted):
+    """The reference's own copy of the karate-club graph (examples/data/data.py:6-15)."""
     return load_nx_karate_club_graph(weighted=weighted), {}
-
-
-def g_er(n, m, seed):
-    return nx.gnm_random_graph(n, m, seed=seed), {}
-
-
-def g_ba(n, m, seed):
-    return nx.barabasi_albert_graph(n, m, seed=seed), {}
-
-
-def g_directed_weighted_attrs(n=200, m=900, seed=3):
-    G = nx.gnm_random_graph(n, m, seed=seed, directed=True)
-    rng = np.random.default_rng(seed)
-    for u, v in G.edges:
-        G[u][v]['weight'] = float(rng.uniform(0.1, 5.0))
-    G.add_edge(5, 5, weight=2.5)
-    G.add_edge(7, 7, weight=1.25)
-    for node in G.nodes:
-        G.nodes[node]['a_uniform'] = float(rng.random())
-        G.nodes[node]['a_poisson'] = int(rng.poisson(3))
-        G.nodes[node]['a_text'] = 'not numeric'
-        if node % 3 == 0:
-            G.nodes[node]['a_sparse'] = float(rng.exponential(1.0))
-    return G, {'attributes': True}
-
-
-def g_loops_dangling(seed=4):
-    G = nx.gnm_random_graph(150, 400, seed=seed)
-    G.add_edge(3, 3)
-    G.add_edge(9, 9)
-    G.add_nodes_from([1000, 1001])
-    return G, {}
-
-
-def g_directed_unweighted(seed=6):
-    G = nx.gnm_random_graph(120, 500, seed=seed, directed=True)
-    G.add_edge(2, 2)
-    return G, {}
-
-
-def g_path4():
-    return nx.Graph([('a', 'b'), ('a', 'c'), ('c', 'd')]), {}
-
-
-def g_iface7():
-    return nx.Graph([(0, 1), (0, 2), (0, 3), (3, 6), (4, 5), (4, 6), (5, 6)]), {}
-
-
-def g_iface7_directed_weighted():
-    edges = [(0, 1), (0, 2), (0, 3), (3, 6), (4, 5), (4, 6), (5, 6)]
-    weights = [2, 1.5, 3, 0.25, 0.75, 2.5, 1]
-    G = nx.DiGraph()
-    for e, w in zip(edges, weights):
-        G.add_edge(*e, weight=w)
-    return G, {}
 
 
 REFEX_CASES = {
     'karate': lambda: g_karate(False),
     'karate_weighted': lambda: g_karate(True),
-    'er300': lambda: g_er(300, 1500, 1),
-    'ba300': lambda: g_ba(300, 3, 2),
-    'dw200_attrs': g_directed_weighted_attrs,
-    'loops_dangling150': g_loops_dangling,
-    'directed120': g_directed_unweighted,
-    'path4': g_path4,
-    'iface7': g_iface7,
-    'iface7_dw': g_iface7_directed_weighted,
-    'er2000': lambda: g_er(2000, 20000, 0),
-    'ba2000': lambda: g_ba(2000, 10, 0),
 }
+REFEX_CASES.update(G_.BUILDERS)
 
 
 # --------------------------------------------------------------------------- ReFeX capture
