@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X ReFeX / RolX hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload ba1m|er100k|ba100k|tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the synthetic graph that is already resident in HBM:
+ReFeX (generation-0 degree/ego-net features + recursive neighbour aggregation with pruning,
+max_generations=4) followed by RolX NMF (NNDSVDa + multiplicative updates to convergence,
+n_roles=6) on the resulting features, device-to-device.  The timed region is K steps between
+barrier + synchronize pairs; the time is the max over ranks.
+
+  value            = ReFeX edges-aggregated / s = nnz * executed recursive generations * K /
+                     (time spent in the ReFeX phase of the K steps), whole job
+  nmf.iters_per_s  = multiplicative-update iterations / s over the NMF phase of the same steps
+  ms_per_step      = whole step (both phases)
+  roofline         = aggregation kernel: algorithmic bytes (4 B/edge +
+                     (8 + 24 f) B/node per launch) / its HIP-event time inside the timed region
+  cpu_baseline     = the oracle (plain-C port, 1 core) on the same graph, rank 0, N = 1 only
+
+With --gpus N > 1 the same graph is node-range sharded over the ranks (strong scaling) with one
+RCCL all-gather of the candidate block per generation.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (generator, n, m, description)
+    'ba1m': ('ba', 1_000_000, 10, 'Barabasi-Albert n=1,000,000 m=10 (~10M edges), seed 0  [BASELINE config 3/4]'),
+    'er100k': ('er', 100_000, 1_000_000, 'Erdos-Renyi G(100,000; 1,000,000), seed 0  [BASELINE config 2]'),
+    'ba100k': ('ba', 100_000, 10, 'Barabasi-Albert n=100,000 m=10 (reduced; not a headline number)'),
+    'tiny': ('ba', 5_000, 5, 'Barabasi-Albert n=5,000 m=5 (smoke only)'),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_ROLES = 6
+MAX_GENERATIONS = 4
+
+
+def build_graph(name):
+    from graphrole_amd import synth
+    kind, n, m, _ = WORKLOADS[name]
+    return synth.ba_graph(n, m, seed=0) if kind == 'ba' else synth.er_graph(n, m, seed=0)
+
+
+def profile_totals(lib):
+    out = {}
+    for kid in range(lib.grx_profile_kernel_count()):
+        ms, cnt = ctypes.c_double(), ctypes.c_longlong()
+        lib.grx_profile_read(kid, ctypes.byref(ms), ctypes.byref(cnt))
+        if cnt.value:
+            out[lib.grx_profile_kernel_name(kid).decode()] = (ms.value, cnt.value)
+    return out
+
+
+def cpu_baseline(G, args, X_features):
+    """Oracle (plain-C port, single thread) on the same graph; bounded to the full workload once."""
+    from oracle import refex, reference_path
+    og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=None, directed=False,
+                           num_edges=G.num_edges)
+    t0 = time.perf_counter()
+    res = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
+    dt = time.perf_counter() - t0
+    gens = res.generation_count
+    out = {
+        'value': G.nnz * gens / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+        'sample': f'full workload once: oracle C port, gen-0 + {gens} generations + pruning in {dt:.1f} s',
+        'seconds': dt, 'host_cpus': os.cpu_count(),
+    }
+    extra = {}
+    # reference-faithful pandas loop (BASELINE.md baseline 1): contiguous node sample of generation 1
+    try:
+        names0, X0 = res.trace[0].retained, None
+        cols = [res.columns.index(c) for c in names0]
+        X0 = res.values[:, cols]
+        sample = min(args.cpu_sample_nodes, G.n)
+        dt_p, edges_p = reference_path.time_aggregate_sample(G.row_ptr, G.col, X0, names0, G.n // 2, sample)
+        extra['cpu_reference_path'] = {
+            'value': edges_p / dt_p, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+            'sample': f'pandas reindex/agg loop (extract.py:104-119) on {sample} contiguous nodes of generation 1 '
+                      f'({edges_p} edges, {dt_p:.1f} s); full graph would take ~{dt_p * G.n / sample / 60:.0f} min/generation (extrapolated)',
+        }
+    except Exception as exc:                       # baseline legs must never kill the bench line
+        extra['cpu_reference_path'] = {'error': repr(exc)}
+    if X_features is not None and args.cpu_nmf:
+        try:
+            _, _, n_iter, dt_n = reference_path.sklearn_nmf(X_features, N_ROLES)
+            from threadpoolctl import threadpool_info
+            threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+            extra['cpu_baseline_nmf'] = {
+                'value': n_iter / dt_n, 'unit': 'iters/s', 'cores': threads, 'kind': 'reference',
+                'sample': f'sklearn NMF(mu, nndsvda) full fit on the {X_features.shape[0]}x{X_features.shape[1]} '
+                          f'feature matrix: {n_iter} iterations in {dt_n:.1f} s (incl. init)',
+            }
+        except Exception as exc:
+            extra['cpu_baseline_nmf'] = {'error': repr(exc)}
+    return out, extra
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='ba1m', choices=list(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-nodes', type=int, default=3000)
+    ap.add_argument('--cpu-nmf', type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from graphrole_amd import RecursiveFeatureExtractor, _lib, backend
+    from graphrole_amd.roles import factor
+    K = backend.get()
+    lib = _lib.load()
+
+    G = build_graph(args.workload)
+    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=(world > 1))
+    fe.graph._device_graph()                       # graph resident in HBM before anything is timed
+    plan = fe._shard()
+    rng = np.random.RandomState(0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = {}
+
+    def step(timers):
+        fe.reset()
+        t0 = time.perf_counter()
+        fe.run_on_device()
+        names, cols = fe.device_features()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        Xd = K.gather_columns(cols, G.n)
+        omega = rng.normal(size=(len(names), N_ROLES + 10))
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega) if plan is None else \
+            factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega)
+        nmf_state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        timers['refex'] += t1 - t0
+        timers['nmf'] += t2 - t1
+        timers['nmf_iters'] += n_iter
+        state.update(names=names, Xd=Xd, n_iter=n_iter, gens=fe.generation_count, stats=list(fe.stats),
+                     F=len(names))
+
+    warm = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+    for _ in range(args.warmup):
+        step(warm)
+    lib.grx_profile_reset()
+    lib.grx_profile_enable(1)
+    timers = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(timers)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    lib.grx_profile_enable(0)
+    prof = profile_totals(lib)
+
+    # max over ranks
+    red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
+
+    if rank == 0:
+        gens = state['gens']
+        edges_per_step = G.nnz * gens
+        value = edges_per_step * args.steps / t_refex
+        # aggregation-kernel roofline (algorithmic bytes per launch)
+        f_per_gen = [s['candidates'] // 2 for s in state['stats'] if s['generation'] >= 1]
+        rows_per_rank = G.n / world
+        nnz_per_rank = G.nnz / world
+        alg_bytes = 0.0
+        launches = 0
+        for f in f_per_gen:
+            for c0 in range(0, f, 16):
+                fc = min(16, f - c0)
+                alg_bytes += nnz_per_rank * 4 + (rows_per_rank + 1) * 8 + G.n * fc * 8 / world + rows_per_rank * 2 * fc * 8
+                launches += 1
+        agg_ms, agg_cnt = prof.get('aggregate_kernel', (0.0, 0))
+        hub_ms, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
+        roofline = None
+        if agg_cnt:
+            per_launch_ms = (agg_ms + hub_ms) / agg_cnt
+            achieved = alg_bytes / launches / (per_launch_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get('workload') == args.workload and tj.get('n_gpus', 1) == world:
+                        traffic = tj.get('aggregate_kernel_hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_hub_kernel)',
+                        'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / launches,
+                        'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen}
+        F, r = state['F'], N_ROLES
+        w_ms, w_cnt = prof.get('nmf_w_pass_kernel', (0.0, 0))
+        roofline_nmf = None
+        if w_cnt:
+            nmf_bytes = (G.n / world) * (F * 8 + 2 * r * 8)
+            ach = nmf_bytes / (w_ms / w_cnt * 1e-3) / 1e9
+            roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_kernel', 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                            'algorithmic_bytes_per_launch': nmf_bytes, 'avg_launch_ms': w_ms / w_cnt}
+        line = {
+            'metric': 'ReFeX edges-aggregated/sec (+ RolX NMF iters/sec in nmf.iters_per_s), 1M-node graph',
+            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'description': WORKLOADS[args.workload][3], 'n_nodes': G.n,
+                       'n_edges': G.num_edges, 'nnz': G.nnz, 'max_generations': MAX_GENERATIONS,
+                       'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
+                       'sharding': 'node-range x%d, RCCL all-gather per generation' % world if world > 1 else 'single GPU'},
+            'refex': {'ms_per_step': t_refex / args.steps * 1e3, 'edges_per_step': edges_per_step,
+                      'generations': state['stats']},
+            'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / args.steps * 1e3,
+                    'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
+            'roofline': roofline, 'roofline_nmf': roofline_nmf,
+            'kernel_ms_per_step': {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            Xh = K.to_host(state['Xd'])[:, :G.n].T.copy() if args.cpu_nmf else None
+            base, extra = cpu_baseline(G, args, Xh)
+            line['cpu_baseline'] = base
+            line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,11 @@ _SIGNATURES = {
     'grx_event_destroy': (c_int, [c_void_p]),
     'grx_event_record': (c_int, [c_void_p, c_void_p]),
     'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'grx_profile_enable': (c_int, [c_int]),
+    'grx_profile_reset': (c_int, []),
+    'grx_profile_kernel_count': (c_int, []),
+    'grx_profile_kernel_name': (c_char_p, [c_int]),
+    'grx_profile_read': (c_int, [c_int, POINTER(c_double), POINTER(ctypes.c_longlong)]),
     'grx_row_sums': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_add_columns': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,

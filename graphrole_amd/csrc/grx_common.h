@@ -30,6 +30,23 @@ void grx_set_error(const char *fmt, ...);
 
 static inline hipStream_t grx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-kernel event timing (grx_profile_* in grx.h).  No-ops unless enabled.
+enum GrxKernelId {
+    GRX_K_ROW_SUMS = 0, GRX_K_EGONET_WAVE, GRX_K_EGONET_BLOCK, GRX_K_PACK_ROWS, GRX_K_AGGREGATE,
+    GRX_K_AGGREGATE_HUB, GRX_K_SORT_COUNT, GRX_K_SORT_SCAN, GRX_K_SORT_SCATTER, GRX_K_BIN_THRESHOLD,
+    GRX_K_BIN_ASSIGN, GRX_K_CHEBYSHEV, GRX_K_GATHER_COLUMNS, GRX_K_GRAM, GRX_K_PROJECT,
+    GRX_K_NNDSVD_APPLY, GRX_K_NMF_W_PASS, GRX_K_REDUCE_PARTIALS, GRX_K_NMF_H_UPDATE,
+    GRX_K_NMF_RESIDUAL, GRX_K_ADD_COLUMNS, GRX_K_COUNT
+};
+void grx_prof_begin(int id, hipStream_t st);
+void grx_prof_end(int id, hipStream_t st);
+struct GrxProfScope {
+    int id; hipStream_t st;
+    GrxProfScope(int i, hipStream_t s) : id(i), st(s) { grx_prof_begin(id, st); }
+    ~GrxProfScope() { grx_prof_end(id, st); }
+};
+#define GRX_PROF(id, st) GrxProfScope grx_prof_scope_##id(id, st)
+
 constexpr int GRX_WAVE = 64;       // CDNA4 wavefront
 constexpr int GRX_NUM_CU = 256;    // MI355X
 

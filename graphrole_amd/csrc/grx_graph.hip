@@ -317,16 +317,21 @@ int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const do
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
     const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
-    switch (G) {
-    case 4:  aggregate_kernel<FP, 4><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-    case 8:  aggregate_kernel<FP, 8><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-    case 16: aggregate_kernel<FP, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-    default: aggregate_kernel<FP, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+    {
+        GRX_PROF(GRX_K_AGGREGATE, st);
+        switch (G) {
+        case 4:  aggregate_kernel<FP, 4><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+        case 8:  aggregate_kernel<FP, 8><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+        case 16: aggregate_kernel<FP, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+        default: aggregate_kernel<FP, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
+        }
     }
     GRX_LAUNCH_CHECK();
     const int64_t hub_blocks = grx_ceil_div(nrows, 256);
     const int hgrid = (int)(hub_blocks > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : hub_blocks);
+    { GRX_PROF(GRX_K_AGGREGATE_HUB, st);
     aggregate_hub_kernel<FP><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -346,8 +351,10 @@ int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, cons
     const int64_t nrows = row_end - row_begin;
     const int64_t want = grx_ceil_div(nrows * 8, 256);
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    { GRX_PROF(GRX_K_ROW_SUMS, grx_stream(stream));
     row_sums_kernel<8><<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, add_self_loop,
                                                             row_begin, row_end, d_out);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -358,7 +365,9 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
     if (n == 0) return GRX_OK;
     GRX_REQUIRE(d_a && d_b && d_out, "grx_add_columns: NULL pointer");
     const int64_t want = grx_ceil_div(n, 256 * 4);
+    { GRX_PROF(GRX_K_ADD_COLUMNS, grx_stream(stream));
     add_columns_kernel<<<(int)(want > 2048 ? 2048 : want), 256, 0, grx_stream(stream)>>>(n, d_a, d_b, d_out);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -379,16 +388,20 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     {
         const int64_t want = grx_ceil_div(nrows, 4);
         const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+        { GRX_PROF(GRX_K_EGONET_WAVE, grx_stream(stream));
         egonet_kernel<64><<<grid, 256, 0, grx_stream(stream)>>>(
             d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, 0, HUB, d_internal,
             d_external);
+        }
         GRX_LAUNCH_CHECK();
     }
     {
         const int grid = (int)(nrows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : nrows);
+        { GRX_PROF(GRX_K_EGONET_BLOCK, grx_stream(stream));
         egonet_kernel<512><<<grid, 512, 0, grx_stream(stream)>>>(
             d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, HUB,
             (int64_t)1 << 62, d_internal, d_external);
+        }
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;
@@ -403,7 +416,9 @@ int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_r
     GRX_REQUIRE(d_col_ptrs && d_rows, "grx_pack_rows: NULL pointer");
     const int64_t want = grx_ceil_div(n, 256);
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    { GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
     pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, f, ldr, d_col_ptrs, d_rows);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

@@ -455,7 +455,9 @@ int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double
     GRX_REQUIRE(d_col_ptrs && d_out, "grx_gather_columns: NULL pointer");
     const int64_t want = grx_ceil_div(n, 256 * 4);
     const dim3 grid((unsigned)(want > 1024 ? 1024 : want), F);
+    { GRX_PROF(GRX_K_GATHER_COLUMNS, grx_stream(stream));
     gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, F, d_col_ptrs, d_out, ld);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -498,9 +500,13 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
     const size_t lds = (size_t)k * GR_LD * 8;
     if (h_T) {
         GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
+        { GRX_PROF(GRX_K_GRAM, st);
         gram_kernel<true><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+        }
     } else {
+        { GRX_PROF(GRX_K_GRAM, st);
         gram_kernel<false><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial);
+        }
     }
     GRX_LAUNCH_CHECK();
     gram_finalize_kernel<<<(k * k + 1 + 63) / 64, 64, 0, st>>>(partial, grid, k, d_out);
@@ -538,7 +544,9 @@ int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_be
     const int64_t want = grx_ceil_div(row_end - row_begin, 256);
     const int grid = (int)(want > PROJ_GRID ? PROJ_GRID : (want < 1 ? 1 : want));
     const size_t lds = ((size_t)F * r + 4 * (size_t)r * 5) * 8;
+    { GRX_PROF(GRX_K_PROJECT, st);
     project_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
+    }
     GRX_LAUNCH_CHECK();
     project_finalize_kernel<<<1, 64, 0, st>>>(partial, grid, r, d_stats);
     GRX_LAUNCH_CHECK();
@@ -557,7 +565,9 @@ int grx_nndsvd_apply(int64_t n, int r, double *d_U, int64_t ldu, int64_t row_beg
     for (int j = 0; j < MAX_R; ++j) { a.sign[j] = j < r ? h_sign[j] : 0.0; a.scale[j] = j < r ? h_scale[j] : 0.0; }
     const int64_t want = grx_ceil_div(row_end - row_begin, 256 * 4);
     const dim3 grid((unsigned)(want > 1024 ? 1024 : want), r);
+    { GRX_PROF(GRX_K_NNDSVD_APPLY, grx_stream(stream));
     nndsvd_apply_kernel<<<grid, 256, 0, grx_stream(stream)>>>(row_begin, row_end, r, d_U, ldu, a, eps, fill);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -592,14 +602,19 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
     const size_t lds = mu_lds_doubles(F, r, TR) * 8;
     double *partial = reinterpret_cast<double *>(d_workspace);
     const int P = r * F + r * r;
-    switch (TR) {
-    case 256: nmf_w_pass_kernel<256><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-    case 128: nmf_w_pass_kernel<128><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-    case 64:  nmf_w_pass_kernel<64><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-    default:  nmf_w_pass_kernel<32><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+    {
+        GRX_PROF(GRX_K_NMF_W_PASS, st);
+        switch (TR) {
+        case 256: nmf_w_pass_kernel<256><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+        case 128: nmf_w_pass_kernel<128><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+        case 64:  nmf_w_pass_kernel<64><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+        default:  nmf_w_pass_kernel<32><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+        }
     }
     GRX_LAUNCH_CHECK();
+    { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
     reduce_partials_kernel<<<(P + 63) / 64, 64, 0, st>>>(partial, grid, P, d_AB);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -610,7 +625,9 @@ int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(d_H && d_AB, "grx_nmf_h_update: NULL pointer");
     const size_t lds = (2 * (size_t)r * F + (size_t)r * r) * 8;
+    { GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
     nmf_h_update_kernel<<<1, 256, lds, grx_stream(stream)>>>(F, r, d_H, d_AB);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -634,10 +651,14 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
                                                  grx_align_up((size_t)GRX_NUM_CU * 2 * P * 8, 256));
     const int64_t want = grx_ceil_div(row_end - row_begin, 256);
     const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
+    { GRX_PROF(GRX_K_NMF_RESIDUAL, st);
     nmf_residual_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
                                                              d_H, partial);
+    }
     GRX_LAUNCH_CHECK();
+    { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
     reduce_partials_kernel<<<1, 64, 0, st>>>(partial, grid, 1, d_out);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

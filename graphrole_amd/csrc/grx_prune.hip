@@ -339,14 +339,22 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         else { src = out; sld = out_ld; }
         if (pass & 1) { dst = out; dld = out_ld; }
         else { dst = keysA; dld = n; }
-        if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
-        else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+        {
+            GRX_PROF(GRX_K_SORT_COUNT, st);
+            if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+            else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+        }
         GRX_LAUNCH_CHECK();
+        { GRX_PROF(GRX_K_SORT_SCAN, st);
         scan_kernel<<<ncols, 1024, 0, st>>>(hist, scan_len);
+        }
         GRX_LAUNCH_CHECK();
-        if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
-        else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
-        else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+        {
+            GRX_PROF(GRX_K_SORT_SCATTER, st);
+            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+        }
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;
@@ -413,11 +421,15 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
     int rc = sort_columns(n, ncols, d_cols, ld, sorted, n, keysA, hist, st);
     if (rc != GRX_OK) return rc;
+    { GRX_PROF(GRX_K_BIN_THRESHOLD, st);
     bin_threshold_kernel<<<ncols, 64, 0, st>>>(sorted, n, n, frac, thr, nb_ws);
+    }
     GRX_LAUNCH_CHECK();
     const int64_t want = grx_ceil_div(n, 256 * 4);
     const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
+    { GRX_PROF(GRX_K_BIN_ASSIGN, st);
     bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins);
+    }
     GRX_LAUNCH_CHECK();
     if (d_nbins)
         GRX_CHECK_HIP(hipMemcpyAsync(d_nbins, nb_ws, (size_t)ncols * 4, hipMemcpyDeviceToDevice, st));
@@ -438,8 +450,10 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
     const int64_t tiles = grx_ceil_div(row_end - row_begin, CH_ROWS);
     const int grid = (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : tiles);
     const size_t lds = (size_t)F * CH_STRIDE;
+    { GRX_PROF(GRX_K_CHEBYSHEV, grx_stream(stream));
     chebyshev_kernel<<<grid, 256, lds, grx_stream(stream)>>>(row_begin, row_end, F, first_new,
                                                             d_bin_ptrs, d_dist);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

@@ -1,6 +1,8 @@
 // grx_runtime.hip -- error state, device info, memory / stream / event helpers of the C ABI.
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "grx_common.h"
 
@@ -14,7 +16,87 @@ void grx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ---------------------------------------------------------------------------------------
+// per-kernel event timing
+// ---------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { int id; hipEvent_t start, stop; };
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_pending;
+thread_local hipEvent_t g_prof_open[GRX_K_COUNT];
+double g_prof_ms[GRX_K_COUNT];
+long long g_prof_cnt[GRX_K_COUNT];
+const char *const g_prof_names[GRX_K_COUNT] = {
+    "row_sums_kernel", "egonet_kernel<64>", "egonet_kernel<512>", "pack_rows_kernel", "aggregate_kernel",
+    "aggregate_hub_kernel", "tile_count_kernel", "scan_kernel", "scatter_kernel", "bin_threshold_kernel",
+    "bin_assign_kernel", "chebyshev_kernel", "gather_columns_kernel", "gram_kernel", "project_kernel",
+    "nndsvd_apply_kernel", "nmf_w_pass_kernel", "reduce_partials_kernel", "nmf_h_update_kernel",
+    "nmf_residual_kernel", "add_columns_kernel"};
+}  // namespace
+
+void grx_prof_begin(int id, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    hipEventRecord(ev, st);
+    g_prof_open[id] = ev;
+}
+
+void grx_prof_end(int id, hipStream_t st)
+{
+    if (!g_prof_on || g_prof_open[id] == nullptr) return;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    hipEventRecord(ev, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({id, g_prof_open[id], ev});
+    g_prof_open[id] = nullptr;
+}
+
 extern "C" {
+
+int grx_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    return GRX_OK;
+}
+
+int grx_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+    g_prof_pending.clear();
+    for (int i = 0; i < GRX_K_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
+    return GRX_OK;
+}
+
+int grx_profile_kernel_count(void) { return GRX_K_COUNT; }
+
+const char *grx_profile_kernel_name(int id)
+{
+    return (id >= 0 && id < GRX_K_COUNT) ? g_prof_names[id] : "";
+}
+
+int grx_profile_read(int id, double *total_ms, long long *launches)
+{
+    GRX_REQUIRE(id >= 0 && id < GRX_K_COUNT, "grx_profile_read: bad kernel id %d", id);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) {
+        GRX_CHECK_HIP(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        GRX_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+        g_prof_ms[r.id] += ms;
+        g_prof_cnt[r.id] += 1;
+        hipEventDestroy(r.start);
+        hipEventDestroy(r.stop);
+    }
+    g_prof_pending.clear();
+    if (total_ms) *total_ms = g_prof_ms[id];
+    if (launches) *launches = g_prof_cnt[id];
+    return GRX_OK;
+}
 
 int grx_version(void) { return GRX_VERSION; }
 

@@ -126,8 +126,18 @@ class RecursiveFeatureExtractor:
         Perform recursive feature extraction to return DataFrame of features
         """
         # return already calculated features if stored in state (extract.py:70-71)
+        if not self._final_names:
+            self.run_on_device()
+        return self._finalize_features()
+
+    def run_on_device(self) -> None:
+        """
+        The generation loop without the final host DataFrame: afterwards every recorded feature
+        is an fp64 column in HBM (``device_features()``).  Benchmarks and device-to-device
+        hand-off to the NMF use this entry point.
+        """
         if self._final_names:
-            return self._finalize_features()
+            return
         self._agg_names()
         self._shard()
 
@@ -147,7 +157,27 @@ class RecursiveFeatureExtractor:
             if not self._final_names[generation]:
                 break
 
-        return self._finalize_features()
+    def reset(self) -> None:
+        """Forget all computed features (the graph stays resident in HBM)."""
+        self.generation_count = 0
+        self._feature_group_thresh = 0
+        self._work.clear()
+        self._work_bins.clear()
+        self._final_names = {}
+        self._final_cols = {}
+        self.stats = []
+
+    def final_columns(self) -> List[str]:
+        """Recorded feature names in output order: latest generation first (extract.py:95)."""
+        columns: List[str] = []
+        for gen in sorted(self._final_names, reverse=True):
+            columns.extend(nm for nm in self._final_names[gen] if nm not in columns)
+        return columns
+
+    def device_features(self):
+        """(names, device columns) of the final features, in output order, without leaving HBM."""
+        names = self.final_columns()
+        return names, [self._final_cols[nm] for nm in names]
 
     # ------------------------------------------------------------------ engine
     def _next_feature_columns(self):
@@ -236,9 +266,7 @@ class RecursiveFeatureExtractor:
     def _finalize_features(self) -> DataFrameLike:
         """DataFrame of every recorded feature, latest generation first (extract.py:91-96)."""
         K = self._K()
-        columns: List[str] = []
-        for gen in sorted(self._final_names, reverse=True):
-            columns.extend(nm for nm in self._final_names[gen] if nm not in columns)
+        columns = self.final_columns()
         data = {nm: K.to_host(self._final_cols[nm]).astype(self._dtypes.get(nm, np.dtype('float64')))
                 for nm in columns}
         return pd.DataFrame(data, index=pd.Index(self._labels()), columns=columns)

@@ -16,12 +16,20 @@ import numpy as np
 
 
 def _csr_from_coo(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarray]):
-    order = np.lexsort((dst, src))
-    src_sorted = src[order]
+    """Rows ascending, columns ascending inside a row.  One int64 key sort (src * n + dst)."""
+    key = src * np.int64(n) + dst
+    if w is None:
+        key.sort()
+        w_sorted = None
+    else:
+        order = np.argsort(key, kind='stable')
+        key = key[order]
+        w_sorted = np.ascontiguousarray(w[order], dtype=np.float64)
+    rows = key // n
     row_ptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(np.bincount(src_sorted, minlength=n), out=row_ptr[1:])
-    col = dst[order].astype(np.int32)
-    return row_ptr, col, (None if w is None else np.ascontiguousarray(w[order], dtype=np.float64))
+    np.cumsum(np.bincount(rows, minlength=n), out=row_ptr[1:])
+    col = (key - rows * n).astype(np.int32)
+    return row_ptr, col, w_sorted
 
 
 class CSRGraph:

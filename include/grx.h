@@ -62,6 +62,19 @@ int grx_event_destroy(void *event);
 int grx_event_record(void *event, void *stream);
 int grx_event_elapsed_ms(void *start, void *stop, float *ms_out);   /* synchronises on stop */
 
+/*
+ * Per-kernel timing with HIP events recorded on the launch stream around every kernel launch
+ * of this library (bench.py's roofline numbers).  Off by default.  Kernel ids are dense in
+ * [0, grx_profile_kernel_count()); grx_profile_kernel_name gives the name rocprofv3 shows.
+ * grx_profile_read synchronises on the recorded events and returns the totals since the last
+ * grx_profile_reset.
+ */
+int grx_profile_enable(int on);
+int grx_profile_reset(void);
+int grx_profile_kernel_count(void);
+const char *grx_profile_kernel_name(int id);
+int grx_profile_read(int id, double *total_ms, long long *launches);
+
 /* ------------------------------------------------------------------ generation 0 -------- */
 /*
  * Weighted row sums of a CSR.  Replaces NetworkxInterface._get_local_features
