@@ -52,7 +52,10 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_aggregate': (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
-                              c_void_p, c_int64, c_int, c_void_p]),
+                              c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    'grx_egonet_unweighted': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     'grx_log_bin_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_vertical_log_bin': (c_int, [c_int64, c_int, c_void_p, c_int64, c_double, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

@@ -170,6 +170,97 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// ego-net features of UNWEIGHTED UNDIRECTED graphs through per-node triangle counts
+// ---------------------------------------------------------------------------------------
+// With A' = adjacency without the diagonal, d'(v) its degrees, L(v) the self-loop flags and
+// T(v) the number of triangles through v (= edges among the neighbours of v):
+//     internal(v) = d'(v) + T(v) + sum_{a in ego(v)} L(a)
+//     external(v) = sum_{a in ego(v)} d'(a) - 2 (d'(v) + T(v))
+// (networkx.py:71-83 counted edge by edge; all quantities are integers, so this is exact.)
+// T comes from the degree-oriented graph (arc u->v iff (d'(u),u) < (d'(v),v)): every triangle
+// is found exactly once as a common out-neighbour of the two ends of its lowest arc; oriented
+// lists are short even for power-law hubs, so a two-pointer merge per arc is cheap.
+__global__ __launch_bounds__(256) void triangle_count_kernel(
+    const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col, int64_t row_begin,
+    int64_t row_end, unsigned long long *__restrict__ T)
+{
+    constexpr int G = 8;
+    const int lane = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t u = row_begin + group; u < row_end; u += ngroups) {
+        const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
+        unsigned long long cu = 0;
+        for (int64_t k = ub + lane; k < ue; k += G) {
+            const int32_t v = o_col[k];
+            int64_t i = ub;                          // lists are id-sorted, ranks are not: full merge
+            int64_t j = o_row_ptr[v];
+            const int64_t je = o_row_ptr[v + 1];
+            unsigned long long c = 0;
+            while (i < ue && j < je) {
+                const int32_t x = o_col[i], y = o_col[j];
+                if (x < y) ++i;
+                else if (x > y) ++j;
+                else { atomicAdd(&T[x], 1ull); ++c; ++i; ++j; }
+            }
+            if (c) atomicAdd(&T[v], c);
+            cu += c;
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) cu += __shfl_xor(cu, off, G);
+        if (lane == 0 && cu) atomicAdd(&T[u], cu);
+    }
+}
+
+// info[v] = (d'(v) << 1) | L(v)
+__global__ __launch_bounds__(256) void node_info_kernel(int64_t n, const int64_t *__restrict__ row_ptr,
+                                                        const int32_t *__restrict__ col,
+                                                        int64_t *__restrict__ info)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += stride) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        const int64_t loop = find_in_row(col, b, e, (int32_t)v) >= 0 ? 1 : 0;
+        info[v] = (((e - b) - loop) << 1) | loop;
+    }
+}
+
+__global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const int64_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
+    int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
+{
+    constexpr int G = 8;
+    const int lane = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        long long sum_d = 0, loops = 0;
+        for (int64_t k = b + lane; k < e; k += G) {
+            const int32_t a = col[k];
+            if (a != (int32_t)v) {
+                const int64_t ia = info[a];
+                sum_d += ia >> 1;
+                loops += ia & 1;
+            }
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+            sum_d += __shfl_xor(sum_d, off, G);
+            loops += __shfl_xor(loops, off, G);
+        }
+        if (lane == 0) {
+            const int64_t iv = info[v];
+            const long long dv = iv >> 1;
+            const long long core = dv + (long long)T[v];
+            internal[v] = (double)(core + loops + (iv & 1));
+            external[v] = (double)(sum_d + dv - 2 * core);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // pack: column-major columns -> row-major n x ldr (zero padded)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ldr,
@@ -256,63 +347,55 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
     }
 }
 
+// One workgroup per high-degree row.  The rows come from a host-built list (hub_rows, ascending)
+// so that the hubs -- which cluster at low indices in preferential-attachment graphs -- spread
+// over the whole chip instead of queueing behind each other.
 template <int FP>
 __global__ __launch_bounds__(256) void aggregate_hub_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ rows, int ldr, int f, int64_t row_begin, int64_t row_end,
-    int64_t hub_deg, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+    const int32_t *__restrict__ hub_rows, int64_t n_hubs, double *__restrict__ out_sum,
+    double *__restrict__ out_mean, int64_t ld)
 {
     __shared__ double red[4][FP];
-    __shared__ int hub_list[256];
-    __shared__ int hub_cnt;
-    for (int64_t v0 = row_begin + (int64_t)blockIdx.x * 256; v0 < row_end;
-         v0 += (int64_t)gridDim.x * 256) {
-        if (threadIdx.x == 0) hub_cnt = 0;
-        __syncthreads();
-        const int64_t mine = v0 + threadIdx.x;
-        if (mine < row_end && (row_ptr[mine + 1] - row_ptr[mine]) > hub_deg) {
-            const int slot = atomicAdd(&hub_cnt, 1);
-            hub_list[slot] = threadIdx.x;
+    for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int64_t v = hub_rows[h];
+        if (v < row_begin || v >= row_end) continue;            // uniform over the workgroup
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        double acc[FP];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) acc[c] = 0.0;
+        for (int64_t k = b + threadIdx.x; k < e; k += 256) {
+            const int64_t u = col[k];
+            const double2 *p = reinterpret_cast<const double2 *>(rows + u * ldr);
+#pragma unroll
+            for (int c = 0; c < FP / 2; ++c) {
+                const double2 x = p[c];
+                acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<64>(acc[c]);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < FP; ++c) red[threadIdx.x >> 6][c] = acc[c];
         }
         __syncthreads();
-        const int cnt = hub_cnt;
-        for (int h = 0; h < cnt; ++h) {
-            const int64_t v = v0 + hub_list[h];
-            const int64_t b = row_ptr[v], e = row_ptr[v + 1];
-            double acc[FP];
-#pragma unroll
-            for (int c = 0; c < FP; ++c) acc[c] = 0.0;
-            for (int64_t k = b + threadIdx.x; k < e; k += 256) {
-                const int64_t u = col[k];
-                const double2 *p = reinterpret_cast<const double2 *>(rows + u * ldr);
-#pragma unroll
-                for (int c = 0; c < FP / 2; ++c) {
-                    const double2 x = p[c];
-                    acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<64>(acc[c]);
-            if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-                for (int c = 0; c < FP; ++c) red[threadIdx.x >> 6][c] = acc[c];
-            }
-            __syncthreads();
-            if (threadIdx.x < f) {
-                const int c = threadIdx.x;
-                const double s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-                if (out_sum) out_sum[(int64_t)c * ld + v] = s;
-                if (out_mean) out_mean[(int64_t)c * ld + v] = s / (double)(e - b);
-            }
-            __syncthreads();
+        if (threadIdx.x < f) {
+            const int c = threadIdx.x;
+            const double sm = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+            if (out_sum) out_sum[(int64_t)c * ld + v] = sm;
+            if (out_mean) out_mean[(int64_t)c * ld + v] = sm / (double)(e - b);
         }
+        __syncthreads();
     }
 }
 
 template <int FP>
 int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const double *rows,
-                     int ldr, int f, int64_t rb, int64_t re, int64_t hub_deg, double *s,
-                     double *m, int64_t ld, hipStream_t st)
+                     int ldr, int f, int64_t rb, int64_t re, int64_t hub_deg,
+                     const int32_t *hub_rows, int64_t n_hubs, double *s, double *m, int64_t ld,
+                     hipStream_t st)
 {
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
@@ -327,10 +410,10 @@ int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const do
         }
     }
     GRX_LAUNCH_CHECK();
-    const int64_t hub_blocks = grx_ceil_div(nrows, 256);
-    const int hgrid = (int)(hub_blocks > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : hub_blocks);
-    { GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-    aggregate_hub_kernel<FP><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld);
+    if (n_hubs > 0) {
+        const int hgrid = (int)(n_hubs > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hubs);
+        GRX_PROF(GRX_K_AGGREGATE_HUB, st);
+        aggregate_hub_kernel<FP><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_rows, n_hubs, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -407,6 +490,47 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     return GRX_OK;
 }
 
+int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_o_col, int64_t row_begin,
+                        int64_t row_end, uint64_t *d_T, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_triangle_counts: bad row range");
+    if (row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_o_row_ptr && d_o_col && d_T, "grx_triangle_counts: NULL pointer");
+    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
+    const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+    { GRX_PROF(GRX_K_TRIANGLES, grx_stream(stream));
+    triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, row_begin, row_end,
+                                                                reinterpret_cast<unsigned long long *>(d_T));
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, const uint64_t *d_T,
+                          int64_t row_begin, int64_t row_end, double *d_internal, double *d_external,
+                          int64_t *d_scratch, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_egonet_unweighted: bad row range");
+    if (n == 0) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_T && d_internal && d_external && d_scratch, "grx_egonet_unweighted: NULL pointer");
+    hipStream_t st = grx_stream(stream);
+    {
+        const int64_t want = grx_ceil_div(n, 256);
+        GRX_PROF(GRX_K_EGONET_FINISH, st);
+        node_info_kernel<<<(int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want), 256, 0, st>>>(n, d_row_ptr, d_col, d_scratch);
+    }
+    GRX_LAUNCH_CHECK();
+    if (row_end > row_begin) {
+        const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
+        GRX_PROF(GRX_K_EGONET_FINISH, st);
+        egonet_from_triangles_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want), 256, 0, st>>>(
+            d_row_ptr, d_col, d_scratch, reinterpret_cast<const unsigned long long *>(d_T), row_begin, row_end,
+            d_internal, d_external);
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
 int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
                   void *stream)
 {
@@ -425,7 +549,8 @@ int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_r
 
 int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                   const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
-                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row, void *stream)
+                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row,
+                  const int32_t *d_hub_rows, int64_t n_hub_rows, void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
                 "grx_aggregate: bad row range");
@@ -437,7 +562,10 @@ int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int
     GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, "grx_aggregate: d_rows must be 16-byte aligned");
     int G = lanes_per_row;
     if (G != 4 && G != 8 && G != 16 && G != 32) G = 8;
-    const int64_t hub_deg = (int64_t)G * 32;
+    GRX_REQUIRE(n_hub_rows >= 0 && (n_hub_rows == 0 || d_hub_rows != nullptr), "grx_aggregate: bad hub list");
+    // rows longer than this are expected in d_hub_rows; without a list every row takes the
+    // lane-group path (correct, but hubs then serialise on one lane group)
+    const int64_t hub_deg = d_hub_rows ? (int64_t)G * GRX_HUB_FACTOR : ((int64_t)1 << 62);
     hipStream_t st = grx_stream(stream);
     // columns are processed in chunks of at most 16 (accumulators stay in registers)
     for (int c0 = 0; c0 < f; c0 += 16) {
@@ -448,14 +576,14 @@ int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int
         double *m = d_mean ? d_mean + (int64_t)c0 * ld : nullptr;
         int rc;
         switch (fp) {
-        case 2:  rc = launch_aggregate<2>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 4:  rc = launch_aggregate<4>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 6:  rc = launch_aggregate<6>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 8:  rc = launch_aggregate<8>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 10: rc = launch_aggregate<10>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 12: rc = launch_aggregate<12>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        case 14: rc = launch_aggregate<14>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
-        default: rc = launch_aggregate<16>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, s, m, ld, st); break;
+        case 2:  rc = launch_aggregate<2>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 4:  rc = launch_aggregate<4>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 6:  rc = launch_aggregate<6>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 8:  rc = launch_aggregate<8>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 10: rc = launch_aggregate<10>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 12: rc = launch_aggregate<12>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        case 14: rc = launch_aggregate<14>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
+        default: rc = launch_aggregate<16>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
         }
         if (rc != GRX_OK) return rc;
     }

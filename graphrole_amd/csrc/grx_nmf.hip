@@ -34,16 +34,19 @@ __global__ __launch_bounds__(256) void gather_columns_kernel(int64_t n, int F,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
-// sum partial[b*P + p] over b in fixed order
-__global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
-                                                             int nblocks, int P,
-                                                             double *__restrict__ out)
+// out[p] = sum_b partial[p*nb + b]: one wavefront per output, per-lane sequential partial sums
+// then a fixed butterfly (bitwise reproducible).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partial,
+                                                              int nb, int P, double *__restrict__ out)
 {
-    const int p = blockIdx.x * 64 + threadIdx.x;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const double *src = partial + (size_t)p * nb;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * P + p];
-    out[p] = s;
+    for (int b = lane; b < nb; b += 64) s += src[b];
+    s = grx_group_sum<64>(s);
+    if (lane == 0) out[p] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -123,25 +126,24 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
             }
         }
     }
-    double *out = partial + (size_t)blockIdx.x * (npairs + 1);
+    // partial layout [npairs + 1][gridDim.x]
 #pragma unroll
     for (int s = 0; s < GR_PSLOTS; ++s) {
         const int id = t + 256 * s;
-        if (id < npairs) out[id] = acc[s];
+        if (id < npairs) partial[(size_t)id * gridDim.x + blockIdx.x] = acc[s];
     }
     xsum = grx_group_sum<64>(xsum);
     if (i == 0) xred[g] = xsum;
     __syncthreads();
-    if (t == 0) out[npairs] = ((xred[0] + xred[1]) + xred[2]) + xred[3];
+    if (t == 0) partial[(size_t)npairs * gridDim.x + blockIdx.x] = ((xred[0] + xred[1]) + xred[2]) + xred[3];
 }
 
-// partial [nblocks][npairs+1] -> out: full symmetric k x k, then the X sum
-__global__ __launch_bounds__(64) void gram_finalize_kernel(const double *__restrict__ partial,
-                                                           int nblocks, int k,
-                                                           double *__restrict__ out)
+// partial [npairs+1][nb] -> out: full symmetric k x k, then the X sum (one wavefront per output)
+__global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__restrict__ partial,
+                                                            int nb, int k, double *__restrict__ out)
 {
     const int npairs = k * (k + 1) / 2;
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx > k * k) return;
     int id;
     if (idx == k * k) {
@@ -151,9 +153,12 @@ __global__ __launch_bounds__(64) void gram_finalize_kernel(const double *__restr
         const int lo = a < b ? a : b, hi = a < b ? b : a;
         id = hi * (hi + 1) / 2 + lo;
     }
+    const int lane = threadIdx.x & 63;
+    const double *src = partial + (size_t)id * nb;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (npairs + 1) + id];
-    out[idx] = s;
+    for (int b = lane; b < nb; b += 64) s += src[b];
+    s = grx_group_sum<64>(s);
+    if (lane == 0) out[idx] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int6
             }
         }
     }
-    double *out = partial + (size_t)blockIdx.x * P;
+    // partial layout [P][gridDim.x]
     if (P <= 256) {
         __syncthreads();
         double *red = sX;                               // ngrp * P <= 256 doubles
@@ -355,13 +360,13 @@ __global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int6
         if (t < P) {
             double s = 0.0;
             for (int gI = 0; gI < ngrp; ++gI) s += red[gI * P + t];
-            out[t] = s;
+            partial[(size_t)t * gridDim.x + blockIdx.x] = s;
         }
     } else {
 #pragma unroll
         for (int s = 0; s < MU_PSLOTS; ++s) {
             const int pid = t + 256 * s;
-            if (pid < P) out[pid] = acc[s];
+            if (pid < P) partial[(size_t)pid * gridDim.x + blockIdx.x] = acc[s];
         }
     }
 }
@@ -509,7 +514,7 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
         }
     }
     GRX_LAUNCH_CHECK();
-    gram_finalize_kernel<<<(k * k + 1 + 63) / 64, 64, 0, st>>>(partial, grid, k, d_out);
+    gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, grid, k, d_out);
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
@@ -613,7 +618,7 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
-    reduce_partials_kernel<<<(P + 63) / 64, 64, 0, st>>>(partial, grid, P, d_AB);
+    reduce_partials_kernel<<<(P + 3) / 4, 256, 0, st>>>(partial, grid, P, d_AB);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -657,7 +662,7 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
-    reduce_partials_kernel<<<1, 64, 0, st>>>(partial, grid, 1, d_out);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(partial, grid, 1, d_out);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

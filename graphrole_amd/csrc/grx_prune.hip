@@ -76,33 +76,43 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
     hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
 
-// One workgroup per column: in-place exclusive scan of RADIX*ntiles counters.
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t *__restrict__ hist, int64_t len)
+// One workgroup (16 waves) per column: in-place exclusive scan of the digit-major counter table
+// hist[RADIX][ntiles].  Wave w scans the tile counts of digits w, w+16, ... (coalesced, 64 tiles
+// per step), the 256 digit totals are scanned once, then the digit bases are added back.
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t *__restrict__ hist, int ntiles)
 {
-    __shared__ uint32_t wave_tot[16];
-    uint32_t *h = hist + (size_t)blockIdx.x * len;
+    __shared__ uint32_t tot[RADIX];
+    uint32_t *h = hist + (size_t)blockIdx.x * RADIX * ntiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = (len + 1023) / 1024;
-    const int64_t b = (int64_t)threadIdx.x * per;
-    const int64_t e = (b + per < len) ? (b + per) : len;
-    uint32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += h[i];
-    // inclusive scan of s across the workgroup
-    uint32_t inc = s;
+    for (int d = wave; d < RADIX; d += 16) {
+        uint32_t *row = h + (size_t)d * ntiles;
+        uint32_t carry = 0;
+        for (int t0 = 0; t0 < ntiles; t0 += 64) {
+            const int t = t0 + lane;
+            const uint32_t x = (t < ntiles) ? row[t] : 0u;
+            uint32_t inc = x;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += y;
+            }
+            if (t < ntiles) row[t] = carry + inc - x;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) tot[d] = carry;
     }
-    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int i = 0; i < 16; ++i) { const uint32_t t = wave_tot[i]; wave_tot[i] = run; run += t; }
+        for (int d = 0; d < RADIX; ++d) { const uint32_t t = tot[d]; tot[d] = run; run += t; }
     }
     __syncthreads();
-    uint32_t run = wave_tot[wave] + inc - s;       // exclusive prefix of this thread's slice
-    for (int64_t i = b; i < e; ++i) { const uint32_t t = h[i]; h[i] = run; run += t; }
+    for (int d = wave; d < RADIX; d += 16) {
+        const uint32_t base = tot[d];
+        if (base == 0) continue;
+        uint32_t *row = h + (size_t)d * ntiles;
+        for (int t = lane; t < ntiles; t += 64) row[t] += base;
+    }
 }
 
 template <bool FROM_F64, bool TO_F64>
@@ -326,7 +336,6 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
 {
     const SortPlan p = make_plan(n, ncols);
     const dim3 grid(p.ntiles, ncols);
-    const int64_t scan_len = (int64_t)RADIX * p.ntiles;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 8 * pass;
         // ping-pong: pass 0 cols->A, odd A->out, even out->A; pass 7 writes fp64 into out
@@ -346,7 +355,7 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         }
         GRX_LAUNCH_CHECK();
         { GRX_PROF(GRX_K_SORT_SCAN, st);
-        scan_kernel<<<ncols, 1024, 0, st>>>(hist, scan_len);
+        scan_kernel<<<ncols, 1024, 0, st>>>(hist, p.ntiles);
         }
         GRX_LAUNCH_CHECK();
         {

@@ -32,7 +32,7 @@ const char *const g_prof_names[GRX_K_COUNT] = {
     "aggregate_hub_kernel", "tile_count_kernel", "scan_kernel", "scatter_kernel", "bin_threshold_kernel",
     "bin_assign_kernel", "chebyshev_kernel", "gather_columns_kernel", "gram_kernel", "project_kernel",
     "nndsvd_apply_kernel", "nmf_w_pass_kernel", "reduce_partials_kernel", "nmf_h_update_kernel",
-    "nmf_residual_kernel", "add_columns_kernel"};
+    "nmf_residual_kernel", "add_columns_kernel", "triangle_count_kernel", "egonet_from_triangles_kernel"};
 }  // namespace
 
 void grx_prof_begin(int id, hipStream_t st)
@@ -40,7 +40,7 @@ void grx_prof_begin(int id, hipStream_t st)
     if (!g_prof_on) return;
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return;
-    hipEventRecord(ev, st);
+    (void)hipEventRecord(ev, st);
     g_prof_open[id] = ev;
 }
 
@@ -49,7 +49,7 @@ void grx_prof_end(int id, hipStream_t st)
     if (!g_prof_on || g_prof_open[id] == nullptr) return;
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return;
-    hipEventRecord(ev, st);
+    (void)hipEventRecord(ev, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pending.push_back({id, g_prof_open[id], ev});
     g_prof_open[id] = nullptr;
@@ -66,7 +66,7 @@ int grx_profile_enable(int on)
 int grx_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &r : g_prof_pending) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+    for (auto &r : g_prof_pending) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     g_prof_pending.clear();
     for (int i = 0; i < GRX_K_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
     return GRX_OK;
@@ -89,8 +89,8 @@ int grx_profile_read(int id, double *total_ms, long long *launches)
         GRX_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
         g_prof_ms[r.id] += ms;
         g_prof_cnt[r.id] += 1;
-        hipEventDestroy(r.start);
-        hipEventDestroy(r.stop);
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
     }
     g_prof_pending.clear();
     if (total_ms) *total_ms = g_prof_ms[id];

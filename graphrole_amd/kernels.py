@@ -16,6 +16,7 @@ import torch
 from . import _lib
 
 c_void_p = ctypes.c_void_p
+HUB_FACTOR = 32          # GRX_HUB_FACTOR in csrc/grx_common.h
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -75,6 +76,28 @@ class DeviceCSR:
         avg = self.nnz / max(self.n, 1)
         # lanes that cooperate on one row in grx_aggregate: ~half the mean degree, power of two
         self.lanes_per_row = 4 if avg < 12 else 8 if avg < 24 else 16 if avg < 48 else 32
+        # rows above 32 * lanes_per_row neighbours get a workgroup each (grx_aggregate hub list)
+        deg = np.diff(np.asarray(row_ptr, dtype=np.int64))
+        hubs = np.nonzero(deg > HUB_FACTOR * self.lanes_per_row)[0].astype(np.int32)
+        self.n_hubs = int(len(hubs))
+        self.hub_rows = torch.from_numpy(hubs).to(dev) if self.n_hubs else None
+        self._host = (np.asarray(row_ptr, dtype=np.int64), col) if w is None else None
+        self._oriented = None
+
+    def oriented(self) -> 'DeviceCSR':
+        """Degree-oriented copy (arc u->v iff (d'(u),u) < (d'(v),v)) for grx_triangle_counts."""
+        if self._oriented is None:
+            row_ptr, col = self._host
+            n = self.n
+            rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(row_ptr))
+            colv = col.astype(np.int64)
+            loops = np.bincount(rows[rows == colv], minlength=n)
+            dprime = np.diff(row_ptr) - loops
+            keep = (dprime[rows] < dprime[colv]) | ((dprime[rows] == dprime[colv]) & (rows < colv))
+            o_ptr = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.bincount(rows[keep], minlength=n), out=o_ptr[1:])
+            self._oriented = DeviceCSR(o_ptr, col[keep])
+        return self._oriented
 
 
 def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: Optional[int] = None,
@@ -95,6 +118,44 @@ def add_columns(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tensor] = None,
                     row_begin: int = 0, row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    row_end = csr.n if row_end is None else row_end
+    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    if csr.w is None and not directed:
+        # exact integer fast path through per-node triangle counts
+        T = triangle_counts(csr)
+        return egonet_from_triangles(csr, T, row_begin, row_end)
+    if csr.w is not None and rowsum is None:
+        rowsum = row_sums(csr, False)
+    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
+              int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _stream())
+    return internal, external
+
+
+def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] = None) -> torch.Tensor:
+    """int64 [n] triangle counts through every node, accumulated over oriented source rows
+    [row_begin,row_end) (all-reduce SUM across ranks when the rows are split)."""
+    row_end = csr.n if row_end is None else row_end
+    o = csr.oriented()
+    T = torch.zeros(max(csr.n, 1), dtype=torch.int64, device=device())
+    _lib.call('grx_triangle_counts', csr.n, _ptr(o.row_ptr), _ptr(o.col), row_begin, row_end, _ptr(T), _stream())
+    return T
+
+
+def egonet_from_triangles(csr: DeviceCSR, T: torch.Tensor, row_begin: int = 0,
+                          row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    row_end = csr.n if row_end is None else row_end
+    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    scratch = torch.empty(max(csr.n, 1), dtype=torch.int64, device=device())
+    _lib.call('grx_egonet_unweighted', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(T), row_begin, row_end,
+              _ptr(internal), _ptr(external), _ptr(scratch), _stream())
+    return internal, external
+
+
+def egonet_features_general(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tensor] = None,
+                            row_begin: int = 0, row_end: Optional[int] = None):
+    """The gather kernel for any graph (weighted / directed); also valid for unweighted undirected."""
     row_end = csr.n if row_end is None else row_end
     internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
     external = torch.zeros(csr.n, dtype=torch.float64, device=device())
@@ -135,7 +196,7 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
         m_ptr = c_void_p(out.data_ptr() + (f + c0) * n * 8) if want_mean else None
         r_ptr = c_void_p(rows.data_ptr() + c0 * 8)
         _lib.call('grx_aggregate', n, _ptr(csr.row_ptr), _ptr(csr.col), fc, r_ptr, ldr, row_begin, row_end,
-                  s_ptr, m_ptr, n, csr.lanes_per_row, _stream())
+                  s_ptr, m_ptr, n, csr.lanes_per_row, _ptr(csr.hub_rows), csr.n_hubs, _stream())
     return out
 
 

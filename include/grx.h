@@ -102,6 +102,23 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
                         int64_t row_begin, int64_t row_end, double *d_internal,
                         double *d_external, void *stream);
 
+/*
+ * Fast path of the same ego-net features for UNWEIGHTED UNDIRECTED graphs (BASELINE configs
+ * 1-4), exact in integer arithmetic:  with d' the loop-free degrees, L the self-loop flags and
+ * T(v) the number of triangles through v,
+ *     internal(v) = d'(v) + T(v) + sum_{a in ego(v)} L(a),
+ *     external(v) = sum_{a in ego(v)} d'(a) - 2 (d'(v) + T(v)).
+ * grx_triangle_counts accumulates T (caller zero-fills d_T, uint64[n]) from the degree-oriented
+ * graph (CSR that keeps arc u->v iff (d'(u),u) < (d'(v),v), columns ascending); only source rows
+ * [row_begin,row_end) are processed, so ranks can split the arcs and all-reduce(SUM) d_T.
+ * grx_egonet_unweighted then writes rows [row_begin,row_end); d_scratch: int64[n].
+ */
+int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_o_col,
+                        int64_t row_begin, int64_t row_end, uint64_t *d_T, void *stream);
+int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
+                          const uint64_t *d_T, int64_t row_begin, int64_t row_end,
+                          double *d_internal, double *d_external, int64_t *d_scratch, void *stream);
+
 /* ------------------------------------------------------------------ recursion ----------- */
 /*
  * Pack f feature columns into the row-major gather source of grx_aggregate.
@@ -122,13 +139,16 @@ int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_r
  * d_sum / d_mean: column-major, column c at d_sum + c*ld (ld >= n); only rows
  * [row_begin,row_end) are written.  Either output may be NULL.  f <= 64.
  * lanes_per_row in {4,8,16,32}: lanes that cooperate on one row (pick ~ half the average
- * degree; anything else selects 8).  Per-row summation order is a fixed function of the row's
- * degree and lanes_per_row, so equal input columns give bitwise-equal output columns and
- * repeated runs are bitwise reproducible.
+ * degree; anything else selects 8).  d_hub_rows / n_hub_rows: ascending int32 list of the rows
+ * with degree > 32 * lanes_per_row (may be NULL / 0): those rows get one workgroup each.
+ * Per-row summation order is a fixed function of the row's degree, lanes_per_row and whether a
+ * hub list is given, so equal input columns give bitwise-equal output columns and repeated
+ * runs are bitwise reproducible.
  */
 int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                   const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
-                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row, void *stream);
+                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row,
+                  const int32_t *d_hub_rows, int64_t n_hub_rows, void *stream);
 
 /* ------------------------------------------------------------------ pruning ------------- */
 /*

@@ -66,6 +66,11 @@ def test_row_sums_and_egonet_vs_oracle(K, spec):
     if not spec['weighted']:
         assert np.array_equal(internal.cpu().numpy(), ego['internal_edges'])
         assert np.array_equal(got_ext, ego['external_edges'])
+    if not spec['weighted'] and not spec['directed']:
+        # K.egonet_features took the triangle-count fast path; the general gather kernel must agree
+        i2, e2 = K.egonet_features_general(csr, False)
+        assert np.array_equal(i2.cpu().numpy(), ego['internal_edges'])
+        assert np.array_equal(e2.cpu().numpy(), ego['external_edges'])
 
 
 def test_egonet_hub_rows_powerlaw(K):
@@ -77,9 +82,15 @@ def test_egonet_hub_rows_powerlaw(K):
     assert np.diff(og.row_ptr).max() > 600
     csr = _dev_csr(K, og)
     ego = refex.egonet_features_c(og)
-    internal, external = K.egonet_features(csr, False)
+    internal, external = K.egonet_features(csr, False)                 # triangle-count fast path
     assert np.array_equal(internal.cpu().numpy(), ego['internal_edges'])
     assert np.array_equal(external.cpu().numpy(), ego['external_edges'])
+    internal, external = K.egonet_features_general(csr, False)         # gather kernel, hub workgroups
+    assert np.array_equal(internal.cpu().numpy(), ego['internal_edges'])
+    assert np.array_equal(external.cpu().numpy(), ego['external_edges'])
+    T = K.triangle_counts(csr).cpu().numpy()
+    Ta = K.triangle_counts(csr, 0, 12345).cpu().numpy() + K.triangle_counts(csr, 12345, None).cpu().numpy()
+    assert np.array_equal(T[:n], Ta[:n])                                # arc ranges add up (all-reduce SUM)
     # node-range slices reproduce the full result
     i2, e2 = K.egonet_features(csr, False, row_begin=1000, row_end=17000)
     assert np.array_equal(i2.cpu().numpy()[1000:17000], ego['internal_edges'][1000:17000])
