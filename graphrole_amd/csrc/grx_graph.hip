@@ -60,6 +60,11 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        if (w == nullptr) {                                 // implicit weight 1: degree from row_ptr
+            if (lane == 0)
+                out[v] = (double)((e - b) + ((add_loop && find_in_row(col, b, e, (int32_t)v) >= 0) ? 1 : 0));
+            continue;
+        }
         double s = 0.0, loop = 0.0;
         for (int64_t k = b + lane; k < e; k += G) {
             const double x = w ? w[k] : 1.0;

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void nndsvd_apply_kernel(int64_t row_begin, in
 // ---------------------------------------------------------------------------------------
 // multiplicative update, W side (fused with the H-side reductions)
 // ---------------------------------------------------------------------------------------
+constexpr int MU_MAX_GRID = GRX_NUM_CU * 4;      // workgroups of the W pass (LDS admits >= 2 per CU)
 constexpr int MU_PSLOTS = (MAX_R * MAX_F + MAX_R * MAX_R + 255) / 256;      // 9
 
 static inline size_t mu_lds_doubles(int F, int r, int TR)
@@ -344,9 +345,17 @@ __global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int6
                     const double *a, *b;
                     if (pid < nA) { a = sW + (pid / F) * LD; b = sX + (pid % F) * LD; }
                     else { const int q = pid - nA; a = sW + (q / r) * LD; b = sW + (q % r) * LD; }
-                    double v = acc[s];
-                    for (int i = grp; i < TR; i += ngrp) v += a[i] * b[i];
-                    acc[s] = v;
+                    // four independent partial sums hide the fp64 FMA latency (fixed order)
+                    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                    int i = grp;
+                    for (; i + 3 * ngrp < TR; i += 4 * ngrp) {
+                        v0 += a[i] * b[i];
+                        v1 += a[i + ngrp] * b[i + ngrp];
+                        v2 += a[i + 2 * ngrp] * b[i + 2 * ngrp];
+                        v3 += a[i + 3 * ngrp] * b[i + 3 * ngrp];
+                    }
+                    for (; i < TR; i += ngrp) v0 += a[i] * b[i];
+                    acc[s] += (v0 + v1) + (v2 + v3);
                 }
             }
         }
@@ -434,7 +443,7 @@ int pick_tr(int F, int r)
 int mu_grid(int64_t nrows, int TR)
 {
     const int64_t tiles = grx_ceil_div(nrows, TR);
-    return (int)(tiles > GRX_NUM_CU * 2 ? GRX_NUM_CU * 2 : (tiles < 1 ? 1 : tiles));
+    return (int)(tiles > MU_MAX_GRID ? MU_MAX_GRID : (tiles < 1 ? 1 : tiles));
 }
 
 constexpr int RES_GRID = GRX_NUM_CU * 4;
@@ -470,7 +479,7 @@ int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double
 static int gram_grid(int64_t nrows)
 {
     const int64_t tiles = grx_ceil_div(nrows, GR_TR);
-    return (int)(tiles > GRX_NUM_CU * 2 ? GRX_NUM_CU * 2 : (tiles < 1 ? 1 : tiles));
+    return (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : (tiles < 1 ? 1 : tiles));
 }
 
 size_t grx_gram_workspace_bytes(int64_t n, int k)
@@ -583,7 +592,7 @@ size_t grx_nmf_workspace_bytes(int64_t n, int F, int r)
     if (F < 1) F = 1;
     if (r < 1) r = 1;
     const size_t P = (size_t)r * F + (size_t)r * r;
-    const size_t a = grx_align_up((size_t)GRX_NUM_CU * 2 * P * 8, 256);
+    const size_t a = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256);
     const size_t b = grx_align_up((size_t)RES_GRID * 8, 256);
     return a + b;
 }
@@ -653,7 +662,7 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
     hipStream_t st = grx_stream(stream);
     const size_t P = (size_t)r * F + (size_t)r * r;
     double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(d_workspace) +
-                                                 grx_align_up((size_t)GRX_NUM_CU * 2 * P * 8, 256));
+                                                 grx_align_up((size_t)MU_MAX_GRID * P * 8, 256));
     const int64_t want = grx_ceil_div(row_end - row_begin, 256);
     const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
     { GRX_PROF(GRX_K_NMF_RESIDUAL, st);

@@ -76,49 +76,63 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
     hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
 
-// One workgroup (16 waves) per column: in-place exclusive scan of the digit-major counter table
-// hist[RADIX][ntiles].  Wave w scans the tile counts of digits w, w+16, ... (coalesced, 64 tiles
-// per step), the 256 digit totals are scanned once, then the digit bases are added back.
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t *__restrict__ hist, int ntiles)
+// Exclusive scan of the digit-major counter table hist[RADIX][ntiles] of every column, in two
+// short kernels with (RADIX x ncols) wavefront-sized workgroups each:
+//   scan_rows_kernel   : per (column, digit) exclusive scan across tiles, digit total -> tot
+//   scan_digits_kernel : per column exclusive scan of the 256 digit totals -> base
+// scatter_kernel adds base[digit] to the per-tile offset.
+__global__ __launch_bounds__(64) void scan_rows_kernel(uint32_t *__restrict__ hist, int ntiles,
+                                                       uint32_t *__restrict__ tot)
 {
-    __shared__ uint32_t tot[RADIX];
-    uint32_t *h = hist + (size_t)blockIdx.x * RADIX * ntiles;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = wave; d < RADIX; d += 16) {
-        uint32_t *row = h + (size_t)d * ntiles;
-        uint32_t carry = 0;
-        for (int t0 = 0; t0 < ntiles; t0 += 64) {
-            const int t = t0 + lane;
-            const uint32_t x = (t < ntiles) ? row[t] : 0u;
-            uint32_t inc = x;
+    const int d = blockIdx.x, col = blockIdx.y, lane = threadIdx.x;
+    uint32_t *row = hist + ((size_t)col * RADIX + d) * ntiles;
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 64 * 4) {
+        uint32_t x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // issue the loads together
+            const int t = t0 + j * 64 + lane;
+            x[j] = (t < ntiles) ? row[t] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * 64 + lane;
+            uint32_t inc = x[j];
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t y = __shfl_up(inc, off, 64);
                 if (lane >= off) inc += y;
             }
-            if (t < ntiles) row[t] = carry + inc - x;
+            if (t < ntiles) row[t] = carry + inc - x[j];
             carry += __shfl(inc, 63, 64);
         }
-        if (lane == 0) tot[d] = carry;
     }
+    if (lane == 0) tot[(size_t)col * RADIX + d] = carry;
+}
+
+__global__ __launch_bounds__(RADIX) void scan_digits_kernel(const uint32_t *__restrict__ tot,
+                                                            uint32_t *__restrict__ base)
+{
+    __shared__ uint32_t wsum[4];
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    const uint32_t x = tot[(size_t)blockIdx.x * RADIX + d];
+    uint32_t inc = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int d = 0; d < RADIX; ++d) { const uint32_t t = tot[d]; tot[d] = run; run += t; }
-    }
-    __syncthreads();
-    for (int d = wave; d < RADIX; d += 16) {
-        const uint32_t base = tot[d];
-        if (base == 0) continue;
-        uint32_t *row = h + (size_t)d * ntiles;
-        for (int t = lane; t < ntiles; t += 64) row[t] += base;
-    }
+    uint32_t pre = 0;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    base[(size_t)blockIdx.x * RADIX + d] = pre + inc - x;
 }
 
 template <bool FROM_F64, bool TO_F64>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     const void *__restrict__ src, int64_t src_ld, void *__restrict__ dst, int64_t dst_ld, int64_t n,
-    int shift, int ntiles, const uint32_t *__restrict__ offsets)
+    int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_base)
 {
     __shared__ uint32_t cnt[4][RADIX];
     const int col = blockIdx.y, tile = blockIdx.x;
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     {
         const int d = threadIdx.x;
         const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
-        const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile];
+        const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile] + digit_base[(size_t)col * RADIX + d];
         cnt[0][d] = g;
         cnt[1][d] = g + c0;
         cnt[2][d] = g + c0 + c1;
@@ -326,7 +340,9 @@ SortPlan make_plan(int64_t n, int ncols)
     SortPlan p;
     p.ntiles = (int)grx_ceil_div(n, SORT_TILE);
     p.keys_bytes = grx_align_up((size_t)ncols * (size_t)n * 8, 256);
-    p.hist_bytes = grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256);
+    // per-tile counters + digit totals + digit bases
+    p.hist_bytes = grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) +
+                   2 * grx_align_up((size_t)ncols * RADIX * 4, 256);
     return p;
 }
 
@@ -336,6 +352,8 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
 {
     const SortPlan p = make_plan(n, ncols);
     const dim3 grid(p.ntiles, ncols);
+    uint32_t *tot = hist + grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) / 4;
+    uint32_t *dbase = tot + grx_align_up((size_t)ncols * RADIX * 4, 256) / 4;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 8 * pass;
         // ping-pong: pass 0 cols->A, odd A->out, even out->A; pass 7 writes fp64 into out
@@ -354,15 +372,17 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
             else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
         }
         GRX_LAUNCH_CHECK();
-        { GRX_PROF(GRX_K_SORT_SCAN, st);
-        scan_kernel<<<ncols, 1024, 0, st>>>(hist, p.ntiles);
+        {
+            GRX_PROF(GRX_K_SORT_SCAN, st);
+            scan_rows_kernel<<<dim3(RADIX, ncols), 64, 0, st>>>(hist, p.ntiles, tot);
+            scan_digits_kernel<<<ncols, RADIX, 0, st>>>(tot, dbase);
         }
         GRX_LAUNCH_CHECK();
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
-            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
-            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist);
+            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
+            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
+            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
         }
         GRX_LAUNCH_CHECK();
     }

@@ -55,8 +55,9 @@ class ShardPlan:
             return block
         send = torch.zeros((ncols, self.max_rows), dtype=block.dtype, device=block.device)
         send[:, :self.row_end - self.row_begin] = block[:, self.row_begin:self.row_end]
-        recv = torch.empty((self.world, ncols, self.max_rows), dtype=block.dtype, device=block.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
+        recv = flat.view(self.world, ncols, self.max_rows)
         for p in range(self.world):
             b, e = int(self.bounds[p]), int(self.bounds[p + 1])
             if p != self.rank and e > b:

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""
+Condense rocprofv3 output collected by tools/profile_gpu.sh (gpurun_out/prof_<tag>/) into
+profiles/<tag>_kernel_stats.csv (per-kernel count / total / average / share) and
+profiles/<tag>_pmc.json (per-kernel averages of the PMC counters, with the gfx950 FETCH_SIZE
+correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128 B request -> doubled).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join('gpurun_out', f'prof_{tag}')
+os.makedirs('profiles', exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    return re.sub(r'\(.*$', '', name)
+
+
+# ---- kernel trace -> stats
+rows = defaultdict(lambda: [0, 0.0])
+for path in glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True):
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3      # us
+            k = short(r['Kernel_Name'])
+            rows[k][0] += 1
+            rows[k][1] += dur
+total = sum(v[1] for v in rows.values()) or 1.0
+with open(os.path.join('profiles', f'{tag}_kernel_stats.csv'), 'w') as fh:
+    fh.write('kernel,calls,total_us,avg_us,percent\n')
+    for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        fh.write(f'"{k}",{c},{t:.1f},{t / c:.2f},{100 * t / total:.2f}\n')
+print(f'{len(rows)} kernels, total {total / 1e3:.2f} ms')
+
+# ---- pmc passes
+pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for path in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            k = short(r['Kernel_Name'])
+            cell = pmc[k][r['Counter_Name']]
+            cell[0] += 1
+            cell[1] += float(r['Counter_Value'])
+out = {}
+for k, ctrs in pmc.items():
+    d = {c: v[1] / v[0] for c, v in ctrs.items()}
+    d['launches_sampled'] = max(v[0] for v in ctrs.values())
+    if 'FETCH_SIZE' in d:
+        # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; gfx950 FETCH_SIZE = 1/2 of the bytes
+        d['hbm_read_bytes_per_launch_corrected'] = d['FETCH_SIZE'] * 1024 * 2
+    if 'WRITE_SIZE' in d:
+        d['hbm_write_bytes_per_launch'] = d['WRITE_SIZE'] * 1024
+    if 'TCC_HIT_sum' in d and 'TCC_MISS_sum' in d and d['TCC_HIT_sum'] + d['TCC_MISS_sum'] > 0:
+        d['l2_hit_rate'] = d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum'])
+    out[k] = d
+json.dump(out, open(os.path.join('profiles', f'{tag}_pmc.json'), 'w'), indent=1, sort_keys=True)
+print(f'pmc kernels: {len(out)}')
