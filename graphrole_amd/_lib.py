@@ -51,6 +51,7 @@ _SIGNATURES = {
     'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p]),
     'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'grx_aggregate_ldr': (c_int, [c_int]),
     'grx_aggregate': (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
                               c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -291,62 +291,61 @@ __global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const doubl
 // ---------------------------------------------------------------------------------------
 // neighbour aggregation
 // ---------------------------------------------------------------------------------------
-// G lanes cooperate on one output row; lane l gathers neighbours l, l+G, ... (two per trip for
-// memory-level parallelism) as FP/2 16-byte loads each, accumulates FP fp64 partials, then a
-// fixed G-wide butterfly produces the row sum.  Rows with degree > hub_deg are left to
-// aggregate_hub_kernel.
-template <int FP, int G>
+// G lanes cooperate on one output row.  A neighbour's feature row is padded to LDR doubles
+// (LDR*8 = 16/32/64/128 bytes, so a row never straddles a 128-byte line and 64-byte rows are
+// exactly one cache line) and is fetched by CL = LDR/2 ADJACENT lanes, 16 bytes each: one
+// wave-level load touches 64/CL distinct lines instead of 64, which is what the address
+// units / L1 care about for a random gather.  Lane = (slot, part): slot = lane / CL walks the
+// neighbour list (two neighbours per trip for memory-level parallelism), part = lane % CL owns
+// columns 2*part, 2*part+1.  The slots are combined by a fixed butterfly, so the addition tree
+// of a row depends only on its degree and the launch geometry.  Rows with degree > hub_deg are
+// left to aggregate_hub_kernel.
+template <int LDR, int G>
 __global__ __launch_bounds__(256) void aggregate_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ rows, int ldr, int f, int64_t row_begin, int64_t row_end,
+    const double *__restrict__ rows, int64_t row_stride, int f, int64_t row_begin, int64_t row_end,
     int64_t hub_deg, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
 {
+    constexpr int CL = LDR / 2;           // lanes per neighbour row
+    constexpr int S = G / CL;             // neighbour slots per output row
+    static_assert(S >= 1 && (S & (S - 1)) == 0, "G must be a power-of-two multiple of LDR/2");
     const int lane = threadIdx.x % G;
+    const int part = lane % CL, slot = lane / CL;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         const int64_t d = e - b;
         if (d > hub_deg) continue;
-        double acc[FP];
-#pragma unroll
-        for (int c = 0; c < FP; ++c) acc[c] = 0.0;
-        int64_t k = b + lane;
-        for (; k + G < e; k += 2 * G) {
-            const int64_t u0 = col[k], u1 = col[k + G];
-            const double2 *p0 = reinterpret_cast<const double2 *>(rows + u0 * ldr);
-            const double2 *p1 = reinterpret_cast<const double2 *>(rows + u1 * ldr);
-            double2 x0[FP / 2], x1[FP / 2];
-#pragma unroll
-            for (int c = 0; c < FP / 2; ++c) { x0[c] = p0[c]; x1[c] = p1[c]; }
-#pragma unroll
-            for (int c = 0; c < FP / 2; ++c) {
-                acc[2 * c] += x0[c].x; acc[2 * c + 1] += x0[c].y;
-            }
-#pragma unroll
-            for (int c = 0; c < FP / 2; ++c) {
-                acc[2 * c] += x1[c].x; acc[2 * c + 1] += x1[c].y;
-            }
+        double a0 = 0.0, a1 = 0.0;
+        int64_t k = b + slot;
+        for (; k + S < e; k += 2 * S) {
+            const int64_t u0 = col[k], u1 = col[k + S];
+            const double2 x0 = *reinterpret_cast<const double2 *>(rows + u0 * row_stride + 2 * part);
+            const double2 x1 = *reinterpret_cast<const double2 *>(rows + u1 * row_stride + 2 * part);
+            a0 += x0.x; a1 += x0.y;
+            a0 += x1.x; a1 += x1.y;
         }
         if (k < e) {
             const int64_t u0 = col[k];
-            const double2 *p0 = reinterpret_cast<const double2 *>(rows + u0 * ldr);
-#pragma unroll
-            for (int c = 0; c < FP / 2; ++c) {
-                const double2 x = p0[c];
-                acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
-            }
+            const double2 x0 = *reinterpret_cast<const double2 *>(rows + u0 * row_stride + 2 * part);
+            a0 += x0.x; a1 += x0.y;
         }
 #pragma unroll
-        for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<G>(acc[c]);
-        if (lane == 0) {
-            const double inv_cnt = (double)d;
-#pragma unroll
-            for (int c = 0; c < FP; ++c) {
-                if (c < f) {
-                    if (out_sum) out_sum[(int64_t)c * ld + v] = acc[c];
-                    if (out_mean) out_mean[(int64_t)c * ld + v] = (d > 0) ? acc[c] / inv_cnt : 0.0;
-                }
+        for (int off = CL; off < G; off <<= 1) {
+            a0 += __shfl_xor(a0, off, G);
+            a1 += __shfl_xor(a1, off, G);
+        }
+        if (slot == 0) {
+            const double cnt = (double)d;
+            const int c0 = 2 * part, c1 = 2 * part + 1;
+            if (c0 < f) {
+                if (out_sum) out_sum[(int64_t)c0 * ld + v] = a0;
+                if (out_mean) out_mean[(int64_t)c0 * ld + v] = (d > 0) ? a0 / cnt : 0.0;
+            }
+            if (c1 < f) {
+                if (out_sum) out_sum[(int64_t)c1 * ld + v] = a1;
+                if (out_mean) out_mean[(int64_t)c1 * ld + v] = (d > 0) ? a1 / cnt : 0.0;
             }
         }
     }
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
 template <int FP>
 __global__ __launch_bounds__(256) void aggregate_hub_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ rows, int ldr, int f, int64_t row_begin, int64_t row_end,
+    const double *__restrict__ rows, int64_t ldr, int f, int64_t row_begin, int64_t row_end,
     const int32_t *__restrict__ hub_rows, int64_t n_hubs, double *__restrict__ out_sum,
     double *__restrict__ out_mean, int64_t ld)
 {
@@ -396,29 +395,29 @@ __global__ __launch_bounds__(256) void aggregate_hub_kernel(
     }
 }
 
-template <int FP>
+template <int LDR>
 int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const double *rows,
-                     int ldr, int f, int64_t rb, int64_t re, int64_t hub_deg,
+                     int64_t row_stride, int f, int64_t rb, int64_t re, int64_t hub_deg,
                      const int32_t *hub_rows, int64_t n_hubs, double *s, double *m, int64_t ld,
                      hipStream_t st)
 {
+    constexpr int CL = LDR / 2;
+    if (G < CL) G = CL;
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
     const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
     {
         GRX_PROF(GRX_K_AGGREGATE, st);
-        switch (G) {
-        case 4:  aggregate_kernel<FP, 4><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-        case 8:  aggregate_kernel<FP, 8><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-        case 16: aggregate_kernel<FP, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-        default: aggregate_kernel<FP, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_deg, s, m, ld); break;
-        }
+        if (G <= 4 && CL <= 4) aggregate_kernel<LDR, (CL > 4 ? CL : 4)><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
+        else if (G <= 8 && CL <= 8) aggregate_kernel<LDR, (CL > 8 ? CL : 8)><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
+        else if (G <= 16) aggregate_kernel<LDR, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
+        else aggregate_kernel<LDR, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
     if (n_hubs > 0) {
         const int hgrid = (int)(n_hubs > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hubs);
         GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-        aggregate_hub_kernel<FP><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, ldr, f, rb, re, hub_rows, n_hubs, s, m, ld);
+        aggregate_hub_kernel<LDR><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_rows, n_hubs, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -559,12 +558,13 @@ int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
                 "grx_aggregate: bad row range");
-    GRX_REQUIRE(f >= 0 && ldr >= f && (ldr % 2) == 0, "grx_aggregate: ldr=%d must be even and >= f=%d", ldr, f);
+    GRX_REQUIRE(f >= 0 && ldr >= f, "grx_aggregate: ldr=%d < f=%d", ldr, f);
+    GRX_REQUIRE(ldr == 2 || ldr == 4 || ldr == 8 || (ldr >= 16 && ldr % 16 == 0),
+                "grx_aggregate: ldr=%d must be 2, 4, 8 or a multiple of 16 (use grx_aggregate_ldr)", ldr);
     if (row_end == row_begin || f == 0) return GRX_OK;
-    GRX_REQUIRE(f <= 64, "grx_aggregate: f=%d > 64 (split the columns)", f);
     GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate: NULL pointer");
     GRX_REQUIRE(ld >= n, "grx_aggregate: ld < n");
-    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, "grx_aggregate: d_rows must be 16-byte aligned");
+    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 127) == 0, "grx_aggregate: d_rows must be 128-byte aligned");
     int G = lanes_per_row;
     if (G != 4 && G != 8 && G != 16 && G != 32) G = 8;
     GRX_REQUIRE(n_hub_rows >= 0 && (n_hub_rows == 0 || d_hub_rows != nullptr), "grx_aggregate: bad hub list");
@@ -572,27 +572,31 @@ int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int
     // lane-group path (correct, but hubs then serialise on one lane group)
     const int64_t hub_deg = d_hub_rows ? (int64_t)G * GRX_HUB_FACTOR : ((int64_t)1 << 62);
     hipStream_t st = grx_stream(stream);
-    // columns are processed in chunks of at most 16 (accumulators stay in registers)
+    if (ldr < 16)
+        switch (ldr) {
+        case 2:  return launch_aggregate<2>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
+        case 4:  return launch_aggregate<4>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
+        default: return launch_aggregate<8>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
+        }
+    // wide rows: 16 columns (one 128-byte segment of every row) per launch
     for (int c0 = 0; c0 < f; c0 += 16) {
         const int fc = (f - c0 < 16) ? (f - c0) : 16;
-        const int fp = (fc + 1) & ~1;
-        const double *rows = d_rows + c0;
         double *s = d_sum ? d_sum + (int64_t)c0 * ld : nullptr;
         double *m = d_mean ? d_mean + (int64_t)c0 * ld : nullptr;
-        int rc;
-        switch (fp) {
-        case 2:  rc = launch_aggregate<2>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 4:  rc = launch_aggregate<4>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 6:  rc = launch_aggregate<6>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 8:  rc = launch_aggregate<8>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 10: rc = launch_aggregate<10>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 12: rc = launch_aggregate<12>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        case 14: rc = launch_aggregate<14>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        default: rc = launch_aggregate<16>(G, d_row_ptr, d_col, rows, ldr, fc, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, s, m, ld, st); break;
-        }
+        int rc = launch_aggregate<16>(G, d_row_ptr, d_col, d_rows + c0, ldr, fc, row_begin, row_end, hub_deg,
+                                      d_hub_rows, n_hub_rows, s, m, ld, st);
         if (rc != GRX_OK) return rc;
     }
     return GRX_OK;
+}
+
+/* row stride (in doubles) grx_pack_rows / grx_aggregate use for f columns */
+int grx_aggregate_ldr(int f)
+{
+    if (f <= 2) return 2;
+    if (f <= 4) return 4;
+    if (f <= 8) return 8;
+    return (f + 15) / 16 * 16;
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ constexpr int GR_LD = GR_TR + 1;
 constexpr int GR_YSLOTS = (MAX_F + 3) / 4;                          // 30
 constexpr int GR_PSLOTS = (MAX_F * (MAX_F + 1) / 2 + 255) / 256;    // 29
 
-template <bool HAS_T>
+template <bool HAS_T, int YS>
 __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t row_end, int F, int k,
                                                    const double *__restrict__ X, int64_t ldx,
                                                    const double *__restrict__ T,
@@ -89,20 +89,20 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
         const bool live = (r0 + i) < row_end;
         __syncthreads();
         if (HAS_T) {
-            double y[GR_YSLOTS];
+            double y[YS];
 #pragma unroll
-            for (int s = 0; s < GR_YSLOTS; ++s) y[s] = 0.0;
+            for (int s = 0; s < YS; ++s) y[s] = 0.0;
             for (int c = 0; c < F; ++c) {
                 const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
                 const double *Tc = T + (size_t)c * k;
 #pragma unroll
-                for (int s = 0; s < GR_YSLOTS; ++s) {
+                for (int s = 0; s < YS; ++s) {
                     const int j = g + 4 * s;
                     if (j < k) y[s] += x * Tc[j];
                 }
             }
 #pragma unroll
-            for (int s = 0; s < GR_YSLOTS; ++s) {
+            for (int s = 0; s < YS; ++s) {
                 const int j = g + 4 * s;
                 if (j < k) sY[j * GR_LD + i] = y[s];
             }
@@ -235,20 +235,31 @@ __global__ __launch_bounds__(256) void project_kernel(int64_t row_begin, int64_t
     }
 }
 
-// stats out: [r][4] = signed value of the max-|.| entry, its row index, sum sq pos, sum sq neg
+// stats out: [r][4] = signed value of the max-|.| entry, its row index, sum sq pos, sum sq neg.
+// One wavefront per column: lanes stride over the workgroup partials, then a fixed butterfly.
 __global__ __launch_bounds__(64) void project_finalize_kernel(const double *__restrict__ partial,
                                                               int nblocks, int r,
                                                               double *__restrict__ stats)
 {
-    const int j = threadIdx.x;
-    if (j >= r) return;
+    const int j = blockIdx.x, lane = threadIdx.x;
     double bm = -1.0, bs = 0.0, bi = 0.0, p = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         const double *o = partial + ((size_t)b * r + j) * 5;
         if (o[0] > bm || (o[0] == bm && o[2] < bi)) { bm = o[0]; bs = o[1]; bi = o[2]; }
         p += o[3]; q += o[4];
     }
-    stats[j * 4 + 0] = bs; stats[j * 4 + 1] = bi; stats[j * 4 + 2] = p; stats[j * 4 + 3] = q;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double om = __shfl_xor(bm, off, 64);
+        const double os = __shfl_xor(bs, off, 64);
+        const double oi = __shfl_xor(bi, off, 64);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bs = os; bi = oi; }
+    }
+    p = grx_group_sum<64>(p);
+    q = grx_group_sum<64>(q);
+    if (lane == 0) {
+        stats[j * 4 + 0] = bs; stats[j * 4 + 1] = bi; stats[j * 4 + 2] = p; stats[j * 4 + 3] = q;
+    }
 }
 
 struct NndsvdArgs { double sign[MAX_R]; double scale[MAX_R]; };
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void nndsvd_apply_kernel(int64_t row_begin, in
 // ---------------------------------------------------------------------------------------
 // multiplicative update, W side (fused with the H-side reductions)
 // ---------------------------------------------------------------------------------------
-constexpr int MU_MAX_GRID = GRX_NUM_CU * 4;      // workgroups of the W pass (LDS admits >= 2 per CU)
+constexpr int MU_MAX_GRID = GRX_NUM_CU * 8;      // workgroups of the W pass (LDS admits >= 2 per CU)
 constexpr int MU_PSLOTS = (MAX_R * MAX_F + MAX_R * MAX_R + 255) / 256;      // 9
 
 static inline size_t mu_lds_doubles(int F, int r, int TR)
@@ -434,7 +445,11 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
 
 int pick_tr(int F, int r)
 {
+    // largest row tile whose LDS footprint still lets 8 workgroups share a CU (160 KiB), else
+    // the largest that fits the 64 KiB per-workgroup limit
     const int cand[4] = {256, 128, 64, 32};
+    for (int i = 0; i < 4; ++i)
+        if (mu_lds_doubles(F, r, cand[i]) * 8 <= 20 * 1024) return cand[i];
     for (int i = 0; i < 4; ++i)
         if (mu_lds_doubles(F, r, cand[i]) * 8 <= 64 * 1024) return cand[i];
     return 0;
@@ -514,12 +529,16 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
     const size_t lds = (size_t)k * GR_LD * 8;
     if (h_T) {
         GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
-        { GRX_PROF(GRX_K_GRAM, st);
-        gram_kernel<true><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+        {
+            GRX_PROF(GRX_K_GRAM, st);
+            if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+            else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+            else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
         }
     } else {
         { GRX_PROF(GRX_K_GRAM, st);
-        gram_kernel<false><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial);
+        gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial);
         }
     }
     GRX_LAUNCH_CHECK();
@@ -562,7 +581,7 @@ int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_be
     project_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
     }
     GRX_LAUNCH_CHECK();
-    project_finalize_kernel<<<1, 64, 0, st>>>(partial, grid, r, d_stats);
+    project_finalize_kernel<<<r, 64, 0, st>>>(partial, grid, r, d_stats);
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

@@ -167,9 +167,10 @@ def egonet_features_general(csr: DeviceCSR, directed: bool, rowsum: Optional[tor
 
 
 def pack_rows(cols: Sequence[torch.Tensor], n: int) -> Tuple[torch.Tensor, int]:
-    """Column tensors -> row-major [n, ldr] gather source (ldr = f rounded up to even)."""
+    """Column tensors -> row-major [n, ldr] gather source, ldr = grx_aggregate_ldr(f) (cache-line
+    friendly row size: 16 / 32 / 64 bytes or whole 128-byte lines)."""
     f = len(cols)
-    ldr = max(2, (f + 1) & ~1)
+    ldr = _lib.load().grx_aggregate_ldr(f)
     rows = torch.empty((max(n, 1), ldr), dtype=torch.float64, device=device())
     if f and n:
         ptrs = ptr_array(cols)
@@ -190,13 +191,10 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
         out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
     if f == 0:
         return out
-    for c0 in range(0, f, 64):
-        fc = min(64, f - c0)
-        s_ptr = c_void_p(out.data_ptr() + c0 * n * 8) if want_sum else None
-        m_ptr = c_void_p(out.data_ptr() + (f + c0) * n * 8) if want_mean else None
-        r_ptr = c_void_p(rows.data_ptr() + c0 * 8)
-        _lib.call('grx_aggregate', n, _ptr(csr.row_ptr), _ptr(csr.col), fc, r_ptr, ldr, row_begin, row_end,
-                  s_ptr, m_ptr, n, csr.lanes_per_row, _ptr(csr.hub_rows), csr.n_hubs, _stream())
+    s_ptr = c_void_p(out.data_ptr()) if want_sum else None
+    m_ptr = c_void_p(out.data_ptr() + f * n * 8) if want_mean else None
+    _lib.call('grx_aggregate', n, _ptr(csr.row_ptr), _ptr(csr.col), f, _ptr(rows), ldr, row_begin, row_end,
+              s_ptr, m_ptr, n, csr.lanes_per_row, _ptr(csr.hub_rows), csr.n_hubs, _stream())
     return out
 
 

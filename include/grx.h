@@ -124,8 +124,10 @@ int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_
  * Pack f feature columns into the row-major gather source of grx_aggregate.
  * d_col_ptrs: DEVICE array of f device pointers (each an fp64 column of n values).
  * d_rows: n x ldr row-major, ldr >= f; columns f..ldr-1 are zero-filled.  grx_aggregate wants
- * ldr even (16-byte aligned rows).
+ * ldr = grx_aggregate_ldr(f): 2, 4, 8 or a multiple of 16 doubles, so that a feature row is a
+ * 16/32/64-byte slice of one cache line or a whole number of 128-byte lines.
  */
+int grx_aggregate_ldr(int f);
 int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
                   void *stream);
 
@@ -134,10 +136,11 @@ int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_r
  * (graphrole/features/extract.py:98-119):
  *     sum[c][v]  = sum_{u in row(v)} rows[u][c]
  *     mean[c][v] = sum[c][v] / |row(v)|      (0 when row(v) is empty)
- * d_rows: n x ldr row-major, ldr even, 16-byte aligned (all n rows are needed: neighbours may
- * live on any rank's slice).
+ * d_rows: n x ldr row-major, ldr = grx_aggregate_ldr(f), 128-byte aligned (all n rows are
+ * needed: neighbours may live on any rank's slice).  A neighbour row is fetched by ldr/2
+ * adjacent lanes (16 bytes each) so one request covers the whole row.
  * d_sum / d_mean: column-major, column c at d_sum + c*ld (ld >= n); only rows
- * [row_begin,row_end) are written.  Either output may be NULL.  f <= 64.
+ * [row_begin,row_end) are written.  Either output may be NULL.
  * lanes_per_row in {4,8,16,32}: lanes that cooperate on one row (pick ~ half the average
  * degree; anything else selects 8).  d_hub_rows / n_hub_rows: ascending int32 list of the rows
  * with degree > 32 * lanes_per_row (may be NULL / 0): those rows get one workgroup each.
