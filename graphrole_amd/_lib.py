@@ -42,6 +42,7 @@ _SIGNATURES = {
     'grx_event_record': (c_int, [c_void_p, c_void_p]),
     'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     'grx_profile_enable': (c_int, [c_int]),
+    'grx_profile_select': (c_int, [ctypes.c_uint64]),
     'grx_profile_reset': (c_int, []),
     'grx_profile_kernel_count': (c_int, []),
     'grx_profile_kernel_name': (c_char_p, [c_int]),
@@ -56,7 +57,7 @@ _SIGNATURES = {
                               c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_egonet_unweighted': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
-                                      c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'grx_log_bin_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_vertical_log_bin': (c_int, [c_int64, c_int, c_void_p, c_int64, c_double, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

@@ -47,6 +47,10 @@ struct GrxProfScope {
 };
 #define GRX_PROF(id, st) GrxProfScope grx_prof_scope_##id(id, st)
 
+// Column-pointer tables travel as kernel arguments (no host->device copy per call).
+constexpr int GRX_MAX_PTRS = 128;
+struct GrxPtrTable { const void *p[GRX_MAX_PTRS]; };
+
 constexpr int GRX_HUB_FACTOR = 32;  // grx_aggregate: rows longer than lanes_per_row * 32 are hubs
 constexpr int GRX_WAVE = 64;       // CDNA4 wavefront
 constexpr int GRX_NUM_CU = 256;    // MI355X

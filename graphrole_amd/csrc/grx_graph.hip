@@ -217,23 +217,37 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
     }
 }
 
-// info[v] = (d'(v) << 1) | L(v)
+// info[v] = (d'(v) << 1) | L(v)   (int32: the whole table is 4 B/node and stays L2-resident)
 __global__ __launch_bounds__(256) void node_info_kernel(int64_t n, const int64_t *__restrict__ row_ptr,
                                                         const int32_t *__restrict__ col,
-                                                        int64_t *__restrict__ info)
+                                                        int32_t *__restrict__ info)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += stride) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         const int64_t loop = find_in_row(col, b, e, (int32_t)v) >= 0 ? 1 : 0;
-        info[v] = (((e - b) - loop) << 1) | loop;
+        info[v] = (int32_t)((((e - b) - loop) << 1) | loop);
     }
 }
 
+__device__ __forceinline__ void egonet_finish_row(int64_t v, long long sum_d, long long loops,
+                                                  const int32_t *__restrict__ info,
+                                                  const unsigned long long *__restrict__ T,
+                                                  double *__restrict__ internal, double *__restrict__ external)
+{
+    const int32_t iv = info[v];
+    const long long dv = iv >> 1;
+    const long long core = dv + (long long)T[v];
+    internal[v] = (double)(core + loops + (iv & 1));
+    external[v] = (double)(sum_d + dv - 2 * core);
+}
+
+// G = 8 lanes per row; rows with more than hub_deg neighbours are left to the workgroup-per-row
+// variant below (integer sums: any order is exact).
 __global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const int64_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
-    int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
+    const int32_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
+    int64_t row_end, int64_t hub_deg, double *__restrict__ internal, double *__restrict__ external)
 {
     constexpr int G = 8;
     const int lane = threadIdx.x % G;
@@ -241,11 +255,12 @@ __global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        if (e - b > hub_deg) continue;
         long long sum_d = 0, loops = 0;
         for (int64_t k = b + lane; k < e; k += G) {
             const int32_t a = col[k];
             if (a != (int32_t)v) {
-                const int64_t ia = info[a];
+                const int32_t ia = info[a];
                 sum_d += ia >> 1;
                 loops += ia & 1;
             }
@@ -255,23 +270,51 @@ __global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
             sum_d += __shfl_xor(sum_d, off, G);
             loops += __shfl_xor(loops, off, G);
         }
-        if (lane == 0) {
-            const int64_t iv = info[v];
-            const long long dv = iv >> 1;
-            const long long core = dv + (long long)T[v];
-            internal[v] = (double)(core + loops + (iv & 1));
-            external[v] = (double)(sum_d + dv - 2 * core);
+        if (lane == 0) egonet_finish_row(v, sum_d, loops, info, T, internal, external);
+    }
+}
+
+__global__ __launch_bounds__(256) void egonet_from_triangles_hub_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
+    int64_t row_end, const int32_t *__restrict__ hub_rows, int64_t n_hubs,
+    double *__restrict__ internal, double *__restrict__ external)
+{
+    __shared__ long long red[2][4];
+    for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int64_t v = hub_rows[h];
+        if (v < row_begin || v >= row_end) continue;
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        long long sum_d = 0, loops = 0;
+        for (int64_t k = b + threadIdx.x; k < e; k += 256) {
+            const int32_t a = col[k];
+            if (a != (int32_t)v) {
+                const int32_t ia = info[a];
+                sum_d += ia >> 1;
+                loops += ia & 1;
+            }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_d += __shfl_xor(sum_d, off, 64);
+            loops += __shfl_xor(loops, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sum_d; red[1][threadIdx.x >> 6] = loops; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            egonet_finish_row(v, red[0][0] + red[0][1] + red[0][2] + red[0][3],
+                              red[1][0] + red[1][1] + red[1][2] + red[1][3], info, T, internal, external);
+        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // pack: column-major columns -> row-major n x ldr (zero padded)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ldr,
-                                                        const double *const *__restrict__ cols,
+__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ldr, GrxPtrTable cols_tab,
                                                         double *__restrict__ rows)
 {
+    const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double *dst = rows + i * ldr;
@@ -512,7 +555,8 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
 
 int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, const uint64_t *d_T,
                           int64_t row_begin, int64_t row_end, double *d_internal, double *d_external,
-                          int64_t *d_scratch, void *stream)
+                          int32_t *d_scratch, const int32_t *d_hub_rows, int64_t n_hub_rows, int64_t hub_degree,
+                          void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_egonet_unweighted: bad row range");
     if (n == 0) return GRX_OK;
@@ -527,25 +571,38 @@ int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_
     if (row_end > row_begin) {
         const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
         GRX_PROF(GRX_K_EGONET_FINISH, st);
+        const int64_t hub_deg = (d_hub_rows && n_hub_rows > 0) ? hub_degree : ((int64_t)1 << 62);
         egonet_from_triangles_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want), 256, 0, st>>>(
             d_row_ptr, d_col, d_scratch, reinterpret_cast<const unsigned long long *>(d_T), row_begin, row_end,
-            d_internal, d_external);
+            hub_deg, d_internal, d_external);
+        if (d_hub_rows && n_hub_rows > 0) {
+            const int hgrid = (int)(n_hub_rows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hub_rows);
+            egonet_from_triangles_hub_kernel<<<hgrid, 256, 0, st>>>(
+                d_row_ptr, d_col, d_scratch, reinterpret_cast<const unsigned long long *>(d_T), row_begin,
+                row_end, d_hub_rows, n_hub_rows, d_internal, d_external);
+        }
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
 
-int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
+int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_rows, int ldr,
                   void *stream)
 {
+    if (f > GRX_MAX_PTRS) {
+        grx_set_error("grx_pack_rows: f=%d > %d columns per call", f, GRX_MAX_PTRS);
+        return GRX_ERR_UNSUPPORTED;
+    }
     GRX_REQUIRE(n >= 0 && f >= 0 && ldr >= f, "grx_pack_rows: bad shape n=%lld f=%d ldr=%d",
                 (long long)n, f, ldr);
     if (n == 0 || ldr == 0) return GRX_OK;
-    GRX_REQUIRE(d_col_ptrs && d_rows, "grx_pack_rows: NULL pointer");
+    GRX_REQUIRE(h_col_ptrs && d_rows, "grx_pack_rows: NULL pointer");
+    GrxPtrTable tab;
+    for (int c = 0; c < f; ++c) tab.p[c] = h_col_ptrs[c];
     const int64_t want = grx_ceil_div(n, 256);
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
     { GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
-    pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, f, ldr, d_col_ptrs, d_rows);
+    pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, f, ldr, tab, d_rows);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

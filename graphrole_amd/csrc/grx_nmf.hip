@@ -24,11 +24,10 @@ constexpr int MAX_R = GRX_MAX_ROLES;                      // 16
 constexpr int MAX_F = 120;                                // LDS budget of the tiled kernels
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_columns_kernel(int64_t n, int F,
-                                                             const double *const *__restrict__ ptrs,
+__global__ __launch_bounds__(256) void gather_columns_kernel(int64_t n, int F, GrxPtrTable ptr_tab,
                                                              double *__restrict__ out, int64_t ld)
 {
-    const double *src = ptrs[blockIdx.y];
+    const double *src = reinterpret_cast<const double *>(ptr_tab.p[blockIdx.y]);
     double *dst = out + (size_t)blockIdx.y * ld;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
@@ -476,16 +475,22 @@ int check_nmf_shape(const char *who, int F, int r)
 
 extern "C" {
 
-int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double *d_out, int64_t ld,
+int grx_gather_columns(int64_t n, int F, const double *const *h_col_ptrs, double *d_out, int64_t ld,
                        void *stream)
 {
+    if (F > GRX_MAX_PTRS) {
+        grx_set_error("grx_gather_columns: F=%d > %d columns per call", F, GRX_MAX_PTRS);
+        return GRX_ERR_UNSUPPORTED;
+    }
     GRX_REQUIRE(n >= 0 && F >= 0 && ld >= n, "grx_gather_columns: bad shape");
     if (n == 0 || F == 0) return GRX_OK;
-    GRX_REQUIRE(d_col_ptrs && d_out, "grx_gather_columns: NULL pointer");
+    GRX_REQUIRE(h_col_ptrs && d_out, "grx_gather_columns: NULL pointer");
+    GrxPtrTable tab;
+    for (int c = 0; c < F; ++c) tab.p[c] = h_col_ptrs[c];
     const int64_t want = grx_ceil_div(n, 256 * 4);
     const dim3 grid((unsigned)(want > 1024 ? 1024 : want), F);
     { GRX_PROF(GRX_K_GATHER_COLUMNS, grx_stream(stream));
-    gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, F, d_col_ptrs, d_out, ld);
+    gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, F, tab, d_out, ld);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

@@ -264,10 +264,10 @@ constexpr int CH_STRIDE = CH_ROWS + 4;       // +4 bytes: column p starts on ban
 constexpr int CH_MAX_F = 120;               // F * CH_STRIDE <= 64 KiB of LDS
 
 __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
-                                                        int first_new,
-                                                        const uint8_t *const *__restrict__ ptrs,
+                                                        int first_new, GrxPtrTable ptr_tab,
                                                         int32_t *__restrict__ dist)
 {
+    const uint8_t *const *ptrs = reinterpret_cast<const uint8_t *const *>(ptr_tab.p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *tile = smem;                                   // F * CH_STRIDE
     const int q0 = first_new > 1 ? first_new : 1;
@@ -466,7 +466,7 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
 }
 
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
-                  const uint8_t *const *d_bin_ptrs, int32_t *d_dist, void *stream)
+                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, void *stream)
 {
     GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end, "grx_chebyshev: bad row range");
     GRX_REQUIRE(F >= 0 && first_new >= 0, "grx_chebyshev: bad F/first_new");
@@ -475,13 +475,14 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
         return GRX_ERR_UNSUPPORTED;
     }
     if (F < 2 || first_new >= F || row_end == row_begin) return GRX_OK;
-    GRX_REQUIRE(d_bin_ptrs && d_dist, "grx_chebyshev: NULL pointer");
+    GRX_REQUIRE(h_bin_ptrs && d_dist, "grx_chebyshev: NULL pointer");
+    GrxPtrTable tab;
+    for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
     const int64_t tiles = grx_ceil_div(row_end - row_begin, CH_ROWS);
     const int grid = (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : tiles);
     const size_t lds = (size_t)F * CH_STRIDE;
     { GRX_PROF(GRX_K_CHEBYSHEV, grx_stream(stream));
-    chebyshev_kernel<<<grid, 256, lds, grx_stream(stream)>>>(row_begin, row_end, F, first_new,
-                                                            d_bin_ptrs, d_dist);
+    chebyshev_kernel<<<grid, 256, lds, grx_stream(stream)>>>(row_begin, row_end, F, first_new, tab, d_dist);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

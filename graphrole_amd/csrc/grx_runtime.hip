@@ -22,6 +22,8 @@ void grx_set_error(const char *fmt, ...)
 namespace {
 struct ProfRec { int id; hipEvent_t start, stop; };
 bool g_prof_on = false;
+unsigned long long g_prof_mask = ~0ull;          // bit id set -> kernel id is timed
+std::vector<hipEvent_t> g_prof_pool;             // recycled events (hipEventCreate is not free)
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_pending;
 thread_local hipEvent_t g_prof_open[GRX_K_COUNT];
@@ -35,11 +37,22 @@ const char *const g_prof_names[GRX_K_COUNT] = {
     "nmf_residual_kernel", "add_columns_kernel", "triangle_count_kernel", "egonet_from_triangles_kernel"};
 }  // namespace
 
+static hipEvent_t prof_get_event()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_pool.empty()) { hipEvent_t ev = g_prof_pool.back(); g_prof_pool.pop_back(); return ev; }
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
 void grx_prof_begin(int id, hipStream_t st)
 {
-    if (!g_prof_on) return;
-    hipEvent_t ev;
-    if (hipEventCreate(&ev) != hipSuccess) return;
+    if (!g_prof_on || !((g_prof_mask >> id) & 1ull)) return;
+    hipEvent_t ev = prof_get_event();
+    if (!ev) return;
     (void)hipEventRecord(ev, st);
     g_prof_open[id] = ev;
 }
@@ -47,8 +60,8 @@ void grx_prof_begin(int id, hipStream_t st)
 void grx_prof_end(int id, hipStream_t st)
 {
     if (!g_prof_on || g_prof_open[id] == nullptr) return;
-    hipEvent_t ev;
-    if (hipEventCreate(&ev) != hipSuccess) return;
+    hipEvent_t ev = prof_get_event();
+    if (!ev) return;
     (void)hipEventRecord(ev, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pending.push_back({id, g_prof_open[id], ev});
@@ -63,10 +76,16 @@ int grx_profile_enable(int on)
     return GRX_OK;
 }
 
+int grx_profile_select(uint64_t kernel_mask)
+{
+    g_prof_mask = kernel_mask ? kernel_mask : ~0ull;
+    return GRX_OK;
+}
+
 int grx_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &r : g_prof_pending) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (auto &r : g_prof_pending) { g_prof_pool.push_back(r.start); g_prof_pool.push_back(r.stop); }
     g_prof_pending.clear();
     for (int i = 0; i < GRX_K_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
     return GRX_OK;
@@ -89,8 +108,8 @@ int grx_profile_read(int id, double *total_ms, long long *launches)
         GRX_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
         g_prof_ms[r.id] += ms;
         g_prof_cnt[r.id] += 1;
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
+        g_prof_pool.push_back(r.start);
+        g_prof_pool.push_back(r.stop);
     }
     g_prof_pending.clear();
     if (total_ms) *total_ms = g_prof_ms[id];

@@ -54,9 +54,9 @@ def zeros(shape, dtype=torch.float64) -> torch.Tensor:
     return torch.zeros(shape, dtype=dtype, device=device())
 
 
-def ptr_array(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Device array of device pointers (the `const T* const*` arguments of the ABI)."""
-    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=device())
+def ptr_array(tensors: Sequence[torch.Tensor]):
+    """Host table of device pointers (the `const T* const* h_*` arguments of the ABI)."""
+    return (c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
 
 
 class DeviceCSR:
@@ -145,11 +145,13 @@ def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] =
 def egonet_from_triangles(csr: DeviceCSR, T: torch.Tensor, row_begin: int = 0,
                           row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     row_end = csr.n if row_end is None else row_end
-    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
-    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
-    scratch = torch.empty(max(csr.n, 1), dtype=torch.int64, device=device())
+    alloc = torch.empty if (row_begin == 0 and row_end == csr.n) else torch.zeros
+    internal = alloc(csr.n, dtype=torch.float64, device=device())
+    external = alloc(csr.n, dtype=torch.float64, device=device())
+    scratch = torch.empty(max(csr.n, 1), dtype=torch.int32, device=device())
     _lib.call('grx_egonet_unweighted', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(T), row_begin, row_end,
-              _ptr(internal), _ptr(external), _ptr(scratch), _stream())
+              _ptr(internal), _ptr(external), _ptr(scratch), _ptr(csr.hub_rows), csr.n_hubs,
+              HUB_FACTOR * csr.lanes_per_row, _stream())
     return internal, external
 
 
@@ -174,7 +176,7 @@ def pack_rows(cols: Sequence[torch.Tensor], n: int) -> Tuple[torch.Tensor, int]:
     rows = torch.empty((max(n, 1), ldr), dtype=torch.float64, device=device())
     if f and n:
         ptrs = ptr_array(cols)
-        _lib.call('grx_pack_rows', n, f, _ptr(ptrs), _ptr(rows), ldr, _stream())
+        _lib.call('grx_pack_rows', n, f, ptrs, _ptr(rows), ldr, _stream())
     return rows, ldr
 
 
@@ -188,7 +190,8 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
     n = csr.n
     row_end = n if row_end is None else row_end
     if out is None:
-        out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+        full = row_begin == 0 and row_end == n and want_sum and want_mean
+        out = (torch.empty if full else torch.zeros)((2 * f, n), dtype=torch.float64, device=device())
     if f == 0:
         return out
     s_ptr = c_void_p(out.data_ptr()) if want_sum else None
@@ -235,7 +238,7 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
     dist = torch.zeros((F, F), dtype=torch.int32, device=device())
     if F >= 2 and row_end > row_begin:
         ptrs = ptr_array(bin_cols)
-        _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, _ptr(ptrs), _ptr(dist), _stream())
+        _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, ptrs, _ptr(dist), _stream())
     return dist
 
 
@@ -245,7 +248,7 @@ def gather_columns(cols: Sequence[torch.Tensor], n: int) -> torch.Tensor:
     out = torch.empty((F, max(n, 1)), dtype=torch.float64, device=device())
     if F and n:
         ptrs = ptr_array(cols)
-        _lib.call('grx_gather_columns', n, F, _ptr(ptrs), _ptr(out), out.stride(0), _stream())
+        _lib.call('grx_gather_columns', n, F, ptrs, _ptr(out), out.stride(0), _stream())
     return out
 
 

@@ -11,7 +11,8 @@
  *   - extern "C", plain pointers and sizes only.  Every function returns 0 on success and a
  *     negative grx_status otherwise; grx_last_error() returns a thread-local message.
  *   - Pointers named d_* are DEVICE pointers (hipMalloc'ed by the caller, by PyTorch's caching
- *     allocator, or by grx_dev_malloc).  h_* are host pointers.
+ *     allocator, or by grx_dev_malloc).  h_* are host pointers (small tables / matrices that
+ *     are consumed before the call returns).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
  *     stream-ordered; nothing here synchronises unless the name says so.
  *   - Feature columns are column-major: one contiguous fp64 array of n values per column.
@@ -70,6 +71,7 @@ int grx_event_elapsed_ms(void *start, void *stop, float *ms_out);   /* synchroni
  * grx_profile_reset.
  */
 int grx_profile_enable(int on);
+int grx_profile_select(uint64_t kernel_mask);   /* bit i = time kernel id i; 0 = all (default) */
 int grx_profile_reset(void);
 int grx_profile_kernel_count(void);
 const char *grx_profile_kernel_name(int id);
@@ -111,24 +113,28 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
  * grx_triangle_counts accumulates T (caller zero-fills d_T, uint64[n]) from the degree-oriented
  * graph (CSR that keeps arc u->v iff (d'(u),u) < (d'(v),v), columns ascending); only source rows
  * [row_begin,row_end) are processed, so ranks can split the arcs and all-reduce(SUM) d_T.
- * grx_egonet_unweighted then writes rows [row_begin,row_end); d_scratch: int64[n].
+ * grx_egonet_unweighted then writes rows [row_begin,row_end); d_scratch: int32[n] (degree < 2^30).
+ * d_hub_rows / n_hub_rows (optional): ascending rows with more than hub_degree neighbours; they get a
+ * workgroup each instead of an 8-lane group.
  */
 int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_o_col,
                         int64_t row_begin, int64_t row_end, uint64_t *d_T, void *stream);
 int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
                           const uint64_t *d_T, int64_t row_begin, int64_t row_end,
-                          double *d_internal, double *d_external, int64_t *d_scratch, void *stream);
+                          double *d_internal, double *d_external, int32_t *d_scratch,
+                          const int32_t *d_hub_rows, int64_t n_hub_rows, int64_t hub_degree, void *stream);
 
 /* ------------------------------------------------------------------ recursion ----------- */
 /*
  * Pack f feature columns into the row-major gather source of grx_aggregate.
- * d_col_ptrs: DEVICE array of f device pointers (each an fp64 column of n values).
+ * h_col_ptrs: HOST array of f device pointers (each an fp64 column of n values); the table
+ * travels as a kernel argument, f <= 128 per call.
  * d_rows: n x ldr row-major, ldr >= f; columns f..ldr-1 are zero-filled.  grx_aggregate wants
  * ldr = grx_aggregate_ldr(f): 2, 4, 8 or a multiple of 16 doubles, so that a feature row is a
  * 16/32/64-byte slice of one cache line or a whole number of 128-byte lines.
  */
 int grx_aggregate_ldr(int f);
-int grx_pack_rows(int64_t n, int f, const double *const *d_col_ptrs, double *d_rows, int ldr,
+int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_rows, int ldr,
                   void *stream);
 
 /*
@@ -176,13 +182,13 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
 /*
  * Pairwise Chebyshev distance between binned columns.  Replaces
  * pdist(binned.T, metric='chebychev') (graphrole/features/prune.py:108).
- * d_bin_ptrs: DEVICE array of F device pointers to uint8 columns.  Only rows
+ * h_bin_ptrs: HOST array of F device pointers to uint8 columns.  Only rows
  * [row_begin,row_end) are scanned (multi-GPU: all-reduce(MAX) the result).  d_dist: int32
  * F x F, must be zero-filled by the caller; pairs (p,q) with q >= first_new are computed
  * (first_new = 0: all pairs), the matrix is written symmetrically.  F <= 120.
  */
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
-                  const uint8_t *const *d_bin_ptrs, int32_t *d_dist, void *stream);
+                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, void *stream);
 
 /* ------------------------------------------------------------------ RolX NMF ------------ */
 /*
@@ -191,8 +197,8 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
  * the node axis are processed (multi-GPU: partial results are summed by the caller).
  */
 
-/* Copy F columns given by a DEVICE pointer array into a contiguous F x ld matrix. */
-int grx_gather_columns(int64_t n, int F, const double *const *d_col_ptrs, double *d_out,
+/* Copy F columns given by a HOST array of device pointers into a contiguous F x ld matrix (F <= 128). */
+int grx_gather_columns(int64_t n, int F, const double *const *h_col_ptrs, double *d_out,
                        int64_t ld, void *stream);
 
 /*

@@ -63,3 +63,21 @@ for k, ctrs in pmc.items():
     out[k] = d
 json.dump(out, open(os.path.join('profiles', f'{tag}_pmc.json'), 'w'), indent=1, sort_keys=True)
 print(f'pmc kernels: {len(out)}')
+
+# ---- traffic figure bench.py attaches to its roofline object (aggregation kernel).
+# Calibration for THIS access pattern (random 32-64 B row gathers): FETCH_SIZE(KiB)*1024 equals
+# TCC_MISS_sum * 64 B within 5 %, i.e. the requests are 64-byte and the 2x correction the guide gives
+# for wide coalesced streams does not apply; WRITE_SIZE is taken as reported.
+agg = {k: d for k, d in out.items() if k.startswith('aggregate_kernel')}
+if agg:
+    w = sum(d['launches_sampled'] for d in agg.values())
+    fetch = sum(d.get('FETCH_SIZE', 0.0) * 1024 * d['launches_sampled'] for d in agg.values()) / w
+    write = sum(d.get('WRITE_SIZE', 0.0) * 1024 * d['launches_sampled'] for d in agg.values()) / w
+    miss = sum(d.get('TCC_MISS_sum', 0.0) * d['launches_sampled'] for d in agg.values()) / w
+    workload = sys.argv[2] if len(sys.argv) > 2 else 'ba1m'
+    json.dump({'workload': workload, 'n_gpus': 1, 'source': f'profiles/{tag}_pmc.json',
+               'aggregate_kernel_hbm_bytes_per_launch': fetch + write,
+               'fetch_bytes': fetch, 'write_bytes': write, 'tcc_miss_x64B': miss * 64,
+               'note': 'fabric-side bytes (L2 misses; Infinity-Cache hits are counted), FETCH_SIZE uncorrected, see script'},
+              open(os.path.join('profiles', 'traffic_latest.json'), 'w'), indent=1)
+    print('traffic', fetch + write)
