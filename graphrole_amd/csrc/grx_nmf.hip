@@ -290,7 +290,7 @@ static inline size_t mu_lds_doubles(int F, int r, int TR)
     return (size_t)(F + 2 * r) * (TR + 1) + (size_t)r * F + (size_t)r * r;
 }
 
-template <int TR>
+template <int TR, int NLD>
 __global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                          const double *__restrict__ X, int64_t ldx,
                                                          double *__restrict__ W, int64_t ldw,
@@ -322,18 +322,44 @@ __global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int6
 #pragma unroll
     for (int s = 0; s < MU_PSLOTS; ++s) acc[s] = 0.0;
 
-    for (int64_t r0 = row_begin + (int64_t)blockIdx.x * TR; r0 < row_end; r0 += (int64_t)gridDim.x * TR) {
+    // Tile staging is software pipelined (issue early / write late): the global loads of tile
+    // n+1 are issued into registers right after tile n has been written to LDS and stay in
+    // flight while phases 1 and 2 of tile n run.  NLD >= ceil((F + r) * TR / 256) = loads per
+    // thread for one tile (template parameter so the staging registers are statically indexed).
+    const int n_elems = (F + r) * TR;                   // X tile then old-W tile, element e -> (col, i)
+    const int my_loads = (n_elems - t + 255) / 256;     // loads this thread issues per tile (<= NLD)
+    double stage[NLD];
+    auto issue_loads = [&](int64_t r0) {
         const int rows = (int)((row_end - r0 < TR) ? (row_end - r0) : TR);
-        __syncthreads();
-        for (int idx = t; idx < F * TR; idx += 256) {
-            const int c = idx / TR, i = idx % TR;
-            sX[c * LD + i] = (i < rows) ? X[(size_t)c * ldx + r0 + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = t + 256 * j;
+            double v = 0.0;
+            if (j < my_loads) {
+                const int cc = e / TR, i = e % TR;
+                if (i < rows)
+                    v = (cc < F) ? X[(size_t)cc * ldx + r0 + i] : W[(size_t)(cc - F) * ldw + r0 + i];
+            }
+            stage[j] = v;
         }
-        for (int idx = t; idx < r * TR; idx += 256) {
-            const int k = idx / TR, i = idx % TR;
-            sWo[k * LD + i] = (i < rows) ? W[(size_t)k * ldw + r0 + i] : 0.0;
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * TR;
+    int64_t r0 = row_begin + (int64_t)blockIdx.x * TR;
+    if (r0 < row_end) issue_loads(r0);
+    for (; r0 < row_end; r0 += tile_stride) {
+        const int rows = (int)((row_end - r0 < TR) ? (row_end - r0) : TR);
+        __syncthreads();                                 // previous tile's phase 2 is done with LDS
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = t + 256 * j;
+            if (j < my_loads) {
+                const int cc = e / TR, i = e % TR;
+                if (cc < F) sX[cc * LD + i] = stage[j];
+                else sWo[(cc - F) * LD + i] = stage[j];
+            }
         }
         __syncthreads();
+        if (r0 + tile_stride < row_end) issue_loads(r0 + tile_stride);
         {
             const int i = t % TR, g = t / TR;
             for (int k = g; k < r; k += PARTS) {
@@ -635,19 +661,25 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
         return GRX_ERR_WORKSPACE;
     }
     hipStream_t st = grx_stream(stream);
-    const int TR = pick_tr(F, r);
-    const int grid = mu_grid(row_end - row_begin, TR);
-    const size_t lds = mu_lds_doubles(F, r, TR) * 8;
     double *partial = reinterpret_cast<double *>(d_workspace);
     const int P = r * F + r * r;
+    int grid;
     {
+        const int TR = pick_tr(F, r);
+        grid = mu_grid(row_end - row_begin, TR);
+        const size_t lds = mu_lds_doubles(F, r, TR) * 8;
         GRX_PROF(GRX_K_NMF_W_PASS, st);
+        const int need = ((F + r) * TR + 255) / 256;
+#define GRX_W_PASS(TRV, NLDV) nmf_w_pass_kernel<TRV, NLDV><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial)
+#define GRX_W_PASS_TR(TRV) do { if (need <= 8) GRX_W_PASS(TRV, 8); else if (need <= 16) GRX_W_PASS(TRV, 16); else GRX_W_PASS(TRV, 32); } while (0)
         switch (TR) {
-        case 256: nmf_w_pass_kernel<256><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-        case 128: nmf_w_pass_kernel<128><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-        case 64:  nmf_w_pass_kernel<64><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
-        default:  nmf_w_pass_kernel<32><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial); break;
+        case 256: GRX_W_PASS_TR(256); break;
+        case 128: GRX_W_PASS_TR(128); break;
+        case 64:  GRX_W_PASS_TR(64); break;
+        default:  GRX_W_PASS_TR(32); break;
         }
+#undef GRX_W_PASS_TR
+#undef GRX_W_PASS
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
