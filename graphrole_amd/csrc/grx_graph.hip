@@ -185,34 +185,52 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 // T comes from the degree-oriented graph (arc u->v iff (d'(u),u) < (d'(v),v)): every triangle
 // is found exactly once as a common out-neighbour of the two ends of its lowest arc; oriented
 // lists are short even for power-law hubs, so a two-pointer merge per arc is cheap.
+// An 8-lane group owns one source u and walks its oriented arcs u->v TOGETHER: the group reads
+// N+(v) with one coalesced 32-byte load per 8 elements (instead of eight lanes chasing eight
+// different lists), keeps N+(u) in registers (3 entries per lane = 24 per pass; degree ordering
+// keeps oriented lists <= ~20 on the BASELINE graphs) and tests membership all-to-all with
+// in-group shuffles.  L2 requests per arc drop from ~16 to ~4, which is what bounded this kernel
+// (rocprof: 165 M TCP->TCC requests per launch).  Counting is integer atomics: exact, any order.
 __global__ __launch_bounds__(256) void triangle_count_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col, int64_t row_begin,
     int64_t row_end, unsigned long long *__restrict__ T)
 {
     constexpr int G = 8;
     const int lane = threadIdx.x % G;
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     for (int64_t u = row_begin + group; u < row_end; u += ngroups) {
         const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
         unsigned long long cu = 0;
-        for (int64_t k = ub + lane; k < ue; k += G) {
-            const int32_t v = o_col[k];
-            int64_t i = ub;                          // lists are id-sorted, ranks are not: full merge
-            int64_t j = o_row_ptr[v];
-            const int64_t je = o_row_ptr[v + 1];
-            unsigned long long c = 0;
-            while (i < ue && j < je) {
-                const int32_t x = o_col[i], y = o_col[j];
-                if (x < y) ++i;
-                else if (x > y) ++j;
-                else { atomicAdd(&T[x], 1ull); ++c; ++i; ++j; }
-            }
-            if (c) atomicAdd(&T[v], c);
-            cu += c;
-        }
+        for (int64_t base = ub; base < ue; base += 3 * G) {     // usually a single pass
+            int32_t uu[3];
 #pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) cu += __shfl_xor(cu, off, G);
+            for (int i = 0; i < 3; ++i) {
+                const int64_t idx = base + lane + (int64_t)G * i;
+                uu[i] = (idx < ue) ? o_col[idx] : -2;
+            }
+            for (int64_t k = ub; k < ue; ++k) {
+                const int32_t v = o_col[k];                     // same address in the group
+                const int64_t vb = o_row_ptr[v], ve = o_row_ptr[v + 1];
+                unsigned c_arc = 0;
+                for (int64_t j0 = vb; j0 < ve; j0 += G) {
+                    const int32_t y = (j0 + lane < ve) ? o_col[j0 + lane] : -1;
+                    unsigned match = 0;
+#pragma unroll
+                    for (int sidx = 0; sidx < G; ++sidx) {
+                        const int32_t ys = __shfl(y, sidx, G);
+                        const bool hit = (ys == uu[0]) | (ys == uu[1]) | (ys == uu[2]);
+                        const unsigned long long bal = __ballot(hit);
+                        if ((bal >> gshift) & 0xFFull) match |= 1u << sidx;
+                    }
+                    if ((match >> lane) & 1u) atomicAdd(&T[y], 1ull);
+                    c_arc += __popc(match);
+                }
+                if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);
+                cu += c_arc;
+            }
+        }
         if (lane == 0 && cu) atomicAdd(&T[u], cu);
     }
 }
