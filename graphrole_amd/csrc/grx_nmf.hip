@@ -59,13 +59,19 @@ constexpr int GR_PSLOTS = (MAX_F * (MAX_F + 1) / 2 + 255) / 256;    // 29
 template <bool HAS_T, int YS>
 __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t row_end, int F, int k,
                                                    const double *__restrict__ X, int64_t ldx,
-                                                   const double *__restrict__ T,
+                                                   const double *__restrict__ T, int t_in_lds,
                                                    double *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double *sY = gsm;                                  // k * GR_LD
+    double *sT = gsm + k * GR_LD;                      // F * k (only when t_in_lds)
     __shared__ double xred[4];
     const int t = threadIdx.x, i = t & 63, g = t >> 6;
+    if (HAS_T && t_in_lds) {
+        for (int idx = t; idx < F * k; idx += 256) sT[idx] = T[idx];
+        __syncthreads();
+    }
+    const double *Tsrc = (HAS_T && t_in_lds) ? sT : T;
     const int npairs = k * (k + 1) / 2;
     int pq[GR_PSLOTS];
     double acc[GR_PSLOTS];
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
             for (int s = 0; s < YS; ++s) y[s] = 0.0;
             for (int c = 0; c < F; ++c) {
                 const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
-                const double *Tc = T + (size_t)c * k;
+                const double *Tc = Tsrc + (size_t)c * k;
 #pragma unroll
                 for (int s = 0; s < YS; ++s) {
                     const int j = g + 4 * s;
@@ -557,19 +563,21 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
     char *ws = reinterpret_cast<char *>(d_workspace);
     double *partial = reinterpret_cast<double *>(ws);
     double *dT = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_grid(n) * (npairs + 1) * 8, 256));
-    const size_t lds = (size_t)k * GR_LD * 8;
+    size_t lds = (size_t)k * GR_LD * 8;
+    const int t_in_lds = (h_T != nullptr) && (lds + (size_t)F * k * 8 <= 60 * 1024);
+    if (t_in_lds) lds += (size_t)F * k * 8;
     if (h_T) {
         GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
         {
             GRX_PROF(GRX_K_GRAM, st);
-            if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
-            else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
-            else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
-            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, partial);
+            if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+            else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+            else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
         }
     } else {
         { GRX_PROF(GRX_K_GRAM, st);
-        gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial);
+        gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, 0, partial);
         }
     }
     GRX_LAUNCH_CHECK();

@@ -295,8 +295,15 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
         __syncthreads();
         for (int c = 0; c < F; ++c) {
             const uint8_t *src = ptrs[c] + r0;
-            for (int i = threadIdx.x; i < CH_ROWS; i += 256)
-                tile[c * CH_STRIDE + i] = (i < rows) ? src[i] : 0;
+            if (rows == CH_ROWS && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+                // full tile, 4-byte aligned column: one dword (4 rows) per lane
+                if (threadIdx.x < CH_ROWS / 4)
+                    reinterpret_cast<uint32_t *>(tile + c * CH_STRIDE)[threadIdx.x] =
+                        reinterpret_cast<const uint32_t *>(src)[threadIdx.x];
+            } else {
+                for (int i = threadIdx.x; i < CH_ROWS; i += 256)
+                    tile[c * CH_STRIDE + i] = (i < rows) ? src[i] : 0;
+            }
         }
         // rows beyond `rows` are zero in every column -> contribute distance 0
         __syncthreads();
