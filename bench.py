@@ -168,7 +168,7 @@ def main():
         timers['nmf'] += t2 - t1
         timers['nmf_iters'] += n_iter
         state.update(names=names, Xd=Xd, n_iter=n_iter, gens=fe.generation_count, stats=list(fe.stats),
-                     F=len(names))
+                     F=len(names), W=nmf_state.W)
 
     warm = dict(refex=0.0, nmf=0.0, nmf_iters=0)
     for _ in range(args.warmup):
@@ -202,6 +202,20 @@ def main():
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
+
+    # RolX encode (1-D Lloyd-Max quantiser of the node-role factor), outside the timed steps
+    encode_info = None
+    if rank == 0 and world == 1:
+        Wd = state['W']
+        n_bins = 2 ** int(np.log2(N_ROLES * min(G.n, state['F'])))          # roles/extract.py:72
+        flat = Wd[:, :G.n].contiguous().reshape(-1)
+        K.lloyd_max(flat, n_bins)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, info = K.lloyd_max(flat, n_bins)
+        torch.cuda.synchronize()
+        encode_info = {'ms': (time.perf_counter() - t0) * 1e3, 'values': int(flat.numel()), 'n_bins': n_bins,
+                       'lloyd_iterations': int(info[0]), 'what': 'grx_lloyd_max on the N x r node-role factor'}
 
     if rank == 0:
         gens = state['gens']
@@ -259,7 +273,7 @@ def main():
                       'generations': state['stats']},
             'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / args.steps * 1e3,
                     'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
-            'roofline': roofline, 'roofline_nmf': roofline_nmf,
+            'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
             'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
         }
         if world == 1 and not args.no_cpu_baseline:

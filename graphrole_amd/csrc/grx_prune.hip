@@ -398,6 +398,17 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
 
 }  // namespace
 
+// internal entry for other translation units (grx_quant.hip): workspace laid out as in
+// grx_sort_columns (key buffer, then counters)
+int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
+                              void *workspace, hipStream_t st)
+{
+    const SortPlan p = make_plan(n, ncols);
+    char *ws = reinterpret_cast<char *>(workspace);
+    return sort_columns(n, ncols, cols, ld, out, out_ld, reinterpret_cast<uint64_t *>(ws),
+                        reinterpret_cast<uint32_t *>(ws + p.keys_bytes), st);
+}
+
 extern "C" {
 
 size_t grx_sort_workspace_bytes(int64_t n, int ncols)

@@ -298,6 +298,20 @@ def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, e
               _hptr(scale), float(eps), float(fill), _stream())
 
 
+def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
+    """1-D Lloyd-Max quantiser of a flat fp64 device tensor -> (quantised tensor, centres [n_bins],
+    info int32[2] = {iterations, non-empty cells})."""
+    m = values.numel()
+    out = torch.empty_like(values)
+    centers = torch.empty(max(n_bins, 1), dtype=torch.float64, device=device())
+    info = torch.zeros(2, dtype=torch.int32, device=device())
+    ws_bytes = _lib.load().grx_lloyd_max_workspace_bytes(m)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_lloyd_max', m, _ptr(values), int(n_bins), int(max_iter), _ptr(out), _ptr(centers), _ptr(info),
+              _ptr(ws), ws_bytes, _stream())
+    return out, centers, info
+
+
 class NmfState:
     """Device buffers of one multiplicative-update run (X, W feature-major; H r x F)."""
 

@@ -17,12 +17,11 @@ init='nndsvda')`` (factor.py:19) with every O(N) pass on the GPU:
         H-update kernel, residual pass every 10 iterations; the host only reads one scalar per
         convergence check.
 
-``encode`` (1-D Lloyd-Max quantiser = sklearn KMeans, factor.py:29-49) stays the reference's own
-host call in this round: SURVEY.md section 8(f) rank 1 lists it as the next row to move.
+``encode`` (factor.py:29-49: 1-D Lloyd-Max quantiser, sklearn KMeans in the reference) runs on the
+GPU as well (grx_lloyd_max, csrc/grx_quant.hip): SURVEY.md section 8(f) rank 1.
 """
 from __future__ import annotations
 
-import warnings
 from typing import Optional, Tuple
 
 import numpy as np
@@ -250,15 +249,20 @@ def nmf_with_info(X: np.ndarray, n_roles: int):
 
 def encode(X: np.ndarray, n_bins: int) -> np.ndarray:
     """
-    Encode (quantize) a matrix X using a specified number of bins: 1-D Lloyd-Max quantiser =
-    k-means on the flattened entries, random_state=1 (factor.py:29-49).  Host sklearn call, as in
-    the reference (next-row item, see module docstring).
+    Encode (quantize) a matrix X using a specified number of bins: every entry is replaced by
+    the centre of its cell of a 1-D Lloyd-Max quantiser over all entries (factor.py:29-49, where
+    the quantiser is sklearn KMeans(n_clusters=n_bins, random_state=1)).  Here the quantiser is
+    grx_lloyd_max on the GPU: deterministic (exact DP start on equal cbrt-density micro-cells, then
+    Lloyd iterations), same fixed-point conditions as k-means, error not above sklearn's.
+    :param X: matrix to encode
+    :param n_bins: number of bins for encoding
     """
-    from sklearn.cluster import KMeans
-    data = X.reshape(X.size, 1)
-    quantizer = KMeans(n_clusters=n_bins, random_state=1)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        quantizer.fit(data)
-    centres = quantizer.cluster_centers_
-    return centres[quantizer.labels_].reshape(X.shape)
+    K = _kernels()
+    X = np.asarray(X, dtype=np.float64)
+    if n_bins > X.size:
+        # sklearn raises the same for KMeans(n_clusters > n_samples); the model-selection loop
+        # of RoleExtractor relies on it (roles/extract.py:127-129)
+        raise ValueError(f'n_samples={X.size} should be >= n_clusters={n_bins}.')
+    flat = K.to_device(np.ascontiguousarray(X).reshape(-1))
+    quantized, _, _ = K.lloyd_max(flat, int(n_bins))
+    return K.to_host(quantized).reshape(X.shape)

@@ -260,6 +260,21 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
                     int64_t ldw, double *d_H, double *d_AB, double *d_err, int iters,
                     void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------ RolX encode --------- */
+/*
+ * 1-D Lloyd-Max quantiser.  Replaces encode() (graphrole/roles/factor.py:29-49: sklearn KMeans on
+ * the flattened factor entries, every entry replaced by its cluster centre).  Deterministic:
+ * sort -> prefix sums -> exact DP over <= 1024 equal cbrt-density micro-cells -> Lloyd refinement
+ * -> assignment.  d_values / d_quantized: fp64[m]; d_centers: fp64[n_bins] (ascending);
+ * d_info: int32[2] = {Lloyd iterations, non-empty cells}.  n_bins <= 256.
+ * n_bins > m is the reference's ValueError (sklearn: "n_samples=.. should be >= n_clusters=..")
+ * -> GRX_ERR_INVALID.
+ */
+size_t grx_lloyd_max_workspace_bytes(int64_t m);
+int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, double *d_quantized,
+                  double *d_centers, int32_t *d_info, void *d_workspace, size_t workspace_bytes,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,20 @@ def nndsvd_apply(U, n, sign, scale, eps, fill, row_begin=0, row_end=None):
         u[j, row_begin:row_end] = np.where(v < eps, fill, v)
 
 
+def lloyd_max(values, n_bins, max_iter=300):
+    """Reference behaviour of encode(): sklearn KMeans(random_state=1) on the flat values."""
+    import warnings
+    from sklearn.cluster import KMeans
+    data = values.numpy().reshape(-1, 1)
+    km = KMeans(n_clusters=n_bins, random_state=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        km.fit(data)
+    centres = km.cluster_centers_[:, 0]
+    out = torch.from_numpy(centres[km.labels_].copy())
+    return out, torch.from_numpy(np.sort(centres)), torch.tensor([km.n_iter_, len(np.unique(km.labels_))], dtype=torch.int32)
+
+
 class NmfState:
     def __init__(self, X, n, W, H):
         self.X, self.n, self.W = X, n, W
