@@ -150,54 +150,73 @@ __global__ __launch_bounds__(Q_CELLS) void q_cells_kernel(const double *__restri
 }
 
 // ---- exact k-clustering of the cells by dynamic programming -------------------------------------
-// D_j[i] = min_{j <= mm < i} D_{j-1}[mm] + cost(cells mm..i-1);  arg[j][i] = minimiser.
-__global__ __launch_bounds__(Q_CELLS) void q_dp_kernel(const int64_t *__restrict__ ce, const int *__restrict__ nb_ptr,
-                                                       const double *__restrict__ P, const double *__restrict__ P2,
-                                                       int k, int32_t *__restrict__ arg, int64_t *__restrict__ edges)
+// D_j[i] = min_{j <= mm < i} D_{j-1}[mm] + cost(cells mm..i-1);  arg[j][i] = minimiser (smallest
+// mm on ties).  One launch per layer j, one wavefront per i (lanes stride over mm, fixed-order
+// argmin butterfly), so a layer is spread over the whole chip instead of one workgroup.
+__global__ __launch_bounds__(256) void q_dp_init_kernel(const int64_t *__restrict__ ce, const int *__restrict__ nb_ptr,
+                                                        const double *__restrict__ P, const double *__restrict__ P2,
+                                                        double *__restrict__ cell, double *__restrict__ D0)
 {
-    __shared__ double Dprev[Q_CELLS + 1], Dcur[Q_CELLS + 1];
-    __shared__ double cp[Q_CELLS + 1], cp2[Q_CELLS + 1], cn[Q_CELLS + 1];
+    const int nb = *nb_ptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) {
+        const int64_t e = ce[i];
+        cell[i] = P[e];
+        cell[(Q_CELLS + 1) + i] = P2[e];
+        cell[2 * (Q_CELLS + 1) + i] = (double)e;
+        D0[i] = (i == 0) ? 0.0 : 1e300;
+    }
+}
+
+__global__ __launch_bounds__(256) void q_dp_layer_kernel(const int *__restrict__ nb_ptr, int j, int k,
+                                                         const double *__restrict__ cell,
+                                                         const double *__restrict__ Dprev, double *__restrict__ Dcur,
+                                                         int32_t *__restrict__ arg)
+{
+    const int nb = *nb_ptr;
+    if (j >= (k < nb ? k : nb)) return;                 // surplus layers (more bins than cells)
+    const double *cp = cell, *cp2 = cell + (Q_CELLS + 1), *cn = cell + 2 * (Q_CELLS + 1);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per i
+    if (i > nb) return;
+    double best = 1e300;
+    int bm = 0x7fffffff;
+    if (i >= j + 1) {
+        const double pi = cp[i], p2i = cp2[i], ni = cn[i];
+        for (int mm = j + lane; mm < i; mm += 64) {
+            const double dprev = Dprev[mm];
+            if (dprev >= 1e300) continue;
+            const double n = ni - cn[mm], sm = pi - cp[mm];
+            double cst = (p2i - cp2[mm]) - sm * sm / n;
+            if (cst < 0.0) cst = 0.0;
+            const double v = dprev + cst;
+            if (v < best) { best = v; bm = mm; }          // ascending mm per lane: first minimum kept
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 64);
+        const int om = __shfl_xor(bm, off, 64);
+        if (ov < best || (ov == best && om < bm)) { best = ov; bm = om; }
+    }
+    if (lane == 0) {
+        Dcur[i] = (i == 0) ? 1e300 : best;
+        arg[(size_t)j * (Q_CELLS + 1) + i] = (bm == 0x7fffffff) ? j : bm;
+    }
+}
+
+__global__ void q_dp_backtrack_kernel(const int64_t *__restrict__ ce, const int *__restrict__ nb_ptr, int k,
+                                      const int32_t *__restrict__ arg, int64_t *__restrict__ edges)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int nb = *nb_ptr;
     const int kk = k < nb ? k : nb;
-    const int t = threadIdx.x;
-    for (int i = t; i <= nb; i += blockDim.x) {
-        const int64_t e = ce[i];
-        cp[i] = P[e]; cp2[i] = P2[e]; cn[i] = (double)e;
-        Dprev[i] = (i == 0) ? 0.0 : 1e300;
+    int i = nb;
+    edges[kk] = ce[nb];
+    for (int j = kk - 1; j >= 0; --j) {
+        i = arg[(size_t)j * (Q_CELLS + 1) + i];
+        edges[j] = ce[i];
     }
-    __syncthreads();
-    for (int j = 0; j < kk; ++j) {
-        for (int i = t + 1; i <= nb; i += blockDim.x) {
-            double best = 1e300;
-            int bm = j;
-            if (i >= j + 1) {
-                for (int mm = j; mm < i; ++mm) {
-                    const double dprev = Dprev[mm];
-                    if (dprev >= 1e300) continue;
-                    const double n = cn[i] - cn[mm], sm = cp[i] - cp[mm];
-                    double cst = (cp2[i] - cp2[mm]) - sm * sm / n;
-                    if (cst < 0.0) cst = 0.0;
-                    const double v = dprev + cst;
-                    if (v < best) { best = v; bm = mm; }
-                }
-            }
-            Dcur[i] = best;
-            arg[(size_t)j * (Q_CELLS + 1) + i] = bm;
-        }
-        if (t == 0) Dcur[0] = 1e300;
-        __syncthreads();
-        for (int i = t; i <= nb; i += blockDim.x) Dprev[i] = Dcur[i];
-        __syncthreads();
-    }
-    if (t == 0) {                                       // backtrack -> element edges of the kk clusters
-        int i = nb;
-        edges[kk] = ce[nb];
-        for (int j = kk - 1; j >= 0; --j) {
-            i = arg[(size_t)j * (Q_CELLS + 1) + i];
-            edges[j] = ce[i];
-        }
-        for (int j = kk + 1; j <= k; ++j) edges[j] = ce[nb];   // surplus clusters stay empty
-    }
+    for (int j = kk + 1; j <= k; ++j) edges[j] = ce[nb];      // surplus clusters stay empty
 }
 
 // ---- Lloyd refinement on the sorted array ------------------------------------------------------
@@ -272,7 +291,8 @@ __global__ __launch_bounds__(256) void q_assign_kernel(const double *__restrict_
 
 struct QuantPlan {
     int64_t ntiles;
-    size_t off_sorted, off_P, off_P2, off_G, off_tsum, off_ce, off_arg, off_edges, off_bounds, off_nb, off_sort_ws, total;
+    size_t off_sorted, off_P, off_P2, off_G, off_tsum, off_ce, off_arg, off_edges, off_bounds, off_nb, off_cell, off_D,
+        off_sort_ws, total;
 };
 
 QuantPlan q_plan(int64_t m)
@@ -291,6 +311,8 @@ QuantPlan q_plan(int64_t m)
     p.off_edges = take((size_t)(Q_MAX_BINS + 1) * 8);
     p.off_bounds = take((size_t)Q_MAX_BINS * 8);
     p.off_nb = take(256);
+    p.off_cell = take((size_t)3 * (Q_CELLS + 1) * 8);
+    p.off_D = take((size_t)2 * (Q_CELLS + 1) * 8);
     p.off_sort_ws = take(grx_sort_workspace_bytes(m, 1));
     p.total = o;
     return p;
@@ -334,6 +356,8 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
     int64_t *edges = reinterpret_cast<int64_t *>(ws + p.off_edges);
     double *bounds = reinterpret_cast<double *>(ws + p.off_bounds);
     int *nb = reinterpret_cast<int *>(ws + p.off_nb);
+    double *cell = reinterpret_cast<double *>(ws + p.off_cell);
+    double *Dbuf = reinterpret_cast<double *>(ws + p.off_D);
     int rc = grx_internal_sort_columns(m, 1, d_values, m, sorted, m, ws + p.off_sort_ws, st);
     if (rc != GRX_OK) return rc;
     {
@@ -342,7 +366,13 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
         q_scan_tiles_kernel<<<1, 64, 0, st>>>(tsum, p.ntiles);
         q_prefix_kernel<<<(int)p.ntiles, 256, 0, st>>>(sorted, m, tsum, P, P2, Gp);
         q_cells_kernel<<<1, Q_CELLS, 0, st>>>(Gp, m, Q_CELLS, ce, nb);
-        q_dp_kernel<<<1, Q_CELLS, 0, st>>>(ce, nb, P, P2, n_bins, arg, edges);
+        q_dp_init_kernel<<<4, 256, 0, st>>>(ce, nb, P, P2, cell, Dbuf);
+        for (int j = 0; j < n_bins; ++j) {
+            double *Dprev = Dbuf + (size_t)(j & 1) * (Q_CELLS + 1);
+            double *Dcur = Dbuf + (size_t)((j + 1) & 1) * (Q_CELLS + 1);
+            q_dp_layer_kernel<<<(Q_CELLS + 1 + 3) / 4, 256, 0, st>>>(nb, j, n_bins, cell, Dprev, Dcur, arg);
+        }
+        q_dp_backtrack_kernel<<<1, 64, 0, st>>>(ce, nb, n_bins, arg, edges);
         q_lloyd_kernel<<<1, Q_MAX_BINS, 0, st>>>(sorted, m, P, n_bins, max_iter, edges, d_centers, bounds, d_info);
         const int64_t want = grx_ceil_div(m, 256 * 4);
         q_assign_kernel<<<(int)(want > 2048 ? 2048 : want), 256, 0, st>>>(d_values, m, n_bins, d_centers, bounds,
