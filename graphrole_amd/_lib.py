@@ -82,6 +82,8 @@ _SIGNATURES = {
     'grx_lloyd_max_workspace_bytes': (c_size_t, [c_int64]),
     'grx_lloyd_max': (c_int, [c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                               c_void_p]),
+    'grx_nmf_kl_cost': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }

@@ -474,6 +474,42 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
     if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
 }
 
+// Generalised KL divergence of X from W H with the zero entries of X masked out
+// (graphrole/roles/description_length.py:44-61): sum_{x != 0} x log(x / v) - x + v, v = (W H)_ic.
+__global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                          const double *__restrict__ X, int64_t ldx,
+                                                          const double *__restrict__ W, int64_t ldw,
+                                                          const double *__restrict__ H,
+                                                          double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double rsm[];
+    double *sH = rsm;                 // r*F
+    __shared__ double wred[4];
+    for (int idx = threadIdx.x; idx < r * F; idx += 256) sH[idx] = H[idx];
+    __syncthreads();
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
+        double w[MAX_R];
+#pragma unroll
+        for (int k = 0; k < MAX_R; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
+        for (int c = 0; c < F; ++c) {
+            const double x = X[(size_t)c * ldx + i];
+            if (x != 0.0) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < MAX_R; ++k)
+                    if (k < r) v += w[k] * sH[k * F + c];
+                s += x * log(x / v) - x + v;
+            }
+        }
+    }
+    s = grx_group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+}
+
 int pick_tr(int F, int r)
 {
     // largest row tile whose LDS footprint still lets 8 workgroups share a CU (160 KiB), else
@@ -732,6 +768,36 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
     { GRX_PROF(GRX_K_NMF_RESIDUAL, st);
     nmf_residual_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
                                                              d_H, partial);
+    }
+    GRX_LAUNCH_CHECK();
+    { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
+    reduce_partials_kernel<<<1, 256, 0, st>>>(partial, grid, 1, d_out);
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *d_W, int64_t ldw,
+                    int64_t row_begin, int64_t row_end, const double *d_H, double *d_out, void *d_workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldw >= n,
+                "grx_nmf_kl_cost: bad row range");
+    int rc = check_nmf_shape("grx_nmf_kl_cost", F, r);
+    if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(d_X && d_W && d_H && d_out && d_workspace, "grx_nmf_kl_cost: NULL pointer");
+    if (workspace_bytes < grx_nmf_workspace_bytes(n, F, r)) {
+        grx_set_error("grx_nmf_kl_cost: workspace too small");
+        return GRX_ERR_WORKSPACE;
+    }
+    hipStream_t st = grx_stream(stream);
+    const size_t P = (size_t)r * F + (size_t)r * r;
+    double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(d_workspace) +
+                                                 grx_align_up((size_t)MU_MAX_GRID * P * 8, 256));
+    const int64_t want = grx_ceil_div(row_end - row_begin, 256);
+    const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
+    { GRX_PROF(GRX_K_NMF_RESIDUAL, st);
+    nmf_kl_cost_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial);
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);

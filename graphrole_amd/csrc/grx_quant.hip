@@ -266,9 +266,16 @@ __global__ __launch_bounds__(Q_MAX_BINS) void q_lloyd_kernel(const double *__res
     if (j < k - 1) bounds[j] = 0.5 * (c[j] + c[j + 1]);
     if (j == 0) {
         info[0] = it;
-        int nonempty = 0;
-        for (int q = 0; q < k; ++q) nonempty += hi[q + 1] > hi[q];
+        int nonempty = 0, distinct = 0;
+        double last = 0.0;
+        for (int q = 0; q < k; ++q) {
+            if (hi[q + 1] > hi[q]) {
+                ++nonempty;
+                if (distinct == 0 || c[q] != last) { ++distinct; last = c[q]; }
+            }
+        }
         info[1] = nonempty;
+        info[2] = distinct;
     }
 }
 

@@ -300,11 +300,11 @@ def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, e
 
 def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
     """1-D Lloyd-Max quantiser of a flat fp64 device tensor -> (quantised tensor, centres [n_bins],
-    info int32[2] = {iterations, non-empty cells})."""
+    info int32[3] = {iterations, non-empty cells, distinct output values})."""
     m = values.numel()
     out = torch.empty_like(values)
     centers = torch.empty(max(n_bins, 1), dtype=torch.float64, device=device())
-    info = torch.zeros(2, dtype=torch.int32, device=device())
+    info = torch.zeros(3, dtype=torch.int32, device=device())
     ws_bytes = _lib.load().grx_lloyd_max_workspace_bytes(m)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     _lib.call('grx_lloyd_max', m, _ptr(values), int(n_bins), int(max_iter), _ptr(out), _ptr(centers), _ptr(info),
@@ -340,6 +340,14 @@ class NmfState:
                   self.W.stride(0), row_begin, row_end, _ptr(self.H), _ptr(self.err), _ptr(self.ws),
                   self.ws_bytes, _stream())
         return self.err
+
+    def kl_cost(self, W: torch.Tensor, H: torch.Tensor, row_begin: int = 0, row_end: Optional[int] = None) -> float:
+        """Generalised-KL error cost of X against the (encoded) factors W [r, ld], H [r, F]."""
+        row_end = self.n if row_end is None else row_end
+        out = torch.zeros(1, dtype=torch.float64, device=device())
+        _lib.call('grx_nmf_kl_cost', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(W), W.stride(0),
+                  row_begin, row_end, _ptr(H), _ptr(out), _ptr(self.ws), self.ws_bytes, _stream())
+        return float(out.cpu()[0])
 
     def iterate(self, iters: int, with_residual: bool = True) -> None:
         _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),

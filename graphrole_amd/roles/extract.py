@@ -1,7 +1,8 @@
 """
 RolX role extraction (reference: graphrole/roles/extract.py).  Same class, constructor,
-properties and error behaviour as the reference's ``RoleExtractor``; the NMF runs on the GPU
-(roles/factor.py), quantisation and MDL model selection follow the reference on the host.
+properties and error behaviour as the reference's ``RoleExtractor``; NMF, quantisation and the
+MDL costs of the model-selection grid run on the GPU (roles/factor.py), the grid loop and the
+cost rescaling / arg-min follow the reference on the host.
 """
 from __future__ import annotations
 
@@ -11,8 +12,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from graphrole_amd.roles.description_length import get_description_length_costs
-from graphrole_amd.roles.factor import encode, get_nmf_decomposition
+from graphrole_amd.roles import factor
 from graphrole_amd.types import DataFrameLike, FactorTuple, Node
 
 
@@ -81,8 +81,14 @@ class RoleExtractor:
         """
         Grid search over (n_roles, n_bits) scored by minimum description length (:98-142).
         Like the reference, the NMF is recomputed for every cell, so numpy's global RNG is
-        consumed in the same order (one Gaussian test matrix per cell).
+        consumed in the same order (one Gaussian test matrix per cell).  The feature matrix is
+        uploaded once; factorisation, quantisation and both MDL costs of every cell are computed
+        in HBM, only the winning factor pair is copied back.
         """
+        from graphrole_amd import backend
+        K = backend.get()
+        V = factor._checked_matrix(features.values)
+        Vd = K.to_device(np.ascontiguousarray(V.T))
         bit_stop = self.max_bits + 1
         role_stop = min(min(features.shape), self.max_roles) + 1
         encoding_costs = np.full((role_stop, bit_stop), np.nan)
@@ -92,25 +98,29 @@ class RoleExtractor:
         for roles in range(self.min_roles, role_stop):
             for bits in range(self.min_bits, bit_stop):
                 try:
-                    model = self._get_encoded_role_factors(features, roles, bits)
-                    encoding_cost, error_cost = get_description_length_costs(features, model)
+                    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits)
                 except ValueError:
                     # more bins requested than there are factor entries to quantise
                     continue
-                encoding_costs[roles, bits] = encoding_cost
-                error_costs[roles, bits] = error_cost
-                factors[roles][bits] = model
+                # description_length.py:32-41 / :44-61 on the device-resident factors
+                encoding_costs[roles, bits] = np.ceil(np.log2(max(uniq_g, uniq_f))) * (Wq.numel() + Hq.numel())
+                error_costs[roles, bits] = state.kl_cost(Wq, Hq)
+                factors[roles][bits] = (Wq, Hq)
 
         costs = self._rescale_costs(encoding_costs) + self._rescale_costs(error_costs)
         best_roles, best_bits = np.argwhere(costs == np.nanmin(costs))[0]
-        return factors[best_roles][best_bits]
+        Wq, Hq = factors[best_roles][best_bits]
+        return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 
     @staticmethod
     def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int) -> FactorTuple:
         """NMF of the feature matrix with both factors quantised to 2**n_bits levels (:144-161)"""
-        n_bins = int(2 ** n_bits)
-        G, F = get_nmf_decomposition(features.values, n_roles)
-        return encode(G, n_bins), encode(F, n_bins)
+        from graphrole_amd import backend
+        K = backend.get()
+        V = factor._checked_matrix(features.values)
+        Vd = K.to_device(np.ascontiguousarray(V.T))
+        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits)
+        return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 
     @staticmethod
     def _rescale_costs(costs: np.ndarray) -> np.ndarray:

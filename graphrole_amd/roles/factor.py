@@ -221,30 +221,66 @@ def get_nmf_decomposition(X: np.ndarray, n_roles: int) -> FactorTuple:
     return G, F
 
 
-def nmf_with_info(X: np.ndarray, n_roles: int):
-    """(G, F, n_iter); G = W (n x r), F = H (r x n_features)."""
-    K = _kernels()
+def _checked_matrix(X) -> np.ndarray:
     X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
     if X.ndim != 2:
         raise ValueError('X must be 2-dimensional')
     if (X < 0).any():
         raise ValueError('Negative values in data passed to NMF (input X)')        # _nmf.py:283
+    return X
+
+
+def nmf_state(Xd, X: np.ndarray, n_roles: int):
+    """
+    Run the factorisation of the host matrix X whose feature-major copy Xd [F, n] is already in
+    HBM; returns (NmfState with W [r, n] and H [r, F] on the device, n_iter).  Consumes numpy's
+    global RNG exactly like sklearn (one Gaussian test matrix).
+    """
+    K = _kernels()
     n, F = X.shape
     if n_roles > min(n, F):
         raise ValueError("init = 'nndsvda' can only be used when n_components <= min(n_samples, n_features)")
     omega = draw_omega(X.shape, n_roles)
-    Xd = K.to_device(np.ascontiguousarray(X.T))
     if n < F:
+        # fewer nodes than features: every matrix of the initialisation is small (k x F algebra)
         W0h, H0 = _host_init(X, n_roles, omega)
         W0h[W0h < NNDSVD_EPS] = 0
         H0[H0 < NNDSVD_EPS] = 0
         W0h[W0h == 0] = X.mean()
         H0[H0 == 0] = X.mean()
-        state = K.NmfState(Xd, n, K.to_device(np.ascontiguousarray(W0h.T)), H0)
-        state, n_iter = run_mu_loop(state)
-    else:
-        state, n_iter = nmf_device(Xd, n, n_roles, omega)
+        return run_mu_loop(K.NmfState(Xd, n, K.to_device(np.ascontiguousarray(W0h.T)), H0))
+    return nmf_device(Xd, n, n_roles, omega)
+
+
+def nmf_with_info(X: np.ndarray, n_roles: int):
+    """(G, F, n_iter); G = W (n x r), F = H (r x n_features)."""
+    K = _kernels()
+    X = _checked_matrix(X)
+    n = X.shape[0]
+    Xd = K.to_device(np.ascontiguousarray(X.T))
+    state, n_iter = nmf_state(Xd, X, n_roles)
     return K.to_host(state.W)[:, :n].T.copy(), K.to_host(state.H).copy(), n_iter
+
+
+def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int):
+    """
+    NMF of X followed by the quantisation of both factors with 2**n_bits levels, without leaving
+    HBM (roles/extract.py:144-161).  Returns (state, Wq [r, n], Hq [r, F], distinct values of Wq,
+    distinct values of Hq); raises ValueError like the reference when there are fewer factor
+    entries than levels.
+    """
+    K = _kernels()
+    n, F = X.shape
+    state, _ = nmf_state(Xd, X, n_roles)
+    n_bins = int(2 ** n_bits)
+    for size in (n_roles * n, n_roles * F):               # encode(G) first, then encode(F)
+        if n_bins > size:
+            raise ValueError(f'n_samples={size} should be >= n_clusters={n_bins}.')
+    W = state.W if state.W.shape[1] == n else state.W[:, :n].contiguous()
+    Wq, _, info_w = K.lloyd_max(W.reshape(-1), n_bins)
+    Hq, _, info_h = K.lloyd_max(state.H.reshape(-1), n_bins)
+    info_w, info_h = K.to_host(info_w), K.to_host(info_h)
+    return state, Wq.view(n_roles, n), Hq.view(n_roles, F), int(info_w[2]), int(info_h[2])
 
 
 def encode(X: np.ndarray, n_bins: int) -> np.ndarray:

@@ -253,6 +253,14 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
                      int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H,
                      double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 /*
+ * MDL error cost of an (encoded) factor pair: generalised KL divergence of X from W H over the
+ * non-zero entries of X (graphrole/roles/description_length.py:44-61), rows [row_begin,row_end).
+ * d_out[0] receives the sum.  Workspace as for the other NMF passes.
+ */
+int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *d_W,
+                    int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H, double *d_out,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+/*
  * Enqueue `iters` full single-GPU iterations (w_pass + h_update each) followed by one residual
  * evaluation into d_err[0]; no host synchronisation.  This is the unit bench.py times.
  */
@@ -266,7 +274,7 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
  * the flattened factor entries, every entry replaced by its cluster centre).  Deterministic:
  * sort -> prefix sums -> exact DP over <= 1024 equal cbrt-density micro-cells -> Lloyd refinement
  * -> assignment.  d_values / d_quantized: fp64[m]; d_centers: fp64[n_bins] (ascending);
- * d_info: int32[2] = {Lloyd iterations, non-empty cells}.  n_bins <= 256.
+ * d_info: int32[3] = {Lloyd iterations, non-empty cells, distinct output values}.  n_bins <= 256.
  * n_bins > m is the reference's ValueError (sklearn: "n_samples=.. should be >= n_clusters=..")
  * -> GRX_ERR_INVALID.
  */

@@ -168,7 +168,9 @@ def lloyd_max(values, n_bins, max_iter=300):
         km.fit(data)
     centres = km.cluster_centers_[:, 0]
     out = torch.from_numpy(centres[km.labels_].copy())
-    return out, torch.from_numpy(np.sort(centres)), torch.tensor([km.n_iter_, len(np.unique(km.labels_))], dtype=torch.int32)
+    nonempty = len(np.unique(km.labels_))
+    return out, torch.from_numpy(np.sort(centres)), torch.tensor([km.n_iter_, nonempty, len(np.unique(out.numpy()))],
+                                                                  dtype=torch.int32)
 
 
 class NmfState:
@@ -206,6 +208,12 @@ class NmfState:
         R = X - W @ self.H.numpy()
         self.err[0] = float((R * R).sum())
         return self.err
+
+    def kl_cost(self, W, H, row_begin=0, row_end=None):
+        row_end = self.n if row_end is None else row_end
+        V = self.X.numpy()[:, row_begin:row_end].T
+        A = W.numpy()[:, row_begin:row_end].T @ H.numpy()
+        return rolx.error_cost(V, A)
 
     def iterate(self, iters, with_residual=True):
         for _ in range(iters):

@@ -217,3 +217,44 @@ def test_end_to_end_karate_roles():
     assert 2 <= k <= 7
     assert set(re_.roles.keys()) == set(labels)
     assert np.allclose(re_.role_percentage.sum(axis=1).values, 1.0)
+
+
+def test_device_mdl_costs_equal_host_formulas():
+    """Encoding / error cost computed in HBM (grx_lloyd_max info, grx_nmf_kl_cost) against the host
+    restatement of graphrole/roles/description_length.py:32-61 on the same encoded factors."""
+    from graphrole_amd import kernels as K
+    from graphrole_amd.roles import description_length as dl
+    from graphrole_amd.roles import factor
+    rng = np.random.RandomState(4)
+    V = np.abs(rng.randn(5000, 9)) * np.linspace(1, 12, 9)
+    V[rng.rand(*V.shape) < 0.1] = 0.0                         # zero entries are masked by the KL cost
+    Vd = K.to_device(np.ascontiguousarray(V.T))
+    np.random.seed(3)
+    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, 4, 5)
+    G, F = K.to_host(Wq).T, K.to_host(Hq)
+    assert uniq_g == len(np.unique(G)) and uniq_f == len(np.unique(F))
+    enc_host, err_host = dl.get_description_length_costs(V, (G, F))
+    assert enc_host == np.ceil(np.log2(max(uniq_g, uniq_f))) * (G.size + F.size)
+    np.testing.assert_allclose(state.kl_cost(Wq, Hq), err_host, rtol=1e-10)
+    # row-range partials add up (multi-GPU all-reduce SUM)
+    np.testing.assert_allclose(state.kl_cost(Wq, Hq, 0, 1234) + state.kl_cost(Wq, Hq, 1234, 5000), err_host,
+                               rtol=1e-10)
+
+
+def test_model_selection_on_a_larger_matrix_runs_in_hbm():
+    """n_roles=None on 50k x 10 features: 7 x 8 grid of NMF + 2 quantisations + MDL costs."""
+    import time
+    from graphrole_amd import RoleExtractor
+    rng = np.random.RandomState(0)
+    base = np.abs(rng.randn(50000, 3))
+    feats = pd.DataFrame(np.abs(base @ np.abs(rng.randn(3, 10)) + 0.05 * rng.randn(50000, 10)),
+                         columns=[f'f{i}' for i in range(10)])
+    np.random.seed(0)
+    re_ = RoleExtractor()
+    t0 = time.perf_counter()
+    re_.extract_role_factors(feats)
+    dt = time.perf_counter() - t0
+    k = re_.node_role_factor.shape[1]
+    assert 2 <= k <= 8 and re_.role_feature_factor.shape == (k, 10)
+    assert np.allclose(re_.role_percentage.sum(axis=1).values, 1.0)
+    assert dt < 60
