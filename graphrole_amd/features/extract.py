@@ -103,10 +103,14 @@ class RecursiveFeatureExtractor:
     def _n(self) -> int:
         return self.graph.to_csr().n
 
+    def _order(self):
+        """InternalGraph of the adapter: device rows are in degree-descending internal order."""
+        return self.graph._device_graph()[0]
+
     def _shard(self):
         if not self._plan_ready:
             from graphrole_amd.parallel import maybe_plan
-            self._plan = maybe_plan(self.graph.to_csr().row_ptr, self._distributed)
+            self._plan = maybe_plan(self._order().row_ptr, self._distributed) if self._distributed else None
             self.graph._shard_plan = self._plan
             self._plan_ready = True
         return self._plan
@@ -266,8 +270,9 @@ class RecursiveFeatureExtractor:
     def _finalize_features(self) -> DataFrameLike:
         """DataFrame of every recorded feature, latest generation first (extract.py:91-96)."""
         K = self._K()
+        order = self._order()
         columns = self.final_columns()
-        data = {nm: K.to_host(self._final_cols[nm]).astype(self._dtypes.get(nm, np.dtype('float64')))
+        data = {nm: order.to_label_order(K.to_host(self._final_cols[nm])).astype(self._dtypes.get(nm, np.dtype('float64')))
                 for nm in columns}
         return pd.DataFrame(data, index=pd.Index(self._labels()), columns=columns)
 
@@ -277,7 +282,8 @@ class RecursiveFeatureExtractor:
     @property
     def _features(self) -> pd.DataFrame:
         K = self._K()
-        data = {nm: K.to_host(col).astype(self._dtypes.get(nm, np.dtype('float64')))
+        order = self._order()
+        data = {nm: order.to_label_order(K.to_host(col)).astype(self._dtypes.get(nm, np.dtype('float64')))
                 for nm, col in self._work.items()}
         if not data:
             return pd.DataFrame()
@@ -294,11 +300,12 @@ class RecursiveFeatureExtractor:
     @property
     def _final_features(self) -> Dict[int, DataFrameDict]:
         K = self._K()
+        order = self._order()
         labels = self._labels()
         out: Dict[int, DataFrameDict] = {}
         for gen, names in self._final_names.items():
             frame = pd.DataFrame(
-                {nm: K.to_host(self._final_cols[nm]).astype(self._dtypes.get(nm, np.dtype('float64')))
+                {nm: order.to_label_order(K.to_host(self._final_cols[nm])).astype(self._dtypes.get(nm, np.dtype('float64')))
                  for nm in names}, index=pd.Index(labels), columns=list(names))
             out[gen] = frame.to_dict()
         return out
@@ -318,9 +325,10 @@ class RecursiveFeatureExtractor:
 
     def _columns_from_frame(self, frame: pd.DataFrame):
         K = self._K()
+        order = self._order()
         frame = frame.reindex(self._labels()).fillna(0)     # nodes missing from the frame -> 0 (:132)
         names = [str(c) if not isinstance(c, str) else c for c in frame.columns]
-        cols = [K.to_device(frame[c].to_numpy(dtype=np.float64)) for c in frame.columns]
+        cols = [K.to_device(order.to_internal(frame[c].to_numpy(dtype=np.float64))) for c in frame.columns]
         dtypes = [frame[c].dtype if frame[c].dtype.kind in 'iu' else np.dtype('float64') for c in frame.columns]
         return names, cols, dtypes
 
@@ -329,7 +337,8 @@ class RecursiveFeatureExtractor:
         self._shard()
         names, cols, _, _ = self._next_feature_columns()
         K = self._K()
-        data = {nm: K.to_host(c) for nm, c in zip(names, cols)}
+        order = self._order()
+        data = {nm: order.to_label_order(K.to_host(c)) for nm, c in zip(names, cols)}
         return pd.DataFrame(data, index=pd.Index(self._labels()), columns=names)
 
     def _update(self, features: DataFrameLike) -> None:

@@ -92,3 +92,42 @@ class CSRGraph:
 
     def neighbors(self, row: int) -> np.ndarray:
         return self.col[self.row_ptr[row]:self.row_ptr[row + 1]]
+
+
+class InternalGraph:
+    """
+    The device-side view of a CSRGraph: rows relabelled in DEGREE-DESCENDING order (ties by
+    label order).  High-degree rows -- the hot gather targets and the hub work list -- become a
+    contiguous prefix, and consecutive rows have similar degrees, which is what lets the
+    aggregation kernels slice the adjacency without padding blow-up.  ``perm[i]`` is the
+    label-order row of internal row i, ``inv`` its inverse; every per-node device array is in
+    internal order and is mapped back with ``to_label_order`` at the host boundary only.
+    """
+
+    def __init__(self, g: CSRGraph) -> None:
+        n = g.n
+        deg = np.diff(g.row_ptr)
+        self.perm = np.argsort(-deg, kind='stable').astype(np.int64)
+        self.inv = np.empty(n, dtype=np.int64)
+        self.inv[self.perm] = np.arange(n, dtype=np.int64)
+        self.n, self.directed, self.weighted, self.integral = n, g.directed, g.weighted, g.integral
+        self.labels, self.num_edges = g.labels, g.num_edges
+        rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+        self.row_ptr, self.col, self.w = _csr_from_coo(n, self.inv[rows], self.inv[g.col], g.w)
+        if g.directed:
+            trows = np.repeat(np.arange(n, dtype=np.int64), np.diff(g.t_row_ptr))
+            self.t_row_ptr, self.t_col, self.t_w = _csr_from_coo(n, self.inv[trows], self.inv[g.t_col], g.t_w)
+        else:
+            self.t_row_ptr = self.t_col = self.t_w = None
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def to_internal(self, values: np.ndarray) -> np.ndarray:
+        """label-order per-node array -> internal order"""
+        return np.ascontiguousarray(np.asarray(values)[self.perm])
+
+    def to_label_order(self, values: np.ndarray) -> np.ndarray:
+        """internal-order per-node array -> label order"""
+        return np.ascontiguousarray(np.asarray(values)[..., self.inv])

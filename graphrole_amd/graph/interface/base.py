@@ -14,7 +14,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from graphrole_amd.graph.csr import CSRGraph
+from graphrole_amd.graph.csr import CSRGraph, InternalGraph
 from graphrole_amd.types import Node
 
 
@@ -79,9 +79,11 @@ class DeviceGraphInterface(BaseGraphInterface):
 
     # -- device state -----------------------------------------------------------------
     def _device_graph(self):
+        """(InternalGraph, device CSR, device transposed CSR or None); rows in internal
+        (degree-descending) order -- see graphrole_amd.graph.csr.InternalGraph."""
         if getattr(self, '_dev', None) is None:
             K = self._K()
-            host = self.to_csr()
+            host = InternalGraph(self.to_csr())
             out = K.DeviceCSR(host.row_ptr, host.col, host.w)
             tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
             self._dev = (host, out, tr)
@@ -127,7 +129,7 @@ class DeviceGraphInterface(BaseGraphInterface):
                 values = attr[name].to_numpy()
                 names.append(name)
                 dtypes.append(values.dtype if values.dtype.kind in 'iu' else np.dtype('float64'))
-                cols.append(K.to_device(values.astype(np.float64)))
+                cols.append(K.to_device(host.to_internal(values.astype(np.float64))))
         return names, cols, dtypes
 
     def egonet_feature_columns(self) -> Tuple[List[str], list, List[np.dtype]]:
@@ -149,7 +151,7 @@ class DeviceGraphInterface(BaseGraphInterface):
     def _frame(self, names, cols, dtypes) -> pd.DataFrame:
         K = self._K()
         host = self._device_graph()[0]
-        data = {nm: K.to_host(c).astype(dt) for nm, c, dt in zip(names, cols, dtypes)}
+        data = {nm: host.to_label_order(K.to_host(c)).astype(dt) for nm, c, dt in zip(names, cols, dtypes)}
         return pd.DataFrame(data, index=pd.Index(host.labels), columns=names)
 
     # -- reference API on top ------------------------------------------------------------
