@@ -38,6 +38,18 @@ def device() -> torch.device:
     return torch.device('cuda', torch.cuda.current_device())
 
 
+_NUM_CUS = None
+
+
+def num_cus() -> int:
+    global _NUM_CUS
+    if _NUM_CUS is None:
+        cu = ctypes.c_int(0)
+        _lib.call('grx_device_info', ctypes.byref(cu), None, None, 0)
+        _NUM_CUS = int(cu.value) or 256
+    return _NUM_CUS
+
+
 def to_device(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(device())
 
@@ -81,8 +93,9 @@ class DeviceCSR:
         hubs = np.nonzero(deg > HUB_FACTOR * self.lanes_per_row)[0].astype(np.int32)
         self.n_hubs = int(len(hubs))
         self.hub_rows = torch.from_numpy(hubs).to(dev) if self.n_hubs else None
-        self._host = (np.asarray(row_ptr, dtype=np.int64), col) if w is None else None
+        self._host = (np.asarray(row_ptr, dtype=np.int64), col)
         self._oriented = None
+        self.degree_sorted = bool(self.n < 2 or np.all(deg[1:] <= deg[:-1]))
 
     def oriented(self) -> 'DeviceCSR':
         """Degree-oriented copy (arc u->v iff (d'(u),u) < (d'(v),v)) for grx_triangle_counts."""
