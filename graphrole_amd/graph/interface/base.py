@@ -138,7 +138,8 @@ class DeviceGraphInterface(BaseGraphInterface):
         host, out, _ = self._device_graph()
         rb, re = self._row_range()
         rowsum = K.row_sums(out, False) if host.weighted else None
-        internal, external = K.egonet_features(out, host.directed, rowsum, rb, re)
+        internal, external = K.egonet_features(out, host.directed, rowsum, rb, re,
+                                               shard=getattr(self, '_shard_plan', None))
         internal, external = self._finish_columns([internal, external])
         dt = np.dtype('int64') if host.integral else np.dtype('float64')
         return ['internal_edges', 'external_edges'], [internal, external], [dt, dt]

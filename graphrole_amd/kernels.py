@@ -112,6 +112,17 @@ class DeviceCSR:
             self._oriented = DeviceCSR(o_ptr, col[keep])
         return self._oriented
 
+    def triangle_split(self, rank: int, world: int) -> Tuple[int, int]:
+        """Source-row range of the oriented CSR that `rank` of `world` counts triangles for:
+        cuts balance sum(d+ * (d+ + 1)), the size of the list intersections a source row starts."""
+        o = self.oriented()
+        dplus = np.diff(o._host[0])
+        work = np.cumsum(dplus * (dplus + 1) + 1)
+        total = int(work[-1]) if len(work) else 0
+        cuts = [0] + [int(np.searchsorted(work, total * p / world, side='left')) for p in range(1, world)] + [self.n]
+        cuts = np.maximum.accumulate(np.array(cuts, dtype=np.int64))
+        return int(cuts[rank]), int(cuts[rank + 1])
+
 
 def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: Optional[int] = None,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -130,14 +141,23 @@ def add_columns(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tensor] = None,
-                    row_begin: int = 0, row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                    row_begin: int = 0, row_end: Optional[int] = None, shard=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """
+    internal / external ego-net edge weight of rows [row_begin,row_end).
+    shard: a ShardPlan (rank, world, all_reduce_sum_) -- the triangle counts of the unweighted
+    undirected path are then split over the ranks by oriented source row and summed once.
+    """
     row_end = csr.n if row_end is None else row_end
-    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
-    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
     if csr.w is None and not directed:
         # exact integer fast path through per-node triangle counts
-        T = triangle_counts(csr)
+        if shard is None:
+            T = triangle_counts(csr)
+        else:
+            T = triangle_counts(csr, *csr.triangle_split(shard.rank, shard.world))
+            shard.all_reduce_sum_(T)
         return egonet_from_triangles(csr, T, row_begin, row_end)
+    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
     if csr.w is not None and rowsum is None:
         rowsum = row_sums(csr, False)
     _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),

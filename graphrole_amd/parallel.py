@@ -46,6 +46,12 @@ class ShardPlan:
         self.max_rows = int(np.diff(self.bounds).max()) if n else 0
 
     # ------------------------------------------------------------------ collectives
+    def _staged(self, t: torch.Tensor) -> bool:
+        """gloo has no device collectives for every op/dtype used here: with that backend (the
+        two-ranks-on-one-GPU test, tests/test_gpu_sharded.py) device tensors travel through the
+        host.  With nccl (= RCCL, the product path) tensors are exchanged in HBM."""
+        return t.is_cuda and dist.get_backend(self.group) == 'gloo'
+
     def all_gather_block(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> every slice valid, in place."""
         if self.world == 1:
@@ -55,8 +61,14 @@ class ShardPlan:
             return block
         send = torch.zeros((ncols, self.max_rows), dtype=block.dtype, device=block.device)
         send[:, :self.row_end - self.row_begin] = block[:, self.row_begin:self.row_end]
-        flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype, device=block.device)
-        dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
+        if self._staged(block):
+            send_h = send.cpu()
+            flat_h = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype)
+            dist.all_gather_into_tensor(flat_h, send_h, group=self.group)
+            flat = flat_h.to(block.device)
+        else:
+            flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype, device=block.device)
+            dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
         recv = flat.view(self.world, ncols, self.max_rows)
         for p in range(self.world):
             b, e = int(self.bounds[p]), int(self.bounds[p + 1])
@@ -72,15 +84,25 @@ class ShardPlan:
         self.all_gather_block(block)
         return [block[j] for j in range(len(cols))]
 
-    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+    def _all_reduce_(self, t: torch.Tensor, op) -> torch.Tensor:
         if self.world > 1 and t.numel():
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if self._staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=op, group=self.group)
+                t.copy_(h)
+            elif t.is_contiguous():
+                dist.all_reduce(t, op=op, group=self.group)
+            else:
+                c = t.contiguous()
+                dist.all_reduce(c, op=op, group=self.group)
+                t.copy_(c)
         return t
 
+    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        return self._all_reduce_(t, dist.ReduceOp.MAX)
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1 and t.numel():
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self._all_reduce_(t, dist.ReduceOp.SUM)
 
 
 def maybe_plan(row_ptr: np.ndarray, distributed) -> Optional[ShardPlan]:

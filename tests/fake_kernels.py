@@ -54,9 +54,16 @@ def add_columns(a, b):
     return a + b
 
 
-def egonet_features(csr, directed, rowsum=None, row_begin=0, row_end=None):
+def egonet_features(csr, directed, rowsum=None, row_begin=0, row_end=None, shard=None):
     row_end = csr.n if row_end is None else row_end
     i, e = ckernels.egonet(csr.row_ptr, csr.col, csr.w, directed)
+    if shard is not None and csr.w is None and not directed:
+        # same collective as the device path: per-rank partial integer counts, summed once
+        part = torch.zeros(csr.n, dtype=torch.int64)
+        mine = slice(shard.rank, csr.n, shard.world)
+        part[mine] = torch.from_numpy(np.rint(i).astype(np.int64))[mine]
+        shard.all_reduce_sum_(part)
+        assert np.array_equal(part.numpy(), np.rint(i).astype(np.int64))
     internal = torch.zeros(csr.n, dtype=torch.float64)
     external = torch.zeros(csr.n, dtype=torch.float64)
     internal[row_begin:row_end] = torch.from_numpy(i[row_begin:row_end])

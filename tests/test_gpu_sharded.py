@@ -1,0 +1,86 @@
+"""
+-m gpu: the N > 1 code path on the real kernels.  A gpurun box has ONE GPU, so two ranks share
+cuda:0 and talk over gloo (ShardPlan stages device tensors through the host for that backend);
+what is exercised is every row-range / column-split argument of the HIP entry points
+(grx_row_sums, grx_triangle_counts + all-reduce, grx_egonet_*, grx_aggregate, column-sharded
+grx_vertical_log_bin, row-sharded grx_chebyshev, grx_nmf_w_pass + all-reduce) and that the ranks
+end up with the table a single process computes -- bit for bit for ReFeX.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _graph(kind):
+    from graphrole_amd import synth
+    if kind == 'ba':
+        return synth.ba_graph(60_000, 8, seed=3)
+    return synth.directed_weighted_graph(40_000, 400_000, seed=4)
+
+
+def _worker(rank, port, kind, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from graphrole_amd import RecursiveFeatureExtractor, kernels as K
+        from graphrole_amd.roles import factor
+        G = _graph(kind)
+        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True)
+        X = fe.extract_features()
+        plan = fe._shard()
+        assert plan is not None and plan.world == WORLD and 0 < plan.row_end - plan.row_begin < G.n
+        Xd = K.gather_columns(fe.device_features()[1], G.n)
+        F = X.shape[1]
+        omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega)
+        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        out = dict(X=X.values.astype(float), cols=np.array(list(X.columns)), gen=fe.generation_count,
+                   W=K.to_host(state.W)[:, :G.n], H=K.to_host(state.H), n_iter=n_iter,
+                   rb=plan.row_begin, re=plan.row_end)
+        if rank == 0:
+            # the single-GPU answer, same process, same kernels
+            fe1 = RecursiveFeatureExtractor(G, max_generations=4)
+            X1 = fe1.extract_features()
+            Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
+            W1, H1 = factor.nndsvda_init_device(Xd1, G.n, 4, omega)
+            s1, it1 = factor.run_mu_loop(K.NmfState(Xd1, G.n, W1, H1))
+            out.update(X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), W1=K.to_host(s1.W)[:, :G.n],
+                       H1=K.to_host(s1.H), it1=it1)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['ba', 'directed_weighted'])
+def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
+    mp.spawn(_worker, args=(_free_port(), kind, str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    assert list(r0['cols']) == list(r1['cols']) == list(r0['cols1'])
+    assert np.array_equal(r0['X'], r1['X'])
+    assert np.array_equal(r0['X'], r0['X1'])                       # ReFeX: bit-exact vs one GPU
+    assert int(r0['n_iter']) == int(r1['n_iter']) == int(r0['it1'])
+    assert np.array_equal(r0['H'], r1['H'])
+    np.testing.assert_allclose(r0['H'], r0['H1'], rtol=1e-9)       # partial sums combine in another order
+    for r in (r0, r1):
+        rb, re = int(r['rb']), int(r['re'])
+        np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-15)
