@@ -125,10 +125,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    # GRX_BENCH_SHARE_GPU=1: functional check of the N > 1 path on a one-GPU box (all ranks on
+    # cuda:0, gloo).  Numbers from that mode are meaningless; the driver never sets it.
+    share_gpu = os.environ.get('GRX_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from graphrole_amd import RecursiveFeatureExtractor, _lib, backend
@@ -198,7 +206,8 @@ def main():
     prof = profile_totals(lib)
 
     # max over ranks
-    red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64, device='cuda')
+    red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64,
+                       device='cpu' if share_gpu else 'cuda')
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
@@ -220,7 +229,9 @@ def main():
     if rank == 0:
         gens = state['gens']
         edges_per_step = G.nnz * gens
-        value = edges_per_step * args.steps / t_refex
+        # headline: edges aggregated per second of the WHOLE step (ReFeX pass + NMF), consistent with
+        # ms_per_step; the per-phase rates are in refex.edges_per_s and nmf.iters_per_s
+        value = edges_per_step * args.steps / elapsed
         # aggregation-kernel roofline (algorithmic bytes per launch)
         f_per_gen = [s['candidates'] // 2 for s in state['stats'] if s['generation'] >= 1]
         rows_per_rank = G.n / world
@@ -270,6 +281,7 @@ def main():
                        'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
                        'sharding': 'node-range x%d, RCCL all-gather per generation' % world if world > 1 else 'single GPU'},
             'refex': {'ms_per_step': t_refex / args.steps * 1e3, 'edges_per_step': edges_per_step,
+                      'edges_per_s': edges_per_step * args.steps / t_refex,
                       'generations': state['stats']},
             'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / args.steps * 1e3,
                     'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
