@@ -67,7 +67,7 @@ def cpu_baseline(G, args, X_features):
     """Oracle (plain-C port, single thread) on the same graph; bounded to the full workload once."""
     from oracle import refex, reference_path
     og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=None, directed=False,
-                           num_edges=G.num_edges)
+                           num_edges=G.num_edges, adj_col=G.adj_col)
     t0 = time.perf_counter()
     res = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
     dt = time.perf_counter() - t0
@@ -167,8 +167,7 @@ def main():
         t1 = time.perf_counter()
         Xd = K.gather_columns(cols, G.n)
         omega = rng.normal(size=(len(names), N_ROLES + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega) if plan is None else \
-            factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega)
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega, plan=plan)
         nmf_state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
         torch.cuda.synchronize()
         t2 = time.perf_counter()

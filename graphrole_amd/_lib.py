@@ -53,8 +53,14 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_aggregate_ldr': (c_int, [c_int]),
-    'grx_aggregate': (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
-                              c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_plan_create': (c_int, [c_int64, c_void_p, c_void_p]),
+    'grx_aggregate_plan_destroy': (None, [c_void_p]),
+    'grx_aggregate_plan_info': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'grx_aggregate_plan_set_lanes': (c_int, [c_void_p, c_int]),
+    'grx_aggregate': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
+                              c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_minmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
+                                     c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_egonet_unweighted': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

@@ -5,12 +5,15 @@
 //   egonet_kernel          ego-net internal/external  networkx.py:71-83,115-123
 //   pack_rows_kernel       column-major -> row-major gather source
 //   aggregate_kernel       sum / mean over neighbours  features/extract.py:98-119
-//   aggregate_hub_kernel   same, one workgroup per high-degree row
+//   aggregate_blocks_kernel / aggregate_combine_kernel   the same for rows with > 128 neighbours
+//   aggregate_minmax_kernel   min / max over neighbours
 //
-// Determinism: every reduction is "per-lane sequential in CSR order, then a fixed butterfly /
-// fixed-order LDS sum", so the addition tree of a row depends only on its degree and the launch
-// geometry chosen from the graph's average degree.
+// Determinism: the neighbour sums follow numpy's pairwise-summation tree (a function of the row
+// length only), so they are bitwise equal to the reference's Series.sum() for any launch
+// geometry; the other reductions are "per-lane sequential, then a fixed butterfly".
 #include "grx_common.h"
+
+#include <vector>
 
 namespace {
 
@@ -329,15 +332,16 @@ __global__ __launch_bounds__(256) void egonet_from_triangles_hub_kernel(
 // ---------------------------------------------------------------------------------------
 // pack: column-major columns -> row-major n x ldr (zero padded)
 // ---------------------------------------------------------------------------------------
+// columns [c_off, c_off + f) of the row-major block; the pad columns [pad_from, ldr) are zeroed
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ldr, GrxPtrTable cols_tab,
-                                                        double *__restrict__ rows)
+                                                        double *__restrict__ rows, int c_off, int pad_from)
 {
     const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double *dst = rows + i * ldr;
-        for (int c = 0; c < f; ++c) dst[c] = cols[c][i];
-        for (int c = f; c < ldr; ++c) dst[c] = 0.0;
+        for (int c = 0; c < f; ++c) dst[c_off + c] = cols[c][i];
+        for (int c = pad_from; c < ldr; ++c) dst[c] = 0.0;
     }
 }
 
@@ -352,24 +356,121 @@ __global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const doubl
 // ---------------------------------------------------------------------------------------
 // neighbour aggregation
 // ---------------------------------------------------------------------------------------
+// The reference sums a node's neighbour rows column by column with Series.sum(), i.e. with
+// numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum_DOUBLE) in
+// the order G[node] lists the neighbours (features/extract.py:108-113).  The kernels reproduce
+// that association bit for bit:
+//     cnt < 8     sequential
+//     cnt <= 128  r[j] = x[j] + x[j+8] + ...;  ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7));  then the
+//                 cnt % 8 trailing elements one by one
+//     cnt > 128   binary tree over blocks: split at cnt/2 rounded down to a multiple of 8
+//     cnt > 8192  ndarray.sum() walks the column in chunks of 8192 elements (the ufunc buffer
+//                 size); each chunk is summed as above and added to the running total
+// which happens to be a good GPU shape: the eight accumulators are eight independent gathers.
+//
 // G lanes cooperate on one output row.  A neighbour's feature row is padded to LDR doubles
-// (LDR*8 = 16/32/64/128 bytes, so a row never straddles a 128-byte line and 64-byte rows are
-// exactly one cache line) and is fetched by CL = LDR/2 ADJACENT lanes, 16 bytes each: one
-// wave-level load touches 64/CL distinct lines instead of 64, which is what the address
-// units / L1 care about for a random gather.  Lane = (slot, part): slot = lane / CL walks the
-// neighbour list (two neighbours per trip for memory-level parallelism), part = lane % CL owns
-// columns 2*part, 2*part+1.  The slots are combined by a fixed butterfly, so the addition tree
-// of a row depends only on its degree and the launch geometry.  Rows with degree > hub_deg are
-// left to aggregate_hub_kernel.
+// (16/32/64/128 bytes, never straddling a 128-byte line) and fetched by CL = LDR/2 ADJACENT
+// lanes, 16 bytes each, so one wave-level load touches 64/CL lines.  Lane = (slot, part):
+// part = lane % CL owns columns 2*part, 2*part+1; slot = lane / CL owns the accumulators
+// r[slot], r[slot+S], ... (S = G/CL slots, A = 8/S accumulators per lane).  The tree levels
+// that pair accumulators of different slots are xor-shuffles, the others are local adds.
+// Rows with more than 128 neighbours are cut into the blocks of numpy's recursion by the host
+// (AggregatePlan): aggregate_blocks_kernel sums each block like a short row and
+// aggregate_combine_kernel adds the block sums along the same binary tree.
+constexpr int PW_BLOCK = 128;
+constexpr int PW_CHUNK = 8192;
+
+template <int LDR, int G>
+__device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col, const double *__restrict__ rows,
+                                                 int64_t row_stride, int64_t b, int cnt, int part, int slot,
+                                                 double &o0, double &o1)
+{
+    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
+    constexpr int S = G / CL, A = 8 / S;
+    static_assert(S >= 1 && S <= 8 && S * A == 8, "lane group must hold 1..8 neighbour slots");
+    const double *base = rows + 2 * part;
+    double res0 = 0.0, res1 = 0.0;
+    const int c8 = cnt & ~7;
+    if (c8) {
+        double r0[A], r1[A];
+#pragma unroll
+        for (int t = 0; t < A; ++t) {
+            const int64_t u = col[b + slot + t * S];
+            const double2 x = *reinterpret_cast<const double2 *>(base + u * row_stride);
+            r0[t] = x.x; r1[t] = x.y;
+        }
+        int i = 8;
+        if constexpr (A <= 2) {                           // two trips of 8 per iteration: 2A gathers in flight
+            for (; i + 8 < c8; i += 16) {
+                double2 x[2 * A];
+#pragma unroll
+                for (int t = 0; t < A; ++t) {
+                    const int64_t u0 = col[b + i + slot + t * S], u1 = col[b + i + 8 + slot + t * S];
+                    x[t] = *reinterpret_cast<const double2 *>(base + u0 * row_stride);
+                    x[A + t] = *reinterpret_cast<const double2 *>(base + u1 * row_stride);
+                }
+#pragma unroll
+                for (int t = 0; t < A; ++t) { r0[t] += x[t].x; r1[t] += x[t].y; }
+#pragma unroll
+                for (int t = 0; t < A; ++t) { r0[t] += x[A + t].x; r1[t] += x[A + t].y; }
+            }
+        }
+        for (; i < c8; i += 8) {
+#pragma unroll
+            for (int t = 0; t < A; ++t) {
+                const int64_t u = col[b + i + slot + t * S];
+                const double2 x = *reinterpret_cast<const double2 *>(base + u * row_stride);
+                r0[t] += x.x; r1[t] += x.y;
+            }
+        }
+        // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): residue j = slot + t*S, level `bit` pairs j ^ (1 << bit)
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {
+            if ((1 << bit) < S) {
+#pragma unroll
+                for (int t = 0; t < A; ++t) {
+                    r0[t] += __shfl_xor(r0[t], CL << bit, G);
+                    r1[t] += __shfl_xor(r1[t], CL << bit, G);
+                }
+            } else {
+                const int step = (1 << bit) / S;              // distance between partners in r[]
+#pragma unroll
+                for (int t = 0; t < A; t += 2 * step) {
+                    if (t + step < A) { r0[t] += r0[t + step]; r1[t] += r1[t + step]; }
+                }
+            }
+        }
+        res0 = r0[0]; res1 = r1[0];
+    }
+    const int rem = cnt - c8;
+    if (rem) {                                            // uniform over the lane group
+        double2 x[A];
+#pragma unroll
+        for (int t = 0; t < A; ++t) {
+            const int idx = c8 + slot + t * S;
+            x[t] = make_double2(0.0, 0.0);
+            if (idx < cnt) {
+                const int64_t u = col[b + idx];
+                x[t] = *reinterpret_cast<const double2 *>(base + u * row_stride);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int src = (i % S) * CL + part;
+            const double v0 = __shfl(x[i / S].x, src, G), v1 = __shfl(x[i / S].y, src, G);
+            if (i < rem) { res0 += v0; res1 += v1; }
+        }
+    }
+    o0 = res0; o1 = res1;
+}
+
 template <int LDR, int G>
 __global__ __launch_bounds__(256) void aggregate_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ rows, int64_t row_stride, int f, int64_t row_begin, int64_t row_end,
-    int64_t hub_deg, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+    double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
 {
-    constexpr int CL = LDR / 2;           // lanes per neighbour row
-    constexpr int S = G / CL;             // neighbour slots per output row
-    static_assert(S >= 1 && (S & (S - 1)) == 0, "G must be a power-of-two multiple of LDR/2");
+    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     const int lane = threadIdx.x % G;
     const int part = lane % CL, slot = lane / CL;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -377,26 +478,9 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         const int64_t d = e - b;
-        if (d > hub_deg) continue;
-        double a0 = 0.0, a1 = 0.0;
-        int64_t k = b + slot;
-        for (; k + S < e; k += 2 * S) {
-            const int64_t u0 = col[k], u1 = col[k + S];
-            const double2 x0 = *reinterpret_cast<const double2 *>(rows + u0 * row_stride + 2 * part);
-            const double2 x1 = *reinterpret_cast<const double2 *>(rows + u1 * row_stride + 2 * part);
-            a0 += x0.x; a1 += x0.y;
-            a0 += x1.x; a1 += x1.y;
-        }
-        if (k < e) {
-            const int64_t u0 = col[k];
-            const double2 x0 = *reinterpret_cast<const double2 *>(rows + u0 * row_stride + 2 * part);
-            a0 += x0.x; a1 += x0.y;
-        }
-#pragma unroll
-        for (int off = CL; off < G; off <<= 1) {
-            a0 += __shfl_xor(a0, off, G);
-            a1 += __shfl_xor(a1, off, G);
-        }
+        if (d > PW_BLOCK) continue;                       // aggregate_blocks_kernel + aggregate_combine_kernel
+        double a0, a1;
+        pairwise_segment<LDR, G>(col, rows, row_stride, b, (int)d, part, slot, a0, a1);
         if (slot == 0) {
             const double cnt = (double)d;
             const int c0 = 2 * part, c1 = 2 * part + 1;
@@ -412,75 +496,272 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
     }
 }
 
-// One workgroup per high-degree row.  The rows come from a host-built list (hub_rows, ascending)
-// so that the hubs -- which cluster at low indices in preferential-attachment graphs -- spread
-// over the whole chip instead of queueing behind each other.
-template <int FP>
-__global__ __launch_bounds__(256) void aggregate_hub_kernel(
-    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ rows, int64_t ldr, int f, int64_t row_begin, int64_t row_end,
-    const int32_t *__restrict__ hub_rows, int64_t n_hubs, double *__restrict__ out_sum,
-    double *__restrict__ out_mean, int64_t ld)
+// One lane group per block of a long row (57..128 neighbours); block sums to blk_sums[blk][16].
+template <int LDR, int G>
+__global__ __launch_bounds__(256) void aggregate_blocks_kernel(
+    const int32_t *__restrict__ col, const double *__restrict__ rows, int64_t row_stride,
+    int64_t row_begin, int64_t row_end, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ blk_begin, const int32_t *__restrict__ blk_len,
+    const int32_t *__restrict__ blk_row, int64_t n_blocks, double *__restrict__ blk_sums)
 {
-    __shared__ double red[4][FP];
-    for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-        const int64_t v = hub_rows[h];
-        if (v < row_begin || v >= row_end) continue;            // uniform over the workgroup
-        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
-        double acc[FP];
-#pragma unroll
-        for (int c = 0; c < FP; ++c) acc[c] = 0.0;
-        for (int64_t k = b + threadIdx.x; k < e; k += 256) {
-            const int64_t u = col[k];
-            const double2 *p = reinterpret_cast<const double2 *>(rows + u * ldr);
-#pragma unroll
-            for (int c = 0; c < FP / 2; ++c) {
-                const double2 x = p[c];
-                acc[2 * c] += x.x; acc[2 * c + 1] += x.y;
-            }
+    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
+    const int lane = threadIdx.x % G;
+    const int part = lane % CL, slot = lane / CL;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t k = group; k < n_blocks; k += ngroups) {
+        const int64_t v = long_rows[blk_row[k]];
+        if (v < row_begin || v >= row_end) continue;
+        double a0, a1;
+        pairwise_segment<LDR, G>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1);
+        if (slot == 0) {
+            blk_sums[k * 16 + 2 * part] = a0;
+            blk_sums[k * 16 + 2 * part + 1] = a1;
         }
-#pragma unroll
-        for (int c = 0; c < FP; ++c) acc[c] = grx_group_sum<64>(acc[c]);
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int c = 0; c < FP; ++c) red[threadIdx.x >> 6][c] = acc[c];
-        }
-        __syncthreads();
-        if (threadIdx.x < f) {
-            const int c = threadIdx.x;
-            const double sm = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-            if (out_sum) out_sum[(int64_t)c * ld + v] = sm;
-            if (out_mean) out_mean[(int64_t)c * ld + v] = sm / (double)(e - b);
-        }
-        __syncthreads();
     }
 }
 
-template <int LDR>
-int launch_aggregate(int G, const int64_t *row_ptr, const int32_t *col, const double *rows,
-                     int64_t row_stride, int f, int64_t rb, int64_t re, int64_t hub_deg,
-                     const int32_t *hub_rows, int64_t n_hubs, double *s, double *m, int64_t ld,
-                     hipStream_t st)
+// One 64-lane workgroup per long row: add the block sums along numpy's recursion
+//   sum(n) = n <= 128 ? block : sum(n2) + sum(n - n2),  n2 = n/2 - (n/2) % 8
+// chunk by chunk (8192 neighbours = at most 144 blocks), running total over the chunks.  The
+// block sums of a chunk are staged in LDS by all lanes; lane c then walks the tree for column c.
+constexpr int PW_MAX_BLOCKS_PER_CHUNK = PW_CHUNK / 57 + 1;      // blocks are 57..128 long
+
+__global__ __launch_bounds__(64) void aggregate_combine_kernel(
+    const int64_t *__restrict__ row_ptr, int f, int64_t row_begin, int64_t row_end,
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ blk_ptr, int64_t n_long,
+    const double *__restrict__ blk_sums, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
 {
-    constexpr int CL = LDR / 2;
-    if (G < CL) G = CL;
+    __shared__ double stage_lds[PW_MAX_BLOCKS_PER_CHUNK * 16];
+    const int c = threadIdx.x & 15;
+    for (int64_t h = blockIdx.x; h < n_long; h += gridDim.x) {
+        const int64_t v = long_rows[h];
+        if (v < row_begin || v >= row_end) continue;            // uniform over the workgroup
+        const int64_t n = row_ptr[v + 1] - row_ptr[v];
+        int64_t leaf = blk_ptr[h];
+        const int64_t leaf_end = blk_ptr[h + 1];
+        double total = 0.0;
+        for (int64_t c0 = 0; c0 < n; c0 += PW_CHUNK) {
+            const int64_t avail = leaf_end - leaf;
+            const int cnt = (int)(avail < PW_MAX_BLOCKS_PER_CHUNK ? avail : PW_MAX_BLOCKS_PER_CHUNK);
+            for (int i = threadIdx.x; i < cnt * 16; i += 64) stage_lds[i] = blk_sums[leaf * 16 + i];
+            __syncthreads();
+            int64_t sn[12];
+            double acc[12];
+            int stage[12];
+            int sp = 0, used = 0;
+            sn[0] = (n - c0 < PW_CHUNK) ? n - c0 : PW_CHUNK;
+            stage[0] = 0;
+            double val = 0.0;
+            bool finished = false;
+            while (!finished) {
+                bool returning = false;
+                if (sn[sp] <= PW_BLOCK) {
+                    val = stage_lds[(used++) * 16 + c];
+                    returning = true;
+                } else {
+                    int64_t n2 = sn[sp] / 2;
+                    n2 -= n2 % 8;
+                    stage[sp] = 1;
+                    sn[sp + 1] = n2; stage[sp + 1] = 0;
+                    ++sp;
+                }
+                while (returning) {
+                    if (sp == 0) { finished = true; break; }
+                    --sp;
+                    if (stage[sp] == 1) {                     // left half returned: descend into the right half
+                        acc[sp] = val;
+                        stage[sp] = 2;
+                        int64_t n2 = sn[sp] / 2;
+                        n2 -= n2 % 8;
+                        sn[sp + 1] = sn[sp] - n2; stage[sp + 1] = 0;
+                        ++sp;
+                        returning = false;
+                    } else {                                  // right half returned
+                        val = acc[sp] + val;
+                    }
+                }
+            }
+            total += val;
+            leaf += used;
+            __syncthreads();
+        }
+        if (threadIdx.x < f) {
+            if (out_sum) out_sum[(int64_t)c * ld + v] = total;
+            if (out_mean) out_mean[(int64_t)c * ld + v] = total / (double)n;
+        }
+    }
+}
+
+// min / max over the neighbours (aggs 'min', 'max' of features/extract.py:36-47); order-free.
+template <int LDR, int G>
+__global__ __launch_bounds__(256) void aggregate_minmax_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ rows, int64_t row_stride, int f, int64_t row_begin, int64_t row_end,
+    double *__restrict__ out_min, double *__restrict__ out_max, int64_t ld)
+{
+    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
+    constexpr int S = G / CL;
+    const int lane = threadIdx.x % G;
+    const int part = lane % CL, slot = lane / CL;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    const double inf = __builtin_huge_val();
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        double lo0 = inf, lo1 = inf, hi0 = -inf, hi1 = -inf;
+        for (int64_t k = b + slot; k < e; k += S) {
+            const int64_t u = col[k];
+            const double2 x = *reinterpret_cast<const double2 *>(rows + u * row_stride + 2 * part);
+            lo0 = fmin(lo0, x.x); hi0 = fmax(hi0, x.x);
+            lo1 = fmin(lo1, x.y); hi1 = fmax(hi1, x.y);
+        }
+#pragma unroll
+        for (int off = CL; off < G; off <<= 1) {
+            lo0 = fmin(lo0, __shfl_xor(lo0, off, G)); hi0 = fmax(hi0, __shfl_xor(hi0, off, G));
+            lo1 = fmin(lo1, __shfl_xor(lo1, off, G)); hi1 = fmax(hi1, __shfl_xor(hi1, off, G));
+        }
+        if (slot == 0) {
+            const bool any = e > b;                       // no neighbours -> NaN -> fillna(0) (:113)
+            const int c0 = 2 * part, c1 = 2 * part + 1;
+            if (c0 < f) {
+                if (out_min) out_min[(int64_t)c0 * ld + v] = any ? lo0 : 0.0;
+                if (out_max) out_max[(int64_t)c0 * ld + v] = any ? hi0 : 0.0;
+            }
+            if (c1 < f) {
+                if (out_min) out_min[(int64_t)c1 * ld + v] = any ? lo1 : 0.0;
+                if (out_max) out_max[(int64_t)c1 * ld + v] = any ? hi1 : 0.0;
+            }
+        }
+    }
+}
+
+// Per-graph preprocessing of grx_aggregate: lane-group width and the block list of the long rows.
+}  // namespace
+
+struct grx_aggregate_plan {
+    int64_t n = 0;
+    int lanes_per_row = 8;
+    int64_t n_long = 0, n_blocks = 0;
+    int32_t *d_long_rows = nullptr;     // [n_long] ascending
+    int64_t *d_blk_ptr = nullptr;       // [n_long + 1]
+    int64_t *d_blk_begin = nullptr;     // [n_blocks] position in d_col
+    int32_t *d_blk_len = nullptr;       // [n_blocks]
+    int32_t *d_blk_row = nullptr;       // [n_blocks] index into d_long_rows
+    double *d_blk_sums = nullptr;       // [n_blocks * 16] scratch
+};
+
+namespace {
+
+void pairwise_blocks(int64_t begin, int64_t n, std::vector<int64_t> &b, std::vector<int32_t> &len)
+{
+    if (n <= PW_BLOCK) { b.push_back(begin); len.push_back((int32_t)n); return; }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    pairwise_blocks(begin, n2, b, len);
+    pairwise_blocks(begin + n2, n - n2, b, len);
+}
+
+template <int LDR, int G>
+int launch_aggregate_g(const grx_aggregate_plan *p, const int64_t *row_ptr, const int32_t *col, const double *rows,
+                       int64_t row_stride, int f, int64_t rb, int64_t re, double *s, double *m, int64_t ld,
+                       hipStream_t st)
+{
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
     const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
     {
         GRX_PROF(GRX_K_AGGREGATE, st);
-        if (G <= 4 && CL <= 4) aggregate_kernel<LDR, (CL > 4 ? CL : 4)><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
-        else if (G <= 8 && CL <= 8) aggregate_kernel<LDR, (CL > 8 ? CL : 8)><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
-        else if (G <= 16) aggregate_kernel<LDR, 16><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
-        else aggregate_kernel<LDR, 32><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_deg, s, m, ld);
+        aggregate_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
-    if (n_hubs > 0) {
-        const int hgrid = (int)(n_hubs > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hubs);
+    if (p->n_long > 0) {
+        const int64_t bwant = grx_ceil_div(p->n_blocks * G, 256);
+        const int bgrid = (int)(bwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : bwant);
         GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-        aggregate_hub_kernel<LDR><<<hgrid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, hub_rows, n_hubs, s, m, ld);
+        aggregate_blocks_kernel<LDR, G><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
+                                                               p->d_blk_begin, p->d_blk_len, p->d_blk_row,
+                                                               p->n_blocks, p->d_blk_sums);
+        aggregate_combine_kernel<<<(unsigned)(p->n_long > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : p->n_long), 64, 0, st>>>(
+            row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_sums, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+template <int LDR, int G>
+int launch_minmax_g(const int64_t *row_ptr, const int32_t *col, const double *rows, int64_t row_stride, int f,
+                    int64_t rb, int64_t re, double *lo, double *hi, int64_t ld, hipStream_t st)
+{
+    const int64_t want = grx_ceil_div((re - rb) * G, 256);
+    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    {
+        GRX_PROF(GRX_K_AGGREGATE, st);
+        aggregate_minmax_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, lo, hi, ld);
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+// lanes per row G for a row stride: S = G / (LDR/2) must be 1, 2, 4 or 8
+template <int LDR>
+int launch_aggregate(bool minmax, const grx_aggregate_plan *p, const int64_t *row_ptr, const int32_t *col,
+                     const double *rows, int64_t row_stride, int f, int64_t rb, int64_t re, double *a, double *b,
+                     int64_t ld, hipStream_t st)
+{
+    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
+    int G = p->lanes_per_row;
+    if (G < CL) G = CL;
+    if (G > 8 * CL) G = 8 * CL;
+    if (G < 4) G = 4;
+#define GRX_AGG_CASE(GG)                                                                                              \
+    case GG:                                                                                                          \
+        if constexpr (GG >= CL && GG <= 8 * CL)                                                                       \
+            return minmax ? launch_minmax_g<LDR, GG>(row_ptr, col, rows, row_stride, f, rb, re, a, b, ld, st)         \
+                          : launch_aggregate_g<LDR, GG>(p, row_ptr, col, rows, row_stride, f, rb, re, a, b, ld, st);  \
+        break;
+    switch (G) {
+        GRX_AGG_CASE(4)
+        GRX_AGG_CASE(8)
+        GRX_AGG_CASE(16)
+        GRX_AGG_CASE(32)
+    default: break;
+    }
+#undef GRX_AGG_CASE
+    grx_set_error("grx_aggregate: no kernel for ldr=%d lanes_per_row=%d", LDR, G);
+    return GRX_ERR_UNSUPPORTED;
+}
+
+int aggregate_dispatch(bool minmax, const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col,
+                       int f, const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, double *d_a,
+                       double *d_b, int64_t ld, void *stream)
+{
+    const char *who = minmax ? "grx_aggregate_minmax" : "grx_aggregate";
+    GRX_REQUIRE(plan != nullptr, "%s: NULL plan (grx_aggregate_plan_create)", who);
+    const int64_t n = plan->n;
+    GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= n, "%s: bad row range", who);
+    GRX_REQUIRE(f >= 0 && ldr >= f, "%s: ldr=%d < f=%d", who, ldr, f);
+    GRX_REQUIRE(ldr == 2 || ldr == 4 || ldr == 8 || (ldr >= 16 && ldr % 16 == 0),
+                "%s: ldr=%d must be 2, 4, 8 or a multiple of 16 (use grx_aggregate_ldr)", who, ldr);
+    if (row_end == row_begin || f == 0) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "%s: NULL pointer", who);
+    GRX_REQUIRE(ld >= n, "%s: ld < n", who);
+    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 127) == 0, "%s: d_rows must be 128-byte aligned", who);
+    hipStream_t st = grx_stream(stream);
+    if (ldr < 16)
+        switch (ldr) {
+        case 2:  return launch_aggregate<2>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
+        case 4:  return launch_aggregate<4>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
+        default: return launch_aggregate<8>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
+        }
+    // wide rows: 16 columns (one 128-byte segment of every row) per launch
+    for (int c0 = 0; c0 < f; c0 += 16) {
+        const int fc = (f - c0 < 16) ? (f - c0) : 16;
+        double *a = d_a ? d_a + (int64_t)c0 * ld : nullptr;
+        double *b = d_b ? d_b + (int64_t)c0 * ld : nullptr;
+        int rc = launch_aggregate<16>(minmax, plan, d_row_ptr, d_col, d_rows + c0, ldr, fc, row_begin, row_end, a, b, ld, st);
+        if (rc != GRX_OK) return rc;
+    }
     return GRX_OK;
 }
 
@@ -607,62 +888,111 @@ int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_
 int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_rows, int ldr,
                   void *stream)
 {
-    if (f > GRX_MAX_PTRS) {
-        grx_set_error("grx_pack_rows: f=%d > %d columns per call", f, GRX_MAX_PTRS);
-        return GRX_ERR_UNSUPPORTED;
-    }
     GRX_REQUIRE(n >= 0 && f >= 0 && ldr >= f, "grx_pack_rows: bad shape n=%lld f=%d ldr=%d",
                 (long long)n, f, ldr);
     if (n == 0 || ldr == 0) return GRX_OK;
     GRX_REQUIRE(h_col_ptrs && d_rows, "grx_pack_rows: NULL pointer");
-    GrxPtrTable tab;
-    for (int c = 0; c < f; ++c) tab.p[c] = h_col_ptrs[c];
     const int64_t want = grx_ceil_div(n, 256);
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
-    { GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
-    pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, f, ldr, tab, d_rows);
+    // the pointer table travels as a kernel argument, GRX_MAX_PTRS columns per launch
+    for (int c0 = 0; c0 < f || c0 == 0; c0 += GRX_MAX_PTRS) {
+        const int fc = (f - c0 < GRX_MAX_PTRS) ? f - c0 : GRX_MAX_PTRS;
+        const bool last = c0 + fc >= f;
+        GrxPtrTable tab;
+        for (int c = 0; c < fc; ++c) tab.p[c] = h_col_ptrs[c0 + c];
+        {
+            GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
+            pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
+        }
+        GRX_LAUNCH_CHECK();
+        if (last) break;
     }
-    GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
 
-int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
-                  const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
-                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row,
-                  const int32_t *d_hub_rows, int64_t n_hub_rows, void *stream)
+int grx_aggregate_plan_create(int64_t n, const int64_t *h_row_ptr, grx_aggregate_plan **out)
 {
-    GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
-                "grx_aggregate: bad row range");
-    GRX_REQUIRE(f >= 0 && ldr >= f, "grx_aggregate: ldr=%d < f=%d", ldr, f);
-    GRX_REQUIRE(ldr == 2 || ldr == 4 || ldr == 8 || (ldr >= 16 && ldr % 16 == 0),
-                "grx_aggregate: ldr=%d must be 2, 4, 8 or a multiple of 16 (use grx_aggregate_ldr)", ldr);
-    if (row_end == row_begin || f == 0) return GRX_OK;
-    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate: NULL pointer");
-    GRX_REQUIRE(ld >= n, "grx_aggregate: ld < n");
-    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 127) == 0, "grx_aggregate: d_rows must be 128-byte aligned");
-    int G = lanes_per_row;
-    if (G != 4 && G != 8 && G != 16 && G != 32) G = 8;
-    GRX_REQUIRE(n_hub_rows >= 0 && (n_hub_rows == 0 || d_hub_rows != nullptr), "grx_aggregate: bad hub list");
-    // rows longer than this are expected in d_hub_rows; without a list every row takes the
-    // lane-group path (correct, but hubs then serialise on one lane group)
-    const int64_t hub_deg = d_hub_rows ? (int64_t)G * GRX_HUB_FACTOR : ((int64_t)1 << 62);
-    hipStream_t st = grx_stream(stream);
-    if (ldr < 16)
-        switch (ldr) {
-        case 2:  return launch_aggregate<2>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
-        case 4:  return launch_aggregate<4>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
-        default: return launch_aggregate<8>(G, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, hub_deg, d_hub_rows, n_hub_rows, d_sum, d_mean, ld, st);
-        }
-    // wide rows: 16 columns (one 128-byte segment of every row) per launch
-    for (int c0 = 0; c0 < f; c0 += 16) {
-        const int fc = (f - c0 < 16) ? (f - c0) : 16;
-        double *s = d_sum ? d_sum + (int64_t)c0 * ld : nullptr;
-        double *m = d_mean ? d_mean + (int64_t)c0 * ld : nullptr;
-        int rc = launch_aggregate<16>(G, d_row_ptr, d_col, d_rows + c0, ldr, fc, row_begin, row_end, hub_deg,
-                                      d_hub_rows, n_hub_rows, s, m, ld, st);
-        if (rc != GRX_OK) return rc;
+    GRX_REQUIRE(n >= 0 && out != nullptr && (n == 0 || h_row_ptr != nullptr), "grx_aggregate_plan_create: bad arguments");
+    auto *p = new grx_aggregate_plan();
+    p->n = n;
+    const double avg = n ? (double)(h_row_ptr[n] - h_row_ptr[0]) / (double)n : 0.0;
+    p->lanes_per_row = avg < 12 ? 4 : avg < 24 ? 8 : avg < 48 ? 16 : 32;
+    std::vector<int32_t> long_rows, blk_len, blk_row;
+    std::vector<int64_t> blk_ptr, blk_begin;
+    for (int64_t v = 0; v < n; ++v) {
+        const int64_t d = h_row_ptr[v + 1] - h_row_ptr[v];
+        if (d <= PW_BLOCK) continue;
+        blk_ptr.push_back((int64_t)blk_begin.size());
+        const size_t before = blk_begin.size();
+        for (int64_t c0 = 0; c0 < d; c0 += PW_CHUNK)
+            pairwise_blocks(h_row_ptr[v] + c0, (d - c0 < PW_CHUNK) ? d - c0 : PW_CHUNK, blk_begin, blk_len);
+        blk_row.insert(blk_row.end(), blk_begin.size() - before, (int32_t)long_rows.size());
+        long_rows.push_back((int32_t)v);
     }
+    blk_ptr.push_back((int64_t)blk_begin.size());
+    p->n_long = (int64_t)long_rows.size();
+    p->n_blocks = (int64_t)blk_begin.size();
+    auto upload = [](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    if (p->n_long) {
+        e = upload((void **)&p->d_long_rows, long_rows.data(), long_rows.size() * 4);
+        if (e == hipSuccess) e = upload((void **)&p->d_blk_ptr, blk_ptr.data(), blk_ptr.size() * 8);
+        if (e == hipSuccess) e = upload((void **)&p->d_blk_begin, blk_begin.data(), blk_begin.size() * 8);
+        if (e == hipSuccess) e = upload((void **)&p->d_blk_len, blk_len.data(), blk_len.size() * 4);
+        if (e == hipSuccess) e = upload((void **)&p->d_blk_row, blk_row.data(), blk_row.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_blk_sums, (size_t)p->n_blocks * 16 * 8);
+    }
+    if (e != hipSuccess) {
+        grx_set_error("grx_aggregate_plan_create: %s", hipGetErrorString(e));
+        grx_aggregate_plan_destroy(p);
+        return GRX_ERR_HIP;
+    }
+    *out = p;
     return GRX_OK;
+}
+
+void grx_aggregate_plan_destroy(grx_aggregate_plan *p)
+{
+    if (!p) return;
+    (void)hipFree(p->d_long_rows); (void)hipFree(p->d_blk_ptr); (void)hipFree(p->d_blk_begin);
+    (void)hipFree(p->d_blk_len); (void)hipFree(p->d_blk_row); (void)hipFree(p->d_blk_sums);
+    delete p;
+}
+
+int grx_aggregate_plan_info(const grx_aggregate_plan *p, int64_t *n_long_rows, int64_t *n_blocks, int *lanes_per_row)
+{
+    GRX_REQUIRE(p != nullptr, "grx_aggregate_plan_info: NULL plan");
+    if (n_long_rows) *n_long_rows = p->n_long;
+    if (n_blocks) *n_blocks = p->n_blocks;
+    if (lanes_per_row) *lanes_per_row = p->lanes_per_row;
+    return GRX_OK;
+}
+
+int grx_aggregate_plan_set_lanes(grx_aggregate_plan *p, int lanes_per_row)
+{
+    GRX_REQUIRE(p != nullptr, "grx_aggregate_plan_set_lanes: NULL plan");
+    GRX_REQUIRE(lanes_per_row == 4 || lanes_per_row == 8 || lanes_per_row == 16 || lanes_per_row == 32,
+                "grx_aggregate_plan_set_lanes: lanes_per_row must be 4, 8, 16 or 32");
+    p->lanes_per_row = lanes_per_row;
+    return GRX_OK;
+}
+
+int grx_aggregate(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                  const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
+                  double *d_sum, double *d_mean, int64_t ld, void *stream)
+{
+    return aggregate_dispatch(false, plan, d_row_ptr, d_col, f, d_rows, ldr, row_begin, row_end, d_sum, d_mean, ld, stream);
+}
+
+int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                         const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
+                         double *d_min, double *d_max, int64_t ld, void *stream)
+{
+    return aggregate_dispatch(true, plan, d_row_ptr, d_col, f, d_rows, ldr, row_begin, row_end, d_min, d_max, ld, stream);
 }
 
 /* row stride (in doubles) grx_pack_rows / grx_aggregate use for f columns */

@@ -546,21 +546,21 @@ extern "C" {
 int grx_gather_columns(int64_t n, int F, const double *const *h_col_ptrs, double *d_out, int64_t ld,
                        void *stream)
 {
-    if (F > GRX_MAX_PTRS) {
-        grx_set_error("grx_gather_columns: F=%d > %d columns per call", F, GRX_MAX_PTRS);
-        return GRX_ERR_UNSUPPORTED;
-    }
     GRX_REQUIRE(n >= 0 && F >= 0 && ld >= n, "grx_gather_columns: bad shape");
     if (n == 0 || F == 0) return GRX_OK;
     GRX_REQUIRE(h_col_ptrs && d_out, "grx_gather_columns: NULL pointer");
-    GrxPtrTable tab;
-    for (int c = 0; c < F; ++c) tab.p[c] = h_col_ptrs[c];
     const int64_t want = grx_ceil_div(n, 256 * 4);
-    const dim3 grid((unsigned)(want > 1024 ? 1024 : want), F);
-    { GRX_PROF(GRX_K_GATHER_COLUMNS, grx_stream(stream));
-    gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, F, tab, d_out, ld);
+    for (int c0 = 0; c0 < F; c0 += GRX_MAX_PTRS) {               // pointer table: GRX_MAX_PTRS per launch
+        const int fc = (F - c0 < GRX_MAX_PTRS) ? F - c0 : GRX_MAX_PTRS;
+        GrxPtrTable tab;
+        for (int c = 0; c < fc; ++c) tab.p[c] = h_col_ptrs[c0 + c];
+        const dim3 grid((unsigned)(want > 1024 ? 1024 : want), fc);
+        {
+            GRX_PROF(GRX_K_GATHER_COLUMNS, grx_stream(stream));
+            gather_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, fc, tab, d_out + (size_t)c0 * ld, ld);
+        }
+        GRX_LAUNCH_CHECK();
     }
-    GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
 

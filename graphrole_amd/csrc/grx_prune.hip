@@ -263,9 +263,12 @@ constexpr int CH_ROWS = 512;                 // rows per LDS tile
 constexpr int CH_STRIDE = CH_ROWS + 4;       // +4 bytes: column p starts on bank p (mod 32)
 constexpr int CH_MAX_F = 120;               // F * CH_STRIDE <= 64 KiB of LDS
 
+// The F local columns are the global columns [a0, a0+na) followed by [b0, b0+F-na); dist is the
+// global ldF x ldF matrix (more than CH_MAX_F columns are covered by several launches).
 __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
                                                         int first_new, GrxPtrTable ptr_tab,
-                                                        int32_t *__restrict__ dist)
+                                                        int32_t *__restrict__ dist, int ldF, int a0, int na,
+                                                        int b0)
 {
     const uint8_t *const *ptrs = reinterpret_cast<const uint8_t *const *>(ptr_tab.p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -329,9 +332,10 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 #pragma unroll
     for (int k = 0; k < MAX_OWN; ++k) {
         if (own_pq[k] >= 0) {
-            const int p = own_pq[k] >> 8, q = own_pq[k] & 0xFF;
-            atomicMax(&dist[p * F + q], own_max[k]);
-            atomicMax(&dist[q * F + p], own_max[k]);
+            const int lp = own_pq[k] >> 8, lq = own_pq[k] & 0xFF;
+            const int p = lp < na ? a0 + lp : b0 + (lp - na), q = lq < na ? a0 + lq : b0 + (lq - na);
+            atomicMax(&dist[(size_t)p * ldF + q], own_max[k]);
+            atomicMax(&dist[(size_t)q * ldF + p], own_max[k]);
         }
     }
 }
@@ -488,21 +492,45 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
 {
     GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end, "grx_chebyshev: bad row range");
     GRX_REQUIRE(F >= 0 && first_new >= 0, "grx_chebyshev: bad F/first_new");
-    if (F > CH_MAX_F) {
-        grx_set_error("grx_chebyshev: F=%d > %d", F, CH_MAX_F);
-        return GRX_ERR_UNSUPPORTED;
-    }
     if (F < 2 || first_new >= F || row_end == row_begin) return GRX_OK;
     GRX_REQUIRE(h_bin_ptrs && d_dist, "grx_chebyshev: NULL pointer");
-    GrxPtrTable tab;
-    for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
+    hipStream_t st = grx_stream(stream);
     const int64_t tiles = grx_ceil_div(row_end - row_begin, CH_ROWS);
     const int grid = (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : tiles);
-    const size_t lds = (size_t)F * CH_STRIDE;
-    { GRX_PROF(GRX_K_CHEBYSHEV, grx_stream(stream));
-    chebyshev_kernel<<<grid, 256, lds, grx_stream(stream)>>>(row_begin, row_end, F, first_new, tab, d_dist);
+    if (F <= CH_MAX_F) {
+        GrxPtrTable tab;
+        for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
+        const size_t lds = (size_t)F * CH_STRIDE;
+        {
+            GRX_PROF(GRX_K_CHEBYSHEV, st);
+            chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, first_new, tab, d_dist, F, 0, F, 0);
+        }
+        GRX_LAUNCH_CHECK();
+        return GRX_OK;
     }
-    GRX_LAUNCH_CHECK();
+    // more columns than one LDS tile holds: column groups of CH_MAX_F/2, one launch per pair of
+    // groups (A, A): all pairs inside A;  (A, B), A < B: the pairs between A and B (q in B, p < q;
+    // the pairs inside B are recomputed, harmless under atomicMax)
+    constexpr int GROUP = CH_MAX_F / 2;
+    const int ngroups = (F + GROUP - 1) / GROUP;
+    for (int A = 0; A < ngroups; ++A) {
+        const int a0 = A * GROUP, na = (F - a0 < GROUP) ? F - a0 : GROUP;
+        for (int B = A; B < ngroups; ++B) {
+            const int b0 = B * GROUP, nb = (B == A) ? 0 : ((F - b0 < GROUP) ? F - b0 : GROUP);
+            GrxPtrTable tab;
+            for (int c = 0; c < na; ++c) tab.p[c] = h_bin_ptrs[a0 + c];
+            for (int c = 0; c < nb; ++c) tab.p[na + c] = h_bin_ptrs[b0 + c];
+            const int Fl = na + nb;
+            if (Fl < 2) continue;
+            const size_t lds = (size_t)Fl * CH_STRIDE;
+            {
+                GRX_PROF(GRX_K_CHEBYSHEV, st);
+                chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, Fl, (B == A) ? 0 : na, tab, d_dist, F,
+                                                         a0, na, b0);
+            }
+            GRX_LAUNCH_CHECK();
+        }
+    }
     return GRX_OK;
 }
 

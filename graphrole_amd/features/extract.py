@@ -23,7 +23,7 @@ from graphrole_amd.features.prune import FeaturePruner
 from graphrole_amd.graph import interface
 from graphrole_amd.types import DataFrameDict, DataFrameLike
 
-_SUPPORTED_AGGS = ('sum', 'mean')
+_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max')
 
 
 def _agg_name(agg) -> str:
@@ -198,17 +198,35 @@ class RecursiveFeatureExtractor:
         _, dev_graph, _ = self.graph._device_graph()
         rows, ldr = K.pack_rows([self._work[c] for c in prev], n)
         rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
-        block = K.aggregate(dev_graph, rows, f, ldr, rb, re,
-                            want_sum='sum' in aggs, want_mean='mean' in aggs)
-        offset = {'sum': 0, 'mean': f}
-        picked = [offset[a] + j for a in aggs for j in range(f)]
-        # the requested rows of the block, in candidate order (all sums, then all means, :158-162)
-        sub = block if picked == list(range(2 * f)) else block[picked].contiguous()
+        pieces = {}
+        if 'sum' in aggs or 'mean' in aggs:
+            block = K.aggregate(dev_graph, rows, f, ldr, rb, re,
+                                want_sum='sum' in aggs, want_mean='mean' in aggs)
+            pieces['sum'], pieces['mean'] = block[:f], block[f:]
+        if 'min' in aggs or 'max' in aggs:
+            mm = K.aggregate_minmax(dev_graph, rows, f, ldr, rb, re,
+                                    want_min='min' in aggs, want_max='max' in aggs)
+            pieces['min'], pieces['max'] = mm[:f], mm[f:]
+        # candidate order: every column under the first aggregation, then the second, ... (:158-162)
+        if list(aggs) == ['sum', 'mean']:
+            sub = block
+        else:
+            import torch
+            sub = torch.cat([pieces[a] for a in aggs], dim=0).contiguous()
+        picked = range(len(aggs) * f)
         if plan is not None:
             plan.all_gather_block(sub)            # the one exchange of this generation
         cols = [sub[j] for j in range(len(picked))]
         names = [f'{c}({a})' for a in aggs for c in prev]
-        return names, cols, [np.dtype('float64')] * len(names), sub
+        # pandas dtype of the reference's frame (extract.py:104-119): the per-node agg frame of an
+        # integer column stays integer unless 'mean' is among the aggs or a node without
+        # neighbours turns min / max into NaN -> 0.0; one float value makes the column float64
+        host = self.graph._device_graph()[0]
+        no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
+        keeps_int = 'mean' not in aggs and (no_empty_rows or set(aggs) <= {'sum'})
+        f64, i64 = np.dtype('float64'), np.dtype('int64')
+        dtypes = [i64 if keeps_int and self._dtypes.get(c, f64).kind in 'iu' else f64 for a in aggs for c in prev]
+        return names, cols, dtypes, sub
 
     def _update_columns(self, names: Sequence[str], cols: Sequence, dtypes: Sequence[np.dtype],
                         block=None) -> None:

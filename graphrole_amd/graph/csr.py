@@ -6,7 +6,10 @@ wherever a networkx graph is accepted.
 
 Host-side ingest: edge arrays -> CSR of the out-adjacency with rows in sorted-label
 order and ascending column indices (+ the transposed CSR for directed graphs, used for the
-weighted in-degree).
+weighted in-degree), plus ``adj_col``: the same rows with every node's neighbours in ADJACENCY
+order -- the order the reference's ``G[node]`` lists them, which is the order its neighbour
+sums are evaluated in (graphrole/features/extract.py:108-113).  For edge arrays that is the order
+of appearance (what networkx would hold after add_edge(src[i], dst[i]) for i = 0, 1, ...).
 """
 from __future__ import annotations
 
@@ -32,6 +35,24 @@ def _csr_from_coo(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarr
     return row_ptr, col, w_sorted
 
 
+def adjacency_order(n: int, src: np.ndarray, dst: np.ndarray, directed: bool) -> np.ndarray:
+    """Out-adjacency rows (sorted-label row order) with neighbours by index of the incident edge:
+    add_edge(u, v) appends v to adj[u] and u to adj[v] (once for a self-loop)."""
+    m = len(src)
+    if directed:
+        rows, cols = src, dst
+    else:
+        rows = np.empty(2 * m, dtype=np.int64)
+        cols = np.empty(2 * m, dtype=np.int64)
+        rows[0::2], rows[1::2] = src, dst
+        cols[0::2], cols[1::2] = dst, src
+        keep = np.ones(2 * m, dtype=bool)
+        keep[1::2] = src != dst
+        rows, cols = rows[keep], cols[keep]
+    order = np.argsort(rows, kind='stable')
+    return cols[order].astype(np.int32)
+
+
 class CSRGraph:
     """
     :param n: number of nodes (row i <-> labels[i]; labels default to 0..n-1 and must be sorted)
@@ -40,11 +61,14 @@ class CSRGraph:
       integer-typed array keeps the degree / ego-net columns int64 like networkx does
     :param directed: arcs src -> dst when True
     :param attributes: optional {name: array of n numbers} numeric node attributes
+    :param adjacency: optional int array [nnz]: every row's neighbours (row indices) in the order
+      the neighbour sums must be evaluated in, rows concatenated in row order; default = order of
+      appearance in (src, dst).  The networkx adapter passes ``G[node]`` order.
     """
 
     def __init__(self, n: int, src, dst, weights=None, directed: bool = False,
                  labels: Optional[Sequence] = None, attributes: Optional[Dict[str, np.ndarray]] = None,
-                 validate: bool = True) -> None:
+                 validate: bool = True, adjacency=None) -> None:
         src = np.ascontiguousarray(src, dtype=np.int64)
         dst = np.ascontiguousarray(dst, dtype=np.int64)
         if src.shape != dst.shape or src.ndim != 1:
@@ -79,6 +103,16 @@ class CSRGraph:
             w2 = None if w is None else np.concatenate([w, w[off]])
             self.row_ptr, self.col, self.w = _csr_from_coo(n, s2, d2, w2)
             self.t_row_ptr = self.t_col = self.t_w = None
+        if adjacency is None:
+            self.adj_col = adjacency_order(n, src, dst, directed)
+        else:
+            self.adj_col = np.ascontiguousarray(adjacency, dtype=np.int32)
+        if self.adj_col.shape != self.col.shape:
+            raise ValueError('adjacency must list every neighbour of every row exactly once')
+        if validate and len(self.col):
+            rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(self.row_ptr))
+            if not np.array_equal(np.sort(rows * n + self.adj_col), rows * n + self.col):
+                raise ValueError('adjacency rows must be permutations of the neighbour sets')
         self.attributes: Dict[str, np.ndarray] = {}
         for name, values in (attributes or {}).items():
             values = np.asarray(values)
@@ -114,6 +148,11 @@ class InternalGraph:
         self.labels, self.num_edges = g.labels, g.num_edges
         rows = np.repeat(np.arange(n, dtype=np.int64), deg)
         self.row_ptr, self.col, self.w = _csr_from_coo(n, self.inv[rows], self.inv[g.col], g.w)
+        # neighbour lists in the reference's visiting order, rows permuted, ids relabelled
+        new_deg = deg[self.perm]
+        src_pos = (np.arange(len(g.col), dtype=np.int64) - np.repeat(self.row_ptr[:-1], new_deg)
+                   + np.repeat(g.row_ptr[:-1][self.perm], new_deg))
+        self.agg_col = self.inv[g.adj_col[src_pos]].astype(np.int32)
         if g.directed:
             trows = np.repeat(np.arange(n, dtype=np.int64), np.diff(g.t_row_ptr))
             self.t_row_ptr, self.t_col, self.t_w = _csr_from_coo(n, self.inv[trows], self.inv[g.t_col], g.t_w)

@@ -84,7 +84,7 @@ class DeviceGraphInterface(BaseGraphInterface):
         if getattr(self, '_dev', None) is None:
             K = self._K()
             host = InternalGraph(self.to_csr())
-            out = K.DeviceCSR(host.row_ptr, host.col, host.w)
+            out = K.DeviceCSR(host.row_ptr, host.col, host.w, agg_col=host.agg_col)
             tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
             self._dev = (host, out, tr)
         return self._dev

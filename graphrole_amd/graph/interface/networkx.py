@@ -59,8 +59,11 @@ class NetworkxInterface(DeviceGraphInterface):
                     integral = integral and isinstance(weight, Integral)
             if weighted and integral:
                 wts = wts.astype(np.int64)
+            # G[node] iteration order = the order the reference's reindex(nbrs) sums in
+            # (features/extract.py:108-110); G.edges is grouped by node, so read adj itself
+            adjacency = np.fromiter((row_of[v] for label in labels for v in self.G.adj[label]), dtype=np.int32)
             self._csr = CSRGraph(len(labels), src, dst, wts if weighted else None, self.directed,
-                                 labels=labels, validate=False)
+                                 labels=labels, validate=False, adjacency=adjacency)
         return self._csr
 
     def _attribute_frame(self) -> Optional[pd.DataFrame]:

@@ -71,10 +71,40 @@ def ptr_array(tensors: Sequence[torch.Tensor]):
     return (c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
 
 
-class DeviceCSR:
-    """CSR adjacency resident in HBM (row_ptr int64[n+1], col int32[nnz], optional w fp64[nnz])."""
+class AggregatePlan:
+    """Owner of a grx_aggregate_plan (per-graph preprocessing of grx_aggregate, see grx.h)."""
 
-    def __init__(self, row_ptr: np.ndarray, col: np.ndarray, w: Optional[np.ndarray] = None):
+    def __init__(self, row_ptr: np.ndarray) -> None:
+        import ctypes
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        handle = ctypes.c_void_p()
+        _lib.call('grx_aggregate_plan_create', len(row_ptr) - 1, row_ptr.ctypes.data_as(c_void_p),
+                  ctypes.byref(handle))
+        self.handle = handle
+        n_long, n_blocks, lanes = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _lib.call('grx_aggregate_plan_info', handle, ctypes.byref(n_long), ctypes.byref(n_blocks), ctypes.byref(lanes))
+        self.n_long_rows, self.n_blocks, self.lanes_per_row = n_long.value, n_blocks.value, lanes.value
+
+    def set_lanes(self, lanes_per_row: int) -> None:
+        _lib.call('grx_aggregate_plan_set_lanes', self.handle, int(lanes_per_row))
+        self.lanes_per_row = int(lanes_per_row)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().grx_aggregate_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceCSR:
+    """CSR adjacency resident in HBM (row_ptr int64[n+1], col int32[nnz] ascending inside a row,
+    optional w fp64[nnz]).  agg_col (optional): the same rows with the neighbours in the order the
+    reference visits them -- the summation order of grx_aggregate (defaults to col)."""
+
+    def __init__(self, row_ptr: np.ndarray, col: np.ndarray, w: Optional[np.ndarray] = None,
+                 agg_col: Optional[np.ndarray] = None):
         dev = device()
         self.n = int(len(row_ptr) - 1)
         self.nnz = int(row_ptr[-1]) if len(row_ptr) else 0
@@ -86,16 +116,25 @@ class DeviceCSR:
             w = np.ascontiguousarray(w, dtype=np.float64)
             self.w = torch.from_numpy(w if len(w) else np.zeros(1)).to(dev)
         avg = self.nnz / max(self.n, 1)
-        # lanes that cooperate on one row in grx_aggregate: ~half the mean degree, power of two
+        # lane-group width of the ego-net finish kernel; rows above 32 * lanes_per_row neighbours
+        # get a workgroup each there (grx_egonet_unweighted hub list)
         self.lanes_per_row = 4 if avg < 12 else 8 if avg < 24 else 16 if avg < 48 else 32
-        # rows above 32 * lanes_per_row neighbours get a workgroup each (grx_aggregate hub list)
         deg = np.diff(np.asarray(row_ptr, dtype=np.int64))
         hubs = np.nonzero(deg > HUB_FACTOR * self.lanes_per_row)[0].astype(np.int32)
         self.n_hubs = int(len(hubs))
         self.hub_rows = torch.from_numpy(hubs).to(dev) if self.n_hubs else None
         self._host = (np.asarray(row_ptr, dtype=np.int64), col)
         self._oriented = None
+        self.agg_col = self.col
+        if agg_col is not None and len(agg_col):
+            self.agg_col = torch.from_numpy(np.ascontiguousarray(agg_col, dtype=np.int32)).to(dev)
+        self._plan = None
         self.degree_sorted = bool(self.n < 2 or np.all(deg[1:] <= deg[:-1]))
+
+    def plan(self) -> AggregatePlan:
+        if self._plan is None:
+            self._plan = AggregatePlan(self._host[0])
+        return self._plan
 
     def oriented(self) -> 'DeviceCSR':
         """Degree-oriented copy (arc u->v iff (d'(u),u) < (d'(v),v)) for grx_triangle_counts."""
@@ -218,7 +257,8 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """
     Returns a [2f, n] block: rows 0..f-1 = neighbour sums, rows f..2f-1 = neighbour means
-    (features/extract.py:152-162 orders all sums before all means).
+    (features/extract.py:152-162 orders all sums before all means).  Bit-exact with the
+    reference's Series.sum() when csr.agg_col lists the neighbours in adjacency order.
     """
     n = csr.n
     row_end = n if row_end is None else row_end
@@ -229,8 +269,23 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
         return out
     s_ptr = c_void_p(out.data_ptr()) if want_sum else None
     m_ptr = c_void_p(out.data_ptr() + f * n * 8) if want_mean else None
-    _lib.call('grx_aggregate', n, _ptr(csr.row_ptr), _ptr(csr.col), f, _ptr(rows), ldr, row_begin, row_end,
-              s_ptr, m_ptr, n, csr.lanes_per_row, _ptr(csr.hub_rows), csr.n_hubs, _stream())
+    _lib.call('grx_aggregate', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr,
+              row_begin, row_end, s_ptr, m_ptr, n, _stream())
+    return out
+
+
+def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
+                     row_end: Optional[int] = None, want_min: bool = True, want_max: bool = True) -> torch.Tensor:
+    """[2f, n] block: rows 0..f-1 = neighbour minima, rows f..2f-1 = neighbour maxima."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+    if f == 0:
+        return out
+    lo = c_void_p(out.data_ptr()) if want_min else None
+    hi = c_void_p(out.data_ptr() + f * n * 8) if want_max else None
+    _lib.call('grx_aggregate_minmax', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr,
+              row_begin, row_end, lo, hi, n, _stream())
     return out
 
 

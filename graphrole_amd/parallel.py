@@ -98,6 +98,28 @@ class ShardPlan:
                 t.copy_(c)
         return t
 
+    def _small_device(self) -> torch.device:
+        return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(self.group) == 'nccl' \
+            else torch.device('cpu')
+
+    def all_reduce_sum_host(self, a: np.ndarray) -> np.ndarray:
+        """Sum of a small host array over the ranks (identical bits on every rank)."""
+        if self.world == 1:
+            return a
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._small_device())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy().reshape(a.shape)
+
+    def all_gather_host(self, a: np.ndarray) -> np.ndarray:
+        """[world, *a.shape]: the small host array of every rank."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.world == 1:
+            return a[None]
+        t = torch.from_numpy(a).to(self._small_device()).reshape(1, -1)
+        out = torch.empty((self.world, t.shape[1]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().numpy().reshape((self.world,) + a.shape)
+
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         return self._all_reduce_(t, dist.ReduceOp.MAX)
 

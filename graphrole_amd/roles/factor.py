@@ -126,14 +126,42 @@ def _host_init(X: np.ndarray, r: int, omega: np.ndarray):
     return W, H
 
 
-def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray):
+def _merge_project_stats(per_rank: np.ndarray) -> np.ndarray:
+    """Combine grx_project column statistics of disjoint row ranges ([world, r, 4]): the entry of
+    largest magnitude (first row wins ties, like argmax) and the sums of squares."""
+    world, r, _ = per_rank.shape
+    out = np.zeros((r, 4))
+    for j in range(r):
+        best = 0
+        for p in range(1, world):
+            a, b = abs(per_rank[p, j, 0]), abs(per_rank[best, j, 0])
+            if a > b or (a == b and per_rank[p, j, 1] < per_rank[best, j, 1]):
+                best = p
+        out[j, 0:2] = per_rank[best, j, 0:2]
+        out[j, 2] = per_rank[:, j, 2].sum()
+        out[j, 3] = per_rank[:, j, 3].sum()
+    return out
+
+
+def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
     """
     NNDSVDa start (W0 on the device, feature-major r x ld; H0 on the host) for the feature-major
     device matrix Xd [F, ld] with n valid rows.  N >= F.
+    With a ShardPlan every rank scans only its rows: the two Gram matrices are summed over the
+    ranks, the projection statistics merged, and W0 is filled for the rank's own rows only.
     """
     K = _kernels()
     F = Xd.shape[0]
-    G1, xsum = K.gram(Xd, n)
+    rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
+
+    def gram(T=None):
+        G, xs = K.gram(Xd, n, T, rb, re)
+        if plan is None:
+            return G, xs
+        packed = plan.all_reduce_sum_host(np.concatenate([G.reshape(-1), [xs]]))
+        return packed[:-1].reshape(G.shape), float(packed[-1])
+
+    G1, xsum = gram()
     x_mean = xsum / (n * F)
     lam, V1 = linalg.eigh(G1)
     floor = max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
@@ -141,15 +169,17 @@ def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray):
     if not keep.any():
         raise ValueError('NMF initialisation: the feature matrix is numerically zero')
     T1 = V1[:, keep] / np.sqrt(lam[keep])
-    G2, _ = K.gram(Xd, n, T1)
+    G2, _ = gram(T1)
     lam2, V2 = linalg.eigh(G2)
     T = (T1 @ V2) / np.sqrt(lam2)                                    # X T = Q, orthonormal columns
     M = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)   # Q^T X
     Us, S, Vt = _range_finder_svd(M, r, omega, (n, F))
     Z = T @ Us                                                       # U = X Z
-    U, stats = K.project(Xd, n, Z)
+    U, stats = K.project(Xd, n, Z, rb, re)
+    if plan is not None:
+        stats = _merge_project_stats(plan.all_gather_host(stats))
     sign, scale, H = _nndsvd_plan(S, Vt, stats)
-    K.nndsvd_apply(U, n, sign, scale, NNDSVD_EPS, x_mean)            # W[W < eps] = 0; W[W == 0] = mean
+    K.nndsvd_apply(U, n, sign, scale, NNDSVD_EPS, x_mean, rb, re)    # W[W < eps] = 0; W[W == 0] = mean
     H[H < NNDSVD_EPS] = 0
     H[H == 0] = x_mean
     return U, H

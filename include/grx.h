@@ -128,7 +128,7 @@ int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_
 /*
  * Pack f feature columns into the row-major gather source of grx_aggregate.
  * h_col_ptrs: HOST array of f device pointers (each an fp64 column of n values); the table
- * travels as a kernel argument, f <= 128 per call.
+ * travels as a kernel argument, 128 columns per launch.
  * d_rows: n x ldr row-major, ldr >= f; columns f..ldr-1 are zero-filled.  grx_aggregate wants
  * ldr = grx_aggregate_ldr(f): 2, 4, 8 or a multiple of 16 doubles, so that a feature row is a
  * 16/32/64-byte slice of one cache line or a whole number of 128-byte lines.
@@ -142,22 +142,38 @@ int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_r
  * (graphrole/features/extract.py:98-119):
  *     sum[c][v]  = sum_{u in row(v)} rows[u][c]
  *     mean[c][v] = sum[c][v] / |row(v)|      (0 when row(v) is empty)
+ * BIT-EXACT with the reference: the reference evaluates every sum with Series.sum(), i.e. numpy's
+ * pairwise summation over the neighbours in G[node] order (extract.py:108-113); the kernels add
+ * in exactly that tree (8 interleaved accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), trailing
+ * elements one by one, rows with more than 128 neighbours as a binary tree of blocks, rows with
+ * more than 8192 as a running total over 8192-element chunks like ndarray.sum()).  d_col must
+ * therefore list every row's neighbours in the order the reference visits them (adjacency /
+ * insertion order; any order gives a correct sum, only this one gives the reference's bits).
+ *
+ * grx_aggregate_plan: per-graph preprocessing (lane-group width from the mean degree, block list
+ * of the rows with more than 128 neighbours).  h_row_ptr is a HOST array int64[n+1].  The plan owns
+ * device memory (block list + scratch); one stream at a time per plan.
+ *
  * d_rows: n x ldr row-major, ldr = grx_aggregate_ldr(f), 128-byte aligned (all n rows are
  * needed: neighbours may live on any rank's slice).  A neighbour row is fetched by ldr/2
  * adjacent lanes (16 bytes each) so one request covers the whole row.
  * d_sum / d_mean: column-major, column c at d_sum + c*ld (ld >= n); only rows
  * [row_begin,row_end) are written.  Either output may be NULL.
- * lanes_per_row in {4,8,16,32}: lanes that cooperate on one row (pick ~ half the average
- * degree; anything else selects 8).  d_hub_rows / n_hub_rows: ascending int32 list of the rows
- * with degree > 32 * lanes_per_row (may be NULL / 0): those rows get one workgroup each.
- * Per-row summation order is a fixed function of the row's degree, lanes_per_row and whether a
- * hub list is given, so equal input columns give bitwise-equal output columns and repeated
- * runs are bitwise reproducible.
+ * grx_aggregate_minmax: column-wise minimum / maximum over the neighbours (aggs 'min' / 'max',
+ * extract.py:36-47); 0 for a row without neighbours (fillna, :113).
  */
-int grx_aggregate(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+typedef struct grx_aggregate_plan grx_aggregate_plan;
+int grx_aggregate_plan_create(int64_t n, const int64_t *h_row_ptr, grx_aggregate_plan **plan);
+void grx_aggregate_plan_destroy(grx_aggregate_plan *plan);
+int grx_aggregate_plan_info(const grx_aggregate_plan *plan, int64_t *n_long_rows, int64_t *n_blocks,
+                            int *lanes_per_row);
+int grx_aggregate_plan_set_lanes(grx_aggregate_plan *plan, int lanes_per_row);   /* 4, 8, 16 or 32 */
+int grx_aggregate(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                   const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
-                  double *d_sum, double *d_mean, int64_t ld, int lanes_per_row,
-                  const int32_t *d_hub_rows, int64_t n_hub_rows, void *stream);
+                  double *d_sum, double *d_mean, int64_t ld, void *stream);
+int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                         const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
+                         double *d_min, double *d_max, int64_t ld, void *stream);
 
 /* ------------------------------------------------------------------ pruning ------------- */
 /*
@@ -185,7 +201,8 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
  * h_bin_ptrs: HOST array of F device pointers to uint8 columns.  Only rows
  * [row_begin,row_end) are scanned (multi-GPU: all-reduce(MAX) the result).  d_dist: int32
  * F x F, must be zero-filled by the caller; pairs (p,q) with q >= first_new are computed
- * (first_new = 0: all pairs), the matrix is written symmetrically.  F <= 120.
+ * (first_new = 0: all pairs), the matrix is written symmetrically.  Any F: up to 120 columns are
+ * one launch (one LDS tile), more are covered by one launch per pair of 60-column groups.
  */
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
                   const uint8_t *const *h_bin_ptrs, int32_t *d_dist, void *stream);

@@ -13,21 +13,91 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* graphrole/features/extract.py:98-119 -- sum and mean of neighbour rows, CSR order.
- * X, S, M row-major n x f. */
+/* numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum_DOUBLE) of the
+ * rows X[col[k]], k in [b, b+cnt), for all f columns at once: the association order of the
+ * Series.sum() the reference runs per column (features/extract.py:110-113).
+ *   cnt < 8     sequential
+ *   cnt <= 128  r[j] = x[j] + x[j+8] + ..., ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail
+ *   cnt > 128   halves split at cnt/2 rounded down to a multiple of 8 */
+static void pairwise_rows(const int32_t *col, const double *X, int f, int64_t b, int64_t cnt, double *out)
+{
+    if (cnt < 8) {
+        for (int c = 0; c < f; ++c) out[c] = 0.0;
+        for (int64_t k = b; k < b + cnt; ++k) {
+            const double *x = X + (int64_t)col[k] * f;
+            for (int c = 0; c < f; ++c) out[c] += x[c];
+        }
+    } else if (cnt <= 128) {
+        const int64_t c8 = cnt - cnt % 8;
+        double r[8][f];
+        for (int j = 0; j < 8; ++j) {
+            const double *x = X + (int64_t)col[b + j] * f;
+            for (int c = 0; c < f; ++c) r[j][c] = x[c];
+        }
+        for (int64_t i = 8; i < c8; i += 8)
+            for (int j = 0; j < 8; ++j) {
+                const double *x = X + (int64_t)col[b + i + j] * f;
+                for (int c = 0; c < f; ++c) r[j][c] += x[c];
+            }
+        for (int c = 0; c < f; ++c)
+            out[c] = ((r[0][c] + r[1][c]) + (r[2][c] + r[3][c])) + ((r[4][c] + r[5][c]) + (r[6][c] + r[7][c]));
+        for (int64_t i = c8; i < cnt; ++i) {
+            const double *x = X + (int64_t)col[b + i] * f;
+            for (int c = 0; c < f; ++c) out[c] += x[c];
+        }
+    } else {
+        int64_t c2 = cnt / 2;
+        c2 -= c2 % 8;
+        double right[f];
+        pairwise_rows(col, X, f, b, c2, out);
+        pairwise_rows(col, X, f, b + c2, cnt - c2, right);
+        for (int c = 0; c < f; ++c) out[c] += right[c];
+    }
+}
+
+/* graphrole/features/extract.py:98-119 -- sum and mean over the neighbour rows; `col` lists every
+ * row's neighbours in the order the reference visits them.  X, S, M row-major n x f. */
 void orc_aggregate(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
                    const double *X, double *S, double *M)
 {
+    if (f <= 0) return;
     for (int64_t v = 0; v < n; ++v) {
         double *s = S + v * f, *m = M + v * f;
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        /* ndarray.sum() walks a column in chunks of 8192 elements (ufunc buffer size): every
+         * chunk is summed pairwise and added to the running total, ((0 + p(c0)) + p(c1)) + ... */
         for (int c = 0; c < f; ++c) s[c] = 0.0;
-        int64_t b = row_ptr[v], e = row_ptr[v + 1];
-        for (int64_t k = b; k < e; ++k) {
-            const double *x = X + (int64_t)col[k] * f;
-            for (int c = 0; c < f; ++c) s[c] += x[c];
+        for (int64_t k = b; k < e; k += 8192) {
+            double part[f];
+            pairwise_rows(col, X, f, k, (e - k < 8192) ? e - k : 8192, part);
+            for (int c = 0; c < f; ++c) s[c] += part[c];
         }
-        double cnt = (double)(e - b);
+        const double cnt = (double)(e - b);
         for (int c = 0; c < f; ++c) m[c] = (e > b) ? s[c] / cnt : 0.0;
+    }
+}
+
+/* graphrole/features/extract.py:98-119 with 'min' / 'max' among the aggregations: column-wise
+ * minimum / maximum over the neighbours' rows; no neighbours -> NaN -> fillna(0) (:113). */
+void orc_aggregate_minmax(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
+                          const double *X, double *LO, double *HI)
+{
+    for (int64_t v = 0; v < n; ++v) {
+        double *lo = LO + v * f, *hi = HI + v * f;
+        int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        if (e == b) {
+            for (int c = 0; c < f; ++c) lo[c] = hi[c] = 0.0;
+            continue;
+        }
+        const double *x0 = X + (int64_t)col[b] * f;
+        for (int c = 0; c < f; ++c) lo[c] = hi[c] = x0[c];
+        for (int64_t k = b + 1; k < e; ++k) {
+            const double *x = X + (int64_t)col[k] * f;
+            for (int c = 0; c < f; ++c) {
+                if (x[c] < lo[c]) lo[c] = x[c];
+                if (x[c] > hi[c]) hi[c] = x[c];
+            }
+        }
     }
 }
 

@@ -10,6 +10,10 @@ Conventions:
   * rows  = node labels sorted ascending            (graph/interface/base.py:24-25)
   * neighbours of v = out-adjacency *set* of v, self-loop included, unweighted in the recursion
                                                      (graph/interface/networkx.py:42-46)
+  * the recursion sums a node's neighbours in ADJACENCY order (G[node] iteration order =
+    order in which the incident edges were added, features/extract.py:108-110) with numpy's
+    pairwise summation (Series.sum -> ndarray.sum): `adj_col` keeps that order, `col` is the
+    same rows sorted ascending for the set-based generation-0 features.
   * every feature value is carried as float64; integer-valued gen-0 columns of unweighted graphs
     are cast to int64 only when a DataFrame is produced.
 """
@@ -39,6 +43,7 @@ class OracleGraph:
     t_col: Optional[np.ndarray] = None
     t_w: Optional[np.ndarray] = None
     attrs: Dict[str, np.ndarray] = field(default_factory=dict)   # 'attribute_<name>' -> float64[n]
+    adj_col: Optional[np.ndarray] = None   # int32 [nnz]: rows of `col` in adjacency (insertion) order
 
     @property
     def n(self) -> int:
@@ -50,6 +55,11 @@ class OracleGraph:
 
     def row(self, v: int) -> np.ndarray:
         return self.col[self.row_ptr[v]:self.row_ptr[v + 1]]
+
+    def adj_row(self, v: int) -> np.ndarray:
+        """Neighbours of v in the order the reference visits them (falls back to ascending)."""
+        c = self.col if self.adj_col is None else self.adj_col
+        return c[self.row_ptr[v]:self.row_ptr[v + 1]]
 
     def row_w(self, v: int) -> np.ndarray:
         s, e = self.row_ptr[v], self.row_ptr[v + 1]
@@ -67,10 +77,32 @@ def _csr_from_coo(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarr
     return row_ptr, dst.astype(np.int32), (None if w is None else w[order].astype(np.float64))
 
 
+def adjacency_order(n: int, src: np.ndarray, dst: np.ndarray, directed: bool) -> np.ndarray:
+    """
+    Rows of the out-adjacency in networkx insertion order for a graph built by adding the edges
+    (src[i], dst[i]) one after the other: add_edge(u, v) appends v to adj[u] and u to adj[v]
+    (once for a self-loop), so row x lists its neighbours by the index of the incident edge.
+    """
+    m = len(src)
+    if directed:
+        rows, cols = src, dst
+    else:
+        rows = np.empty(2 * m, dtype=np.int64)
+        cols = np.empty(2 * m, dtype=np.int64)
+        rows[0::2], rows[1::2] = src, dst
+        cols[0::2], cols[1::2] = dst, src
+        keep = np.ones(2 * m, dtype=bool)
+        keep[1::2] = src != dst
+        rows, cols = rows[keep], cols[keep]
+    order = np.argsort(rows, kind='stable')
+    return cols[order].astype(np.int32)
+
+
 def graph_from_arrays(n: int, src, dst, w=None, directed: bool = False, labels=None) -> OracleGraph:
     """
     Build from unique edge arrays (row indices already refer to sorted labels).
     Undirected input lists every edge once (either orientation); self-loops allowed.
+    The neighbour order of the recursion is the order of appearance in the arrays.
     """
     src = np.asarray(src, dtype=np.int64)
     dst = np.asarray(dst, dtype=np.int64)
@@ -88,7 +120,8 @@ def graph_from_arrays(n: int, src, dst, w=None, directed: bool = False, labels=N
         t_row_ptr = t_col = t_w = None
     return OracleGraph(labels=list(range(n)) if labels is None else list(labels),
                        row_ptr=row_ptr, col=col, w=ww, directed=directed, num_edges=m,
-                       t_row_ptr=t_row_ptr, t_col=t_col, t_w=t_w)
+                       t_row_ptr=t_row_ptr, t_col=t_col, t_w=t_w,
+                       adj_col=adjacency_order(n, src, dst, directed))
 
 
 def graph_from_networkx(G, attributes: bool = False, attributes_include: Sequence[str] = (),
@@ -109,6 +142,8 @@ def graph_from_networkx(G, attributes: bool = False, attributes_include: Sequenc
         ww.append(d.get('weight', 1))
     g = graph_from_arrays(len(labels), src, dst, ww if weighted else None, directed, labels)
     g.num_edges = G.number_of_edges()
+    # G.edges lists edges grouped by node, not in insertion order: take the adjacency order itself
+    g.adj_col = np.array([index[v] for lab in labels for v in G.adj[lab]], dtype=np.int32)
     if attributes:
         g.attrs = _attribute_columns(G, labels, attributes_include, attributes_exclude)
     return g
@@ -222,25 +257,87 @@ def neighborhood_features(g: OracleGraph, fast: bool = False) -> Tuple[List[str]
 # --------------------------------------------------------------------------------------
 # recursion: neighbour aggregation
 # --------------------------------------------------------------------------------------
+PAIRWISE_BLOCK = 128     # numpy PW_BLOCKSIZE
+REDUCE_CHUNK = 8192      # numpy's default ufunc buffer size (np.getbufsize()), in elements
+
+
+def pairwise_sum(A: np.ndarray) -> np.ndarray:
+    """
+    Column sums of the rows of A [k, f] in the association order of numpy's pairwise summation
+    (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum_DOUBLE), which is what
+    ``Series.sum()`` of the reference's ``features.reindex(nbrs).agg(...)`` executes per column
+    (features/extract.py:110-113 -> pandas nanops.nansum -> ndarray.sum on a contiguous column):
+      k < 8     sequential, left to right
+      k <= 128  eight accumulators r[j] = A[j] + A[j+8] + ..., combined as
+                ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the k % 8 trailing rows one by one
+      k > 128   split at k2 = k//2 rounded down to a multiple of 8, recurse, add the halves
+    """
+    k = A.shape[0]
+    if k < 8:
+        res = np.zeros(A.shape[1])
+        for i in range(k):
+            res = res + A[i]
+        return res
+    if k <= PAIRWISE_BLOCK:
+        r = [A[j].copy() for j in range(8)]
+        k8 = k - k % 8
+        for i in range(8, k8, 8):
+            for j in range(8):
+                r[j] = r[j] + A[i + j]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(k8, k):
+            res = res + A[i]
+        return res
+    k2 = k // 2
+    k2 -= k2 % 8
+    return pairwise_sum(A[:k2]) + pairwise_sum(A[k2:])
+
+
+def ndarray_sum(A: np.ndarray) -> np.ndarray:
+    """
+    Column sums of A [k, f] exactly as ``ndarray.sum()`` evaluates a contiguous column: the
+    reduction walks the column in chunks of 8192 elements (the ufunc buffer size), each chunk
+    is summed by pairwise_sum and added to the running total:  ((0 + p(c0)) + p(c1)) + ...
+    (checked against numpy and against the reference on a node with 12 000 neighbours).
+    """
+    total = np.zeros(A.shape[1])
+    for i in range(0, A.shape[0], REDUCE_CHUNK):
+        total = total + pairwise_sum(A[i:i + REDUCE_CHUNK])
+    return total
+
+
 def aggregate(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """
     features/extract.py:98-119.  For every node v and column c:
-        sum[v,c]  = sum_{u in nbrs(v)} X[u,c]
+        sum[v,c]  = sum_{u in nbrs(v)} X[u,c]     neighbours in adjacency order, ndarray_sum
         mean[v,c] = sum[v,c] / |nbrs(v)|          (0 when v has no neighbours, :113 fillna)
-    Summation is sequential in CSR (ascending neighbour index) order.
     """
     n, f = X.shape
     s = np.zeros((n, f))
     m = np.zeros((n, f))
     for v in range(n):
-        nb = g.row(v)
+        nb = g.adj_row(v)
         if len(nb):
-            acc = np.zeros(f)
-            for u in nb:
-                acc = acc + X[u]
+            acc = ndarray_sum(X[nb])
             s[v] = acc
             m[v] = acc / len(nb)
     return s, m
+
+
+def aggregate_minmax(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """
+    features/extract.py:98-119 with 'min' / 'max' in `aggs`: column-wise minimum / maximum over
+    the neighbours' rows; a node without neighbours aggregates an empty frame -> NaN -> 0 (:113).
+    """
+    n, f = X.shape
+    lo = np.zeros((n, f))
+    hi = np.zeros((n, f))
+    for v in range(n):
+        nb = g.row(v)
+        if len(nb):
+            lo[v] = X[nb].min(axis=0)
+            hi[v] = X[nb].max(axis=0)
+    return lo, hi
 
 
 def aggregate_fast(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -380,11 +477,13 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
     """
     if fast:
         from . import ckernels
-        agg_fn = lambda gg, X: ckernels.aggregate(gg.row_ptr, gg.col, X)
+        agg_fn = lambda gg, X: ckernels.aggregate(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
+        minmax_fn = lambda gg, X: ckernels.aggregate_minmax(gg.row_ptr, gg.col, X)
         bin_fn = ckernels.vertical_log_binning
         cheb_fn = lambda B: ckernels.chebyshev(B.T)
     else:
         agg_fn, bin_fn, cheb_fn = aggregate, vertical_log_binning, chebyshev_matrix
+        minmax_fn = aggregate_minmax
     names0, X0 = gen0 if gen0 is not None else neighborhood_features(g, fast)
     work: Dict[str, np.ndarray] = {}
     final_names: Dict[int, List[str]] = {}
@@ -418,6 +517,8 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         Xp = np.column_stack([work[c] for c in prev]) if prev else np.zeros((g.n, 0))
         s, m = agg_fn(g, Xp)
         blocks = {'sum': s, 'mean': m}
+        if 'min' in aggs or 'max' in aggs:
+            blocks['min'], blocks['max'] = minmax_fn(g, Xp)
         cand_names = [f'{c}({a})' for a in aggs for c in prev]        # extract.py:152-162
         cand_vals = np.column_stack([blocks[a] for a in aggs]) if prev else np.zeros((g.n, 0))
         update(gen, cand_names, cand_vals, gen)

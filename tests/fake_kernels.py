@@ -33,13 +33,14 @@ def zeros(shape, dtype=torch.float64):
 
 
 class DeviceCSR:
-    def __init__(self, row_ptr, col, w=None):
+    def __init__(self, row_ptr, col, w=None, agg_col=None):
         self.n = len(row_ptr) - 1
         self.nnz = int(row_ptr[-1])
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
         self.col = np.ascontiguousarray(col, dtype=np.int32)
         self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
         self.lanes_per_row = 8
+        self.agg_col = self.col if agg_col is None else np.ascontiguousarray(agg_col, dtype=np.int32)
 
 
 def row_sums(csr, add_self_loop, row_begin=0, row_end=None, out=None):
@@ -86,11 +87,25 @@ def aggregate(csr, rows, f, ldr, row_begin=0, row_end=None, want_sum=True, want_
     res = torch.zeros((2 * f, n), dtype=torch.float64) if out is None else out
     if f == 0:
         return res
-    S, M = ckernels.aggregate(csr.row_ptr, csr.col, np.ascontiguousarray(rows.numpy()[:n, :f]))
+    S, M = ckernels.aggregate(csr.row_ptr, csr.agg_col, np.ascontiguousarray(rows.numpy()[:n, :f]))
     if want_sum:
         res[:f, row_begin:row_end] = torch.from_numpy(S.T[:, row_begin:row_end].copy())
     if want_mean:
         res[f:, row_begin:row_end] = torch.from_numpy(M.T[:, row_begin:row_end].copy())
+    return res
+
+
+def aggregate_minmax(csr, rows, f, ldr, row_begin=0, row_end=None, want_min=True, want_max=True):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    res = torch.zeros((2 * f, n), dtype=torch.float64)
+    if f == 0:
+        return res
+    lo, hi = ckernels.aggregate_minmax(csr.row_ptr, csr.agg_col, np.ascontiguousarray(rows.numpy()[:n, :f]))
+    if want_min:
+        res[:f, row_begin:row_end] = torch.from_numpy(lo.T[:, row_begin:row_end].copy())
+    if want_max:
+        res[f:, row_begin:row_end] = torch.from_numpy(hi.T[:, row_begin:row_end].copy())
     return res
 
 

@@ -78,6 +78,14 @@ def iface7_attrs():
     return G
 
 
+# golden cases that reuse a graph with another aggregation list (extract.py:36-47 `aggs`)
+CASE_AGGS = {
+    'karate_minmax': ('karate', ['sum', 'mean', 'min', 'max']),
+    'ba300_maxsum': ('ba300', ['max', 'sum']),
+    'dw200_minmax': ('dw200_attrs', ['min', 'max', 'mean']),
+    'loops_dangling150_minmax': ('loops_dangling150', ['sum', 'min', 'max']),
+}
+
 BUILDERS = {
     'er300': lambda: er(300, 1500, 1),
     'ba300': lambda: ba(300, 3, 2),

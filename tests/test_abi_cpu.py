@@ -55,8 +55,22 @@ def test_argument_validation_needs_no_device():
     assert b'frac' in lib.grx_last_error()
     with pytest.raises(ValueError, match='frac'):
         _lib.call('grx_vertical_log_bin', 10, 1, None, 10, ctypes.c_double(0.0), None, 10, None, None, 0, None)
-    rc = lib.grx_aggregate(10, None, None, 3, None, 3, 0, 10, None, None, 10, 8, None, 0, None)   # odd ldr
+    rc = lib.grx_aggregate(None, None, None, 3, None, 4, 0, 10, None, None, 10, None)             # no plan
+    assert rc == -1 and b'plan' in lib.grx_last_error()
+    # a plan for a graph without long rows is pure host work
+    import numpy as np
+    row_ptr = np.arange(0, 33, 3, dtype=np.int64)                                                 # 10 rows x 3
+    plan = ctypes.c_void_p()
+    assert lib.grx_aggregate_plan_create(10, row_ptr.ctypes.data_as(ctypes.c_void_p), ctypes.byref(plan)) == 0
+    n_long, n_blocks, lanes = ctypes.c_int64(-1), ctypes.c_int64(-1), ctypes.c_int(-1)
+    assert lib.grx_aggregate_plan_info(plan, ctypes.byref(n_long), ctypes.byref(n_blocks), ctypes.byref(lanes)) == 0
+    assert (n_long.value, n_blocks.value, lanes.value) == (0, 0, 4)
+    rc = lib.grx_aggregate(plan, None, None, 3, None, 3, 0, 10, None, None, 10, None)             # odd ldr
     assert rc == -1 and b'ldr' in lib.grx_last_error()
+    rc = lib.grx_aggregate_minmax(plan, None, None, 3, None, 4, 0, 11, None, None, 10, None)      # bad row range
+    assert rc == -1 and b'row range' in lib.grx_last_error()
+    assert lib.grx_aggregate_plan_set_lanes(plan, 5) == -1
+    lib.grx_aggregate_plan_destroy(plan)
     rc = lib.grx_row_sums(5, None, None, None, 0, 3, 9, None, None)                               # bad row range
     assert rc == -1
     assert lib.grx_gram(10, 500, None, 10, 0, 10, None, 500, None, None, 0, None) == -4           # unsupported F

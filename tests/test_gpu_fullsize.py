@@ -18,7 +18,8 @@ def ba1m():
 def _oracle_graph(G):
     from oracle import refex
     return refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=G.w, directed=G.directed,
-                             num_edges=G.num_edges, t_row_ptr=G.t_row_ptr, t_col=G.t_col, t_w=G.t_w)
+                             num_edges=G.num_edges, t_row_ptr=G.t_row_ptr, t_col=G.t_col, t_w=G.t_w,
+                             adj_col=G.adj_col)
 
 
 def test_config2_er_100k_1m_matches_oracle():
@@ -33,7 +34,7 @@ def test_config2_er_100k_1m_matches_oracle():
     assert list(X.columns) == ref.columns and fe.generation_count == ref.generation_count
     for gen, tr in enumerate(ref.trace):
         assert fe._final_names[gen] == tr.retained
-    np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=1e-12, atol=0)
+    assert np.array_equal(X.values.astype(float), ref.values)          # unweighted: bit-exact
     np.random.seed(0)
     Gf, Ff, n_iter = factor.nmf_with_info(X.values.astype(float), 6)
     np.random.seed(0)
@@ -53,7 +54,7 @@ def test_config3_ba_1m_10m_matches_oracle(ba1m):
     assert list(X.columns) == ref.columns and fe.generation_count == ref.generation_count
     for gen, tr in enumerate(ref.trace):
         assert fe._final_names[gen] == tr.retained
-    np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=1e-12, atol=0)
+    assert np.array_equal(X.values.astype(float), ref.values)          # unweighted: bit-exact
     # gen-0 integer columns are exact
     for col in ('degree', 'internal_edges', 'external_edges'):
         assert np.array_equal(X[col].values, ref.values[:, ref.columns.index(col)].astype(np.int64))
@@ -63,7 +64,7 @@ def test_fullsize_properties(ba1m):
     import torch
     from graphrole_amd import kernels as K
     n = ba1m.n
-    csr = K.DeviceCSR(ba1m.row_ptr, ba1m.col)
+    csr = K.DeviceCSR(ba1m.row_ptr, ba1m.col, agg_col=ba1m.adj_col)
     deg = torch.from_numpy(np.diff(ba1m.row_ptr).astype(np.float64)).cuda()
     rng = torch.Generator(device='cuda').manual_seed(1)
     a = torch.rand(n, dtype=torch.float64, device='cuda', generator=rng)
@@ -78,7 +79,7 @@ def test_fullsize_properties(ba1m):
     torch.testing.assert_close(blk[2], blk[0] + blk[1], rtol=1e-12, atol=0)
     # mean = sum / degree exactly (IEEE division of the same sum)
     assert torch.equal(blk[4], blk[0] / deg)
-    # bitwise reproducible, and hub list on/off only re-associates
+    # bitwise reproducible
     assert torch.equal(K.aggregate(csr, rows, 4, ldr), blk)
     # sort: sorted, a permutation (order-independent checksums), idempotent
     block = torch.stack([a, b, blk[0], blk[4]])

@@ -29,7 +29,7 @@ def _oracle_graph(n, src, dst, w, directed):
 def _dev_csr(K, og, transpose=False):
     if transpose:
         return K.DeviceCSR(og.t_row_ptr, og.t_col, og.t_w)
-    return K.DeviceCSR(og.row_ptr, og.col, og.w)
+    return K.DeviceCSR(og.row_ptr, og.col, og.w, agg_col=og.adj_col)
 
 
 GRAPHS = [
@@ -121,34 +121,87 @@ def test_gen0_vs_reference_golden(K, name):
         assert np.array_equal(got[nm] == 0, vals[:, j] == 0), f'{name}:{nm} zero pattern'
 
 
+@pytest.mark.parametrize('lanes', [None, 4, 8, 16, 32])
 @pytest.mark.parametrize('f', [1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 26, 40])
-def test_aggregate_vs_oracle(K, f):
+def test_aggregate_bit_exact_vs_oracle(K, f, lanes):
+    """Sums and means equal the oracle's numpy-pairwise sums in adjacency order BIT FOR BIT, for
+    every lane-group width, with rows of every length class (< 8, 8..128, > 128 = block tree)."""
     import torch
     from oracle import ckernels
+    if lanes is not None and f not in (3, 5, 8, 17):
+        pytest.skip('lane-group sweep on a few widths')
     n, m = 20000, 6
     src, dst, _ = util.powerlaw_graph(n, m, seed=f)
     og = _oracle_graph(n, src, dst, None, False)
+    deg = np.diff(og.row_ptr)
+    assert deg.max() > 300 and (deg < 8).any() and ((deg >= 8) & (deg <= 128)).any()
     # a few dangling nodes at the end
     og.row_ptr = np.concatenate([og.row_ptr, np.full(7, og.row_ptr[-1])])
     n2 = og.n
     X = np.abs(np.random.default_rng(f).standard_normal((n2, f))) * 10.0 ** np.arange(f).clip(0, 6)
-    S, M = ckernels.aggregate(og.row_ptr, og.col, X)
+    S, M = ckernels.aggregate(og.row_ptr, og.adj_col, X)
     csr = _dev_csr(K, og)
+    if lanes is not None:
+        csr.plan().set_lanes(lanes)
+    assert csr.plan().n_long_rows == int((deg > 128).sum()) and csr.plan().n_blocks >= 2 * csr.plan().n_long_rows
     Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
     rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
     assert np.array_equal(rows.cpu().numpy()[:, :f], X)
     blk = K.aggregate(csr, rows, f, ldr)
     got = blk.cpu().numpy()
-    np.testing.assert_allclose(got[:f].T, S, rtol=RTOL, atol=0)
-    np.testing.assert_allclose(got[f:].T, M, rtol=RTOL, atol=0)
+    assert np.array_equal(got[:f].T, S), f'{int((got[:f].T != S).sum())} sums differ'
+    assert np.array_equal(got[f:].T, M), f'{int((got[f:].T != M).sum())} means differ'
     assert np.all(got[:, n:] == 0)                              # dangling rows: sum 0, mean 0 (not NaN)
-    # bitwise reproducible
-    blk2 = K.aggregate(csr, rows, f, ldr)
-    assert torch.equal(blk, blk2)
     # row-range slices agree bitwise with the full run
     blk3 = K.aggregate(csr, rows, f, ldr, row_begin=123, row_end=15001)
     assert torch.equal(blk3[:, 123:15001], blk[:, 123:15001])
-    assert float(blk3[:, :123].abs().sum()) == 0.0
+    assert float(blk3[:, :123].abs().sum()) == 0.0 and float(blk3[:, 15001:].abs().sum()) == 0.0
+    # only one of the outputs
+    only_mean = K.aggregate(csr, rows, f, ldr, want_sum=False)
+    assert torch.equal(only_mean[f:], blk[f:]) and float(only_mean[:f].abs().sum()) == 0.0
+
+
+def test_aggregate_equals_numpy_sum_on_huge_row(K):
+    """A star: the centre has 70 001 neighbours -> 1 024 blocks, 10 tree levels; the device sum
+    must equal ndarray.sum() of the neighbour values in adjacency order."""
+    import torch
+    n = 70002
+    src = np.zeros(n - 1, dtype=np.int64)
+    dst = np.arange(1, n, dtype=np.int64)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n - 1)
+    og = _oracle_graph(n, src[perm], dst[perm], None, False)
+    csr = _dev_csr(K, og)
+    x = rng.random(n) ** 4 * 1e3
+    col = torch.from_numpy(x).cuda()
+    rows, ldr = K.pack_rows([col], n)
+    got = K.aggregate(csr, rows, 1, ldr).cpu().numpy()
+    nb = og.adj_row(0)
+    assert np.array_equal(nb, dst[perm])                        # adjacency order = order of appearance
+    assert got[0, 0] == np.ascontiguousarray(x[nb]).sum()
+    assert got[1, 0] == np.ascontiguousarray(x[nb]).sum() / len(nb)
+    assert np.array_equal(got[0, 1:], np.full(n - 1, x[0]))
+
+
+@pytest.mark.parametrize('f', [1, 3, 6, 8, 20])
+def test_aggregate_minmax_vs_oracle(K, f):
+    import torch
+    from oracle import ckernels
+    n, m = 20000, 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=40 + f)
+    og = _oracle_graph(n, src, dst, None, False)
+    og.row_ptr = np.concatenate([og.row_ptr, np.full(5, og.row_ptr[-1])])
+    n2 = og.n
+    X = np.random.default_rng(f).standard_normal((n2, f)) * 10.0 ** np.arange(f).clip(0, 6)   # negatives too
+    lo, hi = ckernels.aggregate_minmax(og.row_ptr, og.adj_col, X)
+    csr = _dev_csr(K, og)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
+    got = K.aggregate_minmax(csr, rows, f, ldr).cpu().numpy()
+    assert np.array_equal(got[:f].T, lo) and np.array_equal(got[f:].T, hi)
+    assert np.all(got[:, n:] == 0)                              # no neighbours -> NaN -> 0
+    part = K.aggregate_minmax(csr, rows, f, ldr, row_begin=77, row_end=9000, want_min=False).cpu().numpy()
+    assert np.array_equal(part[f:, 77:9000], got[f:, 77:9000]) and not part[:f].any() and not part[f:, 9000:].any()
 
 
 def test_aggregate_equal_columns_give_equal_outputs(K):
@@ -173,7 +226,7 @@ def test_aggregate_integer_columns_exact(K):
     og = _oracle_graph(3000, src, dst, None, False)
     csr = _dev_csr(K, og)
     X = np.random.default_rng(1).integers(0, 1000, size=(3000, 3)).astype(np.float64)
-    S, M = ckernels.aggregate(og.row_ptr, og.col, X)
+    S, M = ckernels.aggregate(og.row_ptr, og.adj_col, X)
     Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
     rows, ldr = K.pack_rows([Xd[c] for c in range(3)], 3000)
     got = K.aggregate(csr, rows, 3, ldr).cpu().numpy()

@@ -5,7 +5,9 @@ reference's own unit-test cases (tests/test_features/test_extract.py, tests/test
 test_interface.py) restated against the drop-in classes.
 
 Tolerances: column lists, retained sets per generation, dtypes, index order: exact.
-Values: rtol 1e-12 (fp64 re-association in neighbour sums); integer columns exact.
+Values: BIT-EXACT for unweighted graphs (the neighbour sums follow numpy's pairwise tree in
+adjacency order, like the reference's Series.sum()); rtol 1e-12 for weighted graphs, whose
+generation-0 columns the reference sums with Python's sum() over ego-graph edge views.
 """
 import networkx as nx
 import numpy as np
@@ -19,8 +21,17 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-12
 
 
+def _check_values(actual, expected, weighted):
+    if weighted:
+        np.testing.assert_allclose(actual, expected, rtol=RTOL, atol=0)
+    else:
+        assert np.array_equal(actual, expected), f'{int((actual != expected).sum())} entries differ'
+
+
 def _graph_for(name, g):
-    """networkx graph of a golden case: builders for synthetic cases, fixture arrays for karate."""
+    """networkx graph of a golden case: builders for synthetic cases, fixture arrays for karate
+    (with the adjacency order of the graph the reference ran on restored)."""
+    name = graphs.CASE_AGGS.get(name, (name,))[0]
     if name in graphs.BUILDERS:
         G, kwargs = graphs.BUILDERS[name]()
         return G, kwargs
@@ -34,6 +45,10 @@ def _graph_for(name, g):
             G.add_edge(labels[s], labels[d], weight=int(w[k]) if all_int else float(w[k]))
         else:
             G.add_edge(labels[s], labels[d])
+    adj_ptr, adj_idx = g['adj_ptr'], g['adj_idx']
+    for i, lab in enumerate(labels):                          # same edge-data dicts, golden order
+        want = [labels[j] for j in adj_idx[adj_ptr[i]:adj_ptr[i + 1]]]
+        G._adj[lab] = {v: G._adj[lab][v] for v in want}
     return G, g.js('kwargs')
 
 
@@ -42,13 +57,17 @@ def test_extract_features_matches_reference(name):
     from graphrole_amd import RecursiveFeatureExtractor
     g = util.load_refex(name)
     G, kwargs = _graph_for(name, g)
-    fe = RecursiveFeatureExtractor(G, **kwargs)              # default aggs, like the reference's example
+    aggs = util.golden_aggs(g)
+    if aggs == ['sum', 'mean']:
+        fe = RecursiveFeatureExtractor(G, **kwargs)          # default aggs, like the reference's example
+    else:
+        fe = RecursiveFeatureExtractor(G, aggs=aggs, **kwargs)
     X = fe.extract_features()
     assert list(X.columns) == g.js('final_columns')
     assert list(X.index) == g.js('labels')
     assert fe.generation_count == int(g['generation_count'])
     assert [str(t) for t in X.dtypes] == g.js('final_dtypes')
-    np.testing.assert_allclose(X.values.astype(np.float64), g['final_values'], rtol=RTOL, atol=0)
+    _check_values(X.values.astype(np.float64), g['final_values'], weighted=bool(len(g['w'])))
     for gen in range(int(g['n_generations_recorded'])):
         assert fe._final_names[gen] == g.js(f'g{gen}_retained'), f'generation {gen}'
     # memoised second call is identical (reference test_extract_features_back_to_back)
@@ -74,7 +93,7 @@ def test_generation_trace_matches_reference(name):
         fe._feature_group_thresh = gen
         cand = fe._get_next_features()
         assert list(cand.columns) == g.js(f'g{gen}_cand_names')
-        np.testing.assert_allclose(cand.values, g[f'g{gen}_cand_values'], rtol=RTOL, atol=0)
+        _check_values(cand.values, g[f'g{gen}_cand_values'], weighted=bool(len(g['w'])))
         fe._update(cand)
         assert list(fe._final_features[gen].keys()) == g.js(f'g{gen}_retained')
         assert list(fe._features.columns) == g.js(f'g{gen}_working_after')
@@ -86,9 +105,12 @@ def test_csr_graph_input_equals_networkx_input():
     g = util.load_refex('er2000')
     G, _ = _graph_for('er2000', g)
     X1 = RecursiveFeatureExtractor(G).extract_features()
-    C = CSRGraph(int(g['n']), g['src'], g['dst'])
+    C = CSRGraph(int(g['n']), g['src'], g['dst'], adjacency=g['adj_idx'])
     X2 = RecursiveFeatureExtractor(C).extract_features()
-    pd.testing.assert_frame_equal(X1, X2)
+    pd.testing.assert_frame_equal(X1, X2, check_exact=True)
+    # without an explicit adjacency the sums run in order of appearance: same table up to re-association
+    X3 = RecursiveFeatureExtractor(CSRGraph(int(g['n']), g['src'], g['dst'])).extract_features()
+    pd.testing.assert_frame_equal(X1, X3, rtol=1e-12)
     # weighted + directed + attributes through arrays
     g = util.load_refex('dw200_attrs')
     G, kwargs = _graph_for('dw200_attrs', g)
@@ -97,7 +119,8 @@ def test_csr_graph_input_equals_networkx_input():
     attrs = {}
     for a in ('a_uniform', 'a_poisson', 'a_sparse'):
         attrs[a] = np.array([G.nodes[v].get(a, 0) for v in labels], dtype=float)
-    C = CSRGraph(int(g['n']), g['src'], g['dst'], weights=g['w'], directed=True, attributes=attrs)
+    C = CSRGraph(int(g['n']), g['src'], g['dst'], weights=g['w'], directed=True, attributes=attrs,
+                 adjacency=g['adj_idx'])
     X2 = RecursiveFeatureExtractor(C, attributes=True).extract_features()
     assert list(X1.columns) == list(X2.columns)
     np.testing.assert_allclose(X1.values.astype(float), X2.values.astype(float), rtol=0, atol=0)
@@ -203,7 +226,7 @@ class TestExtractorLikeReference:
     def test_unsupported_aggregation_fails_loudly(self):
         from graphrole_amd import RecursiveFeatureExtractor
         with pytest.raises(NotImplementedError, match='no device kernel'):
-            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['max']).extract_features()
+            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['median']).extract_features()
 
     def test_agg_order_follows_aggs(self):
         from graphrole_amd import RecursiveFeatureExtractor

@@ -52,7 +52,7 @@ def _worker(rank, port, kind, out_dir):
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega)
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
         state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
         out = dict(X=X.values.astype(float), cols=np.array(list(X.columns)), gen=fe.generation_count,
                    W=K.to_host(state.W)[:, :G.n], H=K.to_host(state.H), n_iter=n_iter,

@@ -104,10 +104,17 @@ def test_oracle_refex_matches_reference_golden(name, fast):
     names0 = g.js('gen0_names')
     attr_idx = [j for j, nm in enumerate(names0) if nm.startswith('attribute_')]
     og.attrs = {names0[j]: g['gen0_values'][:, j] for j in attr_idx}     # attributes are input data
-    res = refex.extract_features(og, max_generations=int(g['max_generations']), fast=fast)
+    res = refex.extract_features(og, max_generations=int(g['max_generations']), fast=fast,
+                                 aggs=util.golden_aggs(g))
     assert res.columns == g.js('final_columns')
     assert res.generation_count == int(g['generation_count'])
-    np.testing.assert_allclose(res.values, g['final_values'], rtol=RTOL, atol=0)
+    if len(g['w']):
+        # weighted gen-0 columns: the reference adds edge weights with Python's sum() over ego-graph
+        # edge views, the oracle in CSR order -> last-bit differences
+        np.testing.assert_allclose(res.values, g['final_values'], rtol=RTOL, atol=0)
+    else:
+        # unweighted: adjacency order + numpy's pairwise tree reproduce the reference bit for bit
+        assert np.array_equal(res.values, g['final_values'])
     for gen, tr in enumerate(res.trace):
         assert tr.candidates == g.js(f'g{gen}_cand_names')
         assert tr.working_before == g.js(f'g{gen}_working_before')
@@ -169,5 +176,5 @@ def test_c_twins_equal_numpy_oracle_on_random_graphs():
         np.testing.assert_allclose(a[1], b[1], rtol=1e-13)
         X = np.random.RandomState(0).rand(spec['n'], 5)
         S1, M1 = refex.aggregate(og, X)
-        S2, M2 = ckernels.aggregate(og.row_ptr, og.col, X)
+        S2, M2 = ckernels.aggregate(og.row_ptr, og.adj_col, X)
         assert np.array_equal(S1, S2) and np.array_equal(M1, M2)

@@ -47,7 +47,7 @@ def _worker(rank, port, case, out_dir):
         K = backend.get()
         Xd = K.to_device(np.ascontiguousarray(X.values.astype(float).T))
         omega = np.random.RandomState(5).normal(size=(X.shape[1], 4 + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega)
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
         state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
         W = K.to_host(state.W)[:, :G.n]
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), X=X.values.astype(float), cols=np.array(list(X.columns)),

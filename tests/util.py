@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'loops_dangling150',
-               'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000']
+               'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000',
+               'karate_minmax', 'ba300_maxsum', 'dw200_minmax', 'loops_dangling150_minmax']
 NMF_CASES = ['rand20x30_r3', 'rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'karate_r4', 'er2000_r6',
              'ba2000_r6', 'dw200_r5']
 
@@ -27,6 +28,11 @@ class Golden:
         return k in self.z.files
 
 
+def golden_aggs(g):
+    """aggs list a ReFeX fixture was generated with (older fixtures: the reference default)."""
+    return g.js('aggs') if 'aggs_json' in g else ['sum', 'mean']
+
+
 def load_refex(name):
     return Golden(os.path.join(GOLDEN, f'refex_{name}.npz'))
 
@@ -40,6 +46,10 @@ def oracle_graph_from_golden(g):
     w = g['w'] if len(g['w']) else None
     og = refex.graph_from_arrays(int(g['n']), g['src'], g['dst'], w, bool(g['directed']), g.js('labels'))
     og.num_edges = int(g['num_edges'])
+    if 'adj_idx' in g:
+        # the adjacency (insertion) order of the graph the reference ran on
+        assert np.array_equal(g['adj_ptr'], og.row_ptr)
+        og.adj_col = g['adj_idx'].astype(np.int32)
     return og
 
 

@@ -60,6 +60,10 @@ REFEX_CASES = {
     'karate_weighted': lambda: g_karate(True),
 }
 REFEX_CASES.update(G_.BUILDERS)
+# the same graphs with other aggregation lists (extract.py:36-47 `aggs`; names as pandas labels them)
+CASE_AGGS = G_.CASE_AGGS
+for _name, (_base, _aggs) in CASE_AGGS.items():
+    REFEX_CASES[_name] = REFEX_CASES[_base]
 
 
 # --------------------------------------------------------------------------- ReFeX capture
@@ -74,13 +78,28 @@ def graph_arrays(G):
     return labels, src, dst, w
 
 
+def adjacency_arrays(G, labels):
+    """G[node] iteration order of every node (rows = sorted labels): the order in which the
+    reference's reindex(nbrs) lines up the neighbour rows it sums (features/extract.py:108-110)."""
+    index = {lab: i for i, lab in enumerate(labels)}
+    adj_ptr = np.zeros(len(labels) + 1, dtype=np.int64)
+    adj_idx = []
+    for i, lab in enumerate(labels):
+        nbrs = [index[v] for v in G[lab]]
+        adj_idx.extend(nbrs)
+        adj_ptr[i + 1] = len(adj_idx)
+    return adj_ptr, np.array(adj_idx, dtype=np.int32)
+
+
 def capture_refex(name, G, kwargs, max_generations=10):
     """Drive the reference's own methods in the order extract_features does (extract.py:65-89)."""
-    fe = RecursiveFeatureExtractor(G, max_generations=max_generations, aggs=AGGS, **kwargs)
+    aggs = CASE_AGGS[name][1] if name in CASE_AGGS else AGGS
+    fe = RecursiveFeatureExtractor(G, max_generations=max_generations, aggs=aggs, **kwargs)
     labels, src, dst, w = graph_arrays(G)
     out = dict(n=len(labels), src=src, dst=dst, w=w, directed=G.is_directed(),
                labels_json=json.dumps(labels), kwargs_json=json.dumps(kwargs),
-               num_edges=G.number_of_edges(), max_generations=max_generations)
+               num_edges=G.number_of_edges(), max_generations=max_generations, aggs_json=json.dumps(aggs))
+    out['adj_ptr'], out['adj_idx'] = adjacency_arrays(G, labels)
 
     def record(gen, cand, thresh):
         cand = cand.reindex(labels).fillna(0) if len(cand.index) != len(labels) else cand.loc[labels]
@@ -128,7 +147,7 @@ def capture_refex(name, G, kwargs, max_generations=10):
     out['final_dtypes_json'] = json.dumps([str(t) for t in final.dtypes])
 
     # cross-check: an untouched instance run through the public entry point agrees exactly
-    fe2 = RecursiveFeatureExtractor(G, max_generations=max_generations, aggs=AGGS, **kwargs)
+    fe2 = RecursiveFeatureExtractor(G, max_generations=max_generations, aggs=aggs, **kwargs)
     final2 = fe2.extract_features()
     assert list(final2.columns) == list(final.columns)
     assert fe2.generation_count == fe.generation_count
