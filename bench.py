@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='ba1m', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--agg-lanes', type=int, default=0, help='override the lane-group width of grx_aggregate (tuning)')
     ap.add_argument('--cpu-sample-nodes', type=int, default=3000)
     ap.add_argument('--cpu-nmf', type=int, default=1)
     args = ap.parse_args()
@@ -146,7 +147,9 @@ def main():
 
     G = build_graph(args.workload)
     fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=(world > 1))
-    fe.graph._device_graph()                       # graph resident in HBM before anything is timed
+    dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
+    if args.agg_lanes:
+        dev_graph.plan().set_lanes(args.agg_lanes)
     plan = fe._shard()
     rng = np.random.RandomState(0)
 

@@ -524,65 +524,47 @@ __global__ __launch_bounds__(256) void aggregate_blocks_kernel(
 // One 64-lane workgroup per long row: add the block sums along numpy's recursion
 //   sum(n) = n <= 128 ? block : sum(n2) + sum(n - n2),  n2 = n/2 - (n/2) % 8
 // chunk by chunk (8192 neighbours = at most 144 blocks), running total over the chunks.  The
-// block sums of a chunk are staged in LDS by all lanes; lane c then walks the tree for column c.
+// recursion is flattened by the host into its post-order program: blk_ops[i] & 0x7F = number of
+// pending additions after pushing block i, bit 7 = last block of a chunk.  The block sums of a
+// chunk are staged in LDS by all lanes; lane c then runs the stack machine for column c.
 constexpr int PW_MAX_BLOCKS_PER_CHUNK = PW_CHUNK / 57 + 1;      // blocks are 57..128 long
+constexpr int PW_MAX_DEPTH = 12;
 
 __global__ __launch_bounds__(64) void aggregate_combine_kernel(
     const int64_t *__restrict__ row_ptr, int f, int64_t row_begin, int64_t row_end,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ blk_ptr, int64_t n_long,
-    const double *__restrict__ blk_sums, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+    const uint8_t *__restrict__ blk_ops, const double *__restrict__ blk_sums, double *__restrict__ out_sum,
+    double *__restrict__ out_mean, int64_t ld)
 {
     __shared__ double stage_lds[PW_MAX_BLOCKS_PER_CHUNK * 16];
+    __shared__ uint8_t ops_lds[PW_MAX_BLOCKS_PER_CHUNK];
+    __shared__ double stk[PW_MAX_DEPTH][16];
     const int c = threadIdx.x & 15;
     for (int64_t h = blockIdx.x; h < n_long; h += gridDim.x) {
         const int64_t v = long_rows[h];
         if (v < row_begin || v >= row_end) continue;            // uniform over the workgroup
         const int64_t n = row_ptr[v + 1] - row_ptr[v];
-        int64_t leaf = blk_ptr[h];
         const int64_t leaf_end = blk_ptr[h + 1];
         double total = 0.0;
-        for (int64_t c0 = 0; c0 < n; c0 += PW_CHUNK) {
+        for (int64_t leaf = blk_ptr[h]; leaf < leaf_end;) {
             const int64_t avail = leaf_end - leaf;
             const int cnt = (int)(avail < PW_MAX_BLOCKS_PER_CHUNK ? avail : PW_MAX_BLOCKS_PER_CHUNK);
             for (int i = threadIdx.x; i < cnt * 16; i += 64) stage_lds[i] = blk_sums[leaf * 16 + i];
+            for (int i = threadIdx.x; i < cnt; i += 64) ops_lds[i] = blk_ops[leaf + i];
             __syncthreads();
-            int64_t sn[12];
-            double acc[12];
-            int stage[12];
-            int sp = 0, used = 0;
-            sn[0] = (n - c0 < PW_CHUNK) ? n - c0 : PW_CHUNK;
-            stage[0] = 0;
-            double val = 0.0;
-            bool finished = false;
-            while (!finished) {
-                bool returning = false;
-                if (sn[sp] <= PW_BLOCK) {
-                    val = stage_lds[(used++) * 16 + c];
-                    returning = true;
-                } else {
-                    int64_t n2 = sn[sp] / 2;
-                    n2 -= n2 % 8;
-                    stage[sp] = 1;
-                    sn[sp + 1] = n2; stage[sp + 1] = 0;
-                    ++sp;
+            int used = 0;
+            if (threadIdx.x < 16) {
+                int sp = 0;
+                for (;;) {
+                    double val = stage_lds[used * 16 + c];
+                    const int op = ops_lds[used++];
+                    for (int k = op & 0x7F; k > 0; --k) val = stk[--sp][c] + val;   // left + right
+                    if (op & 0x80) { total += val; break; }      // chunk complete (sp == 0 here)
+                    stk[sp++][c] = val;
                 }
-                while (returning) {
-                    if (sp == 0) { finished = true; break; }
-                    --sp;
-                    if (stage[sp] == 1) {                     // left half returned: descend into the right half
-                        acc[sp] = val;
-                        stage[sp] = 2;
-                        int64_t n2 = sn[sp] / 2;
-                        n2 -= n2 % 8;
-                        sn[sp + 1] = sn[sp] - n2; stage[sp + 1] = 0;
-                        ++sp;
-                        returning = false;
-                    } else {                                  // right half returned
-                        val = acc[sp] + val;
-                    }
-                }
+            } else {
+                while (!(ops_lds[used++] & 0x80)) {}
             }
-            total += val;
             leaf += used;
             __syncthreads();
         }
@@ -648,18 +630,23 @@ struct grx_aggregate_plan {
     int64_t *d_blk_begin = nullptr;     // [n_blocks] position in d_col
     int32_t *d_blk_len = nullptr;       // [n_blocks]
     int32_t *d_blk_row = nullptr;       // [n_blocks] index into d_long_rows
+    uint8_t *d_blk_ops = nullptr;       // [n_blocks] post-order program of the combine step
     double *d_blk_sums = nullptr;       // [n_blocks * 16] scratch
 };
 
 namespace {
 
-void pairwise_blocks(int64_t begin, int64_t n, std::vector<int64_t> &b, std::vector<int32_t> &len)
+// Blocks of numpy's recursion over [begin, begin+n) in order, with the post-order program of the
+// additions: ops[i] = how many times "pop left, add" runs after block i has been pushed.
+void pairwise_blocks(int64_t begin, int64_t n, std::vector<int64_t> &b, std::vector<int32_t> &len,
+                     std::vector<uint8_t> &ops)
 {
-    if (n <= PW_BLOCK) { b.push_back(begin); len.push_back((int32_t)n); return; }
+    if (n <= PW_BLOCK) { b.push_back(begin); len.push_back((int32_t)n); ops.push_back(0); return; }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    pairwise_blocks(begin, n2, b, len);
-    pairwise_blocks(begin + n2, n - n2, b, len);
+    pairwise_blocks(begin, n2, b, len, ops);
+    pairwise_blocks(begin + n2, n - n2, b, len, ops);
+    ++ops.back();
 }
 
 template <int LDR, int G>
@@ -683,7 +670,7 @@ int launch_aggregate_g(const grx_aggregate_plan *p, const int64_t *row_ptr, cons
                                                                p->d_blk_begin, p->d_blk_len, p->d_blk_row,
                                                                p->n_blocks, p->d_blk_sums);
         aggregate_combine_kernel<<<(unsigned)(p->n_long > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : p->n_long), 64, 0, st>>>(
-            row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_sums, s, m, ld);
+            row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_ops, p->d_blk_sums, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -919,13 +906,16 @@ int grx_aggregate_plan_create(int64_t n, const int64_t *h_row_ptr, grx_aggregate
     p->lanes_per_row = avg < 12 ? 4 : avg < 24 ? 8 : avg < 48 ? 16 : 32;
     std::vector<int32_t> long_rows, blk_len, blk_row;
     std::vector<int64_t> blk_ptr, blk_begin;
+    std::vector<uint8_t> blk_ops;
     for (int64_t v = 0; v < n; ++v) {
         const int64_t d = h_row_ptr[v + 1] - h_row_ptr[v];
         if (d <= PW_BLOCK) continue;
         blk_ptr.push_back((int64_t)blk_begin.size());
         const size_t before = blk_begin.size();
-        for (int64_t c0 = 0; c0 < d; c0 += PW_CHUNK)
-            pairwise_blocks(h_row_ptr[v] + c0, (d - c0 < PW_CHUNK) ? d - c0 : PW_CHUNK, blk_begin, blk_len);
+        for (int64_t c0 = 0; c0 < d; c0 += PW_CHUNK) {
+            pairwise_blocks(h_row_ptr[v] + c0, (d - c0 < PW_CHUNK) ? d - c0 : PW_CHUNK, blk_begin, blk_len, blk_ops);
+            blk_ops.back() |= 0x80;                              // end of a chunk
+        }
         blk_row.insert(blk_row.end(), blk_begin.size() - before, (int32_t)long_rows.size());
         long_rows.push_back((int32_t)v);
     }
@@ -944,6 +934,7 @@ int grx_aggregate_plan_create(int64_t n, const int64_t *h_row_ptr, grx_aggregate
         if (e == hipSuccess) e = upload((void **)&p->d_blk_begin, blk_begin.data(), blk_begin.size() * 8);
         if (e == hipSuccess) e = upload((void **)&p->d_blk_len, blk_len.data(), blk_len.size() * 4);
         if (e == hipSuccess) e = upload((void **)&p->d_blk_row, blk_row.data(), blk_row.size() * 4);
+        if (e == hipSuccess) e = upload((void **)&p->d_blk_ops, blk_ops.data(), blk_ops.size());
         if (e == hipSuccess) e = hipMalloc((void **)&p->d_blk_sums, (size_t)p->n_blocks * 16 * 8);
     }
     if (e != hipSuccess) {
@@ -959,7 +950,8 @@ void grx_aggregate_plan_destroy(grx_aggregate_plan *p)
 {
     if (!p) return;
     (void)hipFree(p->d_long_rows); (void)hipFree(p->d_blk_ptr); (void)hipFree(p->d_blk_begin);
-    (void)hipFree(p->d_blk_len); (void)hipFree(p->d_blk_row); (void)hipFree(p->d_blk_sums);
+    (void)hipFree(p->d_blk_len); (void)hipFree(p->d_blk_row); (void)hipFree(p->d_blk_ops);
+    (void)hipFree(p->d_blk_sums);
     delete p;
 }
 
