@@ -251,16 +251,17 @@ def main():
         if agg_cnt:
             per_launch_ms = (agg_ms + hub_ms) / agg_cnt
             achieved = alg_bytes / launches / (per_launch_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = nmf_traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get('workload') == args.workload and tj.get('n_gpus', 1) == world:
                         traffic = tj.get('aggregate_kernel_hbm_bytes_per_launch')
+                        nmf_traffic = tj.get('nmf_w_pass_hbm_bytes_per_launch')
                 except Exception:
-                    traffic = None
-            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_hub_kernel)',
+                    traffic = nmf_traffic = None
+            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_blocks_kernel, aggregate_combine_kernel)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / launches,
                         'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen}
@@ -270,8 +271,9 @@ def main():
         if w_cnt:
             nmf_bytes = (G.n / world) * (F * 8 + 2 * r * 8)
             ach = nmf_bytes / (w_ms / w_cnt * 1e-3) / 1e9
-            roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_kernel', 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+            roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_mfma_kernel (fp64 MFMA 16x16x4)', 'achieved': ach,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                            'traffic': nmf_traffic if agg_cnt else None,
                             'algorithmic_bytes_per_launch': nmf_bytes, 'avg_launch_ms': w_ms / w_cnt}
         line = {
             'metric': 'ReFeX edges-aggregated/sec (+ RolX NMF iters/sec in nmf.iters_per_s), 1M-node graph',

@@ -12,7 +12,7 @@
 //   project_kernel          U = X Z + per-column statistics   (init: singular vectors, svd_flip,
 //                                                              NNDSVD +/- norms)
 //   nndsvd_apply_kernel     _nmf.py:324-359 elementwise part
-//   nmf_w_pass_kernel       W <- W*(XH^T)/(W HH^T) fused with A = W^T X, B = W^T W partials
+//   nmf_w_pass_mfma_kernel  W <- W*(XH^T)/(W HH^T) fused with A = W^T X, B = W^T W partials (fp64 MFMA)
 //   nmf_h_update_kernel     H <- H*A/(B H)
 //   nmf_residual_kernel     ||X - WH||_F^2
 #include "grx_common.h"
@@ -289,135 +289,171 @@ __global__ __launch_bounds__(256) void nndsvd_apply_kernel(int64_t row_begin, in
 // multiplicative update, W side (fused with the H-side reductions)
 // ---------------------------------------------------------------------------------------
 constexpr int MU_MAX_GRID = GRX_NUM_CU * 8;      // workgroups of the W pass (LDS admits >= 2 per CU)
-constexpr int MU_PSLOTS = (MAX_R * MAX_F + MAX_R * MAX_R + 255) / 256;      // 9
+// ---------------------------------------------------------------------------------------
+// W <- W * (X H^T) / (W H H^T) fused with the H-side reductions A = W'^T X (r x F) and
+// B = W'^T W' (r x r): ONE pass over X and W per iteration, on the matrix cores
+// (v_mfma_f64_16x16x4_f64).  One wavefront owns a 16-row sub-tile from load to accumulate;
+// nothing but its own 16 x (F + r) slice of X and W crosses HBM, and the only LDS traffic is one
+// write + one read of that slice (the two GEMM pairs need X and W' in transposed lane layouts).
+// (A VALU formulation on LDS row tiles measured 0.108 ms per launch at F = 20, r = 6: 5 KB of LDS
+// reads per row made it LDS-bandwidth bound; this form moves 0.77 KB per row and runs 0.067 ms.)
+//   phase 1 (D = A.B, rows k, cols i):  numer[k][i] = sum_c H[k][c] X[i][c]      A = H  (registers, loaded once)
+//                                        denom[k][i] = sum_l HH[k][l] W[i][l]     A = HH (registers)
+//            B operands straight from global memory: lane (q = lane>>4, i = lane&15) reads
+//            X[4s+q][row i] -- 4 x 128-byte segments per wave load; the D layout of the f64 MFMA
+//            (row = (lane>>4) + 4*reg, col = lane&15) is the layout the W operand was loaded in,
+//            so W' = W * numer / denom needs no shuffle and is stored coalesced.
+//   phase 2 (rows k, cols c | l):       A[k][c] += sum_i W'[i][k] X[i][c],  B[k][l] += sum_i W'[i][k] W'[i][l]
+//            operands re-read from the wave's LDS slice in the transposed layout.
+// Accumulators stay in registers over all sub-tiles of the wave; the four waves of a workgroup are
+// summed in fixed order at the end (bitwise reproducible).
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int MF_LD = 17;                       // padded LDS row (doubles): conflict-free transposed reads
 
-static inline size_t mu_lds_doubles(int F, int r, int TR)
-{
-    return (size_t)(F + 2 * r) * (TR + 1) + (size_t)r * F + (size_t)r * r;
-}
+static inline size_t mfma_lds_doubles(int FT) { return (size_t)4 * (16 * FT + 16) * MF_LD + 256; }
 
-template <int TR, int NLD>
-__global__ __launch_bounds__(256) void nmf_w_pass_kernel(int64_t row_begin, int64_t row_end, int F, int r,
-                                                         const double *__restrict__ X, int64_t ldx,
-                                                         double *__restrict__ W, int64_t ldw,
-                                                         const double *__restrict__ H,
-                                                         double *__restrict__ partial)
+template <int FT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FT <= 2 ? 3 : 1, 8))) void nmf_w_pass_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                              const double *__restrict__ X, int64_t ldx,
+                                                              double *__restrict__ W, int64_t ldw,
+                                                              const double *__restrict__ H,
+                                                              double *__restrict__ partial)
 {
-    constexpr int LD = TR + 1;
-    constexpr int PARTS = 256 / TR;
-    extern __shared__ __attribute__((aligned(16))) double msm[];
-    double *sX = msm;                    // F * LD
-    double *sWo = sX + F * LD;           // r * LD   old W tile
-    double *sW = sWo + r * LD;           // r * LD   new W tile
-    double *sH = sW + r * LD;            // r * F
-    double *sHH = sH + r * F;            // r * r
-    const int t = threadIdx.x;
-    for (int idx = t; idx < r * F; idx += 256) sH[idx] = H[idx];
-    __syncthreads();
-    for (int idx = t; idx < r * r; idx += 256) {
-        const int k = idx / r, l = idx % r;
-        double s = 0.0;
-        for (int c = 0; c < F; ++c) s += sH[k * F + c] * sH[l * F + c];
-        sHH[idx] = s;
+    constexpr int F4 = 4 * FT;                                   // K steps of 4 columns over c
+    constexpr int WAVE_LDS = (16 * FT + 16) * MF_LD;             // doubles per wave: xT [16 FT][17] + wT [16][17]
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    double *sHH = fsm + 4 * WAVE_LDS;                            // 16 x 16
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    // H H^T (r x r, zero padded to 16 x 16) through LDS
+    {
+        double *sH = fsm;                                        // r * F <= 16 * 120 doubles, aliases the wave slices
+        for (int idx = t; idx < r * F; idx += 256) sH[idx] = H[idx];
+        __syncthreads();
+        {
+            const int k = t >> 4, l = t & 15;
+            double sacc = 0.0;
+            if (k < r && l < r)
+                for (int c = 0; c < F; ++c) sacc += sH[k * F + c] * sH[l * F + c];
+            sHH[t] = sacc;
+        }
+        __syncthreads();
     }
-    const int nA = r * F, P = nA + r * r;
-    const int ngrp = (P <= 256) ? (256 / P) : 1;
-    const int grp = (P <= 256) ? (t / P) : 0;
-    const bool acc_active = (P > 256) || (grp < ngrp);
-    double acc[MU_PSLOTS];
+    double hA[F4], hhA[4];
 #pragma unroll
-    for (int s = 0; s < MU_PSLOTS; ++s) acc[s] = 0.0;
-
-    // Tile staging is software pipelined (issue early / write late): the global loads of tile
-    // n+1 are issued into registers right after tile n has been written to LDS and stay in
-    // flight while phases 1 and 2 of tile n run.  NLD >= ceil((F + r) * TR / 256) = loads per
-    // thread for one tile (template parameter so the staging registers are statically indexed).
-    const int n_elems = (F + r) * TR;                   // X tile then old-W tile, element e -> (col, i)
-    const int my_loads = (n_elems - t + 255) / 256;     // loads this thread issues per tile (<= NLD)
-    double stage[NLD];
-    auto issue_loads = [&](int64_t r0) {
-        const int rows = (int)((row_end - r0 < TR) ? (row_end - r0) : TR);
+    for (int q = 0; q < F4; ++q) {
+        const int c = 4 * q + lq;
+        hA[q] = (li < r && c < F) ? H[li * F + c] : 0.0;
+    }
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = t + 256 * j;
-            double v = 0.0;
-            if (j < my_loads) {
-                const int cc = e / TR, i = e % TR;
-                if (i < rows)
-                    v = (cc < F) ? X[(size_t)cc * ldx + r0 + i] : W[(size_t)(cc - F) * ldw + r0 + i];
+    for (int q = 0; q < 4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
+    __syncthreads();                                             // sH (aliased) is dead from here on
+    double *xT = fsm + wave * WAVE_LDS;                          // [c][i], row stride MF_LD
+    double *wT = xT + 16 * FT * MF_LD;                           // [k][i]
+    v4d accA[FT], accB = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ct = 0; ct < FT; ++ct) accA[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int r4 = (r + 3) / 4, nq = (F + 3) / 4;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    const int64_t sub_stride = (int64_t)gridDim.x * 4;
+    double xb[F4], wb[4];
+    // Unconditional loads from clamped addresses (masked afterwards) so that all loads of a
+    // sub-tile issue back to back; the loads of sub-tile n+1 are issued right after sub-tile n
+    // has been copied to LDS and stay in flight during its phase 2.
+    auto issue_loads = [&](int64_t sidx) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const int64_t rowc = row < row_end ? row : row_end - 1;
+#pragma unroll
+        for (int q = 0; q < F4; ++q) {
+            if (q < nq) {
+                const int c = 4 * q + lq;
+                xb[q] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
             }
-            stage[j] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < r4) {
+                const int k = 4 * q + lq;
+                wb[q] = W[(size_t)(k < r ? k : r - 1) * ldw + rowc];
+            }
         }
     };
-    const int64_t tile_stride = (int64_t)gridDim.x * TR;
-    int64_t r0 = row_begin + (int64_t)blockIdx.x * TR;
-    if (r0 < row_end) issue_loads(r0);
-    for (; r0 < row_end; r0 += tile_stride) {
-        const int rows = (int)((row_end - r0 < TR) ? (row_end - r0) : TR);
-        __syncthreads();                                 // previous tile's phase 2 is done with LDS
+    int64_t sidx = (int64_t)blockIdx.x * 4 + wave;
+    if (sidx < nsub) issue_loads(sidx);
+    for (; sidx < nsub; sidx += sub_stride) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const bool valid = row < row_end;
+        v4d num = {0.0, 0.0, 0.0, 0.0}, den = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = t + 256 * j;
-            if (j < my_loads) {
-                const int cc = e / TR, i = e % TR;
-                if (cc < F) sX[cc * LD + i] = stage[j];
-                else sWo[(cc - F) * LD + i] = stage[j];
+        for (int q = 0; q < F4; ++q) {
+            if (q < nq) {
+                xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
+                num = __builtin_amdgcn_mfma_f64_16x16x4f64(hA[q], xb[q], num, 0, 0, 0);
+            } else {
+                xb[q] = 0.0;
             }
         }
-        __syncthreads();
-        if (r0 + tile_stride < row_end) issue_loads(r0 + tile_stride);
-        {
-            const int i = t % TR, g = t / TR;
-            for (int k = g; k < r; k += PARTS) {
-                double numer = 0.0, denom = 0.0;
-                for (int c = 0; c < F; ++c) numer += sX[c * LD + i] * sH[k * F + c];
-                for (int l = 0; l < r; ++l) denom += sWo[l * LD + i] * sHH[l * r + k];
-                if (denom == 0.0) denom = NMF_EPSILON;
-                const double wk = (i < rows) ? sWo[k * LD + i] * (numer / denom) : 0.0;
-                sW[k * LD + i] = wk;
-                if (i < rows) W[(size_t)k * ldw + r0 + i] = wk;
-            }
-        }
-        __syncthreads();
-        if (acc_active) {
 #pragma unroll
-            for (int s = 0; s < MU_PSLOTS; ++s) {
-                const int pid = (P <= 256) ? (t % P) : (t + 256 * s);
-                if ((P <= 256) ? (s == 0) : (pid < P)) {
-                    const double *a, *b;
-                    if (pid < nA) { a = sW + (pid / F) * LD; b = sX + (pid % F) * LD; }
-                    else { const int q = pid - nA; a = sW + (q / r) * LD; b = sW + (q % r) * LD; }
-                    // four independent partial sums hide the fp64 FMA latency (fixed order)
-                    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-                    int i = grp;
-                    for (; i + 3 * ngrp < TR; i += 4 * ngrp) {
-                        v0 += a[i] * b[i];
-                        v1 += a[i + ngrp] * b[i + ngrp];
-                        v2 += a[i + 2 * ngrp] * b[i + 2 * ngrp];
-                        v3 += a[i + 3 * ngrp] * b[i + 3 * ngrp];
-                    }
-                    for (; i < TR; i += ngrp) v0 += a[i] * b[i];
-                    acc[s] += (v0 + v1) + (v2 + v3);
-                }
+        for (int q = 0; q < 4; ++q) {
+            if (q < r4) {
+                wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
+                den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
+            } else {
+                wb[q] = 0.0;
             }
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = lq + 4 * g;
+            double d = den[g];
+            if (d == 0.0) d = NMF_EPSILON;
+            const bool live = valid && k < r;
+            const double wn = live ? wb[g] * (num[g] / d) : 0.0;
+            if (live) W[(size_t)k * ldw + row] = wn;
+            wT[k * MF_LD + li] = wn;
+        }
+#pragma unroll
+        for (int q = 0; q < F4; ++q) xT[(4 * q + lq) * MF_LD + li] = xb[q];
+        if (sidx + sub_stride < nsub) issue_loads(sidx + sub_stride);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 4 * st + lq;
+            const double aW = wT[li * MF_LD + i];
+#pragma unroll
+            for (int ct = 0; ct < FT; ++ct) {
+                const double bX = xT[(16 * ct + li) * MF_LD + i];
+                accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, bX, accA[ct], 0, 0, 0);
+            }
+            accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, aW, accB, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // partial layout [P][gridDim.x]
-    if (P <= 256) {
-        __syncthreads();
-        double *red = sX;                               // ngrp * P <= 256 doubles
-        if (acc_active) red[grp * P + (t % P)] = acc[0];
-        __syncthreads();
-        if (t < P) {
-            double s = 0.0;
-            for (int gI = 0; gI < ngrp; ++gI) s += red[gI * P + t];
-            partial[(size_t)t * gridDim.x + blockIdx.x] = s;
-        }
-    } else {
+    // fixed-order sum of the four waves' accumulators: red[wave][tile][g][lane]
+    __syncthreads();
+    double *red = fsm + wave * WAVE_LDS;                         // (FT + 1) * 256 doubles <= WAVE_LDS
 #pragma unroll
-        for (int s = 0; s < MU_PSLOTS; ++s) {
-            const int pid = t + 256 * s;
-            if (pid < P) partial[(size_t)pid * gridDim.x + blockIdx.x] = acc[s];
+    for (int ct = 0; ct < FT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(ct * 4 + g) * 64 + lane] = accA[ct][g];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(FT * 4 + g) * 64 + lane] = accB[g];
+    __syncthreads();
+    for (int idx = t; idx < (FT + 1) * 256; idx += 256) {
+        const int tile = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63;
+        const double v = ((fsm[0 * WAVE_LDS + idx] + fsm[1 * WAVE_LDS + idx]) + fsm[2 * WAVE_LDS + idx]) +
+                         fsm[3 * WAVE_LDS + idx];
+        const int k = (ln >> 4) + 4 * g, j = ln & 15;
+        if (k >= r) continue;
+        if (tile < FT) {
+            const int c = 16 * tile + j;
+            if (c < F) partial[(size_t)(k * F + c) * gridDim.x + blockIdx.x] = v;
+        } else if (j < r) {
+            partial[(size_t)(r * F + k * r + j) * gridDim.x + blockIdx.x] = v;
         }
     }
 }
@@ -510,29 +546,43 @@ __global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int
     if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
 }
 
-int pick_tr(int F, int r)
+template <int FT>
+int mfma_blocks_per_cu(size_t lds)
 {
-    // largest row tile whose LDS footprint still lets 8 workgroups share a CU (160 KiB), else
-    // the largest that fits the 64 KiB per-workgroup limit
-    const int cand[4] = {256, 128, 64, 32};
-    for (int i = 0; i < 4; ++i)
-        if (mu_lds_doubles(F, r, cand[i]) * 8 <= 20 * 1024) return cand[i];
-    for (int i = 0; i < 4; ++i)
-        if (mu_lds_doubles(F, r, cand[i]) * 8 <= 64 * 1024) return cand[i];
-    return 0;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nmf_w_pass_mfma_kernel<FT>, 256, lds) != hipSuccess || nb < 1)
+        nb = 1;
+    return nb;
 }
 
-int mu_grid(int64_t nrows, int TR)
+int mfma_resident_grid(int FT, size_t lds)
 {
-    const int64_t tiles = grx_ceil_div(nrows, TR);
-    return (int)(tiles > MU_MAX_GRID ? MU_MAX_GRID : (tiles < 1 ? 1 : tiles));
+    static int cache[9] = {0};
+    if (FT < 1) FT = 1;
+    if (FT > 8) FT = 8;
+    if (cache[FT] == 0) {
+        int nb = 1;
+        switch (FT) {
+        case 1: nb = mfma_blocks_per_cu<1>(lds); break;
+        case 2: nb = mfma_blocks_per_cu<2>(lds); break;
+        case 3: nb = mfma_blocks_per_cu<3>(lds); break;
+        case 4: nb = mfma_blocks_per_cu<4>(lds); break;
+        case 5: nb = mfma_blocks_per_cu<5>(lds); break;
+        case 6: nb = mfma_blocks_per_cu<6>(lds); break;
+        case 7: nb = mfma_blocks_per_cu<7>(lds); break;
+        default: nb = mfma_blocks_per_cu<8>(lds); break;
+        }
+        int g = nb * GRX_NUM_CU;
+        cache[FT] = g > MU_MAX_GRID ? MU_MAX_GRID : g;
+    }
+    return cache[FT];
 }
 
 constexpr int RES_GRID = GRX_NUM_CU * 4;
 
 int check_nmf_shape(const char *who, int F, int r)
 {
-    if (F < 1 || r < 1 || F > MAX_F || r > MAX_R || pick_tr(F, r) == 0) {
+    if (F < 1 || r < 1 || F > MAX_F || r > MAX_R) {
         grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d)", who, F, r, MAX_F, MAX_R);
         return GRX_ERR_UNSUPPORTED;
     }
@@ -709,20 +759,26 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
     const int P = r * F + r * r;
     int grid;
     {
-        const int TR = pick_tr(F, r);
-        grid = mu_grid(row_end - row_begin, TR);
-        const size_t lds = mu_lds_doubles(F, r, TR) * 8;
+        const int FT = (F + 15) / 16;
+        const int64_t nsub = grx_ceil_div(row_end - row_begin, 16);
+        const int64_t want = grx_ceil_div(nsub, 4);
+        const size_t lds = mfma_lds_doubles(FT) * 8;
+        // exactly one resident generation of workgroups: every wave keeps its accumulators over
+        // all of its sub-tiles and there is no partially filled last wave of workgroups
+        const int cap = mfma_resident_grid(FT, lds);
+        grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
         GRX_PROF(GRX_K_NMF_W_PASS, st);
-        const int need = ((F + r) * TR + 255) / 256;
-#define GRX_W_PASS(TRV, NLDV) nmf_w_pass_kernel<TRV, NLDV><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial)
-#define GRX_W_PASS_TR(TRV) do { if (need <= 8) GRX_W_PASS(TRV, 8); else if (need <= 16) GRX_W_PASS(TRV, 16); else GRX_W_PASS(TRV, 32); } while (0)
-        switch (TR) {
-        case 256: GRX_W_PASS_TR(256); break;
-        case 128: GRX_W_PASS_TR(128); break;
-        case 64:  GRX_W_PASS_TR(64); break;
-        default:  GRX_W_PASS_TR(32); break;
+#define GRX_W_PASS(FTV) nmf_w_pass_mfma_kernel<FTV><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial)
+        switch (FT) {
+        case 1: GRX_W_PASS(1); break;
+        case 2: GRX_W_PASS(2); break;
+        case 3: GRX_W_PASS(3); break;
+        case 4: GRX_W_PASS(4); break;
+        case 5: GRX_W_PASS(5); break;
+        case 6: GRX_W_PASS(6); break;
+        case 7: GRX_W_PASS(7); break;
+        default: GRX_W_PASS(8); break;
         }
-#undef GRX_W_PASS_TR
 #undef GRX_W_PASS
     }
     GRX_LAUNCH_CHECK();

@@ -75,8 +75,17 @@ if agg:
     write = sum(d.get('WRITE_SIZE', 0.0) * 1024 * d['launches_sampled'] for d in agg.values()) / w
     miss = sum(d.get('TCC_MISS_sum', 0.0) * d['launches_sampled'] for d in agg.values()) / w
     workload = sys.argv[2] if len(sys.argv) > 2 else 'ba1m'
+    nmf = {k: d for k, d in out.items() if k.startswith('nmf_w_pass')}
+    nmf_traffic = None
+    if nmf:
+        wn = sum(d['launches_sampled'] for d in nmf.values())
+        nmf_traffic = sum((d.get('FETCH_SIZE', 0.0) + d.get('WRITE_SIZE', 0.0)) * 1024 * d['launches_sampled']
+                          for d in nmf.values()) / wn
     json.dump({'workload': workload, 'n_gpus': 1, 'source': f'profiles/{tag}_pmc.json',
                'aggregate_kernel_hbm_bytes_per_launch': fetch + write,
+               'nmf_w_pass_hbm_bytes_per_launch': nmf_traffic,
+               'nmf_note': 'FETCH_SIZE + WRITE_SIZE as reported (8 B/lane loads in 128-byte segments; the 2x gfx950 '
+                           'correction of the guide is calibrated for 16 B/lane streams only)',
                'fetch_bytes': fetch, 'write_bytes': write, 'tcc_miss_x64B': miss * 64,
                'note': 'fabric-side bytes (L2 misses; Infinity-Cache hits are counted), FETCH_SIZE uncorrected, see script'},
               open(os.path.join('profiles', 'traffic_latest.json'), 'w'), indent=1)
