@@ -82,6 +82,60 @@ def test_nmf_rank_deficient_features():
     assert _relmax(G, We) < FACTOR_RTOL and _relmax(F, He) < FACTOR_RTOL
 
 
+@pytest.mark.parametrize('n,F,r', [(1, 1, 1), (15, 3, 2), (16, 4, 4), (17, 5, 3), (1000, 16, 6), (1001, 17, 7),
+                                   (4099, 20, 6), (5000, 33, 16), (3000, 64, 5), (2500, 100, 9), (2049, 120, 16)])
+def test_mu_iteration_kernels_vs_numpy(n, F, r):
+    """One multiplicative update (sklearn _nmf.py:540-702, beta = 2) computed by grx_nmf_w_pass (fp64
+    MFMA tiles) + grx_nmf_h_update against numpy, over the shape limits (F <= 120, r <= 16), row
+    counts that are not multiples of the 16-row sub-tile, zero rows / zero denominators, and a
+    row range (sharded use)."""
+    import torch
+    from graphrole_amd import kernels as K
+    eps = float(np.finfo(np.float32).eps)
+    rng = np.random.default_rng(n * 131 + F * 7 + r)
+    X = np.abs(rng.standard_normal((n, F))) * 10.0 ** rng.integers(-2, 3, size=F)
+    W = np.abs(rng.standard_normal((n, r)))
+    H = np.abs(rng.standard_normal((r, F)))
+    if n > 20:
+        X[5] = 0.0
+        W[7] = 0.0                                     # zero denominator -> EPSILON (_nmf.py:583)
+    ld = n + 3                                         # leading dimension larger than n
+    Xd = torch.zeros((F, ld), dtype=torch.float64, device='cuda')
+    Xd[:, :n] = torch.from_numpy(np.ascontiguousarray(X.T))
+    Wd = torch.zeros((r, ld), dtype=torch.float64, device='cuda')
+    Wd[:, :n] = torch.from_numpy(np.ascontiguousarray(W.T))
+    st = K.NmfState(Xd, n, Wd.clone(), H)
+    st.w_pass()
+    st.h_update()
+    den = W @ (H @ H.T)
+    den[den == 0] = eps
+    W1 = W * ((X @ H.T) / den)
+    A, B = W1.T @ X, W1.T @ W1
+    denh = B @ H
+    denh[denh == 0] = eps
+    H1 = H * (A / denh)
+    got_W = st.W.cpu().numpy()[:, :n].T
+    np.testing.assert_allclose(got_W, W1, rtol=1e-12, atol=1e-300)
+    assert not st.W.cpu().numpy()[:, n:].any()         # padding columns untouched
+    AB = st.AB.cpu().numpy()
+    np.testing.assert_allclose(AB[:r * F].reshape(r, F), A, rtol=1e-11)
+    np.testing.assert_allclose(AB[r * F:].reshape(r, r), B, rtol=1e-11)
+    np.testing.assert_allclose(st.H.cpu().numpy(), H1, rtol=1e-10)
+    # bitwise reproducible, and a row range updates exactly its rows
+    st2 = K.NmfState(Xd, n, Wd.clone(), H)
+    st2.w_pass()
+    assert torch.equal(st2.W, st.W) and torch.equal(st2.AB, st.AB)
+    if n > 100:
+        rb, re = 37, n - 41
+        st3 = K.NmfState(Xd, n, Wd.clone(), H)
+        st3.w_pass(rb, re)
+        w3 = st3.W.cpu().numpy()
+        assert np.array_equal(w3[:, rb:re], st.W.cpu().numpy()[:, rb:re])
+        assert np.array_equal(w3[:, :rb], Wd.cpu().numpy()[:, :rb]) and np.array_equal(w3[:, re:], Wd.cpu().numpy()[:, re:])
+        A3 = W1[rb:re].T @ X[rb:re]
+        np.testing.assert_allclose(st3.AB.cpu().numpy()[:r * F].reshape(r, F), A3, rtol=1e-11)
+
+
 class TestFactorLikeReference:
     """tests/test_roles/test_factor.py of the reference."""
 
