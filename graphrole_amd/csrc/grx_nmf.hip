@@ -17,6 +17,9 @@
 //   nmf_residual_kernel     ||X - WH||_F^2
 #include "grx_common.h"
 
+#include <array>
+#include <utility>
+
 namespace {
 
 constexpr double NMF_EPSILON = 1.1920928955078125e-07;   // np.finfo(np.float32).eps, _nmf.py:39
@@ -312,14 +315,17 @@ constexpr int MF_LD = 17;                       // padded LDS row (doubles): con
 
 static inline size_t mfma_lds_doubles(int FT) { return (size_t)4 * (16 * FT + 16) * MF_LD + 256; }
 
-template <int FT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FT <= 2 ? 3 : 1, 8))) void nmf_w_pass_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+// NQ = ceil(F / 4) K-steps over the feature columns, R4 = K-steps over the roles (2: r <= 8, 4: r <= 16);
+// both compile-time so that the loads and MFMAs of a sub-tile form one straight-line block.
+template <int NQ, int R4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3 : 1, 8))) void nmf_w_pass_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                               const double *__restrict__ X, int64_t ldx,
                                                               double *__restrict__ W, int64_t ldw,
                                                               const double *__restrict__ H,
                                                               double *__restrict__ partial)
 {
-    constexpr int F4 = 4 * FT;                                   // K steps of 4 columns over c
+    constexpr int FT = (NQ + 3) / 4;                             // 16-column tiles of the A accumulator
+    constexpr int F4 = NQ;                                       // K steps of 4 columns over c
     constexpr int WAVE_LDS = (16 * FT + 16) * MF_LD;             // doubles per wave: xT [16 FT][17] + wT [16][17]
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     double *sHH = fsm + 4 * WAVE_LDS;                            // 16 x 16
@@ -353,10 +359,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FT <= 2 ? 3
     v4d accA[FT], accB = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ct = 0; ct < FT; ++ct) accA[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int r4 = (r + 3) / 4, nq = (F + 3) / 4;
     const int64_t nsub = (row_end - row_begin + 15) / 16;
     const int64_t sub_stride = (int64_t)gridDim.x * 4;
-    double xb[F4], wb[4];
+    double xb[F4], wb[R4];
     // Unconditional loads from clamped addresses (masked afterwards) so that all loads of a
     // sub-tile issue back to back; the loads of sub-tile n+1 are issued right after sub-tile n
     // has been copied to LDS and stay in flight during its phase 2.
@@ -365,17 +370,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FT <= 2 ? 3
         const int64_t rowc = row < row_end ? row : row_end - 1;
 #pragma unroll
         for (int q = 0; q < F4; ++q) {
-            if (q < nq) {
-                const int c = 4 * q + lq;
-                xb[q] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
-            }
+            const int c = 4 * q + lq;
+            xb[q] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < r4) {
-                const int k = 4 * q + lq;
-                wb[q] = W[(size_t)(k < r ? k : r - 1) * ldw + rowc];
-            }
+        for (int q = 0; q < R4; ++q) {
+            const int k = 4 * q + lq;
+            wb[q] = W[(size_t)(k < r ? k : r - 1) * ldw + rowc];
         }
     };
     int64_t sidx = (int64_t)blockIdx.x * 4 + wave;
@@ -386,34 +387,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FT <= 2 ? 3
         v4d num = {0.0, 0.0, 0.0, 0.0}, den = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < F4; ++q) {
-            if (q < nq) {
-                xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
-                num = __builtin_amdgcn_mfma_f64_16x16x4f64(hA[q], xb[q], num, 0, 0, 0);
-            } else {
-                xb[q] = 0.0;
-            }
+            xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
+            num = __builtin_amdgcn_mfma_f64_16x16x4f64(hA[q], xb[q], num, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < r4) {
-                wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
-                den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
-            } else {
-                wb[q] = 0.0;
-            }
+        for (int q = 0; q < R4; ++q) {
+            wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
+            den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int k = lq + 4 * g;
-            double d = den[g];
-            if (d == 0.0) d = NMF_EPSILON;
-            const bool live = valid && k < r;
-            const double wn = live ? wb[g] * (num[g] / d) : 0.0;
-            if (live) W[(size_t)k * ldw + row] = wn;
+            double wn = 0.0;
+            if (g < R4) {
+                double d = den[g];
+                if (d == 0.0) d = NMF_EPSILON;
+                const bool live = valid && k < r;
+                wn = live ? wb[g] * (num[g] / d) : 0.0;
+                if (live) W[(size_t)k * ldw + row] = wn;
+            }
             wT[k * MF_LD + li] = wn;
         }
 #pragma unroll
-        for (int q = 0; q < F4; ++q) xT[(4 * q + lq) * MF_LD + li] = xb[q];
+        for (int q = 0; q < 4 * FT; ++q) xT[(4 * q + lq) * MF_LD + li] = (q < F4) ? xb[q] : 0.0;
         if (sidx + sub_stride < nsub) issue_loads(sidx + sub_stride);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -546,36 +542,32 @@ __global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int
     if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
 }
 
-template <int FT>
-int mfma_blocks_per_cu(size_t lds)
+// launch table over (NQ, R4): function pointers of the instantiations
+using WPassKernel = void (*)(int64_t, int64_t, int, int, const double *, int64_t, double *, int64_t, const double *,
+                             double *);
+template <int R4, int... NQs>
+constexpr std::array<WPassKernel, sizeof...(NQs)> w_pass_table(std::integer_sequence<int, NQs...>)
 {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nmf_w_pass_mfma_kernel<FT>, 256, lds) != hipSuccess || nb < 1)
-        nb = 1;
-    return nb;
+    return {nmf_w_pass_mfma_kernel<NQs + 1, R4>...};
 }
+const auto W_PASS_R2 = w_pass_table<2>(std::make_integer_sequence<int, MAX_F / 4>{});
+const auto W_PASS_R4 = w_pass_table<4>(std::make_integer_sequence<int, MAX_F / 4>{});
 
-int mfma_resident_grid(int FT, size_t lds)
+WPassKernel w_pass_kernel(int F, int r) { return (r <= 8 ? W_PASS_R2 : W_PASS_R4)[(F + 3) / 4 - 1]; }
+
+// one resident generation of workgroups (cached per instantiation)
+int mfma_resident_grid(int F, int r, size_t lds)
 {
-    static int cache[9] = {0};
-    if (FT < 1) FT = 1;
-    if (FT > 8) FT = 8;
-    if (cache[FT] == 0) {
-        int nb = 1;
-        switch (FT) {
-        case 1: nb = mfma_blocks_per_cu<1>(lds); break;
-        case 2: nb = mfma_blocks_per_cu<2>(lds); break;
-        case 3: nb = mfma_blocks_per_cu<3>(lds); break;
-        case 4: nb = mfma_blocks_per_cu<4>(lds); break;
-        case 5: nb = mfma_blocks_per_cu<5>(lds); break;
-        case 6: nb = mfma_blocks_per_cu<6>(lds); break;
-        case 7: nb = mfma_blocks_per_cu<7>(lds); break;
-        default: nb = mfma_blocks_per_cu<8>(lds); break;
-        }
-        int g = nb * GRX_NUM_CU;
-        cache[FT] = g > MU_MAX_GRID ? MU_MAX_GRID : g;
+    static int cache[2][MAX_F / 4] = {};
+    int &slot = cache[r <= 8 ? 0 : 1][(F + 3) / 4 - 1];
+    if (slot == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w_pass_kernel(F, r), 256, lds) != hipSuccess || nb < 1)
+            nb = 1;
+        const int g = nb * GRX_NUM_CU;
+        slot = g > MU_MAX_GRID ? MU_MAX_GRID : g;
     }
-    return cache[FT];
+    return slot;
 }
 
 constexpr int RES_GRID = GRX_NUM_CU * 4;
@@ -765,21 +757,11 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
         const size_t lds = mfma_lds_doubles(FT) * 8;
         // exactly one resident generation of workgroups: every wave keeps its accumulators over
         // all of its sub-tiles and there is no partially filled last wave of workgroups
-        const int cap = mfma_resident_grid(FT, lds);
+        const int cap = mfma_resident_grid(F, r, lds);
         grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
         GRX_PROF(GRX_K_NMF_W_PASS, st);
-#define GRX_W_PASS(FTV) nmf_w_pass_mfma_kernel<FTV><<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial)
-        switch (FT) {
-        case 1: GRX_W_PASS(1); break;
-        case 2: GRX_W_PASS(2); break;
-        case 3: GRX_W_PASS(3); break;
-        case 4: GRX_W_PASS(4); break;
-        case 5: GRX_W_PASS(5); break;
-        case 6: GRX_W_PASS(6); break;
-        case 7: GRX_W_PASS(7); break;
-        default: GRX_W_PASS(8); break;
-        }
-#undef GRX_W_PASS
+        hipLaunchKernelGGL(w_pass_kernel(F, r), dim3(grid), dim3(256), lds, st, row_begin, row_end, F, r, d_X, ldx,
+                           d_W, ldw, d_H, partial);
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
