@@ -146,6 +146,152 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
     if (t == 0) partial[(size_t)npairs * gridDim.x + blockIdx.x] = ((xred[0] + xred[1]) + xred[2]) + xred[3];
 }
 
+// ---------------------------------------------------------------------------------------
+// The same Gram matrix on the matrix cores (v_mfma_f64_16x16x4_f64) for F, k <= 48: one wavefront
+// per 16-row sub-tile.  Y^T (k x 16) = T^T X^T is one MFMA chain per 16-column tile of k with the
+// X operand straight from global memory; the sub-tile of Y is then written to the wave's LDS
+// slice and re-read transposed as both operands of G[j][j'] += sum_i Y[i][j] Y[i][j']
+// (upper-triangular tile pairs only).  NQ = ceil(F / 4), KT = ceil(k / 16).
+typedef double gv4d __attribute__((ext_vector_type(4)));
+constexpr int GM_LD = 17;
+constexpr int GM_MAX_NQ = 12, GM_MAX_KT = 3;
+
+static inline size_t gram_mfma_lds_doubles(int KT)
+{
+    const size_t tile = (size_t)16 * KT * GM_LD, red = (size_t)(KT * (KT + 1) / 2) * 256;
+    return 4 * (tile > red ? tile : red) + 8;
+}
+
+template <int NQ, int KT, bool HAS_T>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int k,
+                                                        const double *__restrict__ X, int64_t ldx,
+                                                        const double *__restrict__ T, double *__restrict__ partial)
+{
+    constexpr int NT = KT * (KT + 1) / 2;
+    constexpr int TILE = 16 * KT * GM_LD, RED = NT * 256;
+    constexpr int WAVE_LDS = TILE > RED ? TILE : RED;
+    extern __shared__ __attribute__((aligned(16))) double gms[];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    double *yT = gms + wave * WAVE_LDS;                          // [j][i], row stride GM_LD
+    double tA[HAS_T ? KT : 1][HAS_T ? NQ : 1];
+    if (HAS_T) {
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = 4 * q + lq, j = 16 * jt + li;
+                tA[HAS_T ? jt : 0][HAS_T ? q : 0] = (c < F && j < k) ? T[(size_t)c * k + j] : 0.0;
+            }
+    }
+    gv4d acc[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) acc[p] = (gv4d){0.0, 0.0, 0.0, 0.0};
+    double xsum = 0.0;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    const int64_t sub_stride = (int64_t)gridDim.x * 4;
+    double xb[NQ];
+    auto issue_loads = [&](int64_t sidx) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const int64_t rowc = row < row_end ? row : row_end - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = 4 * q + lq;
+            xb[q] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
+        }
+    };
+    int64_t sidx = (int64_t)blockIdx.x * 4 + wave;
+    if (sidx < nsub) issue_loads(sidx);
+    for (; sidx < nsub; sidx += sub_stride) {
+        const bool valid = row_begin + sidx * 16 + li < row_end;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
+        if (HAS_T) {
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) {
+                gv4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    y = __builtin_amdgcn_mfma_f64_16x16x4f64(tA[HAS_T ? jt : 0][HAS_T ? q : 0], xb[q], y, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yT[(16 * jt + lq + 4 * g) * GM_LD + li] = y[g];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4 * KT; ++q) {
+                const double v = (q < NQ) ? xb[q < NQ ? q : 0] : 0.0;
+                yT[(4 * q + lq) * GM_LD + li] = v;
+                xsum += v;
+            }
+        }
+        if (sidx + sub_stride < nsub) issue_loads(sidx + sub_stride);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            double a[KT];
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) a[jt] = yT[(16 * jt + li) * GM_LD + 4 * st + lq];
+            int p = 0;
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int ju = jt; ju < KT; ++ju, ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt], a[ju], acc[p], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // fixed-order sum over the four waves, then the [pair][block] partial layout of gram_finalize
+    __syncthreads();
+    double *red = gms + wave * WAVE_LDS;
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(p * 4 + g) * 64 + lane] = acc[p][g];
+    double *xred = gms + 4 * WAVE_LDS;
+    xsum = grx_group_sum<64>(xsum);
+    if (lane == 0) xred[wave] = xsum;
+    __syncthreads();
+    const int npairs = k * (k + 1) / 2;
+    for (int idx = t; idx < NT * 256; idx += 256) {
+        const int p = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63;
+        const double v = ((gms[0 * WAVE_LDS + idx] + gms[1 * WAVE_LDS + idx]) + gms[2 * WAVE_LDS + idx]) +
+                         gms[3 * WAVE_LDS + idx];
+        int jt = 0, ju = 0, pp = p;                              // p -> (jt <= ju)
+        for (jt = 0; jt < KT; ++jt) {
+            if (pp < KT - jt) { ju = jt + pp; break; }
+            pp -= KT - jt;
+        }
+        const int j = 16 * jt + (ln >> 4) + 4 * g, j2 = 16 * ju + (ln & 15);
+        if (j <= j2 && j2 < k) partial[(size_t)(j2 * (j2 + 1) / 2 + j) * gridDim.x + blockIdx.x] = v;
+    }
+    if (t == 0) partial[(size_t)npairs * gridDim.x + blockIdx.x] = ((xred[0] + xred[1]) + xred[2]) + xred[3];
+}
+
+using GramKernel = void (*)(int64_t, int64_t, int, int, const double *, int64_t, const double *, double *);
+template <int KT, bool HAS_T, int... NQs>
+constexpr std::array<GramKernel, sizeof...(NQs)> gram_table(std::integer_sequence<int, NQs...>)
+{
+    return {gram_mfma_kernel<NQs + 1, KT, HAS_T>...};
+}
+const auto GRAM_T1 = gram_table<1, true>(std::make_integer_sequence<int, GM_MAX_NQ>{});
+const auto GRAM_T2 = gram_table<2, true>(std::make_integer_sequence<int, GM_MAX_NQ>{});
+const auto GRAM_T3 = gram_table<3, true>(std::make_integer_sequence<int, GM_MAX_NQ>{});
+const auto GRAM_I1 = gram_table<1, false>(std::make_integer_sequence<int, 4>{});      // k = F: NQ <= 4 KT
+const auto GRAM_I2 = gram_table<2, false>(std::make_integer_sequence<int, 8>{});
+const auto GRAM_I3 = gram_table<3, false>(std::make_integer_sequence<int, 12>{});
+
+GramKernel gram_mfma_pick(int F, int k, bool has_t)
+{
+    const int nq = (F + 3) / 4, kt = (k + 15) / 16;
+    if (nq > GM_MAX_NQ || kt > GM_MAX_KT) return nullptr;
+    if (has_t) return (kt == 1 ? GRAM_T1 : kt == 2 ? GRAM_T2 : GRAM_T3)[nq - 1];
+    return kt == 1 ? GRAM_I1[nq - 1] : kt == 2 ? GRAM_I2[nq - 1] : GRAM_I3[nq - 1];
+}
+
 // partial [npairs+1][nb] -> out: full symmetric k x k, then the X sum (one wavefront per output)
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__restrict__ partial,
                                                             int nb, int k, double *__restrict__ out)
@@ -636,27 +782,34 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
         return GRX_ERR_WORKSPACE;
     }
     hipStream_t st = grx_stream(stream);
-    const int grid = gram_grid(row_end - row_begin);
+    int grid = gram_grid(row_end - row_begin);
     const size_t npairs = (size_t)k * (k + 1) / 2;
     char *ws = reinterpret_cast<char *>(d_workspace);
     double *partial = reinterpret_cast<double *>(ws);
     double *dT = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_grid(n) * (npairs + 1) * 8, 256));
-    size_t lds = (size_t)k * GR_LD * 8;
-    const int t_in_lds = (h_T != nullptr) && (lds + (size_t)F * k * 8 <= 60 * 1024);
-    if (t_in_lds) lds += (size_t)F * k * 8;
-    if (h_T) {
-        GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
-        {
-            GRX_PROF(GRX_K_GRAM, st);
-            if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-            else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-            else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-        }
+    if (h_T) GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
+    if (GramKernel mk = gram_mfma_pick(F, k, h_T != nullptr)) {
+        // matrix-core path (F, k <= 48): one resident generation of workgroups
+        const size_t lds = gram_mfma_lds_doubles((k + 15) / 16) * 8;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mk, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        const int64_t want = grx_ceil_div(grx_ceil_div(row_end - row_begin, 16), 4);
+        int cap = nb * GRX_NUM_CU;
+        if (cap > gram_grid(n)) cap = gram_grid(n) > 0 ? gram_grid(n) : 1;     // partial buffer is sized by gram_grid
+        grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
+        GRX_PROF(GRX_K_GRAM, st);
+        hipLaunchKernelGGL(mk, dim3(grid), dim3(256), lds, st, row_begin, row_end, F, k, d_X, ldx,
+                           h_T ? dT : (const double *)nullptr, partial);
     } else {
-        { GRX_PROF(GRX_K_GRAM, st);
-        gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, 0, partial);
-        }
+        size_t lds = (size_t)k * GR_LD * 8;
+        const int t_in_lds = (h_T != nullptr) && (lds + (size_t)F * k * 8 <= 60 * 1024);
+        if (t_in_lds) lds += (size_t)F * k * 8;
+        GRX_PROF(GRX_K_GRAM, st);
+        if (!h_T) gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, 0, partial);
+        else if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+        else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+        else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+        else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
     }
     GRX_LAUNCH_CHECK();
     gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, grid, k, d_out);

@@ -66,6 +66,11 @@ def zeros(shape, dtype=torch.float64) -> torch.Tensor:
     return torch.zeros(shape, dtype=dtype, device=device())
 
 
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension of a [rows, n] block; a single-row tensor may carry any stride(0)."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1], 1)
+
+
 def ptr_array(tensors: Sequence[torch.Tensor]):
     """Host table of device pointers (the `const T* const* h_*` arguments of the ABI)."""
     return (c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
@@ -297,7 +302,7 @@ def sort_columns(block: torch.Tensor) -> torch.Tensor:
         return out
     ws_bytes = _lib.load().grx_sort_workspace_bytes(n, ncols)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
-    _lib.call('grx_sort_columns', n, ncols, _ptr(block), block.stride(0), _ptr(out), out.stride(0), _ptr(ws),
+    _lib.call('grx_sort_columns', n, ncols, _ptr(block), block.stride(0), _ptr(out), _ld(out), _ptr(ws),
               ws_bytes, _stream())
     return out
 
@@ -336,7 +341,7 @@ def gather_columns(cols: Sequence[torch.Tensor], n: int) -> torch.Tensor:
     out = torch.empty((F, max(n, 1)), dtype=torch.float64, device=device())
     if F and n:
         ptrs = ptr_array(cols)
-        _lib.call('grx_gather_columns', n, F, ptrs, _ptr(out), out.stride(0), _stream())
+        _lib.call('grx_gather_columns', n, F, ptrs, _ptr(out), _ld(out), _stream())
     return out
 
 
@@ -353,7 +358,7 @@ def gram(X: torch.Tensor, n: int, T: Optional[np.ndarray] = None, row_begin: int
     ws_bytes = lib.grx_gram_workspace_bytes(n, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     out = torch.empty(k * k + 1, dtype=torch.float64, device=device())
-    _lib.call('grx_gram', n, F, _ptr(X), X.stride(0), row_begin, row_end, _hptr(T), k, _ptr(out), _ptr(ws),
+    _lib.call('grx_gram', n, F, _ptr(X), _ld(X), row_begin, row_end, _hptr(T), k, _ptr(out), _ptr(ws),
               ws_bytes, _stream())
     host = out.cpu().numpy()
     return host[:k * k].reshape(k, k).copy(), float(host[k * k])
@@ -372,8 +377,8 @@ def project(X: torch.Tensor, n: int, Z: np.ndarray, row_begin: int = 0,
     ws_bytes = lib.grx_project_workspace_bytes(n, r)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     stats = torch.empty(r * 4, dtype=torch.float64, device=device())
-    _lib.call('grx_project', n, F, _ptr(X), X.stride(0), row_begin, row_end, _hptr(Z), r, _ptr(out),
-              out.stride(0), _ptr(stats), _ptr(ws), ws_bytes, _stream())
+    _lib.call('grx_project', n, F, _ptr(X), _ld(X), row_begin, row_end, _hptr(Z), r, _ptr(out),
+              _ld(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
     return out, stats.cpu().numpy().reshape(r, 4)
 
 
@@ -382,7 +387,7 @@ def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, e
     row_end = n if row_end is None else row_end
     sign = np.ascontiguousarray(sign, dtype=np.float64)
     scale = np.ascontiguousarray(scale, dtype=np.float64)
-    _lib.call('grx_nndsvd_apply', n, U.shape[0], _ptr(U), U.stride(0), row_begin, row_end, _hptr(sign),
+    _lib.call('grx_nndsvd_apply', n, U.shape[0], _ptr(U), _ld(U), row_begin, row_end, _hptr(sign),
               _hptr(scale), float(eps), float(fill), _stream())
 
 
@@ -415,8 +420,8 @@ class NmfState:
 
     def w_pass(self, row_begin: int = 0, row_end: Optional[int] = None) -> None:
         row_end = self.n if row_end is None else row_end
-        _lib.call('grx_nmf_w_pass', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
-                  self.W.stride(0), row_begin, row_end, _ptr(self.H), _ptr(self.AB), _ptr(self.ws),
+        _lib.call('grx_nmf_w_pass', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),
+                  _ld(self.W), row_begin, row_end, _ptr(self.H), _ptr(self.AB), _ptr(self.ws),
                   self.ws_bytes, _stream())
 
     def h_update(self) -> None:
@@ -424,8 +429,8 @@ class NmfState:
 
     def residual_sq(self, row_begin: int = 0, row_end: Optional[int] = None) -> torch.Tensor:
         row_end = self.n if row_end is None else row_end
-        _lib.call('grx_nmf_residual', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
-                  self.W.stride(0), row_begin, row_end, _ptr(self.H), _ptr(self.err), _ptr(self.ws),
+        _lib.call('grx_nmf_residual', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),
+                  _ld(self.W), row_begin, row_end, _ptr(self.H), _ptr(self.err), _ptr(self.ws),
                   self.ws_bytes, _stream())
         return self.err
 
@@ -433,11 +438,11 @@ class NmfState:
         """Generalised-KL error cost of X against the (encoded) factors W [r, ld], H [r, F]."""
         row_end = self.n if row_end is None else row_end
         out = torch.zeros(1, dtype=torch.float64, device=device())
-        _lib.call('grx_nmf_kl_cost', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(W), W.stride(0),
+        _lib.call('grx_nmf_kl_cost', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(W), _ld(W),
                   row_begin, row_end, _ptr(H), _ptr(out), _ptr(self.ws), self.ws_bytes, _stream())
         return float(out.cpu()[0])
 
     def iterate(self, iters: int, with_residual: bool = True) -> None:
-        _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), self.X.stride(0), _ptr(self.W),
-                  self.W.stride(0), _ptr(self.H), _ptr(self.AB), _ptr(self.err) if with_residual else None,
+        _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),
+                  _ld(self.W), _ptr(self.H), _ptr(self.AB), _ptr(self.err) if with_residual else None,
                   int(iters), _ptr(self.ws), self.ws_bytes, _stream())

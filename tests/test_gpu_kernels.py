@@ -375,7 +375,7 @@ def test_chebyshev_many_columns(K):
 
 # ------------------------------------------------------------------------------------- NMF
 @pytest.mark.parametrize('shape', [(1000, 7, 4), (50000, 12, 6), (3000, 40, 6), (2000, 64, 8), (700, 100, 16),
-                                   (100, 3, 2)])
+                                   (100, 3, 2), (4099, 48, 5), (1001, 17, 3), (333, 33, 2), (17, 1, 1), (5000, 49, 4)])
 def test_nmf_building_blocks_vs_numpy(K, shape):
     import torch
     from oracle import rolx
