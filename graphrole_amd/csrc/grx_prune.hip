@@ -69,9 +69,23 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
     uint64_t keys[SORT_ITEMS];
     uint32_t vm;
     load_keys<FROM_F64>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i)
-        if (vm & (1u << i)) atomicAdd(&cnt[(keys[i] >> shift) & 0xFF], 1u);
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        // same-address LDS atomics serialise lane by lane; columns of small integers (degrees, their
+        // sums) have whole wavefronts agreeing on most digits: count those with one atomic
+        const bool valid = (vm >> i) & 1u;
+        const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
+        const uint64_t active = __ballot(valid);
+        if (active == 0) continue;                              // uniform over the wave
+        const int leader = __ffsll((long long)active) - 1;
+        const uint32_t d0 = __shfl(d, leader, 64);
+        if (__ballot(valid && d != d0) == 0) {
+            if (lane == leader) atomicAdd(&cnt[d0], (uint32_t)__popcll(active));
+        } else if (valid) {
+            atomicAdd(&cnt[d], 1u);
+        }
+    }
     __syncthreads();
     hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
@@ -135,6 +149,9 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_base)
 {
     __shared__ uint32_t cnt[4][RADIX];
+    __shared__ uint32_t gdelta[RADIX];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t stage[SORT_TILE];
     const int col = blockIdx.y, tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -151,11 +168,16 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
         const bool valid = (vm >> i) & 1u;
         const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
         uint64_t peers = __ballot(valid);
+        // lanes holding the same digit: eight ballots -- unless the whole wavefront agrees (every
+        // constant digit position of an integer-valued column), which one shuffle + ballot detects
+        const uint32_t d0 = __shfl(d, peers ? __ffsll((long long)peers) - 1 : 0, 64);
+        if (__ballot(valid && d != d0) != 0) {
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const bool set = (d >> bit) & 1u;
-            const uint64_t m = __ballot(set);
-            peers &= set ? m : ~m;
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const uint64_t m = __ballot(set);
+                peers &= set ? m : ~m;
+            }
         }
         uint32_t r = 0;
         if (valid) {
@@ -169,25 +191,47 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
         rank[i] = r;
     }
     __syncthreads();
+    // The keys are first placed in digit order in LDS (tile-local position = exclusive digit prefix
+    // + wave offset + rank), then written out by consecutive lanes: a digit's run of keys (16 on
+    // average) becomes one contiguous global store instead of 8-byte stores to 64 places.
     {
         const int d = threadIdx.x;
-        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        const uint32_t total = c0 + c1 + c2 + c3;
+        uint32_t inc = total;                                   // exclusive prefix of the digit totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t lp = inc - total;
+        for (int w = 0; w < wave; ++w) lp += wsum[w];
         const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile] + digit_base[(size_t)col * RADIX + d];
-        cnt[0][d] = g;
-        cnt[1][d] = g + c0;
-        cnt[2][d] = g + c0 + c1;
-        cnt[3][d] = g + c0 + c1 + c2;
+        gdelta[d] = g - lp;                                     // global position = gdelta[digit] + local position
+        cnt[0][d] = lp;
+        cnt[1][d] = lp + c0;
+        cnt[2][d] = lp + c0 + c1;
+        cnt[3][d] = lp + c0 + c1 + c2;
     }
     __syncthreads();
-    char *cdst = reinterpret_cast<char *>(dst) + (size_t)col * dst_ld * 8;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         if ((vm >> i) & 1u) {
             const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
-            const uint32_t pos = cnt[wave][d] + rank[i];
-            if (TO_F64) reinterpret_cast<double *>(cdst)[pos] = key_to_f64(keys[i]);
-            else reinterpret_cast<uint64_t *>(cdst)[pos] = keys[i];
+            stage[cnt[wave][d] + rank[i]] = keys[i];
         }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)tile * SORT_TILE;
+    const int nv = (int)(left < SORT_TILE ? left : SORT_TILE);
+    char *cdst = reinterpret_cast<char *>(dst) + (size_t)col * dst_ld * 8;
+    for (int j = threadIdx.x; j < nv; j += SORT_THREADS) {
+        const uint64_t key = stage[j];
+        const uint32_t pos = gdelta[(uint32_t)(key >> shift) & 0xFF] + (uint32_t)j;
+        if (TO_F64) reinterpret_cast<double *>(cdst)[pos] = key_to_f64(key);
+        else reinterpret_cast<uint64_t *>(cdst)[pos] = key;
     }
 }
 
