@@ -90,11 +90,9 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
     hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
 
-// Exclusive scan of the digit-major counter table hist[RADIX][ntiles] of every column, in two
-// short kernels with (RADIX x ncols) wavefront-sized workgroups each:
-//   scan_rows_kernel   : per (column, digit) exclusive scan across tiles, digit total -> tot
-//   scan_digits_kernel : per column exclusive scan of the 256 digit totals -> base
-// scatter_kernel adds base[digit] to the per-tile offset.
+// scan_rows_kernel: per (column, digit) exclusive scan of the digit-major counter table
+// hist[RADIX][ntiles] across tiles, digit total -> tot.  scatter_kernel scans the 256 digit totals
+// itself (digit base) and adds it to the per-tile offset.
 __global__ __launch_bounds__(64) void scan_rows_kernel(uint32_t *__restrict__ hist, int ntiles,
                                                        uint32_t *__restrict__ tot)
 {
@@ -124,33 +122,14 @@ __global__ __launch_bounds__(64) void scan_rows_kernel(uint32_t *__restrict__ hi
     if (lane == 0) tot[(size_t)col * RADIX + d] = carry;
 }
 
-__global__ __launch_bounds__(RADIX) void scan_digits_kernel(const uint32_t *__restrict__ tot,
-                                                            uint32_t *__restrict__ base)
-{
-    __shared__ uint32_t wsum[4];
-    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
-    const uint32_t x = tot[(size_t)blockIdx.x * RADIX + d];
-    uint32_t inc = x;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += y;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    base[(size_t)blockIdx.x * RADIX + d] = pre + inc - x;
-}
-
 template <bool FROM_F64, bool TO_F64>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     const void *__restrict__ src, int64_t src_ld, void *__restrict__ dst, int64_t dst_ld, int64_t n,
-    int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_base)
+    int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_tot)
 {
     __shared__ uint32_t cnt[4][RADIX];
     __shared__ uint32_t gdelta[RADIX];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[8];
     __shared__ uint64_t stage[SORT_TILE];
     const int col = blockIdx.y, tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -198,17 +177,20 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
         const int d = threadIdx.x;
         const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
         const uint32_t total = c0 + c1 + c2 + c3;
-        uint32_t inc = total;                                   // exclusive prefix of the digit totals
+        // two exclusive prefixes over the 256 digits: the tile-local one (digit totals of this tile) and
+        // the global digit base (digit totals of the whole column, from scan_rows_kernel)
+        const uint32_t gtot = digit_tot[(size_t)col * RADIX + d];
+        uint32_t inc = total, ginc = gtot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t y = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += y;
+            const uint32_t y = __shfl_up(inc, off, 64), gy = __shfl_up(ginc, off, 64);
+            if (lane >= off) { inc += y; ginc += gy; }
         }
-        if (lane == 63) wsum[wave] = inc;
+        if (lane == 63) { wsum[wave] = inc; wsum[4 + wave] = ginc; }
         __syncthreads();
-        uint32_t lp = inc - total;
-        for (int w = 0; w < wave; ++w) lp += wsum[w];
-        const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile] + digit_base[(size_t)col * RADIX + d];
+        uint32_t lp = inc - total, gbase = ginc - gtot;
+        for (int w = 0; w < wave; ++w) { lp += wsum[w]; gbase += wsum[4 + w]; }
+        const uint32_t g = offsets[((size_t)col * RADIX + d) * ntiles + tile] + gbase;
         gdelta[d] = g - lp;                                     // global position = gdelta[digit] + local position
         cnt[0][d] = lp;
         cnt[1][d] = lp + c0;
@@ -408,7 +390,6 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
     const SortPlan p = make_plan(n, ncols);
     const dim3 grid(p.ntiles, ncols);
     uint32_t *tot = hist + grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) / 4;
-    uint32_t *dbase = tot + grx_align_up((size_t)ncols * RADIX * 4, 256) / 4;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 8 * pass;
         // ping-pong: pass 0 cols->A, odd A->out, even out->A; pass 7 writes fp64 into out
@@ -430,14 +411,13 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
             scan_rows_kernel<<<dim3(RADIX, ncols), 64, 0, st>>>(hist, p.ntiles, tot);
-            scan_digits_kernel<<<ncols, RADIX, 0, st>>>(tot, dbase);
         }
         GRX_LAUNCH_CHECK();
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
-            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
-            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, dbase);
+            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
+            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
+            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
         }
         GRX_LAUNCH_CHECK();
     }
