@@ -69,7 +69,7 @@ _SIGNATURES = {
                                      c_void_p, c_size_t, c_void_p]),
     'grx_sort_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_sort_columns': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
-    'grx_chebyshev': (c_int, [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_chebyshev': (c_int, [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_gather_columns': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_gram_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_gram': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p,

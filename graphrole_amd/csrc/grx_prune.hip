@@ -286,82 +286,125 @@ __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restric
 // Chebyshev distance between binned columns
 // ---------------------------------------------------------------------------------------
 constexpr int CH_ROWS = 512;                 // rows per LDS tile
-constexpr int CH_STRIDE = CH_ROWS + 4;       // +4 bytes: column p starts on bank p (mod 32)
-constexpr int CH_MAX_F = 120;               // F * CH_STRIDE <= 64 KiB of LDS
+constexpr int CH_STRIDE = CH_ROWS + 8;       // +8 bytes: consecutive columns start two banks apart
+constexpr int CH_MAX_F = 96;                 // F * CH_STRIDE + 3 bytes per pair <= 64 KiB of LDS
 
+// max over the 4 bytes of |x - y| for bytes <= 127 (bin labels are < 128)
+__device__ __forceinline__ uint32_t ch_absdiff_max4(uint32_t x, uint32_t y)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xa = (x >> (8 * j)) & 0xFF, yb = (y >> (8 * j)) & 0xFF;
+        const uint32_t d = (uint32_t)(xa > yb ? xa - yb : yb - xa);
+        m = d > m ? d : m;
+    }
+    return m;
+}
+
+// One workgroup walks a strip of row tiles; a tile of 512 rows x F byte columns sits in LDS.
+// One WAVEFRONT per column pair: lane l compares rows 8l..8l+7 of the tile, a butterfly gives the
+// pair's maximum over the tile, and the pair is dropped from the workgroup's list as soon as its
+// maximum exceeds `cap` -- the pruner only asks "distance <= generation number ?" (prune.py:110-113),
+// and all but a handful of pairs exceed that within the first tile.  Distances <= cap are exact;
+// larger ones are reported as some value > cap (cap = 255: everything exact).
 // The F local columns are the global columns [a0, a0+na) followed by [b0, b0+F-na); dist is the
 // global ldF x ldF matrix (more than CH_MAX_F columns are covered by several launches).
 __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
                                                         int first_new, GrxPtrTable ptr_tab,
                                                         int32_t *__restrict__ dist, int ldF, int a0, int na,
-                                                        int b0)
+                                                        int b0, int cap, int tiles_per_block, int filter)
 {
     const uint8_t *const *ptrs = reinterpret_cast<const uint8_t *const *>(ptr_tab.p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *tile = smem;                                   // F * CH_STRIDE
+    unsigned char *tile = smem;                                            // F * CH_STRIDE
     const int q0 = first_new > 1 ? first_new : 1;
     // pairs (p,q), q in [q0,F), p in [0,q): id = tri(q) - tri(q0) + p, tri(q) = q(q-1)/2
     const int tri0 = q0 * (q0 - 1) / 2;
-    const int npairs = F * (F - 1) / 2 - tri0;
-    constexpr int MAX_OWN = (CH_MAX_F * (CH_MAX_F - 1) / 2 + 255) / 256;   // 28
-    int own_pq[MAX_OWN], own_max[MAX_OWN];
-#pragma unroll
-    for (int k = 0; k < MAX_OWN; ++k) {
-        const int id = threadIdx.x + 256 * k;
-        own_max[k] = 0;
-        own_pq[k] = -1;
-        if (id < npairs) {
-            const int target = id + tri0;
-            int q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)target)) * 0.5f);
-            while (q * (q - 1) / 2 > target) --q;
-            while ((q + 1) * q / 2 <= target) ++q;
-            own_pq[k] = ((target - q * (q - 1) / 2) << 8) | q;
+    const int all_pairs = F * (F - 1) / 2 - tri0;
+    uint16_t *pair_pq = reinterpret_cast<uint16_t *>(smem + (size_t)F * CH_STRIDE);   // (p << 8) | q
+    uint8_t *pair_max = reinterpret_cast<uint8_t *>(pair_pq + all_pairs);              // running maximum
+    __shared__ int n_listed;
+    if (threadIdx.x == 0) n_listed = 0;
+    __syncthreads();
+    for (int id = threadIdx.x; id < all_pairs; id += 256) {
+        const int target = id + tri0;
+        int q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)target)) * 0.5f);
+        while (q * (q - 1) / 2 > target) --q;
+        while ((q + 1) * q / 2 <= target) ++q;
+        const int p = target - q * (q - 1) / 2;
+        int slot = id;
+        if (filter) {
+            // second stage: only the pairs a first stage over a sample of rows left at <= cap
+            const int gp = p < na ? a0 + p : b0 + (p - na), gq = q < na ? a0 + q : b0 + (q - na);
+            slot = (dist[(size_t)gp * ldF + gq] <= cap) ? atomicAdd(&n_listed, 1) : -1;
+        }
+        if (slot >= 0) {
+            pair_pq[slot] = (uint16_t)((p << 8) | q);
+            pair_max[slot] = 0;
         }
     }
-    for (int64_t r0 = row_begin + (int64_t)blockIdx.x * CH_ROWS; r0 < row_end;
-         r0 += (int64_t)gridDim.x * CH_ROWS) {
+    __syncthreads();
+    const int npairs = filter ? n_listed : all_pairs;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t align_or = 0;                                                  // low address bits of all columns
+    for (int c = 0; c < F; ++c) align_or |= (int64_t)(reinterpret_cast<uintptr_t>(ptrs[c]) & 3);
+    const int64_t first_tile = (int64_t)blockIdx.x * tiles_per_block;
+    for (int tl = 0; tl < tiles_per_block; ++tl) {
+        const int64_t r0 = row_begin + (first_tile + tl) * CH_ROWS;
+        if (r0 >= row_end) break;
         const int rows = (int)((row_end - r0 < CH_ROWS) ? (row_end - r0) : CH_ROWS);
         __syncthreads();
-        for (int c = 0; c < F; ++c) {
-            const uint8_t *src = ptrs[c] + r0;
-            if (rows == CH_ROWS && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
-                // full tile, 4-byte aligned column: one dword (4 rows) per lane
-                if (threadIdx.x < CH_ROWS / 4)
-                    reinterpret_cast<uint32_t *>(tile + c * CH_STRIDE)[threadIdx.x] =
-                        reinterpret_cast<const uint32_t *>(src)[threadIdx.x];
-            } else {
-                for (int i = threadIdx.x; i < CH_ROWS; i += 256)
-                    tile[c * CH_STRIDE + i] = (i < rows) ? src[i] : 0;
+        if (rows == CH_ROWS && ((r0 | align_or) & 3) == 0) {
+            // full tile, 4-byte aligned columns: element e = (column, dword) over all 256 lanes, so the
+            // loads of a tile are independent and issue back to back
+            for (int e = threadIdx.x; e < F * (CH_ROWS / 4); e += 256) {
+                const int c = e / (CH_ROWS / 4), w = e % (CH_ROWS / 4);
+                reinterpret_cast<uint32_t *>(tile + c * CH_STRIDE)[w] =
+                    reinterpret_cast<const uint32_t *>(ptrs[c] + r0)[w];
+            }
+        } else {
+            for (int e = threadIdx.x; e < F * CH_ROWS; e += 256) {
+                const int c = e / CH_ROWS, i = e % CH_ROWS;
+                tile[c * CH_STRIDE + i] = (i < rows) ? ptrs[c][r0 + i] : 0;
             }
         }
         // rows beyond `rows` are zero in every column -> contribute distance 0
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < MAX_OWN; ++k) {
-            if (own_pq[k] >= 0) {
-                const uint32_t *a = reinterpret_cast<const uint32_t *>(tile + (own_pq[k] >> 8) * CH_STRIDE);
-                const uint32_t *b = reinterpret_cast<const uint32_t *>(tile + (own_pq[k] & 0xFF) * CH_STRIDE);
-                int mx = own_max[k];
-                for (int i = 0; i < CH_ROWS / 4; ++i) {
-                    const uint32_t x = a[i], y = b[i];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int xa = (x >> (8 * j)) & 0xFF, yb = (y >> (8 * j)) & 0xFF;
-                        const int d = xa > yb ? xa - yb : yb - xa;
-                        mx = d > mx ? d : mx;
-                    }
-                }
-                own_max[k] = mx;
+        for (int id = wave; id < npairs; id += 4) {
+            const uint32_t cur = pair_max[id];
+            if ((int)cur > cap) continue;                                  // uniform over the wavefront
+            const uint32_t pq = pair_pq[id];
+            const uint2 x = *reinterpret_cast<const uint2 *>(tile + (pq >> 8) * CH_STRIDE + lane * 8);
+            const uint2 y = *reinterpret_cast<const uint2 *>(tile + (pq & 0xFF) * CH_STRIDE + lane * 8);
+            uint32_t m = ch_absdiff_max4(x.x, y.x);
+            const uint32_t m2 = ch_absdiff_max4(x.y, y.y);
+            m = m2 > m ? m2 : m;
+            if (__ballot((int)m > cap) != 0) {
+                // beyond the cap: the exact value is not needed, one ballot settles the pair
+                if (lane == 0) pair_max[id] = (uint8_t)(cap + 1);
+                continue;
             }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off, 64);
+                m = o > m ? o : m;
+            }
+            if (lane == 0 && m > cur) pair_max[id] = (uint8_t)m;
         }
     }
-#pragma unroll
-    for (int k = 0; k < MAX_OWN; ++k) {
-        if (own_pq[k] >= 0) {
-            const int lp = own_pq[k] >> 8, lq = own_pq[k] & 0xFF;
-            const int p = lp < na ? a0 + lp : b0 + (lp - na), q = lq < na ? a0 + lq : b0 + (lq - na);
-            atomicMax(&dist[(size_t)p * ldF + q], own_max[k]);
-            atomicMax(&dist[(size_t)q * ldF + p], own_max[k]);
+    __syncthreads();
+    for (int id = threadIdx.x; id < npairs; id += 256) {
+        const int mx = pair_max[id];
+        if (mx == 0) continue;
+        const int lp = pair_pq[id] >> 8, lq = pair_pq[id] & 0xFF;
+        const int p = lp < na ? a0 + lp : b0 + (lp - na), q = lq < na ? a0 + lq : b0 + (lq - na);
+        // hundreds of workgroups report the same pair and same-address read-modify-writes serialise at
+        // the memory side: look first (agent-scope load, coherent across XCDs) and skip the atomic when
+        // the matrix already holds a value at least as large
+        if (__hip_atomic_load(&dist[(size_t)p * ldF + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mx) {
+            atomicMax(&dist[(size_t)p * ldF + q], mx);
+            atomicMax(&dist[(size_t)q * ldF + p], mx);
         }
     }
 }
@@ -512,22 +555,45 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
 }
 
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
-                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, void *stream)
+                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, int cap, void *stream)
 {
     GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end, "grx_chebyshev: bad row range");
     GRX_REQUIRE(F >= 0 && first_new >= 0, "grx_chebyshev: bad F/first_new");
     if (F < 2 || first_new >= F || row_end == row_begin) return GRX_OK;
     GRX_REQUIRE(h_bin_ptrs && d_dist, "grx_chebyshev: NULL pointer");
     hipStream_t st = grx_stream(stream);
+    if (cap < 0 || cap > 254) cap = 254;                                   // bin labels are < 128: 254 = everything exact
     const int64_t tiles = grx_ceil_div(row_end - row_begin, CH_ROWS);
-    const int grid = (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : tiles);
+    // a strip of consecutive tiles per workgroup: a pair that exceeded the cap in the first tile of
+    // the strip costs nothing in the others.  Two workgroups per CU keep the chip busy.
+    const int64_t max_grid = GRX_NUM_CU * 4;
+    const int tiles_per_block = (int)(tiles <= max_grid ? 1 : grx_ceil_div(tiles, max_grid));
+    const int grid = (int)grx_ceil_div(tiles, tiles_per_block);
+    auto lds_bytes = [](int Fl, int fn) {
+        const int q0l = fn > 1 ? fn : 1;
+        const int np = Fl * (Fl - 1) / 2 - q0l * (q0l - 1) / 2;
+        return (size_t)Fl * CH_STRIDE + (size_t)(np > 0 ? np : 0) * 3 + 16;
+    };
     if (F <= CH_MAX_F) {
         GrxPtrTable tab;
         for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
-        const size_t lds = (size_t)F * CH_STRIDE;
-        {
-            GRX_PROF(GRX_K_CHEBYSHEV, st);
-            chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, first_new, tab, d_dist, F, 0, F, 0);
+        GRX_PROF(GRX_K_CHEBYSHEV, st);
+        const size_t lds = lds_bytes(F, first_new);
+        constexpr int SAMPLE_TILES = 16;
+        if (cap < 254 && tiles > 8 * SAMPLE_TILES && F > 4) {
+            // two stages: all pairs on a sample of rows (the first rows of the range: with the
+            // degree-descending node order these are the hubs, where features differ most), then the
+            // whole range for the few pairs that are still within the cap
+            const int64_t split = row_begin + (int64_t)SAMPLE_TILES * CH_ROWS;
+            chebyshev_kernel<<<SAMPLE_TILES, 256, lds, st>>>(row_begin, split, F, first_new, tab, d_dist, F, 0, F, 0,
+                                                            cap, 1, 0);
+            const int64_t rest = tiles - SAMPLE_TILES;
+            const int tpb = (int)(rest <= GRX_NUM_CU * 8 ? 1 : grx_ceil_div(rest, GRX_NUM_CU * 8));
+            chebyshev_kernel<<<(int)grx_ceil_div(rest, tpb), 256, lds, st>>>(split, row_end, F, first_new, tab, d_dist,
+                                                                             F, 0, F, 0, cap, tpb, 1);
+        } else {
+            chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, first_new, tab, d_dist, F, 0, F, 0, cap,
+                                                     tiles_per_block, 0);
         }
         GRX_LAUNCH_CHECK();
         return GRX_OK;
@@ -546,11 +612,10 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
             for (int c = 0; c < nb; ++c) tab.p[na + c] = h_bin_ptrs[b0 + c];
             const int Fl = na + nb;
             if (Fl < 2) continue;
-            const size_t lds = (size_t)Fl * CH_STRIDE;
             {
                 GRX_PROF(GRX_K_CHEBYSHEV, st);
-                chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, Fl, (B == A) ? 0 : na, tab, d_dist, F,
-                                                         a0, na, b0);
+                chebyshev_kernel<<<grid, 256, lds_bytes(Fl, (B == A) ? 0 : na), st>>>(
+                    row_begin, row_end, Fl, (B == A) ? 0 : na, tab, d_dist, F, a0, na, b0, cap, tiles_per_block, 0);
             }
             GRX_LAUNCH_CHECK();
         }

@@ -256,7 +256,8 @@ class RecursiveFeatureExtractor:
                 self._work_bins[nm] = bins[j]
         work_names = list(self._work)
         rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
-        dist = K.chebyshev([self._work_bins[nm] for nm in work_names], n, 0, rb, re)
+        # the pruner only asks whether a distance is <= the generation number (prune.py:110-113)
+        dist = K.chebyshev([self._work_bins[nm] for nm in work_names], n, 0, rb, re, cap=self._feature_group_thresh)
         if plan is not None:
             plan.all_reduce_max_(dist)
         dist_host = K.to_host(dist)

@@ -324,14 +324,15 @@ def vertical_log_bin(block: torch.Tensor, frac: float = 0.5,
 
 
 def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_begin: int = 0,
-              row_end: Optional[int] = None) -> torch.Tensor:
-    """int32 [F, F] pairwise max |bin difference| over rows [row_begin,row_end)."""
+              row_end: Optional[int] = None, cap: int = 255) -> torch.Tensor:
+    """int32 [F, F] pairwise max |bin difference| over rows [row_begin,row_end).  Entries <= cap are
+    exact, larger ones are some value > cap (cap = 255: all exact)."""
     F = len(bin_cols)
     row_end = n if row_end is None else row_end
     dist = torch.zeros((F, F), dtype=torch.int32, device=device())
     if F >= 2 and row_end > row_begin:
         ptrs = ptr_array(bin_cols)
-        _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, ptrs, _ptr(dist), _stream())
+        _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, ptrs, _ptr(dist), int(cap), _stream())
     return dist
 
 

@@ -201,11 +201,14 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
  * h_bin_ptrs: HOST array of F device pointers to uint8 columns.  Only rows
  * [row_begin,row_end) are scanned (multi-GPU: all-reduce(MAX) the result).  d_dist: int32
  * F x F, must be zero-filled by the caller; pairs (p,q) with q >= first_new are computed
- * (first_new = 0: all pairs), the matrix is written symmetrically.  Any F: up to 120 columns are
- * one launch (one LDS tile), more are covered by one launch per pair of 60-column groups.
+ * (first_new = 0: all pairs), the matrix is written symmetrically.  Any F: up to 96 columns are
+ * one launch (one LDS tile), more are covered by one launch per pair of 48-column groups.
+ * cap: the caller only needs distances up to `cap` exactly (the pruner compares with the generation
+ * number, prune.py:110-113): entries <= cap are exact, larger ones are reported as SOME value > cap and
+ * cost almost nothing (a pair leaves the work list once it exceeds the cap).  cap = 255: all exact.
  */
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
-                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, void *stream);
+                  const uint8_t *const *h_bin_ptrs, int32_t *d_dist, int cap, void *stream);
 
 /* ------------------------------------------------------------------ RolX NMF ------------ */
 /*

@@ -126,7 +126,7 @@ def vertical_log_bin(block, frac=0.5, out=None):
     return bins, nb
 
 
-def chebyshev(bin_cols, n, first_new=0, row_begin=0, row_end=None):
+def chebyshev(bin_cols, n, first_new=0, row_begin=0, row_end=None, cap=255):
     F = len(bin_cols)
     row_end = n if row_end is None else row_end
     D = torch.zeros((F, F), dtype=torch.int32)

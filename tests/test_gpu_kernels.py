@@ -373,6 +373,36 @@ def test_chebyshev_many_columns(K):
     assert np.array_equal(D, exp)
 
 
+@pytest.mark.parametrize('F,n', [(40, 200_000), (96, 30_000), (97, 20_000), (230, 9_000)])
+def test_chebyshev_cap_semantics_and_column_groups(K, F, n):
+    """cap: entries <= cap exact, larger ones only known to be > cap (what the pruner needs);
+    more than 96 columns run as launches over pairs of 48-column groups."""
+    import torch
+    rng = np.random.default_rng(F)
+    base = rng.integers(0, 20, size=(8, n)).astype(np.uint8)
+    B = np.empty((F, n), dtype=np.uint8)
+    for j in range(F):                                          # families of near-identical columns
+        B[j] = base[j % 8]
+        flip = rng.integers(0, n, size=(j // 8) * 3)           # j // 8 controls how far a copy drifts
+        B[j, flip] = np.minimum(B[j, flip] + (j // 8) % 4, 127)
+    Bd = torch.from_numpy(B).cuda()
+    exp = np.abs(B[:, None, :].astype(np.int32) - B[None, :, :].astype(np.int32)).max(axis=2)
+    exact = K.chebyshev([Bd[j] for j in range(F)], n).cpu().numpy()
+    assert np.array_equal(exact, exp)
+    for cap in (0, 1, 2, 5):
+        D = K.chebyshev([Bd[j] for j in range(F)], n, cap=cap).cpu().numpy()
+        small = exp <= cap
+        assert np.array_equal(D[small], exp[small])
+        assert np.all(D[~small] > cap) and np.all(D[~small] <= exp[~small])
+        assert np.array_equal(D, D.T)
+    # row ranges combine by elementwise max also under a cap
+    h = n // 2 + 7
+    Da = K.chebyshev([Bd[j] for j in range(F)], n, row_begin=0, row_end=h, cap=1).cpu().numpy()
+    Db = K.chebyshev([Bd[j] for j in range(F)], n, row_begin=h, row_end=n, cap=1).cpu().numpy()
+    both = np.maximum(Da, Db)
+    assert np.array_equal(both <= 1, exp <= 1) and np.array_equal(both[exp <= 1], exp[exp <= 1])
+
+
 # ------------------------------------------------------------------------------------- NMF
 @pytest.mark.parametrize('shape', [(1000, 7, 4), (50000, 12, 6), (3000, 40, 6), (2000, 64, 8), (700, 100, 16),
                                    (100, 3, 2), (4099, 48, 5), (1001, 17, 3), (333, 33, 2), (17, 1, 1), (5000, 49, 4)])
