@@ -41,6 +41,7 @@ WORKLOADS = {
     'er100k': ('er', 100_000, 1_000_000, 'Erdos-Renyi G(100,000; 1,000,000), seed 0  [BASELINE config 2]'),
     'ba100k': ('ba', 100_000, 10, 'Barabasi-Albert n=100,000 m=10 (reduced; not a headline number)'),
     'tiny': ('ba', 5_000, 5, 'Barabasi-Albert n=5,000 m=5 (smoke only)'),
+    'dw1m': ('dw', 1_000_000, 10_000_000, 'weighted directed power-law, 1 M nodes / 10 M arcs + 8 attributes (config-5 shape, reduced)'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_ROLES = 6
@@ -50,6 +51,8 @@ MAX_GENERATIONS = 4
 def build_graph(name):
     from graphrole_amd import synth
     kind, n, m, _ = WORKLOADS[name]
+    if kind == 'dw':
+        return synth.directed_weighted_graph(n, m, seed=0)
     return synth.ba_graph(n, m, seed=0) if kind == 'ba' else synth.er_graph(n, m, seed=0)
 
 
@@ -146,7 +149,8 @@ def main():
     lib = _lib.load()
 
     G = build_graph(args.workload)
-    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=(world > 1))
+    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=(world > 1),
+                                  attributes=bool(G.attributes))
     dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
     if args.agg_lanes:
         dev_graph.plan().set_lanes(args.agg_lanes)
@@ -218,7 +222,7 @@ def main():
     encode_info = None
     if rank == 0 and world == 1:
         Wd = state['W']
-        n_bins = 2 ** int(np.log2(N_ROLES * min(G.n, state['F'])))          # roles/extract.py:72
+        n_bins = min(256, 2 ** int(np.log2(N_ROLES * min(G.n, state['F']))))   # roles/extract.py:72; 8 bits = default range
         flat = Wd[:, :G.n].contiguous().reshape(-1)
         K.lloyd_max(flat, n_bins)
         torch.cuda.synchronize()

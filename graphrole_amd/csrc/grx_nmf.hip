@@ -24,7 +24,8 @@ namespace {
 
 constexpr double NMF_EPSILON = 1.1920928955078125e-07;   // np.finfo(np.float32).eps, _nmf.py:39
 constexpr int MAX_R = GRX_MAX_ROLES;                      // 16
-constexpr int MAX_F = 120;                                // LDS budget of the tiled kernels
+constexpr int MAX_F = 120;                                // single-launch Gram / register-resident W-pass
+constexpr int MAX_F_WIDE = GRX_MAX_NMF_FEATURES;          // 480: r * F * 8 <= 60 KiB of LDS at r = 16
 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_columns_kernel(int64_t n, int F, GrxPtrTable ptr_tab,
@@ -59,22 +60,26 @@ constexpr int GR_LD = GR_TR + 1;
 constexpr int GR_YSLOTS = (MAX_F + 3) / 4;                          // 30
 constexpr int GR_PSLOTS = (MAX_F * (MAX_F + 1) / 2 + 255) / 256;    // 29
 
+// The k outputs of a launch are the columns [ja, ja + na) followed by [jb, jb + k - na) of Y = X T
+// (T has ldt columns; HAS_T = false: Y = X): Gram matrices wider than MAX_F are assembled from
+// launches over pairs of column groups (see grx_gram).
 template <bool HAS_T, int YS>
 __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t row_end, int F, int k,
                                                    const double *__restrict__ X, int64_t ldx,
                                                    const double *__restrict__ T, int t_in_lds,
-                                                   double *__restrict__ partial)
+                                                   double *__restrict__ partial, int ldt, int ja, int na, int jb)
 {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double *sY = gsm;                                  // k * GR_LD
     double *sT = gsm + k * GR_LD;                      // F * k (only when t_in_lds)
     __shared__ double xred[4];
     const int t = threadIdx.x, i = t & 63, g = t >> 6;
-    if (HAS_T && t_in_lds) {
+    if (HAS_T && t_in_lds) {                           // only when ldt == k (single launch)
         for (int idx = t; idx < F * k; idx += 256) sT[idx] = T[idx];
         __syncthreads();
     }
     const double *Tsrc = (HAS_T && t_in_lds) ? sT : T;
+    auto col_of = [&](int j) { return j < na ? ja + j : jb + (j - na); };   // local output -> column of Y
     const int npairs = k * (k + 1) / 2;
     int pq[GR_PSLOTS];
     double acc[GR_PSLOTS];
@@ -102,11 +107,11 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
             for (int s = 0; s < YS; ++s) y[s] = 0.0;
             for (int c = 0; c < F; ++c) {
                 const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
-                const double *Tc = Tsrc + (size_t)c * k;
+                const double *Tc = Tsrc + (size_t)c * ldt;
 #pragma unroll
                 for (int s = 0; s < YS; ++s) {
                     const int j = g + 4 * s;
-                    if (j < k) y[s] += x * Tc[j];
+                    if (j < k) y[s] += x * Tc[col_of(j)];
                 }
             }
 #pragma unroll
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t row_begin, int64_t ro
                 if (j < k) sY[j * GR_LD + i] = y[s];
             }
         } else {
-            for (int c = g; c < F; c += 4) {
-                const double x = live ? X[(size_t)c * ldx + r0 + i] : 0.0;
+            for (int c = g; c < k; c += 4) {
+                const double x = live ? X[(size_t)col_of(c) * ldx + r0 + i] : 0.0;
                 sY[c * GR_LD + i] = x;
                 xsum += x;
             }
@@ -292,27 +297,58 @@ GramKernel gram_mfma_pick(int F, int k, bool has_t)
     return kt == 1 ? GRAM_I1[nq - 1] : kt == 2 ? GRAM_I2[nq - 1] : GRAM_I3[nq - 1];
 }
 
-// partial [npairs+1][nb] -> out: full symmetric k x k, then the X sum (one wavefront per output)
+// sum of X[:, ja .. ja+na) over the row range: per-workgroup partials (fixed order)
+__global__ __launch_bounds__(256) void column_sum_kernel(int64_t row_begin, int64_t row_end,
+                                                         const double *__restrict__ X, int64_t ldx, int ja, int na,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double wred[4];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride)
+        for (int c = 0; c < na; ++c) s += X[(size_t)(ja + c) * ldx + i];
+    s = grx_group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+}
+
+__global__ __launch_bounds__(64) void add_partials_kernel(const double *__restrict__ partial, int nb,
+                                                          double *__restrict__ out)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) s += partial[b];
+    s = grx_group_sum<64>(s);
+    if (threadIdx.x == 0) *out += s;
+}
+
+// partial [npairs+1][nb] -> out: symmetric block of the K x K matrix (local column j <-> global column
+// j < na ? ja + j : jb + j - na), then optionally the X sum at out[K*K] (one wavefront per output)
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__restrict__ partial,
-                                                            int nb, int k, double *__restrict__ out)
+                                                            int nb, int k, double *__restrict__ out, int K,
+                                                            int ja, int na, int jb, int write_sum)
 {
     const int npairs = k * (k + 1) / 2;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx > k * k) return;
-    int id;
+    int id, dst;
     if (idx == k * k) {
+        if (!write_sum) return;
         id = npairs;
+        dst = K * K;
     } else {
         const int a = idx / k, b = idx % k;
         const int lo = a < b ? a : b, hi = a < b ? b : a;
         id = hi * (hi + 1) / 2 + lo;
+        const int ga = a < na ? ja + a : jb + (a - na), gb = b < na ? ja + b : jb + (b - na);
+        dst = ga * K + gb;
     }
     const int lane = threadIdx.x & 63;
     const double *src = partial + (size_t)id * nb;
     double s = 0.0;
     for (int b = lane; b < nb; b += 64) s += src[b];
     s = grx_group_sum<64>(s);
-    if (lane == 0) out[idx] = s;
+    if (lane == 0) out[dst] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -600,23 +636,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
     }
 }
 
-// H <- H * (A / (B H)), one workgroup
+// H <- H * (A / (B H)), one workgroup; B (r x r) in LDS, A and H (r x F, a few KB, cache resident)
+// read in place: every H[l][c] is read before the barrier that precedes the writes.
 __global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, double *__restrict__ H,
                                                            const double *__restrict__ AB)
 {
-    extern __shared__ __attribute__((aligned(16))) double hsm[];
-    double *sA = hsm;                 // r*F
-    double *sB = sA + r * F;          // r*r
-    double *sH = sB + r * r;          // r*F
-    for (int idx = threadIdx.x; idx < r * F; idx += 256) { sA[idx] = AB[idx]; sH[idx] = H[idx]; }
+    __shared__ double sB[MAX_R * MAX_R];
     for (int idx = threadIdx.x; idx < r * r; idx += 256) sB[idx] = AB[r * F + idx];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < r * F; idx += 256) {
-        const int k = idx / F, c = idx % F;
-        double denom = 0.0;
-        for (int l = 0; l < r; ++l) denom += sB[k * r + l] * sH[l * F + c];
-        if (denom == 0.0) denom = NMF_EPSILON;
-        H[idx] = sH[idx] * (sA[idx] / denom);
+    constexpr int PER = (MAX_R * MAX_F_WIDE + 255) / 256;          // 30 outputs per thread at most
+    double hnew[PER];
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const int idx = threadIdx.x + 256 * s;
+        hnew[s] = 0.0;
+        if (idx < r * F) {
+            const int k = idx / F, c = idx % F;
+            double denom = 0.0;
+            for (int l = 0; l < r; ++l) denom += sB[k * r + l] * H[l * F + c];
+            if (denom == 0.0) denom = NMF_EPSILON;
+            hnew[s] = H[idx] * (AB[idx] / denom);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const int idx = threadIdx.x + 256 * s;
+        if (idx < r * F) H[idx] = hnew[s];
     }
 }
 
@@ -688,6 +734,135 @@ __global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int
     if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
 }
 
+// The same update for MORE than 120 features (the register-resident form above would need more
+// than 256 VGPRs), as two kernels with small register footprints (high occupancy):
+//   nmf_w_update_wide_kernel : numerators over all feature columns in chunks of 8 K-steps (H operands
+//                              from global memory, a few KB, cache resident), denominators, W' stored
+//   nmf_w_accum_wide_kernel  : grid.y = 32-column chunk of the features; A[:, chunk] += W'^T X[:, chunk]
+//                              (and B = W'^T W' in chunk 0) with both operands loaded from global memory
+//                              directly in the transposed MFMA layout (4 consecutive rows per lane
+//                              group; the four K-steps of a sub-tile cover whole 128-byte lines)
+// X is read twice per iteration (W' is only known after the last chunk).
+template <int R4>
+__global__ __launch_bounds__(256) void nmf_w_update_wide_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                                const double *__restrict__ X, int64_t ldx,
+                                                                double *__restrict__ W, int64_t ldw,
+                                                                const double *__restrict__ H)
+{
+    constexpr int CH = 8;                                        // K-steps per chunk
+    __shared__ double sHH[256];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    {
+        const int k = t >> 4, l = t & 15;
+        double sacc = 0.0;
+        if (k < r && l < r)
+            for (int c = 0; c < F; ++c) sacc += H[k * F + c] * H[l * F + c];
+        sHH[t] = sacc;
+    }
+    __syncthreads();
+    double hhA[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
+    const int nchunks = (F + 31) / 32;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < nsub; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const bool valid = row < row_end;
+        const int64_t rowc = valid ? row : row_end - 1;
+        double wb[R4];
+#pragma unroll
+        for (int q = 0; q < R4; ++q) {
+            const int k = 4 * q + lq;
+            const double v = W[(size_t)(k < r ? k : r - 1) * ldw + rowc];
+            wb[q] = (valid && k < r) ? v : 0.0;
+        }
+        v4d num = {0.0, 0.0, 0.0, 0.0}, den = {0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nchunks; ++ch) {
+            double x[CH], h[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = 32 * ch + 4 * q + lq;
+                x[q] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
+                h[q] = H[(li < r ? li : r - 1) * F + (c < F ? c : F - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = 32 * ch + 4 * q + lq;
+                num = __builtin_amdgcn_mfma_f64_16x16x4f64((li < r && c < F) ? h[q] : 0.0,
+                                                           (valid && c < F) ? x[q] : 0.0, num, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R4; ++q) den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < R4; ++g) {
+            const int k = lq + 4 * g;
+            double d = den[g];
+            if (d == 0.0) d = NMF_EPSILON;
+            if (valid && k < r) W[(size_t)k * ldw + row] = wb[g] * (num[g] / d);
+        }
+    }
+}
+
+// partial layout [P][gridDim.x] as in the single-kernel form; chunk = blockIdx.y
+__global__ __launch_bounds__(256) void nmf_w_accum_wide_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                               const double *__restrict__ X, int64_t ldx,
+                                                               const double *__restrict__ W, int64_t ldw,
+                                                               double *__restrict__ partial)
+{
+    __shared__ double red[4][3 * 256];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    const int c_base = 32 * blockIdx.y;
+    const bool with_b = blockIdx.y == 0;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+    const int c0 = c_base + li, c1 = c_base + 16 + li;
+    const double *x0p = X + (size_t)(c0 < F ? c0 : F - 1) * ldx;
+    const double *x1p = X + (size_t)(c1 < F ? c1 : F - 1) * ldx;
+    const double *wp = W + (size_t)(li < r ? li : r - 1) * ldw;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < nsub; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = row_begin + sidx * 16;
+        double aW[4], b0[4], b1[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int64_t row = row0 + 4 * st + lq;
+            const bool valid = row < row_end;
+            const int64_t rowc = valid ? row : row_end - 1;
+            const double w = wp[rowc], u = x0p[rowc], v = x1p[rowc];
+            aW[st] = (valid && li < r) ? w : 0.0;
+            b0[st] = (valid && c0 < F) ? u : 0.0;
+            b1[st] = (valid && c1 < F) ? v : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[st], b0[st], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[st], b1[st], acc1, 0, 0, 0);
+            if (with_b) accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[st], aW[st], accB, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        red[wave][(0 * 4 + g) * 64 + lane] = acc0[g];
+        red[wave][(1 * 4 + g) * 64 + lane] = acc1[g];
+        red[wave][(2 * 4 + g) * 64 + lane] = accB[g];
+    }
+    __syncthreads();
+    for (int idx = t; idx < 3 * 256; idx += 256) {
+        const int tile = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63;
+        const double v = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+        const int k = (ln >> 4) + 4 * g, j = ln & 15;
+        if (k >= r) continue;
+        if (tile < 2) {
+            const int c = c_base + 16 * tile + j;
+            if (c < F) partial[(size_t)(k * F + c) * gridDim.x + blockIdx.x] = v;
+        } else if (with_b && j < r) {
+            partial[(size_t)(r * F + k * r + j) * gridDim.x + blockIdx.x] = v;
+        }
+    }
+}
+
 // launch table over (NQ, R4): function pointers of the instantiations
 using WPassKernel = void (*)(int64_t, int64_t, int, int, const double *, int64_t, double *, int64_t, const double *,
                              double *);
@@ -720,8 +895,8 @@ constexpr int RES_GRID = GRX_NUM_CU * 4;
 
 int check_nmf_shape(const char *who, int F, int r)
 {
-    if (F < 1 || r < 1 || F > MAX_F || r > MAX_R) {
-        grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d)", who, F, r, MAX_F, MAX_R);
+    if (F < 1 || r < 1 || F > MAX_F_WIDE || r > MAX_R) {
+        grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d)", who, F, r, MAX_F_WIDE, MAX_R);
         return GRX_ERR_UNSUPPORTED;
     }
     return GRX_OK;
@@ -761,8 +936,10 @@ static int gram_grid(int64_t nrows)
 size_t grx_gram_workspace_bytes(int64_t n, int k)
 {
     if (k < 1) k = 1;
-    const size_t npairs = (size_t)k * (k + 1) / 2 + 1;
-    return grx_align_up((size_t)gram_grid(n) * npairs * 8, 256) + grx_align_up((size_t)MAX_F * MAX_F * 8, 256);
+    const size_t kl = (size_t)(k < MAX_F ? k : MAX_F);              // outputs of one launch
+    const size_t npairs = kl * (kl + 1) / 2 + 1;
+    return grx_align_up((size_t)gram_grid(n) * npairs * 8, 256) +
+           grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256);
 }
 
 int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
@@ -771,8 +948,8 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n,
                 "grx_gram: bad row range");
-    if (F < 1 || F > MAX_F || k < 1 || k > MAX_F) {
-        grx_set_error("grx_gram: F=%d k=%d outside [1,%d]", F, k, MAX_F);
+    if (F < 1 || F > MAX_F_WIDE || k < 1 || k > MAX_F_WIDE) {
+        grx_set_error("grx_gram: F=%d k=%d outside [1,%d]", F, k, MAX_F_WIDE);
         return GRX_ERR_UNSUPPORTED;
     }
     GRX_REQUIRE(h_T != nullptr || k == F, "grx_gram: identity transform needs k == F");
@@ -783,10 +960,11 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
     }
     hipStream_t st = grx_stream(stream);
     int grid = gram_grid(row_end - row_begin);
-    const size_t npairs = (size_t)k * (k + 1) / 2;
+    const int kl_max = k < MAX_F ? k : MAX_F;                    // outputs of one launch
+    const size_t npairs_max = (size_t)kl_max * (kl_max + 1) / 2;
     char *ws = reinterpret_cast<char *>(d_workspace);
     double *partial = reinterpret_cast<double *>(ws);
-    double *dT = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_grid(n) * (npairs + 1) * 8, 256));
+    double *dT = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_grid(n) * (npairs_max + 1) * 8, 256));
     if (h_T) GRX_CHECK_HIP(hipMemcpyAsync(dT, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
     if (GramKernel mk = gram_mfma_pick(F, k, h_T != nullptr)) {
         // matrix-core path (F, k <= 48): one resident generation of workgroups
@@ -797,23 +975,61 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
         int cap = nb * GRX_NUM_CU;
         if (cap > gram_grid(n)) cap = gram_grid(n) > 0 ? gram_grid(n) : 1;     // partial buffer is sized by gram_grid
         grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
-        GRX_PROF(GRX_K_GRAM, st);
-        hipLaunchKernelGGL(mk, dim3(grid), dim3(256), lds, st, row_begin, row_end, F, k, d_X, ldx,
-                           h_T ? dT : (const double *)nullptr, partial);
-    } else {
-        size_t lds = (size_t)k * GR_LD * 8;
-        const int t_in_lds = (h_T != nullptr) && (lds + (size_t)F * k * 8 <= 60 * 1024);
-        if (t_in_lds) lds += (size_t)F * k * 8;
-        GRX_PROF(GRX_K_GRAM, st);
-        if (!h_T) gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, 0, partial);
-        else if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-        else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-        else if (k <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
-        else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial);
+        {
+            GRX_PROF(GRX_K_GRAM, st);
+            hipLaunchKernelGGL(mk, dim3(grid), dim3(256), lds, st, row_begin, row_end, F, k, d_X, ldx,
+                               h_T ? dT : (const double *)nullptr, partial);
+        }
+        GRX_LAUNCH_CHECK();
+        gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, grid, k, d_out, k, 0, k, 0, 1);
+        GRX_LAUNCH_CHECK();
+        return GRX_OK;
     }
-    GRX_LAUNCH_CHECK();
-    gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, grid, k, d_out);
-    GRX_LAUNCH_CHECK();
+    // VALU path.  Up to MAX_F outputs per launch; wider matrices are assembled from launches over
+    // pairs of column groups (A, A): the block inside A, (A, B): A u B, which also yields the cross
+    // block (the diagonal blocks are recomputed -- this is the rarely used wide path).
+    auto launch = [&](int kl, int ja, int na, int jb, int write_sum) -> int {
+        size_t lds = (size_t)kl * GR_LD * 8;
+        const int t_in_lds = (h_T != nullptr) && kl == k && (lds + (size_t)F * k * 8 <= 60 * 1024);
+        if (t_in_lds) lds += (size_t)F * k * 8;
+        {
+            GRX_PROF(GRX_K_GRAM, st);
+            if (!h_T) gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, nullptr, 0, partial, k, ja, na, jb);
+            else if (kl <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
+            else if (kl <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
+            else if (kl <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
+            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
+        }
+        GRX_LAUNCH_CHECK();
+        gram_finalize_kernel<<<(kl * kl + 1 + 3) / 4, 256, 0, st>>>(partial, grid, kl, d_out, k, ja, na, jb, write_sum);
+        GRX_LAUNCH_CHECK();
+        return GRX_OK;
+    };
+    if (k <= MAX_F) return launch(k, 0, k, 0, 1);
+    constexpr int GROUP = MAX_F / 2;
+    const int ngroups = (k + GROUP - 1) / GROUP;
+    if (!h_T) {
+        // the X sum: zero it, every diagonal launch adds its own columns (sum over groups)
+        GRX_CHECK_HIP(hipMemsetAsync(d_out + (size_t)k * k, 0, 8, st));
+    }
+    for (int A = 0; A < ngroups; ++A) {
+        const int ja = A * GROUP, na = (k - ja < GROUP) ? k - ja : GROUP;
+        for (int B = A; B < ngroups; ++B) {
+            const int jb = B * GROUP, nb = (B == A) ? 0 : ((k - jb < GROUP) ? k - jb : GROUP);
+            int rc = launch(na + nb, ja, na, jb, 0);
+            if (rc != GRX_OK) return rc;
+        }
+    }
+    if (!h_T) {
+        // sum(X) of the wide identity case: one extra pass over the columns, group by group
+        for (int A = 0; A < ngroups; ++A) {
+            const int ja = A * GROUP, na = (k - ja < GROUP) ? k - ja : GROUP;
+            column_sum_kernel<<<gram_grid(row_end - row_begin), 256, 0, st>>>(row_begin, row_end, d_X, ldx, ja, na, partial);
+            GRX_LAUNCH_CHECK();
+            add_partials_kernel<<<1, 64, 0, st>>>(partial, gram_grid(row_end - row_begin), d_out + (size_t)k * k);
+            GRX_LAUNCH_CHECK();
+        }
+    }
     return GRX_OK;
 }
 
@@ -823,7 +1039,7 @@ size_t grx_project_workspace_bytes(int64_t n, int r)
 {
     (void)n;
     if (r < 1) r = 1;
-    return grx_align_up((size_t)PROJ_GRID * r * 5 * 8, 256) + grx_align_up((size_t)MAX_F * MAX_R * 8, 256);
+    return grx_align_up((size_t)PROJ_GRID * r * 5 * 8, 256) + grx_align_up((size_t)MAX_F_WIDE * MAX_R * 8, 256);
 }
 
 int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
@@ -907,14 +1123,24 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
         const int FT = (F + 15) / 16;
         const int64_t nsub = grx_ceil_div(row_end - row_begin, 16);
         const int64_t want = grx_ceil_div(nsub, 4);
-        const size_t lds = mfma_lds_doubles(FT) * 8;
-        // exactly one resident generation of workgroups: every wave keeps its accumulators over
-        // all of its sub-tiles and there is no partially filled last wave of workgroups
-        const int cap = mfma_resident_grid(F, r, lds);
-        grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
         GRX_PROF(GRX_K_NMF_W_PASS, st);
-        hipLaunchKernelGGL(w_pass_kernel(F, r), dim3(grid), dim3(256), lds, st, row_begin, row_end, F, r, d_X, ldx,
-                           d_W, ldw, d_H, partial);
+        if (F <= MAX_F) {
+            const size_t lds = mfma_lds_doubles(FT) * 8;
+            // exactly one resident generation of workgroups: every wave keeps its accumulators over
+            // all of its sub-tiles and there is no partially filled last wave of workgroups
+            const int cap = mfma_resident_grid(F, r, lds);
+            grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
+            hipLaunchKernelGGL(w_pass_kernel(F, r), dim3(grid), dim3(256), lds, st, row_begin, row_end, F, r, d_X,
+                               ldx, d_W, ldw, d_H, partial);
+        } else {
+            (void)FT;
+            const int cap = GRX_NUM_CU * 4;
+            grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
+            if (r <= 8) nmf_w_update_wide_kernel<2><<<grid, 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H);
+            else nmf_w_update_wide_kernel<4><<<grid, 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H);
+            nmf_w_accum_wide_kernel<<<dim3(grid, (F + 31) / 32), 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W,
+                                                                               ldw, partial);
+        }
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
@@ -929,9 +1155,8 @@ int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream
     int rc = check_nmf_shape("grx_nmf_h_update", F, r);
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(d_H && d_AB, "grx_nmf_h_update: NULL pointer");
-    const size_t lds = (2 * (size_t)r * F + (size_t)r * r) * 8;
     { GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
-    nmf_h_update_kernel<<<1, 256, lds, grx_stream(stream)>>>(F, r, d_H, d_AB);
+    nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H, d_AB);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

@@ -122,14 +122,25 @@ class DeviceGraphInterface(BaseGraphInterface):
             deg, = self._finish_columns([K.row_sums(out, True, rb, re)])
             names, cols = ['degree'], [deg]
         dtypes = [int_dtype] * len(names)
-        attr = self._attribute_frame() if self._attrs else None
-        if attr is not None and attr.shape[1]:
-            attr = attr.reindex(host.labels).fillna(0)
-            for name in attr.columns:
-                values = attr[name].to_numpy()
-                names.append(name)
-                dtypes.append(values.dtype if values.dtype.kind in 'iu' else np.dtype('float64'))
-                cols.append(K.to_device(host.to_internal(values.astype(np.float64))))
+        if self._attrs:
+            # attribute columns are graph data: uploaded once and cached on the adapter
+            if getattr(self, '_attr_cols', None) is None:
+                a_names, a_cols, a_dtypes = [], [], []
+                arrays = self._attribute_arrays()
+                if arrays is None:
+                    attr = self._attribute_frame()
+                    if attr is not None and attr.shape[1]:
+                        attr = attr.reindex(host.labels).fillna(0)
+                        arrays = {name: attr[name].to_numpy() for name in attr.columns}
+                for name, values in (arrays or {}).items():
+                    values = np.asarray(values)
+                    a_names.append(name)
+                    a_dtypes.append(values.dtype if values.dtype.kind in 'iu' else np.dtype('float64'))
+                    a_cols.append(K.to_device(host.to_internal(values.astype(np.float64))))
+                self._attr_cols = (a_names, a_cols, a_dtypes)
+            names += self._attr_cols[0]
+            cols += self._attr_cols[1]
+            dtypes += self._attr_cols[2]
         return names, cols, dtypes
 
     def egonet_feature_columns(self) -> Tuple[List[str], list, List[np.dtype]]:
@@ -164,4 +175,8 @@ class DeviceGraphInterface(BaseGraphInterface):
 
     def _attribute_frame(self) -> Optional[pd.DataFrame]:
         """Numeric node attributes as a frame indexed by node label (columns already prefixed)."""
+        return None
+
+    def _attribute_arrays(self):
+        """Optional fast path: {prefixed name: array in to_csr() row order} without pandas."""
         return None

@@ -31,6 +31,13 @@ class CSRInterface(DeviceGraphInterface):
     def to_csr(self) -> CSRGraph:
         return self.G
 
+    def _attribute_arrays(self):
+        """The attribute arrays are already in row order: no label index needed."""
+        banned = set(self._attrs_exclude)
+        wanted = self._attrs_include or list(self.G.attributes)
+        return {self._attribute_feature_name(a): self.G.attributes[a]
+                for a in wanted if a not in banned and a in self.G.attributes}
+
     def _attribute_frame(self) -> Optional[pd.DataFrame]:
         banned = set(self._attrs_exclude)
         wanted = self._attrs_include or list(self.G.attributes)

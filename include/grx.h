@@ -35,7 +35,7 @@ extern "C" {
 #define GRX_VERSION 100          /* 0.1.0 */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 16         /* NMF rank limit of the device kernels */
-#define GRX_MAX_NMF_FEATURES 120 /* NMF feature-count limit of the device kernels */
+#define GRX_MAX_NMF_FEATURES 480 /* NMF feature-count limit of the device kernels (fast paths: 120) */
 
 typedef enum {
     GRX_OK = 0,

@@ -405,7 +405,8 @@ def test_chebyshev_cap_semantics_and_column_groups(K, F, n):
 
 # ------------------------------------------------------------------------------------- NMF
 @pytest.mark.parametrize('shape', [(1000, 7, 4), (50000, 12, 6), (3000, 40, 6), (2000, 64, 8), (700, 100, 16),
-                                   (100, 3, 2), (4099, 48, 5), (1001, 17, 3), (333, 33, 2), (17, 1, 1), (5000, 49, 4)])
+                                   (100, 3, 2), (4099, 48, 5), (1001, 17, 3), (333, 33, 2), (17, 1, 1), (5000, 49, 4),
+                                   (1200, 121, 4), (900, 200, 7), (600, 480, 16)])
 def test_nmf_building_blocks_vs_numpy(K, shape):
     import torch
     from oracle import rolx
@@ -500,6 +501,6 @@ def test_nndsvd_apply(K):
 def test_unsupported_shapes_fail_loudly(K):
     import torch
     from graphrole_amd._lib import GrxError
-    X = torch.zeros((130, 10), dtype=torch.float64, device='cuda')
+    X = torch.zeros((481, 10), dtype=torch.float64, device='cuda')          # GRX_MAX_NMF_FEATURES = 480
     with pytest.raises(GrxError):
         K.gram(X, 10)

@@ -67,6 +67,24 @@ def test_nmf_rejects_negative_input():
         factor.get_nmf_decomposition(np.array([[1.0, -1.0], [2.0, 3.0]]), 1)
 
 
+@pytest.mark.parametrize('n,F,r', [(3000, 125, 6), (1500, 260, 4)])
+def test_nmf_more_than_120_features_matches_oracle(n, F, r):
+    """BASELINE config 5 (directed, weighted, 8 attributes) yields 125 features: the wide kernels
+    (column-group Gram, chunked fp64-MFMA W-pass) against the oracle's sklearn restatement."""
+    from graphrole_amd.roles import factor
+    from oracle import rolx
+    rng = np.random.RandomState(F)
+    base = np.abs(rng.randn(n, 12)) * np.linspace(1, 30, 12)
+    mix = np.abs(rng.randn(12, F))
+    X = base @ mix + 0.05 * np.abs(rng.randn(n, F))
+    np.random.seed(3)
+    G, Fm, n_iter = factor.nmf_with_info(X, r)
+    np.random.seed(3)
+    We, He, it = rolx.nmf(X, r)
+    assert n_iter == it
+    assert _relmax(G, We) < FACTOR_RTOL and _relmax(Fm, He) < FACTOR_RTOL
+
+
 def test_nmf_rank_deficient_features():
     """total_degree = in_degree + out_degree is an exact linear dependency (directed graphs)."""
     from graphrole_amd.roles import factor
@@ -83,10 +101,12 @@ def test_nmf_rank_deficient_features():
 
 
 @pytest.mark.parametrize('n,F,r', [(1, 1, 1), (15, 3, 2), (16, 4, 4), (17, 5, 3), (1000, 16, 6), (1001, 17, 7),
-                                   (4099, 20, 6), (5000, 33, 16), (3000, 64, 5), (2500, 100, 9), (2049, 120, 16)])
+                                   (4099, 20, 6), (5000, 33, 16), (3000, 64, 5), (2500, 100, 9), (2049, 120, 16),
+                                   (3001, 121, 6), (2000, 125, 16), (1500, 250, 5), (900, 257, 12), (700, 480, 16)])
 def test_mu_iteration_kernels_vs_numpy(n, F, r):
     """One multiplicative update (sklearn _nmf.py:540-702, beta = 2) computed by grx_nmf_w_pass (fp64
-    MFMA tiles) + grx_nmf_h_update against numpy, over the shape limits (F <= 120, r <= 16), row
+    MFMA tiles; F > 120: the chunked wide kernel) + grx_nmf_h_update against numpy, over the shape
+    limits (F <= 480, r <= 16), row
     counts that are not multiples of the 16-row sub-tile, zero rows / zero denominators, and a
     row range (sharded use)."""
     import torch
