@@ -392,6 +392,44 @@ def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, e
               _hptr(scale), float(eps), float(fill), _stream())
 
 
+# ---- host-side small dense algebra of the NNDSVDa initialisation (grx.h: grx_host_*) ----------
+def _hp(a: np.ndarray):
+    return a.ctypes.data_as(c_void_p)
+
+
+def host_whiten(G1: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Eigen-pairs of the Gram matrix above the numerical floor: (T1 [F, k], lam [k], V [F, k])."""
+    import ctypes
+    F = G1.shape[0]
+    G1 = np.ascontiguousarray(G1, dtype=np.float64)
+    T1, lam, V = np.empty(F * F), np.empty(F), np.empty(F * F)
+    k = ctypes.c_int(0)
+    _lib.call('grx_host_whiten', F, _hp(G1), _hp(T1), _hp(lam), _hp(V), ctypes.byref(k))
+    k = k.value
+    return T1[:F * k].reshape(F, k), lam[:k], V[:F * k].reshape(F, k)
+
+
+def host_range_finder(T1: np.ndarray, lam: np.ndarray, V: np.ndarray, G2: np.ndarray, omega: np.ndarray, r: int,
+                      n_iter: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """sklearn's randomized_svd in the whitened k x F space: (Z [F, r], S [r], Vt [r, F])."""
+    F, k = T1.shape
+    omega = np.ascontiguousarray(omega, dtype=np.float64)
+    assert omega.shape[0] == F
+    Z, S, Vt = np.empty((F, r)), np.empty(r), np.empty((r, F))
+    _lib.call('grx_host_range_finder', F, k, _hp(np.ascontiguousarray(T1)), _hp(np.ascontiguousarray(lam)),
+              _hp(np.ascontiguousarray(V)), _hp(np.ascontiguousarray(G2, dtype=np.float64)), _hp(omega),
+              omega.shape[1], int(r), int(n_iter), _hp(Z), _hp(S), _hp(Vt))
+    return Z, S, Vt
+
+
+def host_nndsvd_plan(S: np.ndarray, Vt: np.ndarray, stats: np.ndarray):
+    r, F = Vt.shape
+    sign, scale, H = np.empty(r), np.empty(r), np.empty((r, F))
+    _lib.call('grx_host_nndsvd_plan', r, F, _hp(np.ascontiguousarray(S)), _hp(np.ascontiguousarray(Vt)),
+              _hp(np.ascontiguousarray(stats, dtype=np.float64)), _hp(sign), _hp(scale), _hp(H))
+    return sign, scale, H
+
+
 def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
     """1-D Lloyd-Max quantiser of a flat fp64 device tensor -> (quantised tensor, centres [n_bins],
     info int32[3] = {iterations, non-empty cells, distinct output values})."""

@@ -32,6 +32,7 @@ from graphrole_amd.types import FactorTuple
 NMF_TOL = 1e-4          # sklearn NMF defaults (_nmf.py:1538-1553)
 NMF_MAX_ITER = 200
 NNDSVD_EPS = 1e-6
+NATIVE_SMALL_SPACE_MAX_F = 64   # Jacobi eigen / SVD of libgrx.so's host routines (O(F^3) per sweep)
 
 
 def _kernels():
@@ -163,22 +164,33 @@ def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
 
     G1, xsum = gram()
     x_mean = xsum / (n * F)
-    lam, V1 = linalg.eigh(G1)
-    floor = max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
-    keep = lam > floor
-    if not keep.any():
-        raise ValueError('NMF initialisation: the feature matrix is numerically zero')
-    T1 = V1[:, keep] / np.sqrt(lam[keep])
-    G2, _ = gram(T1)
-    lam2, V2 = linalg.eigh(G2)
-    T = (T1 @ V2) / np.sqrt(lam2)                                    # X T = Q, orthonormal columns
-    M = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)   # Q^T X
-    Us, S, Vt = _range_finder_svd(M, r, omega, (n, F))
-    Z = T @ Us                                                       # U = X Z
+    n_iter = 7 if r < 0.1 * min(n, F) else 4                          # extmath.py:557-560
+    native = F <= NATIVE_SMALL_SPACE_MAX_F and getattr(K, 'host_whiten', None) is not None
+    if native:
+        # the k x F algebra in libgrx.so's host routines (grx_host_*): same mathematics as below,
+        # without ~25 numpy / LAPACK wrapper round trips (0.6 ms per fit)
+        T1, lam_keep, V_keep = K.host_whiten(G1)
+        if T1.shape[1] == 0:
+            raise ValueError('NMF initialisation: the feature matrix is numerically zero')
+        G2, _ = gram(T1)
+        Z, S, Vt = K.host_range_finder(T1, lam_keep, V_keep, G2, omega, r, n_iter)
+    else:
+        lam, V1 = linalg.eigh(G1)
+        floor = max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
+        keep = lam > floor
+        if not keep.any():
+            raise ValueError('NMF initialisation: the feature matrix is numerically zero')
+        T1 = V1[:, keep] / np.sqrt(lam[keep])
+        G2, _ = gram(T1)
+        lam2, V2 = linalg.eigh(G2)
+        T = (T1 @ V2) / np.sqrt(lam2)                                # X T = Q, orthonormal columns
+        M = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)   # Q^T X
+        Us, S, Vt = _range_finder_svd(M, r, omega, (n, F))
+        Z = T @ Us                                                   # U = X Z
     U, stats = K.project(Xd, n, Z, rb, re)
     if plan is not None:
         stats = _merge_project_stats(plan.all_gather_host(stats))
-    sign, scale, H = _nndsvd_plan(S, Vt, stats)
+    sign, scale, H = K.host_nndsvd_plan(S, Vt, stats) if native else _nndsvd_plan(S, Vt, stats)
     K.nndsvd_apply(U, n, sign, scale, NNDSVD_EPS, x_mean, rb, re)    # W[W < eps] = 0; W[W == 0] = mean
     H[H < NNDSVD_EPS] = 0
     H[H == 0] = x_mean

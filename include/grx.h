@@ -212,6 +212,27 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
 
 /* ------------------------------------------------------------------ RolX NMF ------------ */
 /*
+ * HOST-side small dense algebra of the NNDSVDa initialisation (no device work; plain pointers to host
+ * arrays, row-major).  Between its device passes (grx_gram twice, grx_project) sklearn's
+ * initialisation (_nmf.py:324-359 via randomized_svd, extmath.py:531-604) only touches k x F matrices
+ * with k <= F <= a few dozen; these three calls replace ~25 numpy / LAPACK wrapper calls (0.6 ms per
+ * fit).  Cyclic-Jacobi eigen / singular value decompositions: meant for F <= 64.
+ *   grx_host_whiten        G1 = X^T X -> eigen-pairs above the numerical floor: lam_keep [k],
+ *                          V_keep [F x k], T1 = V_keep / sqrt(lam_keep) [F x k]; *k = 0: X is zero
+ *   grx_host_range_finder  G2 = (X T1)^T (X T1) -> T (X T orthonormal), M = (X T)^T X, randomized_svd of
+ *                          M with the F x n_over test matrix omega and n_iter LU-normalised power
+ *                          iterations -> Z [F x r] (U = X Z), S [r], Vt [r x F] (before svd_flip)
+ *   grx_host_nndsvd_plan   per-column choices of NNDSVD from the grx_project statistics -> sign [r],
+ *                          scale [r] for grx_nndsvd_apply and H [r x F] before thresholding
+ */
+int grx_host_whiten(int F, const double *h_G1, double *h_T1, double *h_lam_keep, double *h_V_keep, int *k);
+int grx_host_range_finder(int F, int k, const double *h_T1, const double *h_lam_keep, const double *h_V_keep,
+                          const double *h_G2, const double *h_omega, int n_over, int r, int n_iter,
+                          double *h_Z, double *h_S, double *h_Vt);
+int grx_host_nndsvd_plan(int r, int F, const double *h_S, const double *h_Vt, const double *h_stats,
+                         double *h_sign, double *h_scale, double *h_H);
+
+/*
  * All NMF matrices are "feature-major": X is F x ldx (row c = feature column c, n valid
  * entries), W is r x ldw.  H is r x F row-major, HHt is r x r.  Rows [row_begin,row_end) of
  * the node axis are processed (multi-GPU: partial results are summed by the caller).

@@ -35,3 +35,11 @@ for trial in range(3):
     t0 = time.perf_counter()
     st.iterate(10, with_residual=True); sync(); t['iterate(10)+res'] = time.perf_counter() - t0
     print(trial, it, {k: round(v * 1e3, 3) for k, v in t.items()})
+
+import cProfile, pstats
+pr = cProfile.Profile()
+sync(); pr.enable()
+for _ in range(20):
+    W0, H0 = factor.nndsvda_init_device(Xd, n, r, omega)
+sync(); pr.disable()
+pstats.Stats(pr).sort_stats('tottime').print_stats(18)
