@@ -42,6 +42,7 @@ WORKLOADS = {
     'ba100k': ('ba', 100_000, 10, 'Barabasi-Albert n=100,000 m=10 (reduced; not a headline number)'),
     'tiny': ('ba', 5_000, 5, 'Barabasi-Albert n=5,000 m=5 (smoke only)'),
     'dw1m': ('dw', 1_000_000, 10_000_000, 'weighted directed power-law, 1 M nodes / 10 M arcs + 8 attributes (config-5 shape, reduced)'),
+    'dw5m': ('dw', 5_000_000, 100_000_000, 'weighted directed power-law, 5 M nodes / 100 M arcs + 8 attributes  [BASELINE config 5, on ONE GPU]'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_ROLES = 6
