@@ -57,7 +57,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
 // ---------------------------------------------------------------------------------------
 constexpr int GR_TR = 64;
 constexpr int GR_LD = GR_TR + 1;
-constexpr int GR_YSLOTS = (MAX_F + 3) / 4;                          // 30
 constexpr int GR_PSLOTS = (MAX_F * (MAX_F + 1) / 2 + 255) / 256;    // 29
 
 // The k outputs of a launch are the columns [ja, ja + na) followed by [jb, jb + k - na) of Y = X T
@@ -297,6 +296,137 @@ GramKernel gram_mfma_pick(int F, int k, bool has_t)
     return kt == 1 ? GRAM_I1[nq - 1] : kt == 2 ? GRAM_I2[nq - 1] : GRAM_I3[nq - 1];
 }
 
+// ---------------------------------------------------------------------------------------
+// Gram matrices of MORE than 48 columns on the matrix cores, in two kernels:
+//   gram_transform_mfma_kernel  Y = X T (feature-major [k][ldy]): per 16-row sub-tile the X operand is
+//                               loaded once per K-step and feeds up to 8 output tiles (128 columns of
+//                               Y per grid.y block); T comes from global memory (cache resident)
+//   gram_pairs_mfma_kernel      G = Y^T Y over pairs of 48-column groups (grid.y = pair): both operands
+//                               are loaded from global memory directly in the transposed MFMA layout
+//                               (lane (j, i): Y[j][row0 + i], four consecutive rows per lane group, the
+//                               four K-steps of a sub-tile cover whole 128-byte lines) -- no LDS.
+// Every group pair writes its own entries of the [pair id][workgroup] partial table of gram_finalize.
+constexpr int GP_GROUP = 48;                                     // columns per group (3 tiles)
+
+__global__ __launch_bounds__(256) void gram_transform_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int k,
+                                                                  const double *__restrict__ X, int64_t ldx,
+                                                                  const double *__restrict__ T,
+                                                                  double *__restrict__ Y, int64_t ldy)
+{
+    constexpr int JT = 8;                                        // output tiles per workgroup column block
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    const int j_base = 16 * JT * blockIdx.y;
+    const int nq = (F + 3) / 4;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < nsub; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const bool valid = row < row_end;
+        const int64_t rowc = valid ? row : row_end - 1;
+        gv4d y[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) y[jt] = (gv4d){0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < nq; ++q) {
+            const int c = 4 * q + lq;
+            const double xv = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
+            const double x = (valid && c < F) ? xv : 0.0;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int j = j_base + 16 * jt + li;
+                const double a = (c < F && j < k) ? T[(size_t)c * k + j] : 0.0;
+                y[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x, y[jt], 0, 0, 0);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j = j_base + 16 * jt + lq + 4 * g;
+                    if (j < k) Y[(size_t)j * ldy + row] = y[jt][g];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_pairs_mfma_kernel(int64_t row_begin, int64_t row_end, int k,
+                                                              const double *__restrict__ Y, int64_t ldy,
+                                                              int ngroups, double *__restrict__ partial)
+{
+    __shared__ double red[4][9 * 256];
+    // pair index -> (A <= B)
+    int A = 0, B = 0;
+    {
+        int p = blockIdx.y;
+        for (A = 0; A < ngroups; ++A) {
+            if (p < ngroups - A) { B = A + p; break; }
+            p -= ngroups - A;
+        }
+    }
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    const int ja = A * GP_GROUP, jb = B * GP_GROUP;
+    gv4d acc[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = (gv4d){0.0, 0.0, 0.0, 0.0};
+    const double *ap[3], *bp[3];
+    bool av[3], bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int j = ja + 16 * m + li, j2 = jb + 16 * m + li;
+        av[m] = j < k && 16 * m + li < GP_GROUP;
+        bv[m] = j2 < k && 16 * m + li < GP_GROUP;
+        ap[m] = Y + (size_t)(av[m] ? j : 0) * ldy;
+        bp[m] = Y + (size_t)(bv[m] ? j2 : 0) * ldy;
+    }
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < nsub; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = row_begin + sidx * 16;
+        double a[4][3], b[4][3];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int64_t row = row0 + 4 * st + lq;
+            const bool valid = row < row_end;
+            const int64_t rowc = valid ? row : row_end - 1;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const double u = ap[m][rowc];
+                a[st][m] = (valid && av[m]) ? u : 0.0;
+                if (A != B) {
+                    const double w = bp[m][rowc];
+                    b[st][m] = (valid && bv[m]) ? w : 0.0;
+                } else {
+                    b[st][m] = a[st][m];
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2)
+                    if (A != B || m2 >= m)
+                        acc[m * 3 + m2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st][m], b[st][m2], acc[m * 3 + m2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[wave][(p * 4 + g) * 64 + lane] = acc[p][g];
+    __syncthreads();
+    for (int idx = t; idx < 9 * 256; idx += 256) {
+        const int p = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63;
+        const int m = p / 3, m2 = p % 3;
+        if (A == B && m2 < m) continue;
+        const double v = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+        const int r1 = 16 * m + (ln >> 4) + 4 * g, r2 = 16 * m2 + (ln & 15);    // within the groups
+        if (r1 >= GP_GROUP || r2 >= GP_GROUP) continue;
+        const int j = ja + r1, j2 = jb + r2;
+        if (j >= k || j2 >= k || j > j2) continue;
+        partial[(size_t)((size_t)j2 * (j2 + 1) / 2 + j) * gridDim.x + blockIdx.x] = v;
+    }
+}
+
 // sum of X[:, ja .. ja+na) over the row range: per-workgroup partials (fixed order)
 __global__ __launch_bounds__(256) void column_sum_kernel(int64_t row_begin, int64_t row_end,
                                                          const double *__restrict__ X, int64_t ldx, int ja, int na,
@@ -311,15 +441,6 @@ __global__ __launch_bounds__(256) void column_sum_kernel(int64_t row_begin, int6
     if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
-}
-
-__global__ __launch_bounds__(64) void add_partials_kernel(const double *__restrict__ partial, int nb,
-                                                          double *__restrict__ out)
-{
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) s += partial[b];
-    s = grx_group_sum<64>(s);
-    if (threadIdx.x == 0) *out += s;
 }
 
 // partial [npairs+1][nb] -> out: symmetric block of the K x K matrix (local column j <-> global column
@@ -933,13 +1054,25 @@ static int gram_grid(int64_t nrows)
     return (int)(tiles > GRX_NUM_CU * 4 ? GRX_NUM_CU * 4 : (tiles < 1 ? 1 : tiles));
 }
 
+// workgroups of the Gram kernels: the [pair][workgroup] partial table is bounded to ~128 MB
+static int gram_pairs_grid(int64_t nrows, int k)
+{
+    const int64_t npairs = (int64_t)k * (k + 1) / 2 + 1;
+    int64_t cap = ((int64_t)1 << 24) / npairs;
+    if (cap > GRX_NUM_CU * 4) cap = GRX_NUM_CU * 4;
+    if (cap < 64) cap = 64;
+    const int64_t want = grx_ceil_div(grx_ceil_div(nrows > 0 ? nrows : 1, 16), 4);
+    return (int)(want > cap ? cap : (want < 1 ? 1 : want));
+}
+
 size_t grx_gram_workspace_bytes(int64_t n, int k)
 {
     if (k < 1) k = 1;
-    const size_t kl = (size_t)(k < MAX_F ? k : MAX_F);              // outputs of one launch
-    const size_t npairs = kl * (kl + 1) / 2 + 1;
-    return grx_align_up((size_t)gram_grid(n) * npairs * 8, 256) +
-           grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256);
+    const size_t npairs = (size_t)k * (k + 1) / 2 + 1;
+    size_t bytes = grx_align_up((size_t)gram_pairs_grid(n, k) * npairs * 8, 256) +
+                   grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256);
+    if (k > GM_MAX_KT * 16) bytes += grx_align_up((size_t)k * (size_t)(n > 0 ? n : 1) * 8, 256);   // Y = X T
+    return bytes;
 }
 
 int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin, int64_t row_end,
@@ -985,51 +1118,52 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
         GRX_LAUNCH_CHECK();
         return GRX_OK;
     }
-    // VALU path.  Up to MAX_F outputs per launch; wider matrices are assembled from launches over
-    // pairs of column groups (A, A): the block inside A, (A, B): A u B, which also yields the cross
-    // block (the diagonal blocks are recomputed -- this is the rarely used wide path).
-    auto launch = [&](int kl, int ja, int na, int jb, int write_sum) -> int {
-        size_t lds = (size_t)kl * GR_LD * 8;
-        const int t_in_lds = (h_T != nullptr) && kl == k && (lds + (size_t)F * k * 8 <= 60 * 1024);
+    if (h_T && k <= GM_MAX_KT * 16 && k <= MAX_F) {
+        // rare: a wide X whitened to few columns (rank-deficient features) -- the VALU kernel
+        size_t lds = (size_t)k * GR_LD * 8;
+        const int t_in_lds = lds + (size_t)F * k * 8 <= 60 * 1024;
         if (t_in_lds) lds += (size_t)F * k * 8;
         {
             GRX_PROF(GRX_K_GRAM, st);
-            if (!h_T) gram_kernel<false, 1><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, nullptr, 0, partial, k, ja, na, jb);
-            else if (kl <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
-            else if (kl <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
-            else if (kl <= 64) gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
-            else gram_kernel<true, GR_YSLOTS><<<grid, 256, lds, st>>>(row_begin, row_end, F, kl, d_X, ldx, dT, t_in_lds, partial, k, ja, na, jb);
+            if (k <= 16) gram_kernel<true, 4><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial, k, 0, k, 0);
+            else if (k <= 32) gram_kernel<true, 8><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial, k, 0, k, 0);
+            else gram_kernel<true, 16><<<grid, 256, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dT, t_in_lds, partial, k, 0, k, 0);
         }
         GRX_LAUNCH_CHECK();
-        gram_finalize_kernel<<<(kl * kl + 1 + 3) / 4, 256, 0, st>>>(partial, grid, kl, d_out, k, ja, na, jb, write_sum);
+        gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, grid, k, d_out, k, 0, k, 0, 1);
         GRX_LAUNCH_CHECK();
         return GRX_OK;
-    };
-    if (k <= MAX_F) return launch(k, 0, k, 0, 1);
-    constexpr int GROUP = MAX_F / 2;
-    const int ngroups = (k + GROUP - 1) / GROUP;
-    if (!h_T) {
-        // the X sum: zero it, every diagonal launch adds its own columns (sum over groups)
-        GRX_CHECK_HIP(hipMemsetAsync(d_out + (size_t)k * k, 0, 8, st));
     }
-    for (int A = 0; A < ngroups; ++A) {
-        const int ja = A * GROUP, na = (k - ja < GROUP) ? k - ja : GROUP;
-        for (int B = A; B < ngroups; ++B) {
-            const int jb = B * GROUP, nb = (B == A) ? 0 : ((k - jb < GROUP) ? k - jb : GROUP);
-            int rc = launch(na + nb, ja, na, jb, 0);
-            if (rc != GRX_OK) return rc;
+    // more than 48 columns: Y = X T materialised once (feature-major, workspace), then the Gram matrix
+    // over pairs of 48-column groups with both operands straight from global memory
+    const size_t npairs_all = (size_t)k * (k + 1) / 2 + 1;
+    double *dTw = reinterpret_cast<double *>(ws + grx_align_up((size_t)gram_pairs_grid(n, k) * npairs_all * 8, 256));
+    double *Yw = reinterpret_cast<double *>(reinterpret_cast<char *>(dTw) +
+                                            grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256));
+    if (h_T) GRX_CHECK_HIP(hipMemcpyAsync(dTw, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
+    const int pgrid = gram_pairs_grid(row_end - row_begin, k);
+    const double *src = d_X;
+    int64_t lds_src = ldx;
+    {
+        GRX_PROF(GRX_K_GRAM, st);
+        if (h_T) {
+            gram_transform_mfma_kernel<<<dim3(pgrid, (k + 127) / 128), 256, 0, st>>>(row_begin, row_end, F, k, d_X, ldx, dTw,
+                                                                                    Yw, n);
+            src = Yw;
+            lds_src = n;
+        }
+        const int ngroups = (k + GP_GROUP - 1) / GP_GROUP;
+        gram_pairs_mfma_kernel<<<dim3(pgrid, ngroups * (ngroups + 1) / 2), 256, 0, st>>>(row_begin, row_end, k, src,
+                                                                                         lds_src, ngroups, partial);
+        if (!h_T) {
+            // sum(X): every workgroup's share into the last row of the partial table
+            column_sum_kernel<<<pgrid, 256, 0, st>>>(row_begin, row_end, d_X, ldx, 0, k,
+                                                     partial + (size_t)(npairs_all - 1) * pgrid);
         }
     }
-    if (!h_T) {
-        // sum(X) of the wide identity case: one extra pass over the columns, group by group
-        for (int A = 0; A < ngroups; ++A) {
-            const int ja = A * GROUP, na = (k - ja < GROUP) ? k - ja : GROUP;
-            column_sum_kernel<<<gram_grid(row_end - row_begin), 256, 0, st>>>(row_begin, row_end, d_X, ldx, ja, na, partial);
-            GRX_LAUNCH_CHECK();
-            add_partials_kernel<<<1, 64, 0, st>>>(partial, gram_grid(row_end - row_begin), d_out + (size_t)k * k);
-            GRX_LAUNCH_CHECK();
-        }
-    }
+    GRX_LAUNCH_CHECK();
+    gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, pgrid, k, d_out, k, 0, k, 0, h_T ? 0 : 1);
+    GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
 
