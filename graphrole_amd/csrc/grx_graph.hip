@@ -89,6 +89,107 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
 //   S2: walk ego(v), look each member up in row(a)                   cost deg(v) * log deg(a)
 // S2 obtains the boundary weight of a as rowsum(a) - matched weight; when every entry of row(a)
 // matched, the boundary contribution is exactly 0 (no cancellation residue).
+// The same features for nodes with at most EGO_GROUP_MAX out-neighbours (almost every node of a
+// sparse graph): EIGHT lanes per node instead of a wavefront.  The ego set sits in registers (three
+// ids per lane); the members are visited one after the other and their rows are either scanned in
+// coalesced chunks of eight arcs, membership by the all-pairs shuffle compare of the triangle
+// kernel, or -- long rows, i.e. hub neighbours -- probed by binary search for the (at most 25) ego
+// members.  Per lane sequential sums, fixed butterfly: bitwise reproducible.
+constexpr int EGO_SLOTS = 4;                                     // ids per lane
+constexpr int EGO_GROUP_MAX = 8 * EGO_SLOTS;
+
+__global__ __launch_bounds__(256) void egonet_group_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ w, const double *__restrict__ rowsum, int directed,
+    int64_t row_begin, int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
+{
+    constexpr int G = 8;
+    const int lane = threadIdx.x % G;
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
+        const int64_t dv = ve - vb;
+        if (dv > EGO_GROUP_MAX) continue;                       // uniform over the group
+        int32_t uu[EGO_SLOTS];
+#pragma unroll
+        for (int i = 0; i < EGO_SLOTS; ++i) {
+            const int64_t idx = vb + lane + (int64_t)G * i;
+            uu[i] = (idx < ve) ? col[idx] : -2;
+        }
+        const bool mine_v = (uu[0] == (int32_t)v) | (uu[1] == (int32_t)v) | (uu[2] == (int32_t)v) | (uu[3] == (int32_t)v);
+        const bool v_in_row = ((__ballot(mine_v) >> gshift) & 0xFFull) != 0;
+        const int members = (int)dv + (v_in_row ? 0 : 1);
+        double ins = 0.0, ext = 0.0;
+        for (int m = 0; m < members; ++m) {
+            int32_t a;
+            if (m < dv) {
+                const int slot = m / G;
+                a = __shfl(slot == 0 ? uu[0] : slot == 1 ? uu[1] : slot == 2 ? uu[2] : uu[3], m % G, G);
+            } else {
+                a = (int32_t)v;
+            }
+            const int64_t ab = row_ptr[a], ae = row_ptr[a + 1];
+            const int64_t da = ae - ab;
+            if (da <= (int64_t)EGO_SLOTS * G * (ilog2_i64(da) + 2)) {
+                // scan row(a) in chunks of eight arcs
+                for (int64_t j0 = ab; j0 < ae; j0 += G) {
+                    const bool live = j0 + lane < ae;
+                    const int32_t b = live ? col[j0 + lane] : -1;
+                    const double x = live ? (w ? w[j0 + lane] : 1.0) : 0.0;
+                    unsigned match = 0;
+#pragma unroll
+                    for (int sidx = 0; sidx < G; ++sidx) {
+                        const int32_t bs = __shfl(b, sidx, G);
+                        const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
+                        if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
+                    }
+                    if (live) {
+                        const bool inside = ((match >> lane) & 1u) || b == (int32_t)v;
+                        if (inside) {
+                            if (directed || b >= a) ins += x;
+                        } else {
+                            ext += x;
+                        }
+                    }
+                }
+            } else {
+                // long row (a hub): look the ego members up in it
+                int matched = 0;
+                double in_all = 0.0;
+#pragma unroll
+                for (int i = 0; i <= EGO_SLOTS; ++i) {
+                    int32_t key = -2;
+                    if (i < EGO_SLOTS) key = uu[i < EGO_SLOTS ? i : 0];
+                    else if (lane == 0 && !v_in_row) key = (int32_t)v;
+                    if (key >= 0) {
+                        const int64_t pos = lower_bound_row(col, ab, ae, key);
+                        if (pos < ae && col[pos] == key) {
+                            const double x = w ? w[pos] : 1.0;
+                            ++matched;
+                            in_all += x;
+                            if (directed || key >= a) ins += x;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < G; off <<= 1) {
+                    matched += __shfl_xor(matched, off, G);
+                    in_all += __shfl_xor(in_all, off, G);
+                }
+                if (lane == 0 && matched != da) ext += (w ? rowsum[a] : (double)da) - in_all;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            ins += __shfl_xor(ins, off, G);
+            ext += __shfl_xor(ext, off, G);
+        }
+        if (lane == 0) { internal[v] = ins; external[v] = ext; }
+    }
+}
+
 template <int TPN>
 __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
@@ -825,11 +926,16 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     const int64_t nrows = row_end - row_begin;
     constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup above this
     {
+        // nodes with at most EGO_GROUP_MAX neighbours: eight lanes each; the rest: a wavefront each
+        const int64_t gwant = grx_ceil_div(nrows * 8, 256);
+        const int ggrid = (int)(gwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : gwant);
         const int64_t want = grx_ceil_div(nrows, 4);
         const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
         { GRX_PROF(GRX_K_EGONET_WAVE, grx_stream(stream));
+        egonet_group_kernel<<<ggrid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin,
+                                                                  row_end, d_internal, d_external);
         egonet_kernel<64><<<grid, 256, 0, grx_stream(stream)>>>(
-            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, 0, HUB, d_internal,
+            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, EGO_GROUP_MAX + 1, HUB, d_internal,
             d_external);
         }
         GRX_LAUNCH_CHECK();
