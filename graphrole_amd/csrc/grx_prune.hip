@@ -574,31 +574,34 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
         const int np = Fl * (Fl - 1) / 2 - q0l * (q0l - 1) / 2;
         return (size_t)Fl * CH_STRIDE + (size_t)(np > 0 ? np : 0) * 3 + 16;
     };
-    if (F <= CH_MAX_F) {
-        GrxPtrTable tab;
-        for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
+    // one column set (<= CH_MAX_F columns: the global columns [a0, a0+na) then [b0, ...)): pairs with
+    // q >= fn.  Two stages when a cap is given and the range is long: all pairs on a sample of rows (the
+    // first rows of the range: with the degree-descending node order these are the hubs, where features
+    // differ most), then the whole range for the few pairs that are still within the cap.
+    constexpr int SAMPLE_TILES = 16;
+    auto run = [&](int Fl, int fn, const GrxPtrTable &tab, int a0, int na, int b0) -> int {
         GRX_PROF(GRX_K_CHEBYSHEV, st);
-        const size_t lds = lds_bytes(F, first_new);
-        constexpr int SAMPLE_TILES = 16;
-        if (cap < 254 && tiles > 8 * SAMPLE_TILES && F > 4) {
-            // two stages: all pairs on a sample of rows (the first rows of the range: with the
-            // degree-descending node order these are the hubs, where features differ most), then the
-            // whole range for the few pairs that are still within the cap
+        const size_t lds = lds_bytes(Fl, fn);
+        if (cap < 254 && tiles > 8 * SAMPLE_TILES && Fl > 4) {
             const int64_t split = row_begin + (int64_t)SAMPLE_TILES * CH_ROWS;
-            chebyshev_kernel<<<SAMPLE_TILES, 256, lds, st>>>(row_begin, split, F, first_new, tab, d_dist, F, 0, F, 0,
-                                                            cap, 1, 0);
+            chebyshev_kernel<<<SAMPLE_TILES, 256, lds, st>>>(row_begin, split, Fl, fn, tab, d_dist, F, a0, na, b0, cap, 1, 0);
             const int64_t rest = tiles - SAMPLE_TILES;
             const int tpb = (int)(rest <= GRX_NUM_CU * 8 ? 1 : grx_ceil_div(rest, GRX_NUM_CU * 8));
-            chebyshev_kernel<<<(int)grx_ceil_div(rest, tpb), 256, lds, st>>>(split, row_end, F, first_new, tab, d_dist,
-                                                                             F, 0, F, 0, cap, tpb, 1);
+            chebyshev_kernel<<<(int)grx_ceil_div(rest, tpb), 256, lds, st>>>(split, row_end, Fl, fn, tab, d_dist, F, a0, na,
+                                                                             b0, cap, tpb, 1);
         } else {
-            chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, first_new, tab, d_dist, F, 0, F, 0, cap,
+            chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, Fl, fn, tab, d_dist, F, a0, na, b0, cap,
                                                      tiles_per_block, 0);
         }
         GRX_LAUNCH_CHECK();
         return GRX_OK;
+    };
+    if (F <= CH_MAX_F) {
+        GrxPtrTable tab;
+        for (int c = 0; c < F; ++c) tab.p[c] = h_bin_ptrs[c];
+        return run(F, first_new, tab, 0, F, 0);
     }
-    // more columns than one LDS tile holds: column groups of CH_MAX_F/2, one launch per pair of
+    // more columns than one LDS tile holds: column groups of CH_MAX_F/2, one column set per pair of
     // groups (A, A): all pairs inside A;  (A, B), A < B: the pairs between A and B (q in B, p < q;
     // the pairs inside B are recomputed, harmless under atomicMax)
     constexpr int GROUP = CH_MAX_F / 2;
@@ -610,14 +613,9 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
             GrxPtrTable tab;
             for (int c = 0; c < na; ++c) tab.p[c] = h_bin_ptrs[a0 + c];
             for (int c = 0; c < nb; ++c) tab.p[na + c] = h_bin_ptrs[b0 + c];
-            const int Fl = na + nb;
-            if (Fl < 2) continue;
-            {
-                GRX_PROF(GRX_K_CHEBYSHEV, st);
-                chebyshev_kernel<<<grid, 256, lds_bytes(Fl, (B == A) ? 0 : na), st>>>(
-                    row_begin, row_end, Fl, (B == A) ? 0 : na, tab, d_dist, F, a0, na, b0, cap, tiles_per_block, 0);
-            }
-            GRX_LAUNCH_CHECK();
+            if (na + nb < 2) continue;
+            int rc = run(na + nb, (B == A) ? 0 : na, tab, a0, na, b0);
+            if (rc != GRX_OK) return rc;
         }
     }
     return GRX_OK;
