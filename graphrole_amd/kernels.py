@@ -449,6 +449,7 @@ class NmfState:
 
     def __init__(self, X: torch.Tensor, n: int, W: torch.Tensor, H: np.ndarray):
         self.X, self.n, self.W = X, n, W
+        self.x_sq_norm = None          # ||X||_F^2 when known (roles/factor.py uses it for cheap residuals)
         self.F, self.r = X.shape[0], W.shape[0]
         dev = device()
         self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)

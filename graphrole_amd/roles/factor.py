@@ -144,6 +144,11 @@ def _merge_project_stats(per_rank: np.ndarray) -> np.ndarray:
     return out
 
 
+# side channel from nndsvda_init_device to the state built from its result: ||X||_F^2 of the matrix the
+# factors were initialised for (NmfState.x_sq_norm; None = unknown -> residuals by the direct kernel)
+_LAST_INIT = {'x_sq_norm': None}
+
+
 def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
     """
     NNDSVDa start (W0 on the device, feature-major r x ld; H0 on the host) for the feature-major
@@ -164,6 +169,7 @@ def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
 
     G1, xsum = gram()
     x_mean = xsum / (n * F)
+    _LAST_INIT['x_sq_norm'] = float(np.trace(G1))                    # ||X||_F^2, used by run_mu_loop
     n_iter = 7 if r < 0.1 * min(n, F) else 4                          # extmath.py:557-560
     native = F <= NATIVE_SMALL_SPACE_MAX_F and getattr(K, 'host_whiten', None) is not None
     if native:
@@ -219,6 +225,21 @@ def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=
         plan.all_reduce_sum_(state.err)
         return float(np.sqrt(K.to_host(state.err)[0]))
 
+    def residual_from_identity():
+        """||X - W H||_F from the W-pass outputs A = W^T X, B = W^T W (already summed over the ranks)
+        and the updated H:  ||X||^2 - 2 <A, H> + <B, H H^T>.  No pass over X.  The identity cancels
+        when the fit is nearly exact, so it is only trusted for a relative residual above 1e-4
+        (its error is then below 1e-8 of the value, far under the 1e-4 stopping tolerance)."""
+        xx = getattr(state, 'x_sq_norm', None)
+        if xx is None or xx <= 0.0:
+            return None
+        r_, F_ = state.r, state.F
+        AB = K.to_host(state.AB)
+        H = K.to_host(state.H)
+        A, B = AB[:r_ * F_].reshape(r_, F_), AB[r_ * F_:].reshape(r_, r_)
+        sq = xx - 2.0 * float((A * H).sum()) + float((B * (H @ H.T)).sum())
+        return float(np.sqrt(sq)) if sq > 1e-8 * xx else None
+
     rb, re = (0, state.n) if plan is None else (plan.row_begin, plan.row_end)
     state.residual_sq(rb, re)
     err_init = residual_norm()                                        # _nmf.py:826
@@ -228,17 +249,18 @@ def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=
         step = min(10, max_iter - n_iter)
         check = tol > 0 and (n_iter + step) % 10 == 0
         if plan is None:
-            state.iterate(step, with_residual=check)
+            state.iterate(step, with_residual=False)
         else:
             for _ in range(step):
                 state.w_pass(rb, re)
                 plan.all_reduce_sum_(state.AB)
                 state.h_update()
-            if check:
-                state.residual_sq(rb, re)
         n_iter += step
         if check:                                                     # _nmf.py:872-885
-            err = residual_norm()
+            err = residual_from_identity()
+            if err is None:
+                state.residual_sq(rb, re)
+                err = residual_norm()
             if (prev - err) / err_init < tol:
                 break
             prev = err
@@ -250,7 +272,9 @@ def nmf_device(Xd, n: int, n_roles: int, omega: np.ndarray,
     """NNDSVDa + multiplicative updates on a device matrix; returns (NmfState, n_iter)."""
     K = _kernels()
     W0, H0 = nndsvda_init_device(Xd, n, n_roles, omega)
-    return run_mu_loop(K.NmfState(Xd, n, W0, H0), tol, max_iter)
+    state = K.NmfState(Xd, n, W0, H0)
+    state.x_sq_norm = _LAST_INIT['x_sq_norm']
+    return run_mu_loop(state, tol, max_iter)
 
 
 def get_nmf_decomposition(X: np.ndarray, n_roles: int) -> FactorTuple:
