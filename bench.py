@@ -40,6 +40,7 @@ WORKLOADS = {
     'ba1m': ('ba', 1_000_000, 10, 'Barabasi-Albert n=1,000,000 m=10 (~10M edges), seed 0  [BASELINE config 3/4]'),
     'er100k': ('er', 100_000, 1_000_000, 'Erdos-Renyi G(100,000; 1,000,000), seed 0  [BASELINE config 2]'),
     'ba100k': ('ba', 100_000, 10, 'Barabasi-Albert n=100,000 m=10 (reduced; not a headline number)'),
+    'ba10m': ('ba', 10_000_000, 10, 'Barabasi-Albert n=10,000,000 m=10 (~100M edges): 10x the BASELINE graph, scale check'),
     'tiny': ('ba', 5_000, 5, 'Barabasi-Albert n=5,000 m=5 (smoke only)'),
     'dw1m': ('dw', 1_000_000, 10_000_000, 'weighted directed power-law, 1 M nodes / 10 M arcs + 8 attributes (config-5 shape, reduced)'),
     'dw5m': ('dw', 5_000_000, 100_000_000, 'weighted directed power-law, 5 M nodes / 100 M arcs + 8 attributes  [BASELINE config 5, on ONE GPU]'),
