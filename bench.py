@@ -46,6 +46,7 @@ WORKLOADS = {
     'dw5m': ('dw', 5_000_000, 100_000_000, 'weighted directed power-law, 5 M nodes / 100 M arcs + 8 attributes  [BASELINE config 5, on ONE GPU]'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+GATHER_CEILING_ROWS_PER_S = 56e9   # random 64-byte rows from a 64 MB table, measured (tools/microbench/gather_bw.hip)
 N_ROLES = 6
 MAX_GENERATIONS = 4
 
@@ -272,7 +273,12 @@ def main():
             roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_blocks_kernel, aggregate_combine_kernel)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / launches,
-                        'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen}
+                        'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,
+                        # the kernel is a random 64-byte-line gather: what the chip sustains on that pattern was
+                        # measured with tools/microbench/gather_bw.hip
+                        'gather_rows_per_s': nnz_per_rank / (per_launch_ms * 1e-3),
+                        'gather_ceiling_rows_per_s': GATHER_CEILING_ROWS_PER_S,
+                        'frac_of_gather_ceiling': nnz_per_rank / (per_launch_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S}
         F, r = state['F'], N_ROLES
         w_ms, w_cnt = prof.get('nmf_w_pass_kernel', (0.0, 0))
         roofline_nmf = None
