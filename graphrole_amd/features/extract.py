@@ -14,7 +14,7 @@ Per generation (device kernels in graphrole_amd/csrc, host decisions in features
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import pandas as pd

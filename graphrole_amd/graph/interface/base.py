@@ -9,7 +9,7 @@ features are computed by HIP kernels (grx_row_sums / grx_egonet_features) on the
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
-from typing import Dict, Iterable, List, Optional, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import numpy as np
 import pandas as pd

@@ -8,7 +8,7 @@ There is no CPU path in this module -- it raises when no GPU / no libgrx.so is p
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch

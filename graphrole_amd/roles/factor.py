@@ -22,7 +22,7 @@ GPU as well (grx_lloyd_max, csrc/grx_quant.hip): SURVEY.md section 8(f) rank 1.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 from scipy import linalg

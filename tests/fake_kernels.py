@@ -4,7 +4,7 @@ oracle/.  Used ONLY by the `-m "not gpu"` tests to exercise the host logic (drop
 pruning decisions, naming, sharding over gloo) in a container without a GPU.  Never shipped,
 never measured.
 """
-from typing import Optional, Sequence
+
 
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """Wall-clock of the drop-in API calls on the bench graph (run on the GPU box)."""
 import sys, time, os, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch  # noqa: F401  (loads the HIP runtime)
 from graphrole_amd import RecursiveFeatureExtractor, RoleExtractor, synth
 
 t0 = time.perf_counter(); G = synth.ba_graph(1_000_000, 10, seed=0); t1 = time.perf_counter()
