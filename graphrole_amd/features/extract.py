@@ -184,7 +184,7 @@ class RecursiveFeatureExtractor:
         return names, [self._final_cols[nm] for nm in names]
 
     # ------------------------------------------------------------------ engine
-    def _next_feature_columns(self):
+    def _next_feature_columns(self, complete: bool = False):
         """Candidate columns of the current generation: every aggregation of every column
         retained in the previous generation (extract.py:98-119,152-162)."""
         K = self._K()
@@ -214,8 +214,12 @@ class RecursiveFeatureExtractor:
             import torch
             sub = torch.cat([pieces[a] for a in aggs], dim=0).contiguous()
         picked = range(len(aggs) * f)
-        if plan is not None:
-            plan.all_gather_block(sub)            # the one exchange of this generation
+        # sharded: only this rank's rows of the candidate block are valid from here on; the
+        # exchanges happen in _update_columns (owners bin whole columns, only retained ones are
+        # gathered everywhere) -- or right here when a caller wants complete columns
+        if plan is not None and complete:
+            plan.all_gather_block(sub)
+        self._partial_block = sub if (plan is not None and not complete) else None
         cols = [sub[j] for j in range(len(picked))]
         names = [f'{c}({a})' for a in aggs for c in prev]
         # pandas dtype of the reference's frame (extract.py:104-119): the per-node agg frame of an
@@ -241,11 +245,21 @@ class RecursiveFeatureExtractor:
             self._dtypes[nm] = dt
         # bin the columns that have no cached bins yet
         fresh = [nm for nm in self._work if nm not in self._work_bins]
+        partial = plan is not None and block is not None and getattr(self, '_partial_block', None) is block \
+            and fresh == names
         if fresh:
             if block is None or fresh != names:
                 block = self._as_block([self._work[nm] for nm in fresh], n)
             if plan is None:
                 bins, _ = K.vertical_log_bin(block)
+            elif partial:
+                # candidate block with only this rank's rows: whole columns to their owners, the
+                # owners' bins of this rank's rows back (parallel.py, steps 1 and 2)
+                owned = plan.columns_to_owners(block)
+                owned_bins = K.zeros((owned.shape[0], max(n, 1)), dtype=self._uint8())[:, :n]
+                if owned.shape[0]:
+                    K.vertical_log_bin(owned, out=owned_bins)
+                bins = plan.owned_to_rows(owned_bins, len(fresh))
             else:
                 bins = K.zeros((len(fresh), max(n, 1)), dtype=self._uint8())[:, :n]
                 mine = slice(plan.rank, len(fresh), plan.world)
@@ -270,6 +284,14 @@ class RecursiveFeatureExtractor:
             del self._work_bins[nm]
         # extract.py:140 Index.difference: name-sorted iff the drop list is non-empty (pandas 2)
         kept = list(dict.fromkeys(nm for nm in names if nm not in dropped))
+        if partial and kept:
+            # step 3: the retained new columns, and only those, become complete on every rank
+            import torch
+            blk = torch.stack([self._work[nm] for nm in kept])
+            plan.all_gather_block(blk)
+            for j, nm in enumerate(kept):
+                self._work[nm] = blk[j]
+        self._partial_block = None
         retained = sorted(kept) if dropped else kept
         self._final_names[self.generation_count] = retained
         for nm in retained:
@@ -354,7 +376,7 @@ class RecursiveFeatureExtractor:
     def _get_next_features(self) -> DataFrameLike:
         """Next level of recursive features as a DataFrame (extract.py:98-119)."""
         self._shard()
-        names, cols, _, _ = self._next_feature_columns()
+        names, cols, _, _ = self._next_feature_columns(complete=True)
         K = self._K()
         order = self._order()
         data = {nm: order.to_label_order(K.to_host(c)) for nm, c in zip(names, cols)}

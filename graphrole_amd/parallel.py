@@ -6,12 +6,17 @@ over xGMI on ROCm, "gloo" in the CPU tests).  The reference has no distributed c
 Scheme:
   * the CSR is replicated; rank p computes rows [bounds[p], bounds[p+1]) of every per-node
     kernel (ego-net, aggregation, NMF row passes).  Bounds balance nnz + n, not n.
-  * ONE exchange per ReFeX generation: all-gather of the rank-local slices of the candidate
-    block, after which every rank holds all columns.
-  * pruning: rank p bins candidate columns p, p+P, ... (whole columns), the uint8 bins are
-    combined by all-reduce(MAX) (non-owned columns are zero); each rank scans its own row range
-    for the Chebyshev matrix, combined by all-reduce(MAX) of the F x F int32 matrix.  All ranks
-    then take identical decisions.
+  * per ReFeX generation the candidate block (all aggregations of all retained columns) never
+    travels whole.  Rank p owns candidate columns p, p+P, ...:
+      1. all-to-all: every rank sends its row slice of every column to the column's owner
+         (volume per rank: candidates x n x 8 / P bytes), the owner bins whole columns;
+      2. all-to-all back: the owner returns the uint8 bins of the receiver's rows (each rank only
+         ever scans its own rows for the Chebyshev matrix), all-reduce(MAX) of the F x F matrix,
+         identical pruning decisions everywhere;
+      3. all-gather of the RETAINED new columns only (they are the next generation's gather
+         source and part of the result) -- typically 1/3 to 1/6 of the candidates.
+    Generation 0 (a handful of columns, complete on every rank) bins by owner and combines the
+    bins with all-reduce(MAX).
   * NMF: W rows sharded, H replicated; one all-reduce(SUM) of [W^T X | W^T W] per iteration and
     of the residual at convergence checks.
 """
@@ -75,6 +80,59 @@ class ShardPlan:
             if p != self.rank and e > b:
                 block[:, b:e] = recv[p, :, :e - b]
         return block
+
+    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, out_split, in_split) -> None:
+        if self._staged(send):
+            recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(recv_h, send.cpu(), output_split_sizes=out_split, input_split_sizes=in_split,
+                                   group=self.group)
+            recv.copy_(recv_h)
+        else:
+            dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split,
+                                   group=self.group)
+
+    def columns_to_owners(self, block: torch.Tensor) -> torch.Tensor:
+        """block [ncols, n] with only this rank's row slice valid -> the WHOLE columns this rank owns
+        (columns rank, rank + world, ...) as a [n_owned, n] tensor."""
+        ncols = block.shape[0]
+        rb, re = self.row_begin, self.row_end
+        parts = [block[q::self.world, rb:re].reshape(-1) for q in range(self.world)]
+        in_split = [int(p.numel()) for p in parts]
+        send = torch.cat(parts) if parts else block.new_empty(0)
+        n_owned = len(range(self.rank, ncols, self.world))
+        rows = [int(self.bounds[p + 1] - self.bounds[p]) for p in range(self.world)]
+        out_split = [n_owned * r for r in rows]
+        recv = torch.empty(sum(out_split), dtype=block.dtype, device=block.device)
+        self._all_to_all(recv, send, out_split, in_split)
+        full = torch.empty((n_owned, self.n), dtype=block.dtype, device=block.device)
+        off = 0
+        for p in range(self.world):
+            b, e = int(self.bounds[p]), int(self.bounds[p + 1])
+            if n_owned and e > b:
+                full[:, b:e] = recv[off:off + n_owned * (e - b)].view(n_owned, e - b)
+            off += n_owned * (e - b)
+        return full
+
+    def owned_to_rows(self, owned: torch.Tensor, ncols: int) -> torch.Tensor:
+        """Inverse direction for per-column results (uint8 bins): owned [n_owned, n] whole columns ->
+        [ncols, n] with this rank's row slice of EVERY column valid (other rows zero)."""
+        rb, re = self.row_begin, self.row_end
+        n_owned = owned.shape[0]
+        parts = [owned[:, int(self.bounds[p]):int(self.bounds[p + 1])].reshape(-1) for p in range(self.world)]
+        in_split = [int(p.numel()) for p in parts]
+        send = torch.cat(parts) if parts else owned.new_empty(0)
+        counts = [len(range(q, ncols, self.world)) for q in range(self.world)]
+        out_split = [c * (re - rb) for c in counts]
+        recv = torch.empty(sum(out_split), dtype=owned.dtype, device=owned.device)
+        self._all_to_all(recv, send, out_split, in_split)
+        out = torch.zeros((ncols, self.n), dtype=owned.dtype, device=owned.device)
+        off = 0
+        for q in range(self.world):
+            if counts[q] and re > rb:
+                out[q::self.world, rb:re] = recv[off:off + counts[q] * (re - rb)].view(counts[q], re - rb)
+            off += counts[q] * (re - rb)
+        assert n_owned == counts[self.rank]
+        return out
 
     def all_gather_columns(self, cols: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Same for a list of separate [n] columns."""

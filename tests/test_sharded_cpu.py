@@ -13,7 +13,6 @@ import torch.multiprocessing as mp
 
 from tests import util
 
-WORLD = 2
 
 
 def _free_port():
@@ -24,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, port, case, out_dir):
+def _worker(rank, port, case, out_dir, WORLD):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -57,12 +56,14 @@ def _worker(rank, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['er300', 'ba2000'])
-def test_two_rank_sharded_pipeline_equals_single_process(case, tmp_path):
+@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('ba2000', 2), ('er300', 3), ('directed120', 3)])
+def test_sharded_pipeline_equals_single_process(case, WORLD, tmp_path):
+    """2 and 3 ranks (3: candidate counts that do not divide by the world size -> uneven column
+    ownership in the owner all-to-all)."""
     port = _free_port()
-    mp.spawn(_worker, args=(port, case, str(tmp_path)), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(port, case, str(tmp_path), WORLD), nprocs=WORLD, join=True)
     r0 = np.load(tmp_path / 'rank0.npz')
-    r1 = np.load(tmp_path / 'rank1.npz')
+    r1 = np.load(tmp_path / f'rank{WORLD - 1}.npz')
     g = util.load_refex(case)
     # both ranks hold the full, identical feature table, equal to the reference's
     assert list(r0['cols']) == list(r1['cols']) == g.js('final_columns')
