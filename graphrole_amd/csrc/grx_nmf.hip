@@ -477,77 +477,78 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__rest
 // ---------------------------------------------------------------------------------------
 struct ColStat { double maxabs; double signed_val; double idx; double sq_pos; double sq_neg; };
 
-__global__ __launch_bounds__(256) void project_kernel(int64_t row_begin, int64_t row_end, int F, int r,
-                                                      const double *__restrict__ X, int64_t ldx,
-                                                      const double *__restrict__ Z,
-                                                      double *__restrict__ U, int64_t ldu,
-                                                      double *__restrict__ partial)
+// U = X Z on the matrix cores (r <= 16 output columns = one MFMA tile): per 16-row
+// sub-tile U^T (16 x 16) = Z^T X^T with the X operand straight from global memory and Z (F x r, a few
+// KB) from the cache; the D layout (row j = (lane>>4) + 4g, col i = lane&15) stores U coalesced.  The
+// column statistics are kept per lane over its sub-tiles (rows ascending, so ties keep the first row)
+// and combined over the 16 lanes of a column group, the four waves, and then by project_finalize.
+__global__ __launch_bounds__(256) void project_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                           const double *__restrict__ X, int64_t ldx,
+                                                           const double *__restrict__ Z,
+                                                           double *__restrict__ U, int64_t ldu,
+                                                           double *__restrict__ partial)
 {
-    extern __shared__ __attribute__((aligned(16))) double psm[];
-    double *sZ = psm;                                  // F * r
-    double *sred = sZ + F * r;                         // 4 waves * r * 5
-    for (int idx = threadIdx.x; idx < F * r; idx += 256) sZ[idx] = Z[idx];
-    __syncthreads();
-    double mx[MAX_R], sv[MAX_R], ix[MAX_R], sp[MAX_R], sn[MAX_R];
+    __shared__ double sred[4][MAX_R][5];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    const int nq = (F + 3) / 4;
+    double mx[4], sv[4], ix[4], sp[4], sn[4];
 #pragma unroll
-    for (int j = 0; j < MAX_R; ++j) { mx[j] = -1.0; sv[j] = 0.0; ix[j] = 0.0; sp[j] = 0.0; sn[j] = 0.0; }
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
-        double u[MAX_R];
-#pragma unroll
-        for (int j = 0; j < MAX_R; ++j) u[j] = 0.0;
-        for (int c = 0; c < F; ++c) {
-            const double x = X[(size_t)c * ldx + i];
-#pragma unroll
-            for (int j = 0; j < MAX_R; ++j)
-                if (j < r) u[j] += x * sZ[c * r + j];
+    for (int g = 0; g < 4; ++g) { mx[g] = -1.0; sv[g] = 0.0; ix[g] = 0.0; sp[g] = 0.0; sn[g] = 0.0; }
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < nsub; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t row = row_begin + sidx * 16 + li;
+        const bool valid = row < row_end;
+        const int64_t rowc = valid ? row : row_end - 1;
+        gv4d u = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < nq; ++q) {
+            const int c = 4 * q + lq;
+            const double xv = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
+            const double zv = Z[(size_t)(c < F ? c : F - 1) * r + (li < r ? li : r - 1)];
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64((c < F && li < r) ? zv : 0.0, (valid && c < F) ? xv : 0.0, u, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < MAX_R; ++j) {
-            if (j < r) {
-                U[(size_t)j * ldu + i] = u[j];
-                const double a = fabs(u[j]);
-                if (a > mx[j]) { mx[j] = a; sv[j] = u[j]; ix[j] = (double)i; }   // i ascending per thread
-                if (u[j] > 0.0) sp[j] += u[j] * u[j]; else sn[j] += u[j] * u[j];
+        for (int g = 0; g < 4; ++g) {
+            const int j = lq + 4 * g;
+            if (valid && j < r) {
+                const double v = u[g];
+                U[(size_t)j * ldu + row] = v;
+                const double a = fabs(v);
+                if (a > mx[g]) { mx[g] = a; sv[g] = v; ix[g] = (double)row; }
+                if (v > 0.0) sp[g] += v * v; else sn[g] += v * v;
             }
         }
     }
-    // wave reduce (max-abs with smallest index on ties; sums by fixed butterfly)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < MAX_R; ++j) {
-        if (j < r) {
+    for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double om = __shfl_xor(mx[j], off, 64);
-                const double os = __shfl_xor(sv[j], off, 64);
-                const double oi = __shfl_xor(ix[j], off, 64);
-                if (om > mx[j] || (om == mx[j] && oi < ix[j])) { mx[j] = om; sv[j] = os; ix[j] = oi; }
-            }
-            sp[j] = grx_group_sum<64>(sp[j]);
-            sn[j] = grx_group_sum<64>(sn[j]);
-            if (lane == 0) {
-                double *o = sred + ((size_t)wave * r + j) * 5;
-                o[0] = mx[j]; o[1] = sv[j]; o[2] = ix[j]; o[3] = sp[j]; o[4] = sn[j];
-            }
+        for (int off = 1; off < 16; off <<= 1) {                 // the 16 lanes that share column j
+            const double om = __shfl_xor(mx[g], off, 64), os = __shfl_xor(sv[g], off, 64);
+            const double oi = __shfl_xor(ix[g], off, 64);
+            if (om > mx[g] || (om == mx[g] && oi < ix[g])) { mx[g] = om; sv[g] = os; ix[g] = oi; }
+            sp[g] += __shfl_xor(sp[g], off, 64);
+            sn[g] += __shfl_xor(sn[g], off, 64);
+        }
+        const int j = lq + 4 * g;
+        if (li == 0 && j < r) {
+            sred[wave][j][0] = mx[g]; sred[wave][j][1] = sv[g]; sred[wave][j][2] = ix[g];
+            sred[wave][j][3] = sp[g]; sred[wave][j][4] = sn[g];
         }
     }
     __syncthreads();
-    if (threadIdx.x < r) {
-        const int j = threadIdx.x;
-        double bm = -1.0, bs = 0.0, bi = 0.0, p = 0.0, q = 0.0;
+    if (t < r) {
+        const int j = t;
+        double bm = -1.0, bs = 0.0, bi = 0.0, p = 0.0, q2 = 0.0;
         for (int w = 0; w < 4; ++w) {
-            const double *o = sred + ((size_t)w * r + j) * 5;
+            const double *o = sred[w][j];
             if (o[0] > bm || (o[0] == bm && o[2] < bi)) { bm = o[0]; bs = o[1]; bi = o[2]; }
-            p += o[3]; q += o[4];
+            p += o[3]; q2 += o[4];
         }
         double *o = partial + ((size_t)blockIdx.x * r + j) * 5;
-        o[0] = bm; o[1] = bs; o[2] = bi; o[3] = p; o[4] = q;
+        o[0] = bm; o[1] = bs; o[2] = bi; o[3] = p; o[4] = q2;
     }
 }
 
-// stats out: [r][4] = signed value of the max-|.| entry, its row index, sum sq pos, sum sq neg.
-// One wavefront per column: lanes stride over the workgroup partials, then a fixed butterfly.
 __global__ __launch_bounds__(64) void project_finalize_kernel(const double *__restrict__ partial,
                                                               int nblocks, int r,
                                                               double *__restrict__ stats)
@@ -1194,11 +1195,10 @@ int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_be
     double *partial = reinterpret_cast<double *>(ws);
     double *dZ = reinterpret_cast<double *>(ws + grx_align_up((size_t)PROJ_GRID * r * 5 * 8, 256));
     GRX_CHECK_HIP(hipMemcpyAsync(dZ, h_Z, (size_t)F * r * 8, hipMemcpyHostToDevice, st));
-    const int64_t want = grx_ceil_div(row_end - row_begin, 256);
+    const int64_t want = grx_ceil_div(grx_ceil_div(row_end - row_begin, 16), 4);
     const int grid = (int)(want > PROJ_GRID ? PROJ_GRID : (want < 1 ? 1 : want));
-    const size_t lds = ((size_t)F * r + 4 * (size_t)r * 5) * 8;
     { GRX_PROF(GRX_K_PROJECT, st);
-    project_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
+    project_mfma_kernel<<<grid, 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
     }
     GRX_LAUNCH_CHECK();
     project_finalize_kernel<<<r, 64, 0, st>>>(partial, grid, r, d_stats);
