@@ -649,14 +649,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
         }
         __syncthreads();
     }
-    double hA[F4], hhA[4];
+    double hA[F4], hhA[R4];
 #pragma unroll
     for (int q = 0; q < F4; ++q) {
         const int c = 4 * q + lq;
         hA[q] = (li < r && c < F) ? H[li * F + c] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
+    for (int q = 0; q < R4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
     __syncthreads();                                             // sH (aliased) is dead from here on
     double *xT = fsm + wave * WAVE_LDS;                          // [c][i], row stride MF_LD
     double *wT = xT + 16 * FT * MF_LD;                           // [k][i]

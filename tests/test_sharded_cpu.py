@@ -56,10 +56,11 @@ def _worker(rank, port, case, out_dir, WORLD):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('ba2000', 2), ('er300', 3), ('directed120', 3)])
+@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('ba2000', 2), ('er300', 3), ('directed120', 3), ('karate', 7)])
 def test_sharded_pipeline_equals_single_process(case, WORLD, tmp_path):
-    """2 and 3 ranks (3: candidate counts that do not divide by the world size -> uneven column
-    ownership in the owner all-to-all)."""
+    """2, 3 and 7 ranks (3: candidate counts that do not divide by the world size -> uneven column
+    ownership in the owner all-to-all; 7 > the 6 candidates of generation 1: ranks that own no column
+    and send / receive zero-length messages)."""
     port = _free_port()
     mp.spawn(_worker, args=(port, case, str(tmp_path), WORLD), nprocs=WORLD, join=True)
     r0 = np.load(tmp_path / 'rank0.npz')
