@@ -127,6 +127,67 @@ class CSRGraph:
     def neighbors(self, row: int) -> np.ndarray:
         return self.col[self.row_ptr[row]:self.row_ptr[row + 1]]
 
+    # ------------------------------------------------------------------ other array-native inputs
+    @classmethod
+    def from_scipy_sparse(cls, A, directed: bool = False, weighted: Optional[bool] = None,
+                          labels: Optional[Sequence] = None,
+                          attributes: Optional[Dict[str, np.ndarray]] = None) -> 'CSRGraph':
+        """
+        Adjacency matrix (any scipy.sparse format, square; entry (i, j) = weight of i -> j).
+        Undirected: the matrix must be symmetric, every edge is taken once from the upper triangle.
+        ``weighted=None`` treats the matrix as unweighted iff every stored value equals 1.
+        The neighbour order of the sums is the stored order of each row of ``A.tocsr()``.
+        """
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        n = A.shape[0]
+        if A.shape[0] != A.shape[1]:
+            raise ValueError('adjacency matrix must be square')
+        A.sum_duplicates()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.indptr))
+        cols = A.indices.astype(np.int64)
+        data = np.asarray(A.data)
+        if weighted is None:
+            weighted = bool(len(data)) and not np.all(data == 1)
+        if directed:
+            src, dst, w = rows, cols, data
+        else:
+            if (abs(A - A.T) > 0).nnz:
+                raise ValueError('undirected input needs a symmetric adjacency matrix')
+            upper = rows <= cols
+            src, dst, w = rows[upper], cols[upper], data[upper]
+        return cls(n, src, dst, weights=w if weighted else None, directed=directed, labels=labels,
+                   attributes=attributes, validate=False, adjacency=A.indices)
+
+    @classmethod
+    def from_edgelist_file(cls, path: str, directed: bool = False, weighted: bool = False,
+                           comments: str = '#', delimiter: Optional[str] = None) -> 'CSRGraph':
+        """
+        Text edge list, one ``u v [w]`` per line with integer node ids (any integers: the sorted unique
+        ids become the labels).  Parallel edges are merged by summing their weights (unweighted: dropped),
+        an undirected edge may appear in either orientation.
+        """
+        table = np.loadtxt(path, comments=comments, delimiter=delimiter, ndmin=2,
+                           dtype=np.float64 if weighted else np.int64)
+        if table.shape[1] < (3 if weighted else 2):
+            raise ValueError(f'{path}: expected {"u v w" if weighted else "u v"} per line')
+        u, v = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
+        labels, inverse = np.unique(np.concatenate([u, v]), return_inverse=True)
+        n = len(labels)
+        src, dst = inverse[:len(u)].astype(np.int64), inverse[len(u):].astype(np.int64)
+        w = table[:, 2] if weighted else None
+        a, b = (src, dst) if directed else (np.minimum(src, dst), np.maximum(src, dst))
+        key = a * n + b
+        first = np.unique(key, return_index=True)[1]
+        if len(first) != len(key):                                  # merge parallel edges, keep first position
+            order = np.sort(first)
+            if weighted:
+                uniq, inv = np.unique(key, return_inverse=True)
+                wsum = np.bincount(inv, weights=w, minlength=len(uniq))
+                w = wsum[np.searchsorted(uniq, key[order])]
+            src, dst = a[order], b[order]
+        return cls(n, src, dst, weights=w, directed=directed, labels=[int(x) for x in labels], validate=False)
+
 
 class InternalGraph:
     """

@@ -85,3 +85,39 @@ def test_internal_graph_keeps_each_rows_sequence():
         assert list(ig.agg_col[ig.row_ptr[i]:ig.row_ptr[i + 1]]) == want_order
     x = rng.random(n)
     assert np.array_equal(ig.to_label_order(ig.to_internal(x)), x)
+
+
+def test_csr_graph_from_scipy_sparse_and_edgelist_file(tmp_path):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1)
+    n = 30
+    src, dst = rng.integers(0, n, 120), rng.integers(0, n, 120)
+    key = np.minimum(src, dst) * n + np.maximum(src, dst)
+    _, idx = np.unique(key, return_index=True)
+    src, dst = src[np.sort(idx)], dst[np.sort(idx)]
+    w = rng.uniform(0.5, 2.0, len(src))
+    ref = CSRGraph(n, src, dst, weights=w)
+    A = sp.coo_matrix((np.concatenate([w, w[src != dst]]),
+                       (np.concatenate([src, dst[src != dst]]), np.concatenate([dst, src[src != dst]]))), shape=(n, n))
+    g = CSRGraph.from_scipy_sparse(A)
+    assert g.weighted and not g.directed and g.num_edges == ref.num_edges
+    assert np.array_equal(g.row_ptr, ref.row_ptr) and np.array_equal(g.col, ref.col)
+    np.testing.assert_allclose(g.w, ref.w)
+    assert sorted(g.adj_col[g.row_ptr[3]:g.row_ptr[4]]) == list(ref.col[ref.row_ptr[3]:ref.row_ptr[4]])
+    gu = CSRGraph.from_scipy_sparse((A != 0).astype(float))
+    assert not gu.weighted and gu.integral
+    gd = CSRGraph.from_scipy_sparse(sp.csr_matrix(([1.0, 2.0], ([0, 2], [1, 0])), shape=(3, 3)), directed=True)
+    assert gd.directed and gd.num_edges == 2 and list(gd.col) == [1, 0]
+    with pytest.raises(ValueError, match='symmetric'):
+        CSRGraph.from_scipy_sparse(sp.csr_matrix(([1.0], ([0], [1])), shape=(2, 2)))
+    # text edge list with arbitrary integer ids, a duplicate and a comment line
+    path = tmp_path / 'edges.txt'
+    path.write_text('# u v\n10 20\n20 30\n30 10\n20 10\n40 40\n')
+    ge = CSRGraph.from_edgelist_file(str(path))
+    assert ge.labels == [10, 20, 30, 40] and ge.num_edges == 4              # 20-10 merged with 10-20
+    assert _rows(ge.row_ptr, ge.col) == [[1, 2], [0, 2], [0, 1], [3]]
+    pathw = tmp_path / 'edges_w.txt'
+    pathw.write_text('1 2 0.5\n2 1 1.5\n2 3 2.0\n')
+    gw = CSRGraph.from_edgelist_file(str(pathw), weighted=True)
+    assert gw.num_edges == 2 and gw.weighted
+    np.testing.assert_allclose(gw.w[gw.row_ptr[0]:gw.row_ptr[1]], [2.0])      # 0.5 + 1.5 merged
