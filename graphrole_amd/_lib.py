@@ -59,6 +59,8 @@ _SIGNATURES = {
     'grx_aggregate_plan_set_lanes': (c_int, [c_void_p, c_int]),
     'grx_aggregate': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
                               c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_var': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_aggregate_minmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -504,11 +504,20 @@ __global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const doubl
 constexpr int PW_BLOCK = 128;
 constexpr int PW_CHUNK = 8192;
 
-template <int LDR, int G>
+// SQDEV: the summands are (m - x)^2 with the per-column values m0, m1 (pandas' nanvar:
+// avg = sum / count; ((avg - values) ** 2).sum() -- the same pairwise tree over the transformed values).
+template <int LDR, int G, bool SQDEV = false>
 __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col, const double *__restrict__ rows,
                                                  int64_t row_stride, int64_t b, int cnt, int part, int slot,
-                                                 double &o0, double &o1)
+                                                 double &o0, double &o1, double m0 = 0.0, double m1 = 0.0)
 {
+    // the squares must be rounded before they are added, as numpy does: no fma contraction in here
+#pragma clang fp contract(off)
+    auto tr = [&](double2 x) {
+#pragma clang fp contract(off)
+        if (SQDEV) { const double t0 = m0 - x.x, t1 = m1 - x.y; x.x = t0 * t0; x.y = t1 * t1; }
+        return x;
+    };
     constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     constexpr int S = G / CL, A = 8 / S;
     static_assert(S >= 1 && S <= 8 && S * A == 8, "lane group must hold 1..8 neighbour slots");
@@ -520,7 +529,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
 #pragma unroll
         for (int t = 0; t < A; ++t) {
             const int64_t u = col[b + slot + t * S];
-            const double2 x = *reinterpret_cast<const double2 *>(base + u * row_stride);
+            const double2 x = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
             r0[t] = x.x; r1[t] = x.y;
         }
         int i = 8;
@@ -530,8 +539,8 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
 #pragma unroll
                 for (int t = 0; t < A; ++t) {
                     const int64_t u0 = col[b + i + slot + t * S], u1 = col[b + i + 8 + slot + t * S];
-                    x[t] = *reinterpret_cast<const double2 *>(base + u0 * row_stride);
-                    x[A + t] = *reinterpret_cast<const double2 *>(base + u1 * row_stride);
+                    x[t] = tr(*reinterpret_cast<const double2 *>(base + u0 * row_stride));
+                    x[A + t] = tr(*reinterpret_cast<const double2 *>(base + u1 * row_stride));
                 }
 #pragma unroll
                 for (int t = 0; t < A; ++t) { r0[t] += x[t].x; r1[t] += x[t].y; }
@@ -543,7 +552,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
 #pragma unroll
             for (int t = 0; t < A; ++t) {
                 const int64_t u = col[b + i + slot + t * S];
-                const double2 x = *reinterpret_cast<const double2 *>(base + u * row_stride);
+                const double2 x = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
                 r0[t] += x.x; r1[t] += x.y;
             }
         }
@@ -575,7 +584,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
             x[t] = make_double2(0.0, 0.0);
             if (idx < cnt) {
                 const int64_t u = col[b + idx];
-                x[t] = *reinterpret_cast<const double2 *>(base + u * row_stride);
+                x[t] = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
             }
         }
 #pragma unroll
@@ -588,11 +597,14 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
     o0 = res0; o1 = res1;
 }
 
-template <int LDR, int G>
+// VAR: out_sum / out_mean become out_var / out_std -- the sample variance (ddof = 1, pandas' default)
+// of the neighbours' values around mean_in (the 'mean' output of a previous launch) and its root.
+template <int LDR, int G, bool VAR = false>
 __global__ __launch_bounds__(256) void aggregate_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ rows, int64_t row_stride, int f, int64_t row_begin, int64_t row_end,
-    double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld)
+    double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld,
+    const double *__restrict__ mean_in = nullptr)
 {
     constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     const int lane = threadIdx.x % G;
@@ -604,29 +616,49 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
         const int64_t d = e - b;
         if (d > PW_BLOCK) continue;                       // aggregate_blocks_kernel + aggregate_combine_kernel
         double a0, a1;
-        pairwise_segment<LDR, G>(col, rows, row_stride, b, (int)d, part, slot, a0, a1);
+        const int c0 = 2 * part, c1 = 2 * part + 1;
+        if (VAR) {
+            const double m0 = c0 < f ? mean_in[(int64_t)c0 * ld + v] : 0.0;
+            const double m1 = c1 < f ? mean_in[(int64_t)c1 * ld + v] : 0.0;
+            pairwise_segment<LDR, G, true>(col, rows, row_stride, b, (int)d, part, slot, a0, a1, m0, m1);
+        } else {
+            pairwise_segment<LDR, G>(col, rows, row_stride, b, (int)d, part, slot, a0, a1);
+        }
         if (slot == 0) {
             const double cnt = (double)d;
-            const int c0 = 2 * part, c1 = 2 * part + 1;
-            if (c0 < f) {
-                if (out_sum) out_sum[(int64_t)c0 * ld + v] = a0;
-                if (out_mean) out_mean[(int64_t)c0 * ld + v] = (d > 0) ? a0 / cnt : 0.0;
-            }
-            if (c1 < f) {
-                if (out_sum) out_sum[(int64_t)c1 * ld + v] = a1;
-                if (out_mean) out_mean[(int64_t)c1 * ld + v] = (d > 0) ? a1 / cnt : 0.0;
+            if (VAR) {
+                // count - ddof <= 0 -> NaN -> fillna(0) (extract.py:113)
+                const double v0 = (d > 1) ? a0 / (cnt - 1.0) : 0.0, v1 = (d > 1) ? a1 / (cnt - 1.0) : 0.0;
+                if (c0 < f) {
+                    if (out_sum) out_sum[(int64_t)c0 * ld + v] = v0;
+                    if (out_mean) out_mean[(int64_t)c0 * ld + v] = sqrt(v0);
+                }
+                if (c1 < f) {
+                    if (out_sum) out_sum[(int64_t)c1 * ld + v] = v1;
+                    if (out_mean) out_mean[(int64_t)c1 * ld + v] = sqrt(v1);
+                }
+            } else {
+                if (c0 < f) {
+                    if (out_sum) out_sum[(int64_t)c0 * ld + v] = a0;
+                    if (out_mean) out_mean[(int64_t)c0 * ld + v] = (d > 0) ? a0 / cnt : 0.0;
+                }
+                if (c1 < f) {
+                    if (out_sum) out_sum[(int64_t)c1 * ld + v] = a1;
+                    if (out_mean) out_mean[(int64_t)c1 * ld + v] = (d > 0) ? a1 / cnt : 0.0;
+                }
             }
         }
     }
 }
 
 // One lane group per block of a long row (57..128 neighbours); block sums to blk_sums[blk][16].
-template <int LDR, int G>
+template <int LDR, int G, bool VAR = false>
 __global__ __launch_bounds__(256) void aggregate_blocks_kernel(
     const int32_t *__restrict__ col, const double *__restrict__ rows, int64_t row_stride,
     int64_t row_begin, int64_t row_end, const int32_t *__restrict__ long_rows,
     const int64_t *__restrict__ blk_begin, const int32_t *__restrict__ blk_len,
-    const int32_t *__restrict__ blk_row, int64_t n_blocks, double *__restrict__ blk_sums)
+    const int32_t *__restrict__ blk_row, int64_t n_blocks, double *__restrict__ blk_sums,
+    const double *__restrict__ mean_in = nullptr, int64_t ld = 0, int f = 0)
 {
     constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     const int lane = threadIdx.x % G;
@@ -637,7 +669,14 @@ __global__ __launch_bounds__(256) void aggregate_blocks_kernel(
         const int64_t v = long_rows[blk_row[k]];
         if (v < row_begin || v >= row_end) continue;
         double a0, a1;
-        pairwise_segment<LDR, G>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1);
+        if (VAR) {
+            const int c0 = 2 * part, c1 = 2 * part + 1;
+            const double m0 = c0 < f ? mean_in[(int64_t)c0 * ld + v] : 0.0;
+            const double m1 = c1 < f ? mean_in[(int64_t)c1 * ld + v] : 0.0;
+            pairwise_segment<LDR, G, true>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1, m0, m1);
+        } else {
+            pairwise_segment<LDR, G>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1);
+        }
         if (slot == 0) {
             blk_sums[k * 16 + 2 * part] = a0;
             blk_sums[k * 16 + 2 * part + 1] = a1;
@@ -658,7 +697,7 @@ __global__ __launch_bounds__(64) void aggregate_combine_kernel(
     const int64_t *__restrict__ row_ptr, int f, int64_t row_begin, int64_t row_end,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ blk_ptr, int64_t n_long,
     const uint8_t *__restrict__ blk_ops, const double *__restrict__ blk_sums, double *__restrict__ out_sum,
-    double *__restrict__ out_mean, int64_t ld)
+    double *__restrict__ out_mean, int64_t ld, int var_mode)
 {
     __shared__ double stage_lds[PW_MAX_BLOCKS_PER_CHUNK * 16];
     __shared__ uint8_t ops_lds[PW_MAX_BLOCKS_PER_CHUNK];
@@ -693,8 +732,14 @@ __global__ __launch_bounds__(64) void aggregate_combine_kernel(
             __syncthreads();
         }
         if (threadIdx.x < f) {
-            if (out_sum) out_sum[(int64_t)c * ld + v] = total;
-            if (out_mean) out_mean[(int64_t)c * ld + v] = total / (double)n;
+            if (var_mode) {                                     // long rows have n > 128 >= 2
+                const double var = total / ((double)n - 1.0);
+                if (out_sum) out_sum[(int64_t)c * ld + v] = var;
+                if (out_mean) out_mean[(int64_t)c * ld + v] = sqrt(var);
+            } else {
+                if (out_sum) out_sum[(int64_t)c * ld + v] = total;
+                if (out_mean) out_mean[(int64_t)c * ld + v] = total / (double)n;
+            }
         }
     }
 }
@@ -776,25 +821,32 @@ void pairwise_blocks(int64_t begin, int64_t n, std::vector<int64_t> &b, std::vec
 template <int LDR, int G>
 int launch_aggregate_g(const grx_aggregate_plan *p, const int64_t *row_ptr, const int32_t *col, const double *rows,
                        int64_t row_stride, int f, int64_t rb, int64_t re, double *s, double *m, int64_t ld,
-                       hipStream_t st)
+                       hipStream_t st, const double *mean_in = nullptr)
 {
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
     const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
     {
         GRX_PROF(GRX_K_AGGREGATE, st);
-        aggregate_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld);
+        if (mean_in) aggregate_kernel<LDR, G, true><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld, mean_in);
+        else aggregate_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld);
     }
     GRX_LAUNCH_CHECK();
     if (p->n_long > 0) {
         const int64_t bwant = grx_ceil_div(p->n_blocks * G, 256);
         const int bgrid = (int)(bwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : bwant);
         GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-        aggregate_blocks_kernel<LDR, G><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
-                                                               p->d_blk_begin, p->d_blk_len, p->d_blk_row,
-                                                               p->n_blocks, p->d_blk_sums);
+        if (mean_in)
+            aggregate_blocks_kernel<LDR, G, true><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
+                                                                         p->d_blk_begin, p->d_blk_len, p->d_blk_row,
+                                                                         p->n_blocks, p->d_blk_sums, mean_in, ld, f);
+        else
+            aggregate_blocks_kernel<LDR, G><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
+                                                                   p->d_blk_begin, p->d_blk_len, p->d_blk_row,
+                                                                   p->n_blocks, p->d_blk_sums);
         aggregate_combine_kernel<<<(unsigned)(p->n_long > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : p->n_long), 64, 0, st>>>(
-            row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_ops, p->d_blk_sums, s, m, ld);
+            row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_ops, p->d_blk_sums, s, m, ld,
+            mean_in ? 1 : 0);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -818,7 +870,7 @@ int launch_minmax_g(const int64_t *row_ptr, const int32_t *col, const double *ro
 template <int LDR>
 int launch_aggregate(bool minmax, const grx_aggregate_plan *p, const int64_t *row_ptr, const int32_t *col,
                      const double *rows, int64_t row_stride, int f, int64_t rb, int64_t re, double *a, double *b,
-                     int64_t ld, hipStream_t st)
+                     int64_t ld, hipStream_t st, const double *mean_in = nullptr)
 {
     constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     int G = p->lanes_per_row;
@@ -829,7 +881,8 @@ int launch_aggregate(bool minmax, const grx_aggregate_plan *p, const int64_t *ro
     case GG:                                                                                                          \
         if constexpr (GG >= CL && GG <= 8 * CL)                                                                       \
             return minmax ? launch_minmax_g<LDR, GG>(row_ptr, col, rows, row_stride, f, rb, re, a, b, ld, st)         \
-                          : launch_aggregate_g<LDR, GG>(p, row_ptr, col, rows, row_stride, f, rb, re, a, b, ld, st);  \
+                          : launch_aggregate_g<LDR, GG>(p, row_ptr, col, rows, row_stride, f, rb, re, a, b, ld, st,   \
+                                                        mean_in);                                                     \
         break;
     switch (G) {
         GRX_AGG_CASE(4)
@@ -845,9 +898,9 @@ int launch_aggregate(bool minmax, const grx_aggregate_plan *p, const int64_t *ro
 
 int aggregate_dispatch(bool minmax, const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col,
                        int f, const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, double *d_a,
-                       double *d_b, int64_t ld, void *stream)
+                       double *d_b, int64_t ld, void *stream, const double *d_mean_in = nullptr)
 {
-    const char *who = minmax ? "grx_aggregate_minmax" : "grx_aggregate";
+    const char *who = minmax ? "grx_aggregate_minmax" : (d_mean_in ? "grx_aggregate_var" : "grx_aggregate");
     GRX_REQUIRE(plan != nullptr, "%s: NULL plan (grx_aggregate_plan_create)", who);
     const int64_t n = plan->n;
     GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= n, "%s: bad row range", who);
@@ -861,16 +914,17 @@ int aggregate_dispatch(bool minmax, const grx_aggregate_plan *plan, const int64_
     hipStream_t st = grx_stream(stream);
     if (ldr < 16)
         switch (ldr) {
-        case 2:  return launch_aggregate<2>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
-        case 4:  return launch_aggregate<4>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
-        default: return launch_aggregate<8>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st);
+        case 2:  return launch_aggregate<2>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st, d_mean_in);
+        case 4:  return launch_aggregate<4>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st, d_mean_in);
+        default: return launch_aggregate<8>(minmax, plan, d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end, d_a, d_b, ld, st, d_mean_in);
         }
     // wide rows: 16 columns (one 128-byte segment of every row) per launch
     for (int c0 = 0; c0 < f; c0 += 16) {
         const int fc = (f - c0 < 16) ? (f - c0) : 16;
         double *a = d_a ? d_a + (int64_t)c0 * ld : nullptr;
         double *b = d_b ? d_b + (int64_t)c0 * ld : nullptr;
-        int rc = launch_aggregate<16>(minmax, plan, d_row_ptr, d_col, d_rows + c0, ldr, fc, row_begin, row_end, a, b, ld, st);
+        int rc = launch_aggregate<16>(minmax, plan, d_row_ptr, d_col, d_rows + c0, ldr, fc, row_begin, row_end, a, b, ld, st,
+                                      d_mean_in ? d_mean_in + (int64_t)c0 * ld : nullptr);
         if (rc != GRX_OK) return rc;
     }
     return GRX_OK;
@@ -1107,6 +1161,15 @@ int grx_aggregate(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, cons
                   double *d_sum, double *d_mean, int64_t ld, void *stream)
 {
     return aggregate_dispatch(false, plan, d_row_ptr, d_col, f, d_rows, ldr, row_begin, row_end, d_sum, d_mean, ld, stream);
+}
+
+int grx_aggregate_var(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                      const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, const double *d_mean,
+                      double *d_var, double *d_std, int64_t ld, void *stream)
+{
+    GRX_REQUIRE(d_mean != nullptr || f == 0 || row_begin == row_end, "grx_aggregate_var: needs the neighbour means (grx_aggregate)");
+    return aggregate_dispatch(false, plan, d_row_ptr, d_col, f, d_rows, ldr, row_begin, row_end, d_var, d_std, ld, stream,
+                              d_mean);
 }
 
 int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,

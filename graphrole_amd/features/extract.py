@@ -23,7 +23,7 @@ from graphrole_amd.features.prune import FeaturePruner
 from graphrole_amd.graph import interface
 from graphrole_amd.types import DataFrameDict, DataFrameLike
 
-_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max')
+_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std')
 
 
 def _agg_name(agg) -> str:
@@ -199,10 +199,16 @@ class RecursiveFeatureExtractor:
         rows, ldr = K.pack_rows([self._work[c] for c in prev], n)
         rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
         pieces = {}
-        if 'sum' in aggs or 'mean' in aggs:
+        need_var = 'var' in aggs or 'std' in aggs
+        if 'sum' in aggs or 'mean' in aggs or need_var:
             block = K.aggregate(dev_graph, rows, f, ldr, rb, re,
-                                want_sum='sum' in aggs, want_mean='mean' in aggs)
+                                want_sum='sum' in aggs, want_mean='mean' in aggs or need_var)
             pieces['sum'], pieces['mean'] = block[:f], block[f:]
+        if need_var:
+            # pandas' nanvar: squared deviations from the neighbour mean, ddof = 1
+            vs = K.aggregate_var(dev_graph, rows, f, ldr, pieces['mean'], rb, re,
+                                 want_var='var' in aggs, want_std='std' in aggs)
+            pieces['var'], pieces['std'] = vs[:f], vs[f:]
         if 'min' in aggs or 'max' in aggs:
             mm = K.aggregate_minmax(dev_graph, rows, f, ldr, rb, re,
                                     want_min='min' in aggs, want_max='max' in aggs)
@@ -223,11 +229,11 @@ class RecursiveFeatureExtractor:
         cols = [sub[j] for j in range(len(picked))]
         names = [f'{c}({a})' for a in aggs for c in prev]
         # pandas dtype of the reference's frame (extract.py:104-119): the per-node agg frame of an
-        # integer column stays integer unless 'mean' is among the aggs or a node without
-        # neighbours turns min / max into NaN -> 0.0; one float value makes the column float64
+        # integer column stays integer unless 'mean' / 'std' / 'var' is among the aggs or a node
+        # without neighbours turns min / max into NaN -> 0.0; one float value makes the column float64
         host = self.graph._device_graph()[0]
         no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
-        keeps_int = 'mean' not in aggs and (no_empty_rows or set(aggs) <= {'sum'})
+        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum'})
         f64, i64 = np.dtype('float64'), np.dtype('int64')
         dtypes = [i64 if keeps_int and self._dtypes.get(c, f64).kind in 'iu' else f64 for a in aggs for c in prev]
         return names, cols, dtypes, sub

@@ -279,6 +279,23 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
     return out
 
 
+def aggregate_var(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, mean: torch.Tensor, row_begin: int = 0,
+                  row_end: Optional[int] = None, want_var: bool = True, want_std: bool = True) -> torch.Tensor:
+    """[2f, n] block: rows 0..f-1 = sample variance (ddof = 1) of the neighbours' values, rows f..2f-1 =
+    its square root; `mean` = the [f, n] neighbour means of the same rows (aggregate()[f:])."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+    if f == 0:
+        return out
+    assert mean.shape == (f, n) and mean.is_contiguous()
+    v_ptr = c_void_p(out.data_ptr()) if want_var else None
+    s_ptr = c_void_p(out.data_ptr() + f * n * 8) if want_std else None
+    _lib.call('grx_aggregate_var', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr,
+              row_begin, row_end, _ptr(mean), v_ptr, s_ptr, n, _stream())
+    return out
+
+
 def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
                      row_end: Optional[int] = None, want_min: bool = True, want_max: bool = True) -> torch.Tensor:
     """[2f, n] block: rows 0..f-1 = neighbour minima, rows f..2f-1 = neighbour maxima."""

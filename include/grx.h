@@ -171,6 +171,12 @@ int grx_aggregate_plan_set_lanes(grx_aggregate_plan *plan, int lanes_per_row);  
 int grx_aggregate(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                   const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
                   double *d_sum, double *d_mean, int64_t ld, void *stream);
+/* aggs 'var' / 'std' (pandas: sample variance, ddof = 1): with d_mean the 'mean' output of grx_aggregate for
+ * the same rows, var = pairwise-sum((mean - x)^2) / (count - 1) and std = sqrt(var) -- pandas' nanvar, bit for
+ * bit; 0 for rows with fewer than two neighbours (NaN -> fillna(0)).  Either output may be NULL. */
+int grx_aggregate_var(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                      const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, const double *d_mean,
+                      double *d_var, double *d_std, int64_t ld, void *stream);
 int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                          const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
                          double *d_min, double *d_max, int64_t ld, void *stream);

@@ -33,6 +33,8 @@ def lib():
         L = ctypes.CDLL(_SO)
         L.orc_aggregate.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p, _f64p]
         L.orc_aggregate.restype = None
+        L.orc_aggregate_var.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p, _f64p]
+        L.orc_aggregate_var.restype = None
         L.orc_aggregate_minmax.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p, _f64p]
         L.orc_aggregate_minmax.restype = None
         L.orc_rowsum.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_void_p, ctypes.c_int, _f64p]
@@ -58,6 +60,15 @@ def aggregate(row_ptr, col, X):
     M = np.empty_like(X)
     lib().orc_aggregate(n, row_ptr, col, f, X, S, M)
     return S, M
+
+
+def aggregate_var(row_ptr, col, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, f = X.shape
+    var = np.empty_like(X)
+    std = np.empty_like(X)
+    lib().orc_aggregate_var(n, row_ptr, col, f, X, var, std)
+    return var, std
 
 
 def aggregate_minmax(row_ptr, col, X):

@@ -77,6 +77,45 @@ void orc_aggregate(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
     }
 }
 
+/* graphrole/features/extract.py:98-119 with 'var' / 'std' among the aggregations: pandas' nanvar, ddof = 1:
+ * avg = sum / count, var = sum((avg - x)^2) / (count - 1), both sums in ndarray.sum() order; std = sqrt(var);
+ * fewer than two neighbours -> NaN -> 0. */
+void orc_aggregate_var(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
+                       const double *X, double *VAR, double *STD)
+{
+    if (f <= 0) return;
+    for (int64_t v = 0; v < n; ++v) {
+        double *var = VAR + v * f, *sd = STD + v * f;
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1], cnt = e - b;
+        for (int c = 0; c < f; ++c) var[c] = sd[c] = 0.0;
+        if (cnt < 2) continue;
+        /* the transformed rows (avg - x)^2 in neighbour order, then the same summation routine */
+        double avg[f];
+        int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)cnt);
+        double *T = (double *)malloc(sizeof(double) * (size_t)cnt * (size_t)f);
+        for (int c = 0; c < f; ++c) avg[c] = 0.0;
+        for (int64_t k = b; k < e; k += 8192) {
+            double part[f];
+            pairwise_rows(col, X, f, k, (e - k < 8192) ? e - k : 8192, part);
+            for (int c = 0; c < f; ++c) avg[c] += part[c];
+        }
+        for (int c = 0; c < f; ++c) avg[c] /= (double)cnt;
+        for (int64_t k = 0; k < cnt; ++k) {
+            const double *x = X + (int64_t)col[b + k] * f;
+            idx[k] = (int32_t)k;
+            for (int c = 0; c < f; ++c) { const double t = avg[c] - x[c]; T[k * f + c] = t * t; }
+        }
+        for (int64_t k = 0; k < cnt; k += 8192) {
+            double part[f];
+            pairwise_rows(idx, T, f, k, (cnt - k < 8192) ? cnt - k : 8192, part);
+            for (int c = 0; c < f; ++c) var[c] += part[c];
+        }
+        for (int c = 0; c < f; ++c) { var[c] /= (double)(cnt - 1); sd[c] = sqrt(var[c]); }
+        free(idx);
+        free(T);
+    }
+}
+
 /* graphrole/features/extract.py:98-119 with 'min' / 'max' among the aggregations: column-wise
  * minimum / maximum over the neighbours' rows; no neighbours -> NaN -> fillna(0) (:113). */
 void orc_aggregate_minmax(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,

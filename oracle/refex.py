@@ -324,6 +324,28 @@ def aggregate(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return s, m
 
 
+def aggregate_var(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """
+    features/extract.py:98-119 with 'var' / 'std' in `aggs`: pandas' nanvar with ddof = 1
+    (pandas/core/nanops.py: avg = values.sum() / count; sqr = (avg - values) ** 2;
+    var = sqr.sum() / (count - 1)), both sums by ndarray_sum in adjacency order; std = sqrt(var);
+    fewer than two neighbours -> NaN -> 0 (:113).
+    """
+    n, f = X.shape
+    var = np.zeros((n, f))
+    std = np.zeros((n, f))
+    for v in range(n):
+        nb = g.adj_row(v)
+        k = len(nb)
+        if k >= 2:
+            A = X[nb]
+            avg = ndarray_sum(A) / k
+            sq = ndarray_sum((avg - A) ** 2)
+            var[v] = sq / (k - 1)
+            std[v] = np.sqrt(var[v])
+    return var, std
+
+
 def aggregate_minmax(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """
     features/extract.py:98-119 with 'min' / 'max' in `aggs`: column-wise minimum / maximum over
@@ -479,11 +501,13 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         from . import ckernels
         agg_fn = lambda gg, X: ckernels.aggregate(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
         minmax_fn = lambda gg, X: ckernels.aggregate_minmax(gg.row_ptr, gg.col, X)
+        var_fn = lambda gg, X: ckernels.aggregate_var(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
         bin_fn = ckernels.vertical_log_binning
         cheb_fn = lambda B: ckernels.chebyshev(B.T)
     else:
         agg_fn, bin_fn, cheb_fn = aggregate, vertical_log_binning, chebyshev_matrix
         minmax_fn = aggregate_minmax
+        var_fn = aggregate_var
     names0, X0 = gen0 if gen0 is not None else neighborhood_features(g, fast)
     work: Dict[str, np.ndarray] = {}
     final_names: Dict[int, List[str]] = {}
@@ -519,6 +543,8 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         blocks = {'sum': s, 'mean': m}
         if 'min' in aggs or 'max' in aggs:
             blocks['min'], blocks['max'] = minmax_fn(g, Xp)
+        if 'var' in aggs or 'std' in aggs:
+            blocks['var'], blocks['std'] = var_fn(g, Xp)
         cand_names = [f'{c}({a})' for a in aggs for c in prev]        # extract.py:152-162
         cand_vals = np.column_stack([blocks[a] for a in aggs]) if prev else np.zeros((g.n, 0))
         update(gen, cand_names, cand_vals, gen)

@@ -95,6 +95,20 @@ def aggregate(csr, rows, f, ldr, row_begin=0, row_end=None, want_sum=True, want_
     return res
 
 
+def aggregate_var(csr, rows, f, ldr, mean, row_begin=0, row_end=None, want_var=True, want_std=True):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    res = torch.zeros((2 * f, n), dtype=torch.float64)
+    if f == 0:
+        return res
+    var, std = ckernels.aggregate_var(csr.row_ptr, csr.agg_col, np.ascontiguousarray(rows.numpy()[:n, :f]))
+    if want_var:
+        res[:f, row_begin:row_end] = torch.from_numpy(var.T[:, row_begin:row_end].copy())
+    if want_std:
+        res[f:, row_begin:row_end] = torch.from_numpy(std.T[:, row_begin:row_end].copy())
+    return res
+
+
 def aggregate_minmax(csr, rows, f, ldr, row_begin=0, row_end=None, want_min=True, want_max=True):
     n = csr.n
     row_end = n if row_end is None else row_end

@@ -84,6 +84,8 @@ CASE_AGGS = {
     'ba300_maxsum': ('ba300', ['max', 'sum']),
     'dw200_minmax': ('dw200_attrs', ['min', 'max', 'mean']),
     'loops_dangling150_minmax': ('loops_dangling150', ['sum', 'min', 'max']),
+    'ba300_stdvar': ('ba300', ['mean', 'std', 'var']),
+    'karate_sumstd': ('karate', ['sum', 'std']),
 }
 
 BUILDERS = {

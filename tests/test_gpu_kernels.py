@@ -183,6 +183,61 @@ def test_aggregate_equals_numpy_sum_on_huge_row(K):
     assert np.array_equal(got[0, 1:], np.full(n - 1, x[0]))
 
 
+@pytest.mark.parametrize('lanes', [None, 4, 16])
+@pytest.mark.parametrize('f', [1, 2, 3, 5, 8, 13, 17, 26])
+def test_aggregate_var_bit_exact_vs_oracle(K, f, lanes):
+    """var / std = pandas' nanvar (ddof 1): the squared deviations from the neighbour mean are summed
+    with the same numpy-pairwise order as the sums; rows with < 2 neighbours give NaN -> 0."""
+    import torch
+    from oracle import ckernels
+    if lanes is not None and f not in (3, 8, 17):
+        pytest.skip('lane-group sweep on a few widths')
+    n, m = 20000, 1 if f == 2 else 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=100 + f)
+    og = _oracle_graph(n, src, dst, None, False)
+    deg = np.diff(og.row_ptr)
+    assert deg.max() > (300 if m == 6 else 64) and (m == 6 or (deg == 1).any())
+    og.row_ptr = np.concatenate([og.row_ptr, np.full(3, og.row_ptr[-1])])
+    n2 = og.n
+    X = np.random.default_rng(f).standard_normal((n2, f)) * 10.0 ** np.arange(f).clip(0, 6)
+    V, S = ckernels.aggregate_var(og.row_ptr, og.adj_col, X)
+    csr = _dev_csr(K, og)
+    if lanes is not None:
+        csr.plan().set_lanes(lanes)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
+    mean = K.aggregate(csr, rows, f, ldr, want_sum=False)[f:].contiguous()
+    got = K.aggregate_var(csr, rows, f, ldr, mean).cpu().numpy()
+    assert np.array_equal(got[:f].T, V), f'{int((got[:f].T != V).sum())} variances differ'
+    assert np.array_equal(got[f:].T, S), f'{int((got[f:].T != S).sum())} stds differ'
+    one = np.flatnonzero(np.diff(og.row_ptr) < 2)
+    assert not got[:, one].any()
+    part = K.aggregate_var(csr, rows, f, ldr, mean, row_begin=50, row_end=7000, want_var=False).cpu().numpy()
+    assert np.array_equal(part[f:, 50:7000], got[f:, 50:7000]) and not part[:f].any() and not part[f:, 7000:].any()
+
+
+def test_aggregate_var_equals_pandas_on_huge_row(K):
+    """70 001 neighbours: block tree + 8192-element chunks, against DataFrame.var() itself."""
+    import pandas as pd
+    import torch
+    n = 70002
+    src = np.zeros(n - 1, dtype=np.int64)
+    dst = np.arange(1, n, dtype=np.int64)
+    rng = np.random.default_rng(6)
+    perm = rng.permutation(n - 1)
+    og = _oracle_graph(n, src[perm], dst[perm], None, False)
+    csr = _dev_csr(K, og)
+    x = rng.random((n, 2)) ** 3 * 1e2
+    Xd = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[0], Xd[1]], n)
+    mean = K.aggregate(csr, rows, 2, ldr, want_sum=False)[2:].contiguous()
+    got = K.aggregate_var(csr, rows, 2, ldr, mean).cpu().numpy()
+    frame = pd.DataFrame(x[og.adj_row(0)])
+    assert np.array_equal(got[:2, 0], frame.var().to_numpy())
+    assert np.array_equal(got[2:, 0], frame.std().to_numpy())
+    assert not got[:, 1:].any()                                 # leaves have one neighbour
+
+
 @pytest.mark.parametrize('f', [1, 3, 6, 8, 20])
 def test_aggregate_minmax_vs_oracle(K, f):
     import torch

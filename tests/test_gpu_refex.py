@@ -385,7 +385,8 @@ _FUZZ = [dict(n=n, m=m, seed=seed, directed=d, weighted=w, self_loops=sl)
 
 
 @pytest.mark.parametrize('spec', _FUZZ, ids=[f"n{s['n']}_m{s['m']}_{'d' if s['directed'] else 'u'}{'w' if s['weighted'] else ''}" for s in _FUZZ])
-@pytest.mark.parametrize('aggs', [['sum', 'mean'], ['max', 'sum', 'min']], ids=['summean', 'maxsummin'])
+@pytest.mark.parametrize('aggs', [['sum', 'mean'], ['max', 'sum', 'min'], ['std', 'mean', 'var']],
+                         ids=['summean', 'maxsummin', 'stdmeanvar'])
 def test_random_graphs_match_oracle(spec, aggs):
     """Whole pipeline on random graphs of every kind (sparse, dense, directed, weighted, self-loops,
     isolated nodes, rows longer than 128) against the oracle: column lists, per-generation retained
@@ -405,7 +406,13 @@ def test_random_graphs_match_oracle(spec, aggs):
     for gen, tr in enumerate(ref.trace):
         assert fe._final_names[gen] == tr.retained, f'generation {gen}'
     got = X.values.astype(np.float64)
-    if spec['weighted']:
+    if spec['weighted'] and ('std' in aggs or 'var' in aggs):
+        # generation 0 of a weighted graph agrees to 1e-12 only, and a variance of nearly equal
+        # values amplifies that by its cancellation: compare against the scale of each column
+        scale = np.abs(ref.values).max(axis=0, keepdims=True) + 1e-300
+        assert np.abs(got - ref.values).max() <= 1e-9 * scale.max()
+        np.testing.assert_allclose(got / scale, ref.values / scale, rtol=0, atol=1e-7)
+    elif spec['weighted']:
         np.testing.assert_allclose(got, ref.values, rtol=RTOL, atol=0)
     else:
         assert np.array_equal(got, ref.values), f'{int((got != ref.values).sum())} entries differ'
