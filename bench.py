@@ -138,7 +138,10 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GRX_FORCE_COLLECTIVES=1 under torchrun with one rank: the sharded code path with its real RCCL
+    # calls on a one-GPU box (functional check, see graphrole_amd/parallel.py)
+    multi = world > 1 or (os.environ.get('GRX_FORCE_COLLECTIVES') == '1' and 'RANK' in os.environ)
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if share_gpu:
             dist.init_process_group('gloo')
@@ -152,7 +155,7 @@ def main():
     lib = _lib.load()
 
     G = build_graph(args.workload)
-    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=(world > 1),
+    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=multi,
                                   attributes=bool(G.attributes))
     dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
     if args.agg_lanes:
@@ -162,7 +165,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -219,7 +222,7 @@ def main():
     # max over ranks
     red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64,
                        device='cpu' if share_gpu else 'cuda')
-    if world > 1:
+    if multi:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
 
@@ -312,7 +315,7 @@ def main():
             line['cpu_baseline'] = base
             line.update(extra)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

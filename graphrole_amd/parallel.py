@@ -49,6 +49,9 @@ class ShardPlan:
         self.row_begin = int(self.bounds[self.rank])
         self.row_end = int(self.bounds[self.rank + 1])
         self.max_rows = int(np.diff(self.bounds).max()) if n else 0
+        # a one-rank group skips every exchange -- unless GRX_FORCE_COLLECTIVES=1 (test hook: drives the
+        # real RCCL calls, dtypes and split sizes on a one-GPU box, tests/test_gpu_sharded.py)
+        self._solo = self.world == 1 and not _force_collectives()
 
     # ------------------------------------------------------------------ collectives
     def _staged(self, t: torch.Tensor) -> bool:
@@ -59,7 +62,7 @@ class ShardPlan:
 
     def all_gather_block(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> every slice valid, in place."""
-        if self.world == 1:
+        if self._solo:
             return block
         ncols = block.shape[0]
         if ncols == 0 or self.n == 0:
@@ -136,14 +139,14 @@ class ShardPlan:
 
     def all_gather_columns(self, cols: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Same for a list of separate [n] columns."""
-        if self.world == 1 or not cols:
+        if self._solo or not cols:
             return list(cols)
         block = torch.stack(list(cols))
         self.all_gather_block(block)
         return [block[j] for j in range(len(cols))]
 
     def _all_reduce_(self, t: torch.Tensor, op) -> torch.Tensor:
-        if self.world > 1 and t.numel():
+        if not self._solo and t.numel():
             if self._staged(t):
                 h = t.cpu()
                 dist.all_reduce(h, op=op, group=self.group)
@@ -162,7 +165,7 @@ class ShardPlan:
 
     def all_reduce_sum_host(self, a: np.ndarray) -> np.ndarray:
         """Sum of a small host array over the ranks (identical bits on every rank)."""
-        if self.world == 1:
+        if self._solo:
             return a
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._small_device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -171,7 +174,7 @@ class ShardPlan:
     def all_gather_host(self, a: np.ndarray) -> np.ndarray:
         """[world, *a.shape]: the small host array of every rank."""
         a = np.ascontiguousarray(a, dtype=np.float64)
-        if self.world == 1:
+        if self._solo:
             return a[None]
         t = torch.from_numpy(a).to(self._small_device()).reshape(1, -1)
         out = torch.empty((self.world, t.shape[1]), dtype=t.dtype, device=t.device)
@@ -183,6 +186,11 @@ class ShardPlan:
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         return self._all_reduce_(t, dist.ReduceOp.SUM)
+
+
+def _force_collectives() -> bool:
+    import os
+    return os.environ.get('GRX_FORCE_COLLECTIVES') == '1'
 
 
 def maybe_plan(row_ptr: np.ndarray, distributed) -> Optional[ShardPlan]:
@@ -197,6 +205,6 @@ def maybe_plan(row_ptr: np.ndarray, distributed) -> Optional[ShardPlan]:
             return None
         raise RuntimeError('distributed= was given but torch.distributed is not initialised')
     group = None if distributed is True else distributed
-    if dist.get_world_size(group) == 1:
+    if dist.get_world_size(group) == 1 and not _force_collectives():
         return None
     return ShardPlan(row_ptr, group)

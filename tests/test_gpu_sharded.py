@@ -84,3 +84,52 @@ def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
     for r in (r0, r1):
         rb, re = int(r['rb']), int(r['re'])
         np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-15)
+
+
+def _worker_rccl(rank, port, kind, out_dir):
+    """One rank, backend 'nccl' (= RCCL), GRX_FORCE_COLLECTIVES=1: every exchange of the N > 1 path
+    runs as a real RCCL call on HBM tensors (all_to_all_single on fp64 / uint8, all_gather_into_tensor,
+    all_reduce SUM / MAX on fp64 / int32) -- what a gloo test cannot cover."""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['GRX_FORCE_COLLECTIVES'] = '1'
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from graphrole_amd import RecursiveFeatureExtractor, kernels as K
+        from graphrole_amd.roles import factor
+        G = _graph(kind)
+        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, aggs=['sum', 'mean', 'max'])
+        X = fe.extract_features()
+        plan = fe._shard()
+        assert plan is not None and plan.world == 1 and not plan._solo
+        Xd = K.gather_columns(fe.device_features()[1], G.n)
+        F = X.shape[1]
+        omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
+        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
+        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        os.environ['GRX_FORCE_COLLECTIVES'] = '0'
+        fe1 = RecursiveFeatureExtractor(G, max_generations=4, aggs=['sum', 'mean', 'max'])
+        X1 = fe1.extract_features()
+        Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
+        W1, H1 = factor.nndsvda_init_device(Xd1, G.n, 4, omega)
+        s1, it1 = factor.run_mu_loop(K.NmfState(Xd1, G.n, W1, H1))
+        np.savez(os.path.join(out_dir, 'rccl.npz'), X=X.values.astype(float), cols=np.array(list(X.columns)),
+                 X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), n_iter=n_iter, it1=it1,
+                 H=K.to_host(state.H), H1=K.to_host(s1.H), W=K.to_host(state.W)[:, :G.n], W1=K.to_host(s1.W)[:, :G.n])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['ba', 'directed_weighted'])
+def test_rccl_collectives_one_rank(kind, tmp_path):
+    mp.spawn(_worker_rccl, args=(_free_port(), kind, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / 'rccl.npz')
+    assert list(r['cols']) == list(r['cols1'])
+    assert np.array_equal(r['X'], r['X1'])
+    assert int(r['n_iter']) == int(r['it1'])
+    np.testing.assert_allclose(r['H'], r['H1'], rtol=1e-9)
+    np.testing.assert_allclose(r['W'], r['W1'], rtol=1e-9, atol=1e-15)
