@@ -31,10 +31,28 @@ __device__ __forceinline__ double key_to_f64(uint64_t k)
     return __longlong_as_double((long long)b);
 }
 
+// Pass skipping (grx_vertical_log_bin only): a byte position that is constant over a whole column
+// makes its LSD pass the identity permutation.  Pass 0's counting kernel also accumulates the OR of
+// the keys and of their complements; scan pass 0 turns them into flags[pass][col].  A skipped pass
+// launches nothing useful (every workgroup returns at once) and does not flip the ping-pong, so scan
+// pass 0 also records the buffer each column is in before every pass: 0 = the fp64 input, 1 = bufA,
+// 2 = bufB (one byte for a workgroup to read before it can issue its loads).  flags == nullptr: plain
+// sort, explicit src / dst.
+struct SkipCtl {
+    uint8_t *flags;            // [9][ncols]: PASS_SKIPPED, or the buffer the column is in before pass p (row 8: at the end)
+    uint64_t *bits;            // [ncols][ntiles][2]: per tile, OR of the keys and OR of their complements
+    const double *cols;
+    int64_t cols_ld;
+    uint64_t *buf_a, *buf_b;   // column stride n
+    int ncols;
+};
+
+constexpr uint8_t PASS_SKIPPED = 0xFF;
+
 // Load the ITEMS keys of this thread.  Wave w of the tile owns the contiguous slice
 // [w*64*ITEMS, (w+1)*64*ITEMS); item i of lane l is element i*64 + l of that slice, so
 // (wave, item, lane) order == memory order (needed for LSD stability) and loads coalesce.
-template <bool FROM_F64>
+template <bool from_f64>
 __device__ __forceinline__ void load_keys(const void *__restrict__ src, int64_t n, int64_t tile_base,
                                           uint64_t (&keys)[SORT_ITEMS], uint32_t &valid_mask)
 {
@@ -46,7 +64,7 @@ __device__ __forceinline__ void load_keys(const void *__restrict__ src, int64_t 
         const int64_t idx = base + (int64_t)i * 64;
         if (idx < n) {
             valid_mask |= 1u << i;
-            if (FROM_F64) keys[i] = f64_to_key(reinterpret_cast<const double *>(src)[idx]);
+            if (from_f64) keys[i] = f64_to_key(reinterpret_cast<const double *>(src)[idx]);
             else keys[i] = reinterpret_cast<const uint64_t *>(src)[idx];
         } else {
             keys[i] = 0xFFFFFFFFFFFFFFFFull;
@@ -59,17 +77,49 @@ __device__ __forceinline__ void load_keys(const void *__restrict__ src, int64_t 
 template <bool FROM_F64>
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
     const void *__restrict__ src, int64_t src_ld, int64_t n, int shift, int ntiles,
-    uint32_t *__restrict__ hist)
+    uint32_t *__restrict__ hist, SkipCtl ctl)
 {
     __shared__ uint32_t cnt[RADIX];
     const int col = blockIdx.y, tile = blockIdx.x;
+    const int pass = shift >> 3;
+    const char *csrc = reinterpret_cast<const char *>(src) + (size_t)col * src_ld * 8;
+    bool from_f64 = FROM_F64;
+    if (ctl.flags && pass > 0) {
+        const int cur = ctl.flags[pass * ctl.ncols + col];
+        if (cur == PASS_SKIPPED) return;                        // constant byte: nothing to count
+        from_f64 = cur == 0;
+        csrc = cur == 0 ? reinterpret_cast<const char *>(ctl.cols + (size_t)col * ctl.cols_ld)
+                        : reinterpret_cast<const char *>((cur == 1 ? ctl.buf_a : ctl.buf_b) + (size_t)col * n);
+    }
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    const char *csrc = reinterpret_cast<const char *>(src) + (size_t)col * src_ld * 8;
     uint64_t keys[SORT_ITEMS];
     uint32_t vm;
-    load_keys<FROM_F64>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    // one uniform branch around the sixteen loads (fp64 input after pass 0 only when every lower byte was constant)
+    if (FROM_F64 || from_f64) load_keys<true>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys<false>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
     const int lane = threadIdx.x & 63;
+    if (ctl.flags && pass == 0) {
+        // which bit positions vary over the column: OR of the keys and OR of their complements
+        uint64_t o = 0, z = 0;
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i)
+            if ((vm >> i) & 1u) { o |= keys[i]; z |= ~keys[i]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            o |= __shfl_xor(o, off, 64);
+            z |= __shfl_xor(z, off, 64);
+        }
+        // per-tile pair, OR-ed over the tiles by scan pass 0 (no atomics: every wave of the first
+        // resident batch would hit the same address at once)
+        __shared__ uint64_t wbits[4][2];
+        if (lane == 0) { wbits[threadIdx.x >> 6][0] = o; wbits[threadIdx.x >> 6][1] = z; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int k = threadIdx.x;
+            ctl.bits[((size_t)col * ntiles + tile) * 2 + k] = wbits[0][k] | wbits[1][k] | wbits[2][k] | wbits[3][k];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         // same-address LDS atomics serialise lane by lane; columns of small integers (degrees, their
@@ -94,9 +144,35 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(
 // hist[RADIX][ntiles] across tiles, digit total -> tot.  scatter_kernel scans the 256 digit totals
 // itself (digit base) and adds it to the per-tile offset.
 __global__ __launch_bounds__(64) void scan_rows_kernel(uint32_t *__restrict__ hist, int ntiles,
-                                                       uint32_t *__restrict__ tot)
+                                                       uint32_t *__restrict__ tot, SkipCtl ctl, int pass)
 {
     const int d = blockIdx.x, col = blockIdx.y, lane = threadIdx.x;
+    if (ctl.flags) {
+        if (pass > 0 && ctl.flags[pass * ctl.ncols + col] == PASS_SKIPPED) return;
+        if (pass == 0 && d == 0) {
+            // a bit varies iff it is set in some key and clear in another
+            uint64_t o = 0, z = 0;
+            for (int t = lane; t < ntiles; t += 64) {
+                o |= ctl.bits[((size_t)col * ntiles + t) * 2];
+                z |= ctl.bits[((size_t)col * ntiles + t) * 2 + 1];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                o |= __shfl_xor(o, off, 64);
+                z |= __shfl_xor(z, off, 64);
+            }
+            const uint64_t varying = o & z;
+            if (lane == 0) {
+                int cur = 0;
+                for (int p = 0; p < 8; ++p) {
+                    const bool skip = ((varying >> (8 * p)) & 0xFF) == 0;
+                    ctl.flags[p * ctl.ncols + col] = skip ? PASS_SKIPPED : (uint8_t)cur;
+                    if (!skip) cur = (cur == 1) ? 2 : 1;
+                }
+                ctl.flags[8 * ctl.ncols + col] = (uint8_t)cur;
+            }
+        }
+    }
     uint32_t *row = hist + ((size_t)col * RADIX + d) * ntiles;
     uint32_t carry = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 64 * 4) {
@@ -125,7 +201,8 @@ __global__ __launch_bounds__(64) void scan_rows_kernel(uint32_t *__restrict__ hi
 template <bool FROM_F64, bool TO_F64>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     const void *__restrict__ src, int64_t src_ld, void *__restrict__ dst, int64_t dst_ld, int64_t n,
-    int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_tot)
+    int shift, int ntiles, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ digit_tot,
+    SkipCtl ctl)
 {
     __shared__ uint32_t cnt[4][RADIX];
     __shared__ uint32_t gdelta[RADIX];
@@ -133,13 +210,25 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     __shared__ uint64_t stage[SORT_TILE];
     const int col = blockIdx.y, tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cur = ctl.flags ? ctl.flags[(shift >> 3) * ctl.ncols + col] : 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
     const char *csrc = reinterpret_cast<const char *>(src) + (size_t)col * src_ld * 8;
+    char *cdst = reinterpret_cast<char *>(dst) + (size_t)col * dst_ld * 8;
+    bool from_f64 = FROM_F64;
+    if (ctl.flags) {
+        if (cur == PASS_SKIPPED) return;                        // identity permutation: the keys stay put
+        from_f64 = cur == 0;
+        csrc = cur == 0 ? reinterpret_cast<const char *>(ctl.cols + (size_t)col * ctl.cols_ld)
+                        : reinterpret_cast<const char *>((cur == 1 ? ctl.buf_a : ctl.buf_b) + (size_t)col * n);
+        cdst = reinterpret_cast<char *>((cur == 1 ? ctl.buf_b : ctl.buf_a) + (size_t)col * n);
+    }
     uint64_t keys[SORT_ITEMS];
     uint32_t vm;
-    load_keys<FROM_F64>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    // one uniform branch around the sixteen loads (fp64 input after pass 0 only when every lower byte was constant)
+    if (FROM_F64 || from_f64) load_keys<true>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys<false>(csrc, n, (int64_t)tile * SORT_TILE, keys, vm);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rank[SORT_ITEMS];
 #pragma unroll
@@ -208,7 +297,6 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     __syncthreads();
     const int64_t left = n - (int64_t)tile * SORT_TILE;
     const int nv = (int)(left < SORT_TILE ? left : SORT_TILE);
-    char *cdst = reinterpret_cast<char *>(dst) + (size_t)col * dst_ld * 8;
     for (int j = threadIdx.x; j < nv; j += SORT_THREADS) {
         const uint64_t key = stage[j];
         const uint32_t pos = gdelta[(uint32_t)(key >> shift) & 0xFF] + (uint32_t)j;
@@ -222,9 +310,16 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
 __global__ __launch_bounds__(64) void bin_threshold_kernel(const double *__restrict__ sorted,
                                                            int64_t ld, int64_t n, double frac,
                                                            double *__restrict__ thr,
-                                                           int32_t *__restrict__ nbins)
+                                                           int32_t *__restrict__ nbins, SkipCtl ctl)
 {
-    const double *s = sorted + (size_t)blockIdx.x * ld;
+    // with pass skipping the sorted column is wherever its last executed pass left it, as keys
+    // (buffer 0 = the input itself: every byte constant, i.e. all values equal)
+    const int where = ctl.flags ? ctl.flags[8 * ctl.ncols + blockIdx.x] : 0;
+    const double *sd = ctl.flags ? ctl.cols + (size_t)blockIdx.x * ctl.cols_ld : sorted + (size_t)blockIdx.x * ld;
+    const uint64_t *sk = (where == 1 ? ctl.buf_a : ctl.buf_b) + (size_t)blockIdx.x * n;
+    struct { const double *d; const uint64_t *k; bool keys;
+             __device__ double operator[](int64_t i) const { return keys ? key_to_f64(k[i]) : d[i]; } }
+        s{sd, sk, where != 0};
     double *t = thr + (size_t)blockIdx.x * GRX_MAX_BINS;
     const int lane = threadIdx.x;
     int64_t done = 0;
@@ -428,9 +523,10 @@ SortPlan make_plan(int64_t n, int ncols)
 
 // sort ncols columns; keysA/hist are scratch; result (fp64 ascending) in out (column stride out_ld)
 int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
-                 uint64_t *keysA, uint32_t *hist, hipStream_t st)
+                 uint64_t *keysA, uint32_t *hist, hipStream_t st, SkipCtl ctl = SkipCtl{})
 {
     const SortPlan p = make_plan(n, ncols);
+    const bool skipping = ctl.flags != nullptr;             // then out is a key buffer with stride n
     const dim3 grid(p.ntiles, ncols);
     uint32_t *tot = hist + grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) / 4;
     for (int pass = 0; pass < 8; ++pass) {
@@ -447,20 +543,20 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         else { dst = keysA; dld = n; }
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
-            else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist);
+            if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist, ctl);
+            else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist, ctl);
         }
         GRX_LAUNCH_CHECK();
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
-            scan_rows_kernel<<<dim3(RADIX, ncols), 64, 0, st>>>(hist, p.ntiles, tot);
+            scan_rows_kernel<<<dim3(RADIX, ncols), 64, 0, st>>>(hist, p.ntiles, tot, ctl, pass);
         }
         GRX_LAUNCH_CHECK();
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
-            else if (pass == 7) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
-            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot);
+            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
+            else if (pass == 7 && !skipping) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
+            else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
         }
         GRX_LAUNCH_CHECK();
     }
@@ -493,9 +589,10 @@ size_t grx_log_bin_workspace_bytes(int64_t n, int ncols)
 {
     if (n <= 0 || ncols <= 0) return 256;
     const SortPlan p = make_plan(n, ncols);
-    // keysA + sorted + hist + thresholds + nbins
+    // keysA + sorted + hist + thresholds + nbins + pass-skipping state (key bits, flags)
     return 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
-           grx_align_up((size_t)ncols * 4, 256);
+           grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 16, 256) +
+           grx_align_up((size_t)ncols * 9, 256);
 }
 
 int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, double *d_sorted,
@@ -537,10 +634,19 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
     double *thr = reinterpret_cast<double *>(ws + 2 * p.keys_bytes + p.hist_bytes);
     int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
-    int rc = sort_columns(n, ncols, d_cols, ld, sorted, n, keysA, hist, st);
+    char *skip_ws = reinterpret_cast<char *>(nb_ws) + grx_align_up((size_t)ncols * 4, 256);
+    SkipCtl ctl;
+    ctl.bits = reinterpret_cast<uint64_t *>(skip_ws);
+    ctl.flags = reinterpret_cast<uint8_t *>(skip_ws + grx_align_up((size_t)ncols * p.ntiles * 16, 256));
+    ctl.cols = d_cols;
+    ctl.cols_ld = ld;
+    ctl.buf_a = keysA;
+    ctl.buf_b = reinterpret_cast<uint64_t *>(sorted);
+    ctl.ncols = ncols;
+    int rc = sort_columns(n, ncols, d_cols, ld, sorted, n, keysA, hist, st, ctl);
     if (rc != GRX_OK) return rc;
     { GRX_PROF(GRX_K_BIN_THRESHOLD, st);
-    bin_threshold_kernel<<<ncols, 64, 0, st>>>(sorted, n, n, frac, thr, nb_ws);
+    bin_threshold_kernel<<<ncols, 64, 0, st>>>(sorted, n, n, frac, thr, nb_ws, ctl);
     }
     GRX_LAUNCH_CHECK();
     const int64_t want = grx_ceil_div(n, 256 * 4);

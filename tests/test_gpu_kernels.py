@@ -380,6 +380,37 @@ def _working_columns(g, gen):
     return cols
 
 
+@pytest.mark.parametrize('n', [5000, 300001])
+def test_log_bin_pass_skipping_patterns(K, n):
+    """grx_vertical_log_bin skips the radix passes of byte positions that are constant over a column;
+    every pattern of constant / varying bytes must give the oracle's bins."""
+    import torch
+    from oracle import ckernels
+    rng = np.random.default_rng(n)
+    ints = rng.integers(0, 200, n).astype(np.float64)
+    cols = [
+        ints,                                                           # low five mantissa bytes constant
+        ints + 2.0 ** 40,                                               # top bytes constant too
+        np.full(n, 7.25),                                               # every byte constant: no pass at all
+        np.where(rng.random(n) < 0.5, 3.0, 5.0),                        # two values
+        2.0 ** rng.integers(-20, 20, n).astype(np.float64),             # only exponent bytes vary
+        rng.standard_normal(n),                                         # sign + everything varies
+        -ints - 1.0,                                                    # negative: complemented keys
+        rng.integers(0, 2 ** 31, n).astype(np.float64),                 # one constant byte (the lowest)
+        (rng.integers(0, 256, n) * 2.0 ** -52 + 1.0),                   # only the LOWEST byte varies
+        rng.random(n).astype(np.float32).astype(np.float64),            # low 29 mantissa bits zero
+        np.where(rng.random(n) < 0.5, -0.0, 0.0),                       # -0.0 == 0.0: one bin
+    ]
+    for k in (1, 4, len(cols)):                                         # column subsets -> other launch shapes
+        block = torch.from_numpy(np.stack(cols[:k] if k < len(cols) else cols)).cuda()
+        bins, nb = K.vertical_log_bin(block)
+        got = bins.cpu().numpy()
+        for j in range(block.shape[0]):
+            exp = ckernels.vertical_log_binning(cols[j])
+            assert np.array_equal(got[j], exp), f'col {j} of {k}'
+            assert int(nb[j]) == exp.max() + 1
+
+
 @pytest.mark.parametrize('n', [1000, 123457, 1 << 20])
 def test_log_bin_vs_oracle_random(K, n):
     import torch
