@@ -37,7 +37,8 @@ def _worker(rank, port, case, out_dir, WORLD):
         g = util.load_refex(case)
         w = g['w'] if len(g['w']) else None
         G = CSRGraph(int(g['n']), g['src'], g['dst'], weights=w, directed=bool(g['directed']))
-        fe = RecursiveFeatureExtractor(G, max_generations=int(g['max_generations']), distributed=True)
+        fe = RecursiveFeatureExtractor(G, max_generations=int(g['max_generations']), distributed=True,
+                                      aggs=util.golden_aggs(g))
         X = fe.extract_features()
         plan = fe._shard()
         assert plan is not None and plan.world == WORLD
@@ -56,7 +57,8 @@ def _worker(rank, port, case, out_dir, WORLD):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('ba2000', 2), ('er300', 3), ('directed120', 3), ('karate', 7)])
+@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('ba2000', 2), ('er300', 3), ('directed120', 3), ('karate', 7),
+                                        ('ba300_stdvar', 2), ('loops_dangling150_minmax', 3)])
 def test_sharded_pipeline_equals_single_process(case, WORLD, tmp_path):
     """2, 3 and 7 ranks (3: candidate counts that do not divide by the world size -> uneven column
     ownership in the owner all-to-all; 7 > the 6 candidates of generation 1: ranks that own no column
