@@ -54,8 +54,28 @@ def to_device(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(device())
 
 
+_PINNED: dict = {}
+_PINNED_MAX_BYTES = 1 << 20
+
+
 def to_host(t: torch.Tensor) -> np.ndarray:
-    return t.detach().cpu().numpy()
+    """Device -> host copy of a result.  Small tensors (everything the drivers read back between
+    launches: distance matrices, Gram matrices, residuals) go through a pinned staging buffer with
+    an asynchronous copy + stream synchronise: in isolation 23 us behind a queued kernel against 110 us
+    for Tensor.cpu() (synchronous hipMemcpy); inside the pipeline, where the stream holds milliseconds
+    of queued work at every read-back, the step time did not change measurably."""
+    t = t.detach()
+    nbytes = t.numel() * t.element_size()
+    if not t.is_cuda or nbytes == 0 or nbytes > _PINNED_MAX_BYTES:
+        return t.cpu().numpy()
+    buf = _PINNED.get(t.dtype)
+    if buf is None or buf.numel() < t.numel():
+        buf = torch.empty(max(t.numel(), 4096), dtype=t.dtype, pin_memory=True)
+        _PINNED[t.dtype] = buf
+    view = buf[:t.numel()]
+    view.copy_(t.contiguous().view(-1), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return view.numpy().reshape(tuple(t.shape)).copy()
 
 
 def empty(shape, dtype=torch.float64) -> torch.Tensor:
@@ -378,7 +398,7 @@ def gram(X: torch.Tensor, n: int, T: Optional[np.ndarray] = None, row_begin: int
     out = torch.empty(k * k + 1, dtype=torch.float64, device=device())
     _lib.call('grx_gram', n, F, _ptr(X), _ld(X), row_begin, row_end, _hptr(T), k, _ptr(out), _ptr(ws),
               ws_bytes, _stream())
-    host = out.cpu().numpy()
+    host = to_host(out)
     return host[:k * k].reshape(k, k).copy(), float(host[k * k])
 
 
@@ -397,7 +417,7 @@ def project(X: torch.Tensor, n: int, Z: np.ndarray, row_begin: int = 0,
     stats = torch.empty(r * 4, dtype=torch.float64, device=device())
     _lib.call('grx_project', n, F, _ptr(X), _ld(X), row_begin, row_end, _hptr(Z), r, _ptr(out),
               _ld(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
-    return out, stats.cpu().numpy().reshape(r, 4)
+    return out, to_host(stats).reshape(r, 4)
 
 
 def nndsvd_apply(U: torch.Tensor, n: int, sign: np.ndarray, scale: np.ndarray, eps: float, fill: float,
@@ -497,7 +517,7 @@ class NmfState:
         out = torch.zeros(1, dtype=torch.float64, device=device())
         _lib.call('grx_nmf_kl_cost', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(W), _ld(W),
                   row_begin, row_end, _ptr(H), _ptr(out), _ptr(self.ws), self.ws_bytes, _stream())
-        return float(out.cpu()[0])
+        return float(to_host(out)[0])
 
     def iterate(self, iters: int, with_residual: bool = True) -> None:
         _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),

@@ -169,7 +169,8 @@ class ShardPlan:
             return a
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._small_device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy().reshape(a.shape)
+        from graphrole_amd import kernels as K
+        return (K.to_host(t) if t.is_cuda else t.numpy()).reshape(a.shape)
 
     def all_gather_host(self, a: np.ndarray) -> np.ndarray:
         """[world, *a.shape]: the small host array of every rank."""
@@ -179,7 +180,8 @@ class ShardPlan:
         t = torch.from_numpy(a).to(self._small_device()).reshape(1, -1)
         out = torch.empty((self.world, t.shape[1]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.cpu().numpy().reshape((self.world,) + a.shape)
+        from graphrole_amd import kernels as K
+        return (K.to_host(out) if out.is_cuda else out.numpy()).reshape((self.world,) + a.shape)
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         return self._all_reduce_(t, dist.ReduceOp.MAX)
