@@ -63,7 +63,7 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_aggregate_minmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int64, c_void_p]),
-    'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_egonet_unweighted': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'grx_log_bin_workspace_bytes': (c_size_t, [c_int64, c_int]),

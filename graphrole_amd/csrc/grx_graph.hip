@@ -295,11 +295,20 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 // keeps oriented lists <= ~20 on the BASELINE graphs) and tests membership all-to-all with
 // in-group shuffles.  L2 requests per arc drop from ~16 to ~4, which is what bounded this kernel
 // (rocprof: 165 M TCP->TCC requests per launch).  Counting is integer atomics: exact, any order.
+// o_arc[k] = begin | (length << 40) of N+(v) for the k-th oriented arc u->v: the target's list is
+// located from the (sequentially read) arc table instead of a dependent, random o_row_ptr[v] lookup,
+// so the group knows the addresses of eight target lists at once and keeps the first two 8-element
+// chunks of each in flight (16 independent loads per lane) before it starts comparing.
+constexpr int TRI_ARC_SHIFT = 40;
+constexpr int TRI_G = 8;                     // lanes per source row
+
 __global__ __launch_bounds__(256) void triangle_count_kernel(
-    const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col, int64_t row_begin,
-    int64_t row_end, unsigned long long *__restrict__ T)
+    const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
+    const uint64_t *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
+    unsigned long long *__restrict__ T)
 {
-    constexpr int G = 8;
+    constexpr int G = TRI_G;
+    constexpr unsigned long long GMASK = (1ull << G) - 1;
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -333,29 +342,58 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
                 f0 |= __shfl_xor(f0, off, G); f1 |= __shfl_xor(f1, off, G);
                 f2 |= __shfl_xor(f2, off, G); f3 |= __shfl_xor(f3, off, G);
             }
-            for (int64_t k = ub; k < ue; ++k) {
-                const int32_t v = o_col[k];                     // same address in the group
-                const int64_t vb = o_row_ptr[v], ve = o_row_ptr[v + 1];
-                unsigned c_arc = 0;
-                for (int64_t j0 = vb; j0 < ve; j0 += G) {
-                    const int32_t y = (j0 + lane < ve) ? o_col[j0 + lane] : -1;
-                    const int yw = (y >> 6) & 3;
-                    const unsigned long long fw = yw == 0 ? f0 : yw == 1 ? f1 : yw == 2 ? f2 : f3;
-                    const bool maybe = y >= 0 && ((fw >> (y & 63)) & 1ull);
-                    if (((__ballot(maybe) >> gshift) & 0xFFull) == 0) continue;   // uniform over the group
-                    unsigned match = 0;
-#pragma unroll
-                    for (int sidx = 0; sidx < G; ++sidx) {
-                        const int32_t ys = __shfl(y, sidx, G);
-                        const bool hit = (ys == uu[0]) | (ys == uu[1]) | (ys == uu[2]);
-                        const unsigned long long bal = __ballot(hit);
-                        if ((bal >> gshift) & 0xFFull) match |= 1u << sidx;
-                    }
-                    if ((match >> lane) & 1u) atomicAdd(&T[y], 1ull);
-                    c_arc += __popc(match);
+            // one 8-element chunk of a target list against the ids held by the group (a macro, not a
+            // lambda: the closure object put uu[] and the filter words into scratch memory)
+#define TRI_CHUNK(YEXPR, ACC)                                                                            \
+            do {                                                                                          \
+                const int32_t y_ = (YEXPR);                                                               \
+                const int yw_ = (y_ >> 6) & 3;                                                            \
+                const unsigned long long fw_ = yw_ == 0 ? f0 : yw_ == 1 ? f1 : yw_ == 2 ? f2 : f3;        \
+                const bool maybe_ = y_ >= 0 && ((fw_ >> (y_ & 63)) & 1ull);                               \
+                if (((__ballot(maybe_) >> gshift) & GMASK) != 0) {          /* uniform over the group */  \
+                    unsigned match_ = 0;                                                                  \
+                    _Pragma("unroll") for (int sidx = 0; sidx < G; ++sidx) {                              \
+                        const int32_t ys = __shfl(y_, sidx, G);                                           \
+                        const bool hit = (ys == uu0) | (ys == uu1) | (ys == uu2);                         \
+                        const unsigned long long bal = __ballot(hit);                                     \
+                        if ((bal >> gshift) & GMASK) match_ |= 1u << sidx;                              \
+                    }                                                                                     \
+                    if ((match_ >> lane) & 1u) atomicAdd(&T[y_], 1ull);                                   \
+                    ACC += (unsigned)__popc(match_);                                                      \
+                }                                                                                         \
+            } while (0)
+            const int32_t uu0 = uu[0], uu1 = uu[1], uu2 = uu[2];
+            for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
+                const bool have = k0 + lane < ue;
+                const int32_t v_mine = have ? o_col[k0 + lane] : -1;
+                const unsigned long long d_mine = have ? o_arc[k0 + lane] : 0ull;
+                const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
+                // four target lists at a time: their first two chunks are eight independent loads in
+                // flight per lane (scalars, not arrays: arrays end up in scratch memory here)
+#define TRI_LOAD(A, Y0, Y1)                                                                              \
+                const unsigned long long d##A = __shfl(d_mine, a0 + A, G);                                \
+                const int64_t vb##A = (int64_t)(d##A & ((1ull << TRI_ARC_SHIFT) - 1));                      \
+                const int len##A = (int)(d##A >> TRI_ARC_SHIFT);                                            \
+                const int32_t Y0 = (lane < len##A) ? o_col[vb##A + lane] : -1;                              \
+                const int32_t Y1 = (lane + G < len##A) ? o_col[vb##A + G + lane] : -1;
+#define TRI_ARC(A, Y0, Y1)                                                                               \
+                if (a0 + A < nb) {                                                                        \
+                    unsigned c_arc = 0;                                                                   \
+                    if (len##A > 0) TRI_CHUNK(Y0, c_arc);                                                 \
+                    if (len##A > G) TRI_CHUNK(Y1, c_arc);                                                 \
+                    for (int j0 = 2 * G; j0 < len##A; j0 += G)                                            \
+                        TRI_CHUNK((j0 + lane < len##A) ? o_col[vb##A + j0 + lane] : -1, c_arc);           \
+                    const int32_t v = __shfl(v_mine, a0 + A, G);                                          \
+                    if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);                  \
+                    cu += c_arc;                                                                          \
                 }
-                if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);
-                cu += c_arc;
+                for (int a0 = 0; a0 < nb; a0 += 4) {                        // uniform over the group
+                    TRI_LOAD(0, ya0, ya1) TRI_LOAD(1, yb0, yb1) TRI_LOAD(2, yc0, yc1) TRI_LOAD(3, yd0, yd1)
+                    TRI_ARC(0, ya0, ya1) TRI_ARC(1, yb0, yb1) TRI_ARC(2, yc0, yc1) TRI_ARC(3, yd0, yd1)
+                }
+#undef TRI_LOAD
+#undef TRI_ARC
+#undef TRI_CHUNK
             }
         }
         if (lane == 0 && cu) atomicAdd(&T[u], cu);
@@ -1006,16 +1044,16 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     return GRX_OK;
 }
 
-int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_o_col, int64_t row_begin,
-                        int64_t row_end, uint64_t *d_T, void *stream)
+int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_o_col, const uint64_t *d_o_arc,
+                        int64_t row_begin, int64_t row_end, uint64_t *d_T, void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_triangle_counts: bad row range");
     if (row_end == row_begin) return GRX_OK;
-    GRX_REQUIRE(d_o_row_ptr && d_o_col && d_T, "grx_triangle_counts: NULL pointer");
-    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
+    GRX_REQUIRE(d_o_row_ptr && d_o_col && d_o_arc && d_T, "grx_triangle_counts: NULL pointer");
+    const int64_t want = grx_ceil_div((row_end - row_begin) * TRI_G, 256);
     const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
     { GRX_PROF(GRX_K_TRIANGLES, grx_stream(stream));
-    triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, row_begin, row_end,
+    triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
                                                                 reinterpret_cast<unsigned long long *>(d_T));
     }
     GRX_LAUNCH_CHECK();

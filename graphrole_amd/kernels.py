@@ -174,6 +174,10 @@ class DeviceCSR:
             o_ptr = np.zeros(n + 1, dtype=np.int64)
             np.cumsum(np.bincount(rows[keep], minlength=n), out=o_ptr[1:])
             self._oriented = DeviceCSR(o_ptr, col[keep])
+            # per oriented arc u->v: where N+(v) lies (begin | length << 40), see grx_triangle_counts
+            tgt = col[keep].astype(np.int64)
+            arc = o_ptr[tgt] | ((o_ptr[tgt + 1] - o_ptr[tgt]) << 40)
+            self._oriented.arc = torch.from_numpy(arc if len(arc) else np.zeros(1, np.int64)).to(device())
         return self._oriented
 
     def triangle_split(self, rank: int, world: int) -> Tuple[int, int]:
@@ -235,7 +239,8 @@ def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] =
     row_end = csr.n if row_end is None else row_end
     o = csr.oriented()
     T = torch.zeros(max(csr.n, 1), dtype=torch.int64, device=device())
-    _lib.call('grx_triangle_counts', csr.n, _ptr(o.row_ptr), _ptr(o.col), row_begin, row_end, _ptr(T), _stream())
+    _lib.call('grx_triangle_counts', csr.n, _ptr(o.row_ptr), _ptr(o.col), _ptr(o.arc), row_begin, row_end, _ptr(T),
+              _stream())
     return T
 
 
