@@ -1,16 +1,19 @@
 """
 Adapter registry (reference: graphrole/graph/interface/__init__.py:12-53): the adapter is looked
-up by the root package of ``G.__module__``.  ``graphrole_amd`` is an added key for CSRGraph;
-igraph is not supported (out of scope, igraph absent from the image).
+up by the root package of ``G.__module__``.  ``graphrole_amd`` is an added key for CSRGraph.
+The igraph adapter never imports igraph (absent from this image): it uses the Graph object's
+public methods only, so the key is always registered.
 """
 from typing import List, Optional
 
 from graphrole_amd.graph.interface.base import BaseGraphInterface, DeviceGraphInterface  # noqa: F401
 from graphrole_amd.graph.interface.csr import CSRInterface
+from graphrole_amd.graph.interface.igraph import IgraphInterface
 from graphrole_amd.graph.interface.networkx import NetworkxInterface
 
 INTERFACES = {
     'networkx': NetworkxInterface,
+    'igraph': IgraphInterface,
     'graphrole_amd': CSRInterface,
 }
 
