@@ -47,7 +47,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     const int lane = threadIdx.x & 63;
     const double *src = partial + (size_t)p * nb;
     double s = 0.0;
-    for (int b = lane; b < nb; b += 64) s += src[b];
+    // sixteen loads in flight, then the additions in the same order as a plain loop (a lane's
+    // dependent load-add chain was most of this kernel's 9 us)
+    for (int b0 = lane; b0 < nb; b0 += 64 * 16) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = b0 + 64 * j;
+            v[j] = (b < nb) ? src[b] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+    }
     s = grx_group_sum<64>(s);
     if (lane == 0) out[p] = s;
 }
