@@ -63,6 +63,8 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_aggregate_minmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_prod': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64,
+                                   c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_egonet_unweighted': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

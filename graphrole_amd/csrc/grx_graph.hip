@@ -782,6 +782,24 @@ __global__ __launch_bounds__(64) void aggregate_combine_kernel(
     }
 }
 
+// product over the neighbours (agg 'prod'): np.multiply.reduce is a plain left-to-right product, so
+// one lane per (row, column) multiplies in adjacency order; the empty product is 1.  Not a tuned
+// kernel: the lanes of a row read adjacent doubles of each neighbour row, nothing more.
+__global__ __launch_bounds__(256) void aggregate_prod_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ rows,
+    int64_t row_stride, int f, int64_t row_begin, int64_t row_end, double *__restrict__ out, int64_t ld)
+{
+    const int64_t total = (row_end - row_begin) * f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t v = row_begin + i / f;
+        const int c = (int)(i % f);
+        double p = 1.0;
+        for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) p *= rows[(int64_t)col[k] * row_stride + c];
+        out[(int64_t)c * ld + v] = p;
+    }
+}
+
 // min / max over the neighbours (aggs 'min', 'max' of features/extract.py:36-47); order-free.
 template <int LDR, int G>
 __global__ __launch_bounds__(256) void aggregate_minmax_kernel(
@@ -1215,6 +1233,21 @@ int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_pt
                          double *d_min, double *d_max, int64_t ld, void *stream)
 {
     return aggregate_dispatch(true, plan, d_row_ptr, d_col, f, d_rows, ldr, row_begin, row_end, d_min, d_max, ld, stream);
+}
+
+int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, const double *d_rows, int ldr,
+                       int64_t row_begin, int64_t row_end, double *d_prod, int64_t ld, void *stream)
+{
+    GRX_REQUIRE(f >= 0 && ldr >= f && row_begin >= 0 && row_begin <= row_end && ld >= row_end,
+                "grx_aggregate_prod: bad shape");
+    if (f == 0 || row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_rows && d_prod, "grx_aggregate_prod: NULL pointer");
+    const int64_t want = grx_ceil_div((row_end - row_begin) * f, 256);
+    const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+    aggregate_prod_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end,
+                                                               d_prod, ld);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
 }
 
 /* row stride (in doubles) grx_pack_rows / grx_aggregate use for f columns */

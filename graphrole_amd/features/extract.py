@@ -23,7 +23,8 @@ from graphrole_amd.features.prune import FeaturePruner
 from graphrole_amd.graph import interface
 from graphrole_amd.types import DataFrameDict, DataFrameLike
 
-_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std')
+_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std', 'prod')
+_EXACT_INT_LIMIT = 2.0 ** 53          # fp64 holds every integer below it
 
 
 def _agg_name(agg) -> str:
@@ -213,6 +214,20 @@ class RecursiveFeatureExtractor:
             mm = K.aggregate_minmax(dev_graph, rows, f, ldr, rb, re,
                                     want_min='min' in aggs, want_max='max' in aggs)
             pieces['min'], pieces['max'] = mm[:f], mm[f:]
+        if 'prod' in aggs:
+            pieces['prod'] = K.aggregate_prod(dev_graph, rows, f, ldr, rb, re)
+            # the reference multiplies integer columns in int64 (and wraps silently past 2^63); the
+            # columns here are fp64, exact below 2^53: refuse anything beyond instead of drifting
+            int_parents = [j for j, c in enumerate(prev) if self._dtypes.get(c, np.dtype('float64')).kind in 'iu']
+            if int_parents and re > rb:
+                peak = pieces['prod'][int_parents][:, rb:re].abs().max().reshape(1)
+                if plan is not None:
+                    plan.all_reduce_max_(peak)
+                if float(K.to_host(peak)[0]) >= _EXACT_INT_LIMIT:
+                    raise OverflowError(
+                        "'prod' of an integer feature exceeds 2**53 in generation "
+                        f'{self.generation_count}: not representable in the fp64 feature columns (the reference '
+                        'would continue in wrapping int64 arithmetic); lower max_generations or drop prod')
         # candidate order: every column under the first aggregation, then the second, ... (:158-162)
         if list(aggs) == ['sum', 'mean']:
             sub = block
@@ -230,10 +245,11 @@ class RecursiveFeatureExtractor:
         names = [f'{c}({a})' for a in aggs for c in prev]
         # pandas dtype of the reference's frame (extract.py:104-119): the per-node agg frame of an
         # integer column stays integer unless 'mean' / 'std' / 'var' is among the aggs or a node
-        # without neighbours turns min / max into NaN -> 0.0; one float value makes the column float64
+        # without neighbours turns min / max into NaN -> 0.0 (sum and prod of nothing are the integers 0
+        # and 1); one float value makes the column float64
         host = self.graph._device_graph()[0]
         no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
-        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum'})
+        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum', 'prod'})
         f64, i64 = np.dtype('float64'), np.dtype('int64')
         dtypes = [i64 if keeps_int and self._dtypes.get(c, f64).kind in 'iu' else f64 for a in aggs for c in prev]
         return names, cols, dtypes, sub

@@ -321,6 +321,19 @@ def aggregate_var(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, mean: to
     return out
 
 
+def aggregate_prod(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
+                   row_end: Optional[int] = None) -> torch.Tensor:
+    """[f, n] block: left-to-right product of the neighbours' values (agg 'prod'); rows outside
+    [row_begin, row_end) hold 1 like rows without neighbours."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.ones((f, n), dtype=torch.float64, device=device())
+    if f:
+        _lib.call('grx_aggregate_prod', _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr, row_begin, row_end,
+                  _ptr(out), n, _stream())
+    return out
+
+
 def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
                      row_end: Optional[int] = None, want_min: bool = True, want_max: bool = True) -> torch.Tensor:
     """[2f, n] block: rows 0..f-1 = neighbour minima, rows f..2f-1 = neighbour maxima."""

@@ -183,6 +183,11 @@ int grx_aggregate_var(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, 
 int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                          const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
                          double *d_min, double *d_max, int64_t ld, void *stream);
+/* agg 'prod' (extract.py:36-47 with Series.prod): left-to-right product over the neighbours in the order
+ * of d_col, 1 for a row without neighbours.  fp64 arithmetic: exact for integer columns below 2^53 (the
+ * reference multiplies int64 columns in int64 and wraps silently beyond 2^63; the caller checks). */
+int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, const double *d_rows, int ldr,
+                       int64_t row_begin, int64_t row_end, double *d_prod, int64_t ld, void *stream);
 
 /* ------------------------------------------------------------------ pruning ------------- */
 /*

@@ -35,6 +35,8 @@ def lib():
         L.orc_aggregate.restype = None
         L.orc_aggregate_var.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p, _f64p]
         L.orc_aggregate_var.restype = None
+        L.orc_aggregate_prod.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p]
+        L.orc_aggregate_prod.restype = None
         L.orc_aggregate_minmax.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_int, _f64p, _f64p, _f64p]
         L.orc_aggregate_minmax.restype = None
         L.orc_rowsum.argtypes = [ctypes.c_int64, _i64p, _i32p, ctypes.c_void_p, ctypes.c_int, _f64p]
@@ -69,6 +71,14 @@ def aggregate_var(row_ptr, col, X):
     std = np.empty_like(X)
     lib().orc_aggregate_var(n, row_ptr, col, f, X, var, std)
     return var, std
+
+
+def aggregate_prod(row_ptr, col, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, f = X.shape
+    out = np.empty_like(X)
+    lib().orc_aggregate_prod(n, row_ptr, col, f, X, out)
+    return out
 
 
 def aggregate_minmax(row_ptr, col, X):

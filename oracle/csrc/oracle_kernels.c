@@ -116,6 +116,21 @@ void orc_aggregate_var(int64_t n, const int64_t *row_ptr, const int32_t *col, in
     }
 }
 
+/* graphrole/features/extract.py:98-119 with 'prod' among the aggregations: np.multiply.reduce is a
+ * plain left-to-right product (neighbours in the order given); the empty product is 1. */
+void orc_aggregate_prod(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
+                        const double *X, double *P)
+{
+    for (int64_t v = 0; v < n; ++v) {
+        double *p = P + v * f;
+        for (int c = 0; c < f; ++c) p[c] = 1.0;
+        for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) {
+            const double *x = X + (int64_t)col[k] * f;
+            for (int c = 0; c < f; ++c) p[c] *= x[c];
+        }
+    }
+}
+
 /* graphrole/features/extract.py:98-119 with 'min' / 'max' among the aggregations: column-wise
  * minimum / maximum over the neighbours' rows; no neighbours -> NaN -> fillna(0) (:113). */
 void orc_aggregate_minmax(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,

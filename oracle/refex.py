@@ -346,6 +346,21 @@ def aggregate_var(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray
     return var, std
 
 
+def aggregate_prod(g: OracleGraph, X: np.ndarray) -> np.ndarray:
+    """
+    features/extract.py:98-119 with 'prod' in `aggs`: Series.prod() = np.multiply.reduce, a plain
+    left-to-right product over the neighbours in adjacency order (no pairwise tree for multiply);
+    the product over no neighbours is 1, not NaN.  (On int64 columns pandas multiplies in int64
+    and wraps silently; the restatement is in fp64, exact below 2**53 -- the engine refuses beyond.)
+    """
+    n, f = X.shape
+    out = np.ones((n, f))
+    for v in range(n):
+        for u in g.adj_row(v):
+            out[v] = out[v] * X[u]
+    return out
+
+
 def aggregate_minmax(g: OracleGraph, X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """
     features/extract.py:98-119 with 'min' / 'max' in `aggs`: column-wise minimum / maximum over
@@ -502,12 +517,14 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         agg_fn = lambda gg, X: ckernels.aggregate(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
         minmax_fn = lambda gg, X: ckernels.aggregate_minmax(gg.row_ptr, gg.col, X)
         var_fn = lambda gg, X: ckernels.aggregate_var(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
+        prod_fn = lambda gg, X: ckernels.aggregate_prod(gg.row_ptr, gg.col if gg.adj_col is None else gg.adj_col, X)
         bin_fn = ckernels.vertical_log_binning
         cheb_fn = lambda B: ckernels.chebyshev(B.T)
     else:
         agg_fn, bin_fn, cheb_fn = aggregate, vertical_log_binning, chebyshev_matrix
         minmax_fn = aggregate_minmax
         var_fn = aggregate_var
+        prod_fn = aggregate_prod
     names0, X0 = gen0 if gen0 is not None else neighborhood_features(g, fast)
     work: Dict[str, np.ndarray] = {}
     final_names: Dict[int, List[str]] = {}
@@ -545,6 +562,8 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
             blocks['min'], blocks['max'] = minmax_fn(g, Xp)
         if 'var' in aggs or 'std' in aggs:
             blocks['var'], blocks['std'] = var_fn(g, Xp)
+        if 'prod' in aggs:
+            blocks['prod'] = prod_fn(g, Xp)
         cand_names = [f'{c}({a})' for a in aggs for c in prev]        # extract.py:152-162
         cand_vals = np.column_stack([blocks[a] for a in aggs]) if prev else np.zeros((g.n, 0))
         update(gen, cand_names, cand_vals, gen)

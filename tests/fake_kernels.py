@@ -109,6 +109,16 @@ def aggregate_var(csr, rows, f, ldr, mean, row_begin=0, row_end=None, want_var=T
     return res
 
 
+def aggregate_prod(csr, rows, f, ldr, row_begin=0, row_end=None):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    res = torch.ones((f, n), dtype=torch.float64)
+    if f:
+        P = ckernels.aggregate_prod(csr.row_ptr, csr.agg_col, np.ascontiguousarray(rows.numpy()[:n, :f]))
+        res[:, row_begin:row_end] = torch.from_numpy(P.T[:, row_begin:row_end].copy())
+    return res
+
+
 def aggregate_minmax(csr, rows, f, ldr, row_begin=0, row_end=None, want_min=True, want_max=True):
     n = csr.n
     row_end = n if row_end is None else row_end

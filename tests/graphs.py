@@ -86,6 +86,10 @@ CASE_AGGS = {
     'loops_dangling150_minmax': ('loops_dangling150', ['sum', 'min', 'max']),
     'ba300_stdvar': ('ba300', ['mean', 'std', 'var']),
     'karate_sumstd': ('karate', ['sum', 'std']),
+    # third entry: max_generations (products grow doubly exponentially; the reference wraps int64 beyond 2^63)
+    'iface7_prod': ('iface7', ['sum', 'prod'], 4),
+    'dw200_prod': ('dw200_attrs', ['prod', 'mean'], 2),
+    'path4_prod': ('path4', ['prod', 'max'], 3),
 }
 
 BUILDERS = {

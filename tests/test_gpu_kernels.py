@@ -238,6 +238,29 @@ def test_aggregate_var_equals_pandas_on_huge_row(K):
     assert not got[:, 1:].any()                                 # leaves have one neighbour
 
 
+@pytest.mark.parametrize('f', [1, 3, 8, 20])
+def test_aggregate_prod_bit_exact_vs_oracle(K, f):
+    """agg 'prod': left-to-right product in adjacency order (np.multiply.reduce), 1 for no neighbours."""
+    import torch
+    from oracle import ckernels
+    n, m = 20000, 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=200 + f)
+    og = _oracle_graph(n, src, dst, None, False)
+    og.row_ptr = np.concatenate([og.row_ptr, np.full(4, og.row_ptr[-1])])
+    n2 = og.n
+    X = np.random.default_rng(f).uniform(0.7, 1.4, (n2, f))
+    X[:, 0] *= np.where(np.random.default_rng(1).random(n2) < 0.3, -1.0, 1.0)      # signs too
+    P = ckernels.aggregate_prod(og.row_ptr, og.adj_col, X)
+    csr = _dev_csr(K, og)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
+    got = K.aggregate_prod(csr, rows, f, ldr).cpu().numpy()
+    assert np.array_equal(got.T, P)
+    assert np.all(got[:, n:] == 1.0)
+    part = K.aggregate_prod(csr, rows, f, ldr, row_begin=10, row_end=5000).cpu().numpy()
+    assert np.array_equal(part[:, 10:5000], got[:, 10:5000]) and np.all(part[:, :10] == 1.0) and np.all(part[:, 5000:] == 1.0)
+
+
 @pytest.mark.parametrize('f', [1, 3, 6, 8, 20])
 def test_aggregate_minmax_vs_oracle(K, f):
     import torch

@@ -60,6 +60,8 @@ def test_extract_features_matches_reference(name):
     aggs = util.golden_aggs(g)
     if aggs == ['sum', 'mean']:
         fe = RecursiveFeatureExtractor(G, **kwargs)          # default aggs, like the reference's example
+    elif int(g['max_generations']) != 10:
+        fe = RecursiveFeatureExtractor(G, aggs=aggs, max_generations=int(g['max_generations']), **kwargs)
     else:
         fe = RecursiveFeatureExtractor(G, aggs=aggs, **kwargs)
     X = fe.extract_features()
@@ -416,3 +418,35 @@ def test_random_graphs_match_oracle(spec, aggs):
         np.testing.assert_allclose(got, ref.values, rtol=RTOL, atol=0)
     else:
         assert np.array_equal(got, ref.values), f'{int((got != ref.values).sum())} entries differ'
+
+
+def test_prod_on_integer_features_refuses_beyond_2_53():
+    """The reference multiplies int64 columns in int64 (wrapping past 2^63); the fp64 columns here are
+    exact below 2^53 only, so a larger integer product is an error, not a silently different number."""
+    from graphrole_amd import RecursiveFeatureExtractor
+    G, _ = graphs.BUILDERS['ba300']()
+    with pytest.raises(OverflowError, match='2\\*\\*53'):
+        RecursiveFeatureExtractor(G, aggs=['sum', 'prod'], max_generations=3).extract_features()
+
+
+def test_prod_on_float_features_matches_oracle():
+    from graphrole_amd import RecursiveFeatureExtractor
+    from graphrole_amd.graph import CSRGraph
+    from oracle import refex
+    rng = np.random.default_rng(12)
+    n, m = 400, 1600
+    src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    keep = src != dst
+    key = np.minimum(src, dst) * n + np.maximum(src, dst)
+    _, first = np.unique(key, return_index=True)
+    sel = np.intersect1d(first, np.flatnonzero(keep))
+    src, dst = src[sel], dst[sel]
+    w = rng.uniform(0.05, 0.3, len(src))                       # weighted degrees around 1: products stay finite
+    G = CSRGraph(n, src, dst, weights=w)
+    aggs = ['prod', 'mean']
+    fe = RecursiveFeatureExtractor(G, max_generations=3, aggs=aggs)
+    X = fe.extract_features()
+    og = refex.graph_from_arrays(n, src, dst, w, False)
+    ref = refex.extract_features(og, max_generations=3, fast=True, aggs=aggs)
+    assert list(X.columns) == ref.columns and any('(prod)' in c for c in X.columns)
+    np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=1e-9, atol=0)

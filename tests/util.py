@@ -10,7 +10,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'loops_dangling150',
                'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000',
                'karate_minmax', 'ba300_maxsum', 'dw200_minmax', 'loops_dangling150_minmax', 'ba300_stdvar',
-               'karate_sumstd']
+               'karate_sumstd', 'iface7_prod', 'dw200_prod', 'path4_prod']
 NMF_CASES = ['rand20x30_r3', 'rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'karate_r4', 'er2000_r6',
              'ba2000_r6', 'dw200_r5']
 

@@ -62,8 +62,8 @@ REFEX_CASES = {
 REFEX_CASES.update(G_.BUILDERS)
 # the same graphs with other aggregation lists (extract.py:36-47 `aggs`; names as pandas labels them)
 CASE_AGGS = G_.CASE_AGGS
-for _name, (_base, _aggs) in CASE_AGGS.items():
-    REFEX_CASES[_name] = REFEX_CASES[_base]
+for _name, _spec in CASE_AGGS.items():
+    REFEX_CASES[_name] = REFEX_CASES[_spec[0]]
 
 
 # --------------------------------------------------------------------------- ReFeX capture
@@ -189,7 +189,8 @@ def main():
         if args.only and name not in args.only:
             continue
         G, kwargs = make()
-        finals[name] = capture_refex(name, G, kwargs)
+        spec = CASE_AGGS.get(name, ())
+        finals[name] = capture_refex(name, G, kwargs, *([spec[2]] if len(spec) > 2 else []))
 
     if args.only and not any(x.startswith('nmf') for x in args.only):
         return
