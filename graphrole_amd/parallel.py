@@ -22,7 +22,7 @@ Scheme:
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -52,6 +52,7 @@ class ShardPlan:
         # a one-rank group skips every exchange -- unless GRX_FORCE_COLLECTIVES=1 (test hook: drives the
         # real RCCL calls, dtypes and split sizes on a one-GPU box, tests/test_gpu_sharded.py)
         self._solo = self.world == 1 and not _force_collectives()
+        self._perm_cache: dict = {}
 
     # ------------------------------------------------------------------ collectives
     def _staged(self, t: torch.Tensor) -> bool:
@@ -78,10 +79,11 @@ class ShardPlan:
             flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype, device=block.device)
             dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
         recv = flat.view(self.world, ncols, self.max_rows)
-        for p in range(self.world):
-            b, e = int(self.bounds[p]), int(self.bounds[p + 1])
-            if p != self.rank and e > b:
-                block[:, b:e] = recv[p, :, :e - b]
+        # one concatenation + one copy instead of a slice copy per rank (every small launch is host time
+        # on the critical path of a sharded generation)
+        pieces = [recv[p, :, :int(self.bounds[p + 1] - self.bounds[p])] for p in range(self.world)
+                  if self.bounds[p + 1] > self.bounds[p]]
+        block.copy_(torch.cat(pieces, dim=1))
         return block
 
     def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, out_split, in_split) -> None:
@@ -99,43 +101,58 @@ class ShardPlan:
         (columns rank, rank + world, ...) as a [n_owned, n] tensor."""
         ncols = block.shape[0]
         rb, re = self.row_begin, self.row_end
-        parts = [block[q::self.world, rb:re].reshape(-1) for q in range(self.world)]
-        in_split = [int(p.numel()) for p in parts]
-        send = torch.cat(parts) if parts else block.new_empty(0)
-        n_owned = len(range(self.rank, ncols, self.world))
+        counts, perm = self._owner_order(ncols, block.device)
+        # columns in owner-major order (owner 0's columns, then owner 1's, ...): one gather launch
+        send = block[:, rb:re].index_select(0, perm).reshape(-1)
+        in_split = [c * (re - rb) for c in counts]
+        n_owned = counts[self.rank]
         rows = [int(self.bounds[p + 1] - self.bounds[p]) for p in range(self.world)]
         out_split = [n_owned * r for r in rows]
         recv = torch.empty(sum(out_split), dtype=block.dtype, device=block.device)
         self._all_to_all(recv, send, out_split, in_split)
-        full = torch.empty((n_owned, self.n), dtype=block.dtype, device=block.device)
-        off = 0
-        for p in range(self.world):
-            b, e = int(self.bounds[p]), int(self.bounds[p + 1])
-            if n_owned and e > b:
-                full[:, b:e] = recv[off:off + n_owned * (e - b)].view(n_owned, e - b)
-            off += n_owned * (e - b)
-        return full
+        if n_owned == 0:
+            return torch.empty((0, self.n), dtype=block.dtype, device=block.device)
+        pieces, off = [], 0
+        for r in rows:
+            if r:
+                pieces.append(recv[off:off + n_owned * r].view(n_owned, r))
+            off += n_owned * r
+        return torch.cat(pieces, dim=1)                             # [n_owned, n] in one launch
 
     def owned_to_rows(self, owned: torch.Tensor, ncols: int) -> torch.Tensor:
         """Inverse direction for per-column results (uint8 bins): owned [n_owned, n] whole columns ->
         [ncols, n] with this rank's row slice of EVERY column valid (other rows zero)."""
         rb, re = self.row_begin, self.row_end
         n_owned = owned.shape[0]
-        parts = [owned[:, int(self.bounds[p]):int(self.bounds[p + 1])].reshape(-1) for p in range(self.world)]
-        in_split = [int(p.numel()) for p in parts]
-        send = torch.cat(parts) if parts else owned.new_empty(0)
-        counts = [len(range(q, ncols, self.world)) for q in range(self.world)]
+        counts, perm = self._owner_order(ncols, owned.device)
+        assert n_owned == counts[self.rank]
+        rows = [int(self.bounds[p + 1] - self.bounds[p]) for p in range(self.world)]
+        in_split = [n_owned * r for r in rows]
+        send = torch.empty(sum(in_split), dtype=owned.dtype, device=owned.device)
+        off = 0
+        for p, r in enumerate(rows):                                # the row slice each rank gets back
+            if n_owned and r:
+                send[off:off + n_owned * r].view(n_owned, r).copy_(owned[:, int(self.bounds[p]):int(self.bounds[p + 1])])
+            off += n_owned * r
         out_split = [c * (re - rb) for c in counts]
         recv = torch.empty(sum(out_split), dtype=owned.dtype, device=owned.device)
         self._all_to_all(recv, send, out_split, in_split)
         out = torch.zeros((ncols, self.n), dtype=owned.dtype, device=owned.device)
-        off = 0
-        for q in range(self.world):
-            if counts[q] and re > rb:
-                out[q::self.world, rb:re] = recv[off:off + counts[q] * (re - rb)].view(counts[q], re - rb)
-            off += counts[q] * (re - rb)
-        assert n_owned == counts[self.rank]
+        if ncols and re > rb:
+            # the received chunks are the columns in owner-major order: one scatter back to column order
+            out[:, rb:re].index_copy_(0, perm, recv.view(ncols, re - rb))
         return out
+
+    def _owner_order(self, ncols: int, device) -> Tuple[List[int], torch.Tensor]:
+        """(columns per owner, column indices in owner-major order) for the round-robin column split."""
+        key = (ncols, str(device))
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            counts = [len(range(q, ncols, self.world)) for q in range(self.world)]
+            order = [c for q in range(self.world) for c in range(q, ncols, self.world)]
+            hit = (counts, torch.tensor(order, dtype=torch.int64, device=device))
+            self._perm_cache[key] = hit
+        return hit
 
     def all_gather_columns(self, cols: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Same for a list of separate [n] columns."""
