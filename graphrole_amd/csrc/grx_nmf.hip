@@ -674,6 +674,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
     v4d accA[FT], accB = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ct = 0; ct < FT; ++ct) accA[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // When the last 16-column tile of A has r spare columns (F = 20, r = 6: columns 4..9 of tile 1),
+    // W' rides along as extra "feature" columns F..F+r-1 of the LDS tile and B = W'^T W' comes out of
+    // the same MFMAs as A: four matrix instructions fewer per sub-tile (12 -> 8 in phase 2).
+    const bool fuse_b = (F & 15) != 0 && (F & 15) + r <= 16;
     const int64_t nsub = (row_end - row_begin + 15) / 16;
     const int64_t sub_stride = (int64_t)gridDim.x * 4;
     double xb[F4], wb[R4];
@@ -710,6 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
             wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
             den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
         }
+        double wnew[R4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int k = lq + 4 * g;
@@ -720,11 +725,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
                 const bool live = valid && k < r;
                 wn = live ? wb[g] * (num[g] / d) : 0.0;
                 if (live) W[(size_t)k * ldw + row] = wn;
+                wnew[g] = wn;
             }
             wT[k * MF_LD + li] = wn;
         }
 #pragma unroll
         for (int q = 0; q < 4 * FT; ++q) xT[(4 * q + lq) * MF_LD + li] = (q < F4) ? xb[q] : 0.0;
+        if (fuse_b) {                                            // after the zero fill of the same rows (in-order LDS)
+#pragma unroll
+            for (int g = 0; g < R4; ++g) {
+                const int k = lq + 4 * g;
+                if (k < r) xT[(F + k) * MF_LD + li] = wnew[g];
+            }
+        }
         if (sidx + sub_stride < nsub) issue_loads(sidx + sub_stride);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
                 const double bX = xT[(16 * ct + li) * MF_LD + i];
                 accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, bX, accA[ct], 0, 0, 0);
             }
-            accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, aW, accB, 0, 0, 0);
+            if (!fuse_b) accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, aW, accB, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -763,7 +776,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
         if (tile < FT) {
             const int c = 16 * tile + j;
             if (c < F) partial[(size_t)(k * F + c) * gridDim.x + blockIdx.x] = v;
-        } else if (j < r) {
+            else if (fuse_b && c < F + r) partial[(size_t)(r * F + k * r + (c - F)) * gridDim.x + blockIdx.x] = v;
+        } else if (!fuse_b && j < r) {
             partial[(size_t)(r * F + k * r + j) * gridDim.x + blockIdx.x] = v;
         }
     }
