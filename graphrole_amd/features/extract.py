@@ -219,8 +219,10 @@ class RecursiveFeatureExtractor:
             # the reference multiplies integer columns in int64 (and wraps silently past 2^63); the
             # columns here are fp64, exact below 2^53: refuse anything beyond instead of drifting
             int_parents = [j for j, c in enumerate(prev) if self._dtypes.get(c, np.dtype('float64')).kind in 'iu']
-            if int_parents and re > rb:
-                peak = pieces['prod'][int_parents][:, rb:re].abs().max().reshape(1)
+            if int_parents:
+                # every rank takes part in the all-reduce, also one that owns no rows
+                peak = (pieces['prod'][int_parents][:, rb:re].abs().max().reshape(1) if re > rb
+                        else pieces['prod'].new_zeros(1))
                 if plan is not None:
                     plan.all_reduce_max_(peak)
                 if float(K.to_host(peak)[0]) >= _EXACT_INT_LIMIT:
