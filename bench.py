@@ -273,7 +273,7 @@ def main():
                         nmf_traffic = tj.get('nmf_w_pass_hbm_bytes_per_launch')
                 except Exception:
                     traffic = nmf_traffic = None
-            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_blocks_kernel, aggregate_combine_kernel)',
+            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / launches,
                         'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,

@@ -5,7 +5,7 @@
 //   egonet_kernel          ego-net internal/external  networkx.py:71-83,115-123
 //   pack_rows_kernel       column-major -> row-major gather source
 //   aggregate_kernel       sum / mean over neighbours  features/extract.py:98-119
-//   aggregate_blocks_kernel / aggregate_combine_kernel   the same for rows with > 128 neighbours
+//   aggregate_combine_kernel                             rows with > 128 neighbours: block sums -> row sums
 //   aggregate_minmax_kernel   min / max over neighbours
 //
 // Determinism: the neighbour sums follow numpy's pairwise-summation tree (a function of the row
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const doubl
 // r[slot], r[slot+S], ... (S = G/CL slots, A = 8/S accumulators per lane).  The tree levels
 // that pair accumulators of different slots are xor-shuffles, the others are local adds.
 // Rows with more than 128 neighbours are cut into the blocks of numpy's recursion by the host
-// (AggregatePlan): aggregate_blocks_kernel sums each block like a short row and
+// (AggregatePlan): aggregate_kernel sums each block like a short row and
 // aggregate_combine_kernel adds the block sums along the same binary tree.
 constexpr int PW_BLOCK = 128;
 constexpr int PW_CHUNK = 8192;
@@ -635,6 +635,18 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
     o0 = res0; o1 = res1;
 }
 
+// Blocks of the rows with more than PW_BLOCK neighbours (grx_aggregate_plan): handled by the same launch
+// as the short rows, one lane group per block of 57..128 neighbours -> blk_sums[blk][16]; the
+// combine kernel adds them along numpy's recursion afterwards.
+struct BlockWork {
+    const int32_t *long_rows;
+    const int64_t *blk_begin;
+    const int32_t *blk_len;
+    const int32_t *blk_row;
+    int64_t n_blocks;
+    double *blk_sums;
+};
+
 // VAR: out_sum / out_mean become out_var / out_std -- the sample variance (ddof = 1, pandas' default)
 // of the neighbours' values around mean_in (the 'mean' output of a previous launch) and its root.
 template <int LDR, int G, bool VAR = false>
@@ -642,17 +654,35 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ rows, int64_t row_stride, int f, int64_t row_begin, int64_t row_end,
     double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld,
-    const double *__restrict__ mean_in = nullptr)
+    const double *__restrict__ mean_in, BlockWork bw)
 {
     constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
     const int lane = threadIdx.x % G;
     const int part = lane % CL, slot = lane / CL;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    // the long rows' blocks first (the longest work items of the launch), then the short rows
+    for (int64_t k = group; k < bw.n_blocks; k += ngroups) {
+        const int64_t v = bw.long_rows[bw.blk_row[k]];
+        if (v < row_begin || v >= row_end) continue;
+        double a0, a1;
+        if (VAR) {
+            const int c0 = 2 * part, c1 = 2 * part + 1;
+            const double m0 = c0 < f ? mean_in[(int64_t)c0 * ld + v] : 0.0;
+            const double m1 = c1 < f ? mean_in[(int64_t)c1 * ld + v] : 0.0;
+            pairwise_segment<LDR, G, true>(col, rows, row_stride, bw.blk_begin[k], bw.blk_len[k], part, slot, a0, a1, m0, m1);
+        } else {
+            pairwise_segment<LDR, G>(col, rows, row_stride, bw.blk_begin[k], bw.blk_len[k], part, slot, a0, a1);
+        }
+        if (slot == 0) {
+            bw.blk_sums[k * 16 + 2 * part] = a0;
+            bw.blk_sums[k * 16 + 2 * part + 1] = a1;
+        }
+    }
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         const int64_t d = e - b;
-        if (d > PW_BLOCK) continue;                       // aggregate_blocks_kernel + aggregate_combine_kernel
+        if (d > PW_BLOCK) continue;                       // the block loop above + aggregate_combine_kernel
         double a0, a1;
         const int c0 = 2 * part, c1 = 2 * part + 1;
         if (VAR) {
@@ -689,87 +719,57 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
     }
 }
 
-// One lane group per block of a long row (57..128 neighbours); block sums to blk_sums[blk][16].
-template <int LDR, int G, bool VAR = false>
-__global__ __launch_bounds__(256) void aggregate_blocks_kernel(
-    const int32_t *__restrict__ col, const double *__restrict__ rows, int64_t row_stride,
-    int64_t row_begin, int64_t row_end, const int32_t *__restrict__ long_rows,
-    const int64_t *__restrict__ blk_begin, const int32_t *__restrict__ blk_len,
-    const int32_t *__restrict__ blk_row, int64_t n_blocks, double *__restrict__ blk_sums,
-    const double *__restrict__ mean_in = nullptr, int64_t ld = 0, int f = 0)
-{
-    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
-    const int lane = threadIdx.x % G;
-    const int part = lane % CL, slot = lane / CL;
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t k = group; k < n_blocks; k += ngroups) {
-        const int64_t v = long_rows[blk_row[k]];
-        if (v < row_begin || v >= row_end) continue;
-        double a0, a1;
-        if (VAR) {
-            const int c0 = 2 * part, c1 = 2 * part + 1;
-            const double m0 = c0 < f ? mean_in[(int64_t)c0 * ld + v] : 0.0;
-            const double m1 = c1 < f ? mean_in[(int64_t)c1 * ld + v] : 0.0;
-            pairwise_segment<LDR, G, true>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1, m0, m1);
-        } else {
-            pairwise_segment<LDR, G>(col, rows, row_stride, blk_begin[k], blk_len[k], part, slot, a0, a1);
-        }
-        if (slot == 0) {
-            blk_sums[k * 16 + 2 * part] = a0;
-            blk_sums[k * 16 + 2 * part + 1] = a1;
-        }
-    }
-}
-
-// One 64-lane workgroup per long row: add the block sums along numpy's recursion
+// Sixteen lanes per long row (lane c = column c): add the block sums along numpy's recursion
 //   sum(n) = n <= 128 ? block : sum(n2) + sum(n - n2),  n2 = n/2 - (n/2) % 8
-// chunk by chunk (8192 neighbours = at most 144 blocks), running total over the chunks.  The
-// recursion is flattened by the host into its post-order program: blk_ops[i] & 0x7F = number of
-// pending additions after pushing block i, bit 7 = last block of a chunk.  The block sums of a
-// chunk are staged in LDS by all lanes; lane c then runs the stack machine for column c.
-constexpr int PW_MAX_BLOCKS_PER_CHUNK = PW_CHUNK / 57 + 1;      // blocks are 57..128 long
+// chunk by chunk (8192 neighbours), running total over the chunks.  The recursion is flattened by the
+// host into its post-order program: blk_ops[i] & 0x7F = number of pending additions after pushing
+// block i, bit 7 = last block of a chunk.  Every lane runs the stack machine of its column on a
+// private LDS stack (no barriers, no staging: the block sums of a row are read once, 128 bytes per
+// block and group, sixteen blocks in flight at a time).
+// (First version: one 64-lane workgroup per row with the block sums staged in LDS -- 42 us per launch
+// for the 6.7 k long rows of BA 1 M, a chain of five dependent round trips per workgroup.)
 constexpr int PW_MAX_DEPTH = 12;
 
-__global__ __launch_bounds__(64) void aggregate_combine_kernel(
+__global__ __launch_bounds__(256) void aggregate_combine_kernel(
     const int64_t *__restrict__ row_ptr, int f, int64_t row_begin, int64_t row_end,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ blk_ptr, int64_t n_long,
     const uint8_t *__restrict__ blk_ops, const double *__restrict__ blk_sums, double *__restrict__ out_sum,
     double *__restrict__ out_mean, int64_t ld, int var_mode)
 {
-    __shared__ double stage_lds[PW_MAX_BLOCKS_PER_CHUNK * 16];
-    __shared__ uint8_t ops_lds[PW_MAX_BLOCKS_PER_CHUNK];
-    __shared__ double stk[PW_MAX_DEPTH][16];
-    const int c = threadIdx.x & 15;
-    for (int64_t h = blockIdx.x; h < n_long; h += gridDim.x) {
+    __shared__ double stk[16][PW_MAX_DEPTH][16];
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t gstride = (int64_t)gridDim.x * 16;
+    for (int64_t h = (int64_t)blockIdx.x * 16 + grp; h < n_long; h += gstride) {
         const int64_t v = long_rows[h];
-        if (v < row_begin || v >= row_end) continue;            // uniform over the workgroup
+        if (v < row_begin || v >= row_end) continue;               // uniform over the 16 lanes
         const int64_t n = row_ptr[v + 1] - row_ptr[v];
         const int64_t leaf_end = blk_ptr[h + 1];
+        int64_t leaf = blk_ptr[h];
         double total = 0.0;
-        for (int64_t leaf = blk_ptr[h]; leaf < leaf_end;) {
-            const int64_t avail = leaf_end - leaf;
-            const int cnt = (int)(avail < PW_MAX_BLOCKS_PER_CHUNK ? avail : PW_MAX_BLOCKS_PER_CHUNK);
-            for (int i = threadIdx.x; i < cnt * 16; i += 64) stage_lds[i] = blk_sums[leaf * 16 + i];
-            for (int i = threadIdx.x; i < cnt; i += 64) ops_lds[i] = blk_ops[leaf + i];
-            __syncthreads();
-            int used = 0;
-            if (threadIdx.x < 16) {
-                int sp = 0;
-                for (;;) {
-                    double val = stage_lds[used * 16 + c];
-                    const int op = ops_lds[used++];
-                    for (int k = op & 0x7F; k > 0; --k) val = stk[--sp][c] + val;   // left + right
-                    if (op & 0x80) { total += val; break; }      // chunk complete (sp == 0 here)
-                    stk[sp++][c] = val;
-                }
-            } else {
-                while (!(ops_lds[used++] & 0x80)) {}
+        int sp = 0;
+        // batches of 16 blocks: the loads of a batch are independent (hubs have ~100 blocks -- one load
+        // at a time would be a 100-deep latency chain), the folding is sequential
+        while (leaf < leaf_end) {
+            const int m = (int)((leaf_end - leaf) < 16 ? (leaf_end - leaf) : 16);
+            double buf[16];
+            int ops[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                buf[j] = (j < m) ? blk_sums[(leaf + j) * 16 + c] : 0.0;
+                ops[j] = (j < m) ? (int)blk_ops[leaf + j] : 0;
             }
-            leaf += used;
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < m) {
+                    double val = buf[j];
+                    for (int k = ops[j] & 0x7F; k > 0; --k) val = stk[grp][--sp][c] + val;   // left + right
+                    if (ops[j] & 0x80) total += val;             // chunk complete (sp == 0 here)
+                    else stk[grp][sp++][c] = val;
+                }
+            }
+            leaf += m;
         }
-        if (threadIdx.x < f) {
+        if (c < f) {
             if (var_mode) {                                     // long rows have n > 128 >= 2
                 const double var = total / ((double)n - 1.0);
                 if (out_sum) out_sum[(int64_t)c * ld + v] = var;
@@ -882,25 +882,18 @@ int launch_aggregate_g(const grx_aggregate_plan *p, const int64_t *row_ptr, cons
     const int64_t nrows = re - rb;
     const int64_t want = grx_ceil_div(nrows * G, 256);
     const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    const BlockWork bw{p->d_long_rows, p->d_blk_begin, p->d_blk_len, p->d_blk_row, p->n_long > 0 ? p->n_blocks : 0,
+                       p->d_blk_sums};
     {
         GRX_PROF(GRX_K_AGGREGATE, st);
-        if (mean_in) aggregate_kernel<LDR, G, true><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld, mean_in);
-        else aggregate_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld);
+        if (mean_in) aggregate_kernel<LDR, G, true><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld, mean_in, bw);
+        else aggregate_kernel<LDR, G><<<grid, 256, 0, st>>>(row_ptr, col, rows, row_stride, f, rb, re, s, m, ld, nullptr, bw);
     }
     GRX_LAUNCH_CHECK();
     if (p->n_long > 0) {
-        const int64_t bwant = grx_ceil_div(p->n_blocks * G, 256);
-        const int bgrid = (int)(bwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : bwant);
         GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-        if (mean_in)
-            aggregate_blocks_kernel<LDR, G, true><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
-                                                                         p->d_blk_begin, p->d_blk_len, p->d_blk_row,
-                                                                         p->n_blocks, p->d_blk_sums, mean_in, ld, f);
-        else
-            aggregate_blocks_kernel<LDR, G><<<bgrid, 256, 0, st>>>(col, rows, row_stride, rb, re, p->d_long_rows,
-                                                                   p->d_blk_begin, p->d_blk_len, p->d_blk_row,
-                                                                   p->n_blocks, p->d_blk_sums);
-        aggregate_combine_kernel<<<(unsigned)(p->n_long > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : p->n_long), 64, 0, st>>>(
+        const int64_t cwant = grx_ceil_div(p->n_long, 16);
+        aggregate_combine_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
             row_ptr, f, rb, re, p->d_long_rows, p->d_blk_ptr, p->n_long, p->d_blk_ops, p->d_blk_sums, s, m, ld,
             mean_in ? 1 : 0);
     }
