@@ -12,16 +12,27 @@ max_generations=4) followed by RolX NMF (NNDSVDa + multiplicative updates to con
 n_roles=6) on the resulting features, device-to-device.  The timed region is K steps between
 barrier + synchronize pairs; the time is the max over ranks.
 
-  value            = ReFeX edges-aggregated / s = nnz * executed recursive generations * K /
-                     (time spent in the ReFeX phase of the K steps), whole job
+  value            = edges aggregated per second of the WHOLE step = nnz * executed recursive
+                     generations * K / (time of the K timed steps, ReFeX pass + NMF), whole job
+  refex.edges_per_s = the same numerator over the time spent in the ReFeX phase only
   nmf.iters_per_s  = multiplicative-update iterations / s over the NMF phase of the same steps
   ms_per_step      = whole step (both phases)
   roofline         = aggregation kernel: algorithmic bytes (4 B/edge +
-                     (8 + 24 f) B/node per launch) / its HIP-event time inside the timed region
+                     (8 + 24 f) B/node per launch) / its HIP-event time inside the timed region;
+                     `traffic` comes from the committed rocprofv3 --pmc pass of the same command
+                     (profiles/traffic_latest.json) and says so in `traffic_source` -- counters cannot
+                     be read from inside the process
   cpu_baseline     = the oracle (plain-C port, 1 core) on the same graph, rank 0, N = 1 only
+  cpu_reference_path = BASELINE.md baseline (1): the reference's own pandas / networkx / scipy /
+                     sklearn call sequences (oracle/reference_path.py) on bounded samples, extrapolated
+                     to the whole workload; `speedup_vs_reference_path` compares it with `api_wall_s`
+  api_wall_s       = cold wall-clock of the drop-in calls a GraphRole user makes:
+                     RecursiveFeatureExtractor(G).extract_features() -> DataFrame and
+                     RoleExtractor(6).extract_role_factors(X) (NMF + encode), ingest share broken out
 
-With --gpus N > 1 the same graph is node-range sharded over the ranks (strong scaling) with one
-RCCL all-gather of the candidate block per generation.
+With --gpus N > 1 the same graph is node-range sharded over the ranks (strong scaling); per
+generation the candidate columns go to their owners (all-to-all), bins come back, and only the
+retained columns are all-gathered (graphrole_amd/parallel.py).
 """
 import argparse
 import ctypes
@@ -70,7 +81,8 @@ def profile_totals(lib):
 
 
 def cpu_baseline(G, args, X_features):
-    """Oracle (plain-C port, single thread) on the same graph; bounded to the full workload once."""
+    """Oracle (plain-C port, single thread) on the same graph once, plus the reference-faithful legs of
+    BASELINE.md baseline (1) on bounded samples."""
     from oracle import refex, reference_path
     og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=None, directed=False,
                            num_edges=G.num_edges, adj_col=G.adj_col)
@@ -84,20 +96,50 @@ def cpu_baseline(G, args, X_features):
         'seconds': dt, 'host_cpus': os.cpu_count(),
     }
     extra = {}
-    # reference-faithful pandas loop (BASELINE.md baseline 1): contiguous node sample of generation 1
+    ref = {'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+           'what': 'reference-faithful CPU path (BASELINE.md baseline 1): the pandas / networkx / scipy / sklearn call '
+                   'sequences of the reference (oracle/reference_path.py, pinned on the reference\'s golden tables by '
+                   'tests/test_oracle_pinned.py::test_reference_path_equals_golden)'}
     try:
-        names0, X0 = res.trace[0].retained, None
-        cols = [res.columns.index(c) for c in names0]
-        X0 = res.values[:, cols]
-        sample = min(args.cpu_sample_nodes, G.n)
-        dt_p, edges_p = reference_path.time_aggregate_sample(G.row_ptr, G.col, X0, names0, G.n // 2, sample)
-        extra['cpu_reference_path'] = {
-            'value': edges_p / dt_p, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
-            'sample': f'pandas reindex/agg loop (extract.py:104-119) on {sample} contiguous nodes of generation 1 '
-                      f'({edges_p} edges, {dt_p:.1f} s); full graph would take ~{dt_p * G.n / sample / 60:.0f} min/generation (extrapolated)',
-        }
+        import pandas as pd
+        names0 = res.trace[0].retained
+        X0 = res.values[:, [res.columns.index(c) for c in names0]]
+        first = G.n // 2
+        legs = {}
+        # (a) neighbour aggregation, features/extract.py:104-119: two contiguous samples (linearity)
+        agg = []
+        for sample in (min(args.cpu_sample_nodes, G.n), min(2 * args.cpu_sample_nodes, G.n)):
+            dt_p, edges_p = reference_path.time_aggregate_sample(G.row_ptr, G.adj_col, X0, names0, first, sample)
+            agg.append({'nodes': sample, 'edges': edges_p, 'seconds': dt_p, 'ms_per_node': 1e3 * dt_p / sample})
+        legs['aggregate'] = agg
+        ms_node = agg[-1]['ms_per_node']
+        ref['value'] = agg[-1]['edges'] / agg[-1]['seconds']
+        # (b) ego-net features, graph/interface/networkx.py:71-83
+        n_ego = min(args.cpu_ego_nodes, G.n)
+        Gs, rows = reference_path.networkx_sample_graph(G.row_ptr, G.col, first, n_ego)
+        t0 = time.perf_counter()
+        reference_path.egonet_rows_networkx(Gs, rows)
+        dt_e = time.perf_counter() - t0
+        legs['egonet'] = {'nodes': n_ego, 'seconds': dt_e, 'ms_per_node': 1e3 * dt_e / n_ego}
+        # (c) pruning, features/prune.py:13-56,94-116: binning of every column + pdist, full height
+        width = min(res.values.shape[1], args.cpu_prune_columns)
+        frame = pd.DataFrame(res.values[:, :width])
+        t0 = time.perf_counter()
+        reference_path.prune_distances(frame)
+        dt_b = time.perf_counter() - t0
+        legs['prune'] = {'rows': G.n, 'columns': width, 'seconds': dt_b,
+                         'note': 'one prune call: np.unique binning of every column + scipy pdist(chebychev), all rows'}
+        ref['legs'] = legs
+        total = ms_node * 1e-3 * G.n * gens + legs['egonet']['ms_per_node'] * 1e-3 * G.n + dt_b * (gens + 1)
+        ref['extrapolated_refex_seconds'] = total
+        ref['sample'] = (f'aggregation loop on {agg[0]["nodes"]} and {agg[1]["nodes"]} contiguous nodes of generation 1 '
+                         f'({agg[0]["ms_per_node"]:.2f} / {agg[1]["ms_per_node"]:.2f} ms per node), nx.ego_graph loop on '
+                         f'{n_ego} nodes ({legs["egonet"]["ms_per_node"]:.2f} ms per node), one full-height prune call '
+                         f'({dt_b:.1f} s for {width} columns); whole ReFeX pass extrapolated: {ms_node * 1e-3 * G.n * gens / 60:.0f} min '
+                         f'aggregation + {legs["egonet"]["ms_per_node"] * 1e-3 * G.n / 60:.0f} min ego-nets + {dt_b * (gens + 1):.0f} s pruning')
     except Exception as exc:                       # baseline legs must never kill the bench line
-        extra['cpu_reference_path'] = {'error': repr(exc)}
+        ref['error'] = repr(exc)
+    extra['cpu_reference_path'] = ref
     if X_features is not None and args.cpu_nmf:
         try:
             _, _, n_iter, dt_n = reference_path.sklearn_nmf(X_features, N_ROLES)
@@ -105,12 +147,50 @@ def cpu_baseline(G, args, X_features):
             threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
             extra['cpu_baseline_nmf'] = {
                 'value': n_iter / dt_n, 'unit': 'iters/s', 'cores': threads, 'kind': 'reference',
+                'seconds': dt_n,
                 'sample': f'sklearn NMF(mu, nndsvda) full fit on the {X_features.shape[0]}x{X_features.shape[1]} '
                           f'feature matrix: {n_iter} iterations in {dt_n:.1f} s (incl. init)',
             }
         except Exception as exc:
             extra['cpu_baseline_nmf'] = {'error': repr(exc)}
     return out, extra
+
+
+def api_wall(G, args):
+    """Cold wall-clock of the two calls a GraphRole user makes (graphrole/features/extract.py:65-96,
+    graphrole/roles/extract.py:59-93) on the bench graph: a fresh adapter, nothing resident in HBM."""
+    import torch
+    from graphrole_amd import RecursiveFeatureExtractor, RoleExtractor
+    from graphrole_amd.graph.csr import CSRGraph
+    out = {}
+    if not G.directed and not G.weighted:
+        rows = np.repeat(np.arange(G.n, dtype=np.int64), np.diff(G.row_ptr))
+        upper = rows <= G.col
+        src, dst = rows[upper], G.col[upper].astype(np.int64)
+        t0 = time.perf_counter()
+        CSRGraph(G.n, src, dst, validate=False)
+        out['csr_from_edge_arrays_s'] = time.perf_counter() - t0
+    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, attributes=bool(G.attributes))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host, dev, _ = fe.graph._device_graph()        # degree-descending relabelling, CSR upload
+    dev.plan()
+    if not host.directed and not host.weighted:
+        dev.oriented()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    X = fe.extract_features()
+    t2 = time.perf_counter()
+    np.random.seed(0)
+    rx = RoleExtractor(n_roles=N_ROLES)
+    rx.extract_role_factors(X)
+    t3 = time.perf_counter()
+    out.update({'device_ingest_s': t1 - t0, 'extract_features_s': t2 - t0, 'extract_role_factors_s': t3 - t2,
+                'total_s': t3 - t0, 'features_shape': list(X.shape),
+                'what': 'cold RecursiveFeatureExtractor(CSRGraph).extract_features() -> DataFrame (device_ingest_s = '
+                        'relabelling + CSR / plan / oriented-graph upload, included in extract_features_s) and '
+                        'RoleExtractor(6).extract_role_factors(X) incl. encode'})
+    return out
 
 
 def main():
@@ -121,7 +201,12 @@ def main():
     ap.add_argument('--workload', default='ba1m', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--agg-lanes', type=int, default=0, help='override the lane-group width of grx_aggregate (tuning)')
-    ap.add_argument('--cpu-sample-nodes', type=int, default=3000)
+    ap.add_argument('--cpu-sample-nodes', type=int, default=2500,
+                    help='reference-path aggregation samples: this many and twice as many contiguous nodes '
+                         '(BASELINE.md section 3 sizes: 20000)')
+    ap.add_argument('--cpu-ego-nodes', type=int, default=400)
+    ap.add_argument('--cpu-prune-columns', type=int, default=24)
+    ap.add_argument('--no-api-wall', action='store_true')
     ap.add_argument('--cpu-nmf', type=int, default=1)
     args = ap.parse_args()
 
@@ -263,7 +348,7 @@ def main():
         if agg_cnt:
             per_launch_ms = (agg_ms + hub_ms) / agg_cnt
             achieved = alg_bytes / launches / (per_launch_ms * 1e-3) / 1e9
-            traffic = nmf_traffic = None
+            traffic = nmf_traffic = traffic_source = nmf_mfma = agg_l2 = None
             tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
             if os.path.exists(tpath):
                 try:
@@ -271,11 +356,16 @@ def main():
                     if tj.get('workload') == args.workload and tj.get('n_gpus', 1) == world:
                         traffic = tj.get('aggregate_kernel_hbm_bytes_per_launch')
                         nmf_traffic = tj.get('nmf_w_pass_hbm_bytes_per_launch')
+                        nmf_mfma = tj.get('nmf_w_pass_mfma')
+                        agg_l2 = tj.get('aggregate_l2_hit_rate')
+                        traffic_source = (f'static: {tj.get("source")} (committed rocprofv3 --pmc passes of this command, '
+                                          'tools/profile_gpu.sh; NOT measured in this run)')
                 except Exception:
                     traffic = nmf_traffic = None
             roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': traffic, 'algorithmic_bytes_per_launch': alg_bytes / launches,
+                        'traffic': traffic, 'traffic_source': traffic_source, 'l2_hit_rate': agg_l2,
+                        'algorithmic_bytes_per_launch': alg_bytes / launches,
                         'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,
                         # the kernel is a random 64-byte-line gather: what the chip sustains on that pattern was
                         # measured with tools/microbench/gather_bw.hip
@@ -291,6 +381,9 @@ def main():
             roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_mfma_kernel (fp64 MFMA 16x16x4)', 'achieved': ach,
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                             'traffic': nmf_traffic if agg_cnt else None,
+                            'traffic_source': traffic_source if agg_cnt else None,
+                            'mfma_util': (nmf_mfma or {}).get('mfma_util') if agg_cnt else None,
+                            'mfma_counters': nmf_mfma if agg_cnt else None,
                             'algorithmic_bytes_per_launch': nmf_bytes, 'avg_launch_ms': w_ms / w_cnt}
         line = {
             'metric': 'ReFeX edges-aggregated/sec (+ RolX NMF iters/sec in nmf.iters_per_s), 1M-node graph',
@@ -300,7 +393,8 @@ def main():
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload][3], 'n_nodes': G.n,
                        'n_edges': G.num_edges, 'nnz': G.nnz, 'max_generations': MAX_GENERATIONS,
                        'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
-                       'sharding': 'node-range x%d, RCCL all-gather per generation' % world if world > 1 else 'single GPU'},
+                       'sharding': ('node-range x%d; per generation all-to-all of candidate columns to their owners, bins back, '
+                                    'RCCL all-gather of the retained columns' % world) if world > 1 else 'single GPU'},
             'refex': {'ms_per_step': t_refex / args.steps * 1e3, 'edges_per_step': edges_per_step,
                       'edges_per_s': edges_per_step * args.steps / t_refex,
                       'generations': state['stats']},
@@ -314,6 +408,18 @@ def main():
             base, extra = cpu_baseline(G, args, Xh)
             line['cpu_baseline'] = base
             line.update(extra)
+        if world == 1 and not args.no_api_wall:
+            try:
+                line['api_wall_s'] = api_wall(G, args)
+                refp = line.get('cpu_reference_path') or {}
+                if 'extrapolated_refex_seconds' in refp:
+                    nmf_s = (line.get('cpu_baseline_nmf') or {}).get('seconds', 0.0)
+                    line['speedup_vs_reference_path'] = {
+                        'value': (refp['extrapolated_refex_seconds'] + nmf_s) / line['api_wall_s']['total_s'],
+                        'what': 'reference-faithful CPU path (extrapolated ReFeX pass + measured sklearn NMF, without its '
+                                'KMeans encode) / api_wall_s.total_s; north_star target: >= 10'}
+            except Exception as exc:
+                line['api_wall_s'] = {'error': repr(exc)}
         print(json.dumps(line))
     if multi:
         dist.barrier()

@@ -38,8 +38,9 @@ def ba_edges(n: int, m: int, seed: int = 0):
     Preferential attachment by the repeated-nodes method: the i-th edge of new node v goes to an
     endpoint drawn uniformly from the endpoint list of all earlier edges.  Vectorised: endpoint
     slot 2k holds the (known) source of edge k, slot 2k+1 its target; a target that points at
-    another target slot is resolved by pointer jumping.  Parallel edges are dropped, so the
-    edge count is slightly below (n - m) * m.
+    another target slot is resolved by pointer jumping.  A new node's m targets are distinct
+    (like networkx.barabasi_albert_graph): a repeated target is drawn again, so the graph has
+    exactly (n - m) * m edges.
     """
     rng = np.random.default_rng(seed)
     nodes = np.arange(m, n, dtype=np.int64)
@@ -50,25 +51,43 @@ def ba_edges(n: int, m: int, seed: int = 0):
     limit = 2 * (k // m) * m                           # endpoint slots that exist when node v arrives
     ptr = (rng.random(M) * np.maximum(limit, 1)).astype(np.int64)
     dst = np.where(first, k, -1)
-    # resolve: even slot 2j -> src[j]; odd slot 2j+1 -> dst[j]
-    pending = ~first
-    cur = ptr.copy()
-    while pending.any():
-        idx = np.nonzero(pending)[0]
-        c = cur[idx]
-        even = (c & 1) == 0
-        j = c >> 1
-        done_even = idx[even]
-        dst[done_even] = src[j[even]]
-        pending[done_even] = False
-        odd_idx = idx[~even]
-        jo = j[~even]
-        known = dst[jo] >= 0
-        dst[odd_idx[known]] = dst[jo[known]]
-        pending[odd_idx[known]] = False
-        cur[odd_idx[~known]] = cur[jo[~known]]           # jump to what that slot is waiting for
-    key = np.unique(src * n + dst)
-    return key // n, key % n
+
+    def resolve(pending):
+        # even slot 2j -> src[j]; odd slot 2j+1 -> dst[j]
+        cur = ptr.copy()
+        while pending.any():
+            idx = np.nonzero(pending)[0]
+            c = cur[idx]
+            even = (c & 1) == 0
+            j = c >> 1
+            done_even = idx[even]
+            dst[done_even] = src[j[even]]
+            pending[done_even] = False
+            odd_idx = idx[~even]
+            jo = j[~even]
+            known = dst[jo] >= 0
+            dst[odd_idx[known]] = dst[jo[known]]
+            pending[odd_idx[known]] = False
+            cur[odd_idx[~known]] = cur[jo[~known]]       # jump to what that slot is waiting for
+
+    resolve(~first)
+    while True:
+        # repeated targets of one new node (all but the first occurrence) are drawn again
+        tgt = dst.reshape(-1, m)
+        order = np.argsort(tgt, axis=1, kind='stable')
+        srt = np.take_along_axis(tgt, order, axis=1)
+        rows, pos = np.nonzero(srt[:, 1:] == srt[:, :-1])
+        if not len(rows):
+            break
+        dup = np.zeros(M, dtype=bool)
+        dup[rows * m + order[rows, pos + 1]] = True
+        idx = np.nonzero(dup)[0]
+        ptr[idx] = (rng.random(len(idx)) * np.maximum(limit[idx], 1)).astype(np.int64)
+        # later edges may have copied a redrawn target: they keep the value they copied (any
+        # endpoint that was a valid draw stays one), only the repeated edges themselves change
+        dst[idx] = -1
+        resolve(dup)
+    return src, dst
 
 
 def ba_graph(n: int, m: int, seed: int = 0) -> CSRGraph:

@@ -4,7 +4,7 @@
  * Plain-C twins of the heavy ReFeX loops, single thread, used (a) as the checker for large
  * parity cases where the numpy loops of oracle/refex.py would take minutes and (b) as the
  * "port" CPU baseline timed by bench.py.  Each function restates the reference lines cited;
- * tests/test_oracle_refex.py checks them against oracle/refex.py and the golden vectors.
+ * tests/test_oracle_pinned.py checks them against oracle/refex.py and the golden vectors.
  *
  *   gcc -O2 -shared -fPIC -o oracle/liboracle.so oracle/csrc/oracle_kernels.c -lm
  */

@@ -2,7 +2,7 @@
 oracle/refex.py -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Numpy restatement of the ReFeX half of the GraphRole hot path.  Citations are
-``/root/reference/<file>:<line>``.  Parity: pinned by tests/test_oracle_refex.py against the
+``/root/reference/<file>:<line>``.  Parity: pinned by tests/test_oracle_pinned.py against the
 reference's own known-answer tables and against golden vectors produced by the reference
 (tools/make_golden.py).
 

@@ -10,7 +10,7 @@ requirements.txt:4).  The published algorithm is restated here from
 :815-885 loop) and ``sklearn/utils/extmath.py`` (:287-357 range finder, :531-604 randomized
 SVD, :895-953 svd_flip).
 
-Parity: pinned by tests/test_oracle_rolx.py against factors produced by the reference's
+Parity: pinned by tests/test_oracle_pinned.py (test_oracle_nmf_matches_reference_golden) against factors produced by the reference's
 ``get_nmf_decomposition`` (tests/golden/nmf_*.npz, generated with ``np.random.seed`` fixed).
 """
 from __future__ import annotations

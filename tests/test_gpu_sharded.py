@@ -30,6 +30,9 @@ def _graph(kind):
     from graphrole_amd import synth
     if kind == 'ba':
         return synth.ba_graph(60_000, 8, seed=3)
+    if kind == 'ba1m':
+        # BASELINE config 4's graph (the 1 M / 10 M power-law graph of config 3, node-range sharded)
+        return synth.ba_graph(1_000_000, 10, seed=0)
     return synth.directed_weighted_graph(40_000, 400_000, seed=4)
 
 
@@ -71,7 +74,7 @@ def _worker(rank, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['ba', 'directed_weighted'])
+@pytest.mark.parametrize('kind', ['ba', 'directed_weighted', 'ba1m'])
 def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
     mp.spawn(_worker, args=(_free_port(), kind, str(tmp_path)), nprocs=WORLD, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
@@ -124,7 +127,7 @@ def _worker_rccl(rank, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['ba', 'directed_weighted'])
+@pytest.mark.parametrize('kind', ['ba', 'directed_weighted', 'ba1m'])
 def test_rccl_collectives_one_rank(kind, tmp_path):
     mp.spawn(_worker_rccl, args=(_free_port(), kind, str(tmp_path)), nprocs=1, join=True)
     r = np.load(tmp_path / 'rccl.npz')

@@ -178,3 +178,57 @@ def test_c_twins_equal_numpy_oracle_on_random_graphs():
         S1, M1 = refex.aggregate(og, X)
         S2, M2 = ckernels.aggregate(og.row_ptr, og.adj_col, X)
         assert np.array_equal(S1, S2) and np.array_equal(M1, M2)
+
+
+# ------------------------------------------------------------------ CPU baseline (1): reference-faithful path
+@pytest.mark.parametrize('name', ['karate', 'er300', 'ba300'])
+def test_reference_path_equals_golden(name):
+    """oracle/reference_path.py (bench.py's `cpu_reference_path` legs) reproduces the imported
+    reference's own tables: neighbour aggregation bit for bit, ego-net features, binned columns and
+    the Chebyshev distance vector."""
+    import networkx as nx
+    import pandas as pd
+    from oracle import reference_path as rp
+    g = util.load_refex(name)
+    og = util.oracle_graph_from_golden(g)
+    n = og.n
+    # aggregation leg: generation 1 candidates from the columns generation 0 retained
+    prev = g.js('g0_retained')
+    names0 = g.js('g0_cand_names')
+    X0 = pd.DataFrame(g['g0_cand_values'][:, [names0.index(c) for c in prev]], columns=prev)
+    got = rp.aggregate_rows_pandas(og.row_ptr, og.adj_col, X0, range(n))
+    cand = g.js('g1_cand_names')
+    assert sorted(got.columns) == sorted(cand)
+    assert np.array_equal(got[cand].to_numpy(dtype=float), g['g1_cand_values'])
+    # ego-net leg on the networkx graph rebuilt from the fixture's edge list
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    G.add_edges_from(zip(g['src'].tolist(), g['dst'].tolist()))
+    ego = rp.egonet_rows_networkx(G, range(n))
+    for col in ('internal_edges', 'external_edges'):
+        assert np.array_equal(ego[col].to_numpy(dtype=float), g['gen0_values'][:, g.js('gen0_names').index(col)])
+    # sampled graph: ego-net features of the sampled rows equal the whole-graph ones
+    Gs, rows = rp.networkx_sample_graph(og.row_ptr, og.col, n // 3, 20)
+    ego_s = rp.egonet_rows_networkx(Gs, rows)
+    assert np.array_equal(ego_s.to_numpy(dtype=float), ego.loc[rows].to_numpy(dtype=float))
+    # pruning leg: binning of every working column and the condensed distance vector
+    cols = {}
+    for gen in range(2):
+        for j, nm in enumerate(g.js(f'g{gen}_cand_names')):
+            cols[nm] = g[f'g{gen}_cand_values'][:, j]
+    work = g.js('g1_working_before')
+    frame = pd.DataFrame({nm: cols[nm] for nm in work}, columns=work)
+    for j, nm in enumerate(work):
+        assert np.array_equal(rp.bin_column_numpy(frame[nm].to_numpy()), g['g1_binned'][:, j])
+    iu = np.triu_indices(len(work), 1)
+    assert np.array_equal(rp.prune_distances(frame), g['g1_cheb'][iu].astype(float))
+
+
+def test_reference_path_nmf_equals_golden():
+    from oracle import reference_path as rp
+    g = util.load_nmf('rand500x12_r6')
+    np.random.seed(int(g['seed']))
+    W, H, n_iter, _ = rp.sklearn_nmf(g['X'], int(g['r']))
+    assert n_iter == int(g['n_iter'])
+    np.testing.assert_allclose(W, g['W'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(H, g['H'], rtol=1e-12, atol=0)

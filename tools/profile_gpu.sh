@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
 # Outputs go to gpurun_out/prof_<tag>/ ; tools/summarize_rocprof.py condenses them into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 WORKLOAD=${2:-ba1m}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -10,7 +10,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WORKLOAD --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
-for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+# one --pmc pass per counter group (never combined with a trace domain); the last two groups are the
+# matrix-core counters north_star asks for: fp64 MFMA ops, MFMA busy cycles, and the cycle base they
+# are divided by (tools/summarize_rocprof.py: mfma_util)
+for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE"; do
   name=$(echo $ctr | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
 done

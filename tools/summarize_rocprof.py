@@ -13,7 +13,7 @@ import re
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join('gpurun_out', f'prof_{tag}')
 os.makedirs('profiles', exist_ok=True)
 
@@ -60,6 +60,15 @@ for k, ctrs in pmc.items():
         d['hbm_write_bytes_per_launch'] = d['WRITE_SIZE'] * 1024
     if 'TCC_HIT_sum' in d and 'TCC_MISS_sum' in d and d['TCC_HIT_sum'] + d['TCC_MISS_sum'] > 0:
         d['l2_hit_rate'] = d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum'])
+    if d.get('SQ_VALU_MFMA_BUSY_CYCLES') and d.get('SQ_BUSY_CU_CYCLES'):
+        # matrix-core utilisation = cycles a SIMD's MFMA pipe was busy / (cycles a CU was busy x 4 SIMDs);
+        # both SQ counters are sums over all CUs of the chip
+        d['mfma_util'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * d['SQ_BUSY_CU_CYCLES'])
+    if d.get('SQ_VALU_MFMA_BUSY_CYCLES') and d.get('GRBM_GUI_ACTIVE'):
+        # the same against the whole chip for the whole launch: 256 CUs x 4 SIMDs x GPU-active cycles
+        # (GRBM_GUI_ACTIVE is reported once per XCD and averaged over them by the accumulation above
+        # when rocprofv3 emits one row per XCD; a single summed row is 8 x the cycle count)
+        d['mfma_util_chip'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * d['GRBM_GUI_ACTIVE'])
     out[k] = d
 json.dump(out, open(os.path.join('profiles', f'{tag}_pmc.json'), 'w'), indent=1, sort_keys=True)
 print(f'pmc kernels: {len(out)}')
@@ -84,12 +93,17 @@ if agg:
         # coalesced streaming reads: FETCH_SIZE reports half the bytes on gfx950 (MI355X_MICROARCH.md, HBM
         # section); this kernel confirms it on a known byte count (208 MB read, 48 MB written per launch)
         nmf_traffic = 2.0 * nmf_fetch + nmf_write
+        nmf_first = max(nmf.values(), key=lambda d: d['launches_sampled'])
     json.dump({'workload': workload, 'n_gpus': 1, 'source': f'profiles/{tag}_pmc.json',
                'aggregate_kernel_hbm_bytes_per_launch': fetch + write,
                'nmf_w_pass_hbm_bytes_per_launch': nmf_traffic,
                'nmf_w_pass_fetch_reported': nmf_fetch if nmf else None,
                'nmf_w_pass_write_reported': nmf_write if nmf else None,
                'nmf_note': '2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction for coalesced streaming reads',
+               'nmf_w_pass_mfma': ({k: nmf_first.get(k) for k in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F64',
+                                                               'SQ_INSTS_VALU_MFMA_F64', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE',
+                                                               'mfma_util', 'mfma_util_chip')} if nmf else None),
+               'aggregate_l2_hit_rate': (sum(d.get('l2_hit_rate', 0.0) * d['launches_sampled'] for d in agg.values()) / w),
                'fetch_bytes': fetch, 'write_bytes': write, 'tcc_miss_x64B': miss * 64,
                'note': 'fabric-side bytes (L2 misses; Infinity-Cache hits are counted), FETCH_SIZE uncorrected, see script'},
               open(os.path.join('profiles', 'traffic_latest.json'), 'w'), indent=1)
