@@ -265,10 +265,7 @@ def main():
         t1 = time.perf_counter()
         Xd = K.gather_columns(cols, G.n)
         omega = rng.normal(size=(len(names), N_ROLES + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, N_ROLES, omega, plan=plan)
-        st0 = K.NmfState(Xd, G.n, W0, H0)
-        st0.x_sq_norm = factor._LAST_INIT['x_sq_norm']
-        nmf_state, n_iter = factor.run_mu_loop(st0, plan=plan)
+        nmf_state, n_iter = factor.nmf_device(Xd, G.n, N_ROLES, omega, plan=plan)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         timers['refex'] += t1 - t0

@@ -24,6 +24,29 @@ class GrxInvalid(GrxError, ValueError):
     """GRX_ERR_INVALID: the reference raises ValueError for the same condition."""
 
 
+class GrxDegenerate(GrxError, ValueError):
+    """GRX_ERR_DEGENERATE: numerically degenerate input (an all-zero feature matrix)."""
+
+
+class NmfInfo(ctypes.Structure):
+    """grx_nmf_info of include/grx.h."""
+    _fields_ = [('n_iter', c_int), ('direct_residuals', c_int), ('err_init', c_double), ('err_last', c_double),
+                ('x_sq_norm', c_double)]
+
+
+class RefexColumn(ctypes.Structure):
+    """grx_refex_column of include/grx.h."""
+    _fields_ = [('generation', c_int), ('parent', c_int), ('agg', c_int), ('gen0_index', c_int),
+                ('work_position', c_int), ('d_col', c_void_p)]
+
+
+class RefexGeneration(ctypes.Structure):
+    """grx_refex_generation of include/grx.h."""
+    _fields_ = [('candidates', c_int), ('working', c_int), ('dropped', c_int), ('retained', c_int)]
+
+
+AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5}       # grx_agg
+
 _lib = None
 
 # name -> (restype, argtypes); every entry mirrors include/grx.h
@@ -98,6 +121,17 @@ _SIGNATURES = {
                               c_void_p]),
     'grx_nmf_kl_cost': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                              c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p, POINTER(c_int),
+                              POINTER(c_size_t), c_void_p]),
+    'grx_host_eigh': (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_nmf_fit_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'grx_nmf_init': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p,
+                             POINTER(c_double), c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_mu': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_double, c_double,
+                           c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_fit': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_double, c_int, c_void_p,
+                            c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }
@@ -131,6 +165,8 @@ def check(status: int, what: str = '') -> None:
     text = f'{what}: {msg}' if what else msg
     if status == -1:
         raise GrxInvalid(text)
+    if status == -5:
+        raise GrxDegenerate(text)
     raise GrxError(f'[status {status}] {text}')
 
 

@@ -100,6 +100,136 @@ void jacobi_eigh(int n, double *A, double *w, double *V)
     std::memcpy(V, Vs.data(), sizeof(double) * n * n);
 }
 
+// Symmetric eigen-decomposition in O(n^3): Householder reduction to tridiagonal form with the
+// transformations accumulated in place, then implicit-shift QL sweeps on the tridiagonal (the classical
+// EISPACK pair).  Used above 64 columns, where the ~10 Jacobi sweeps (9 n^3 flops each) would cost tens of
+// milliseconds; same interface as jacobi_eigh (A destroyed, w ascending, eigenvectors in the columns of V).
+// Absolute accuracy eps * ||A|| like LAPACK's tridiagonal drivers; the second Gram pass of the
+// initialisation re-orthogonalises, so small eigenvalues need no more than that.
+bool tridiagonal_eigh(int n, double *A, double *w, double *V)
+{
+    std::vector<double> e(n, 0.0);
+    double *a = A, *d = w;
+    auto at = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0) {
+            double scale = 0.0;
+            for (int k = 0; k <= l; ++k) scale += std::fabs(at(i, k));
+            if (scale == 0.0) {
+                e[i] = at(i, l);
+            } else {
+                for (int k = 0; k <= l; ++k) { at(i, k) /= scale; h += at(i, k) * at(i, k); }
+                double f = at(i, l);
+                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                at(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    at(j, i) = at(i, j) / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += at(j, k) * at(i, k);
+                    for (int k = j + 1; k <= l; ++k) g += at(k, j) * at(i, k);
+                    e[j] = g / h;
+                    f += e[j] * at(i, j);
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = at(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) at(j, k) -= f * e[k] + g * at(i, k);
+                }
+            }
+        } else {
+            e[i] = at(i, l);
+        }
+        d[i] = h;
+    }
+    d[0] = 0.0;
+    e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (d[i] != 0.0) {
+            for (int j = 0; j < i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k < i; ++k) g += at(i, k) * at(k, j);
+                for (int k = 0; k < i; ++k) at(k, j) -= g * at(k, i);
+            }
+        }
+        d[i] = at(i, i);
+        at(i, i) = 1.0;
+        for (int j = 0; j < i; ++j) at(j, i) = at(i, j) = 0.0;
+    }
+    // QL with implicit shifts on (d, e); the rotations are applied to the columns of a
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    bool ok = true;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 80) { ok = false; break; }
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    e[i + 1] = r = std::hypot(f, g);
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                    for (int k = 0; k < n; ++k) {
+                        f = at(k, i + 1);
+                        at(k, i + 1) = s * at(k, i) + c * f;
+                        at(k, i) = c * at(k, i) - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+        if (!ok) break;
+    }
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] < d[y]; });
+    std::vector<double> ds(d, d + n);
+    for (int j = 0; j < n; ++j) {
+        w[j] = ds[order[j]];
+        for (int i = 0; i < n; ++i) V[(size_t)i * n + j] = a[(size_t)i * n + order[j]];
+    }
+    return ok;
+}
+
+constexpr int JACOBI_MAX_N = 64;
+
+// eigen-decomposition used by the initialisation: Jacobi for small matrices, tridiagonal QL above
+void sym_eigh(int n, double *A, double *w, double *V)
+{
+    if (n <= JACOBI_MAX_N) { jacobi_eigh(n, A, w, V); return; }
+    Mat keep(A, A + (size_t)n * n);
+    if (!tridiagonal_eigh(n, A, w, V)) jacobi_eigh(n, keep.data(), w, V);   // QL did not converge (never seen)
+}
+
 // scipy.linalg.lu(a, permute_l=True)[0]: the m x min(m, k) factor P L of a (m x k) = (P L) U,
 // LU with partial pivoting (first maximum, like LAPACK's idamax).  a is destroyed.
 void lu_permuted_l(int m, int k, double *a, double *PL)
@@ -230,6 +360,14 @@ void jacobi_svd(int m, int n, const double *B, double *U, double *s, double *Vt)
 
 extern "C" {
 
+int grx_host_eigh(int n, const double *A_in, double *w, double *V)
+{
+    GRX_REQUIRE(n >= 1 && A_in && w && V, "grx_host_eigh: bad arguments");
+    Mat A(A_in, A_in + (size_t)n * n);
+    sym_eigh(n, A.data(), w, V);
+    return GRX_OK;
+}
+
 // Whitening transform of the first Gram matrix G1 = X^T X (F x F):  eigen-pairs above the
 // numerical floor, T1 = V[:, keep] / sqrt(lam[keep]) (F x k, row-major with k columns).
 // lam_keep [k], V_keep [F x k].  Returns k (0: the feature matrix is numerically zero).
@@ -238,7 +376,7 @@ int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, doubl
     GRX_REQUIRE(F >= 1 && G1 && T1 && lam_keep && V_keep && k_out, "grx_host_whiten: bad arguments");
     Mat A(G1, G1 + (size_t)F * F), V((size_t)F * F);
     std::vector<double> w(F);
-    jacobi_eigh(F, A.data(), w.data(), V.data());
+    sym_eigh(F, A.data(), w.data(), V.data());
     const double lam_max = std::max(w[F - 1], 0.0);
     const double floor = lam_max * F * 2.220446049250313e-16 * 16;
     int k = 0;
@@ -271,7 +409,7 @@ int grx_host_range_finder(int F, int k, const double *T1, const double *lam_keep
     GRX_REQUIRE(T1 && lam_keep && V_keep && G2 && omega && Z && S && Vt_out, "grx_host_range_finder: NULL pointer");
     Mat A(G2, G2 + (size_t)k * k), V2((size_t)k * k);
     std::vector<double> lam2(k);
-    jacobi_eigh(k, A.data(), lam2.data(), V2.data());
+    sym_eigh(k, A.data(), lam2.data(), V2.data());
     // T = (T1 V2) / sqrt(lam2)           F x k
     Mat T((size_t)F * k);
     matmul(F, k, k, T1, V2.data(), T.data());

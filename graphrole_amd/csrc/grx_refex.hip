@@ -1,0 +1,283 @@
+// grx_refex.hip -- the ReFeX generation loop below the C ABI (host driver, no device code of its own).
+//
+// Reference: RecursiveFeatureExtractor.extract_features / _get_next_features / _update
+// (graphrole/features/extract.py:65-142) with FeaturePruner (graphrole/features/prune.py:76-139) and the
+// feature graph's connected components (graphrole/graph/graph.py:7-57).
+//
+// Every generation is "pack the retained columns -> aggregate over neighbours -> bin the new columns ->
+// Chebyshev distances over the working set -> prune", and the next generation cannot start before the
+// pruning decision of this one is known.  Driven from Python that dependency chain costs ~10 boundary
+// crossings, half a dozen allocations and an interpreter-speed pruner per generation -- more than the
+// kernels themselves on a 100 k-node graph.  Here the whole chain is C++: kernels are enqueued back to
+// back into one caller-provided arena, the only host <-> device traffic is the F x F distance matrix of
+// each generation, and the pruner is a few dozen string compares.
+#include "grx_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+const char *const AGG_NAMES[] = {"sum", "mean", "min", "max", "var", "std"};
+constexpr int N_AGG_KINDS = 6;
+
+struct Column {
+    std::string name;
+    int generation;
+    int parent;               // index into the column list, -1 for generation 0
+    int agg;                  // grx_agg, -1 for generation 0
+    const double *data;
+    const uint8_t *bins;
+    int record_index;         // position in the output table, -1 while not recorded
+};
+
+// bump allocator over the caller's arena; keeps counting past the end so that the caller learns how
+// much would have been needed
+struct Arena {
+    char *base;
+    size_t cap, top = 0, peak = 0;
+    bool overflow = false;
+    void *take(size_t bytes)
+    {
+        const size_t at = grx_align_up(top, 256);
+        top = at + bytes;
+        if (top > peak) peak = top;
+        if (top > cap) { overflow = true; return nullptr; }
+        return base + at;
+    }
+};
+
+thread_local void *g_pinned = nullptr;
+thread_local size_t g_pinned_bytes = 0;
+
+int pinned(size_t bytes, void **out)
+{
+    if (g_pinned_bytes < bytes) {
+        if (g_pinned) (void)hipHostFree(g_pinned);
+        g_pinned = nullptr;
+        g_pinned_bytes = 0;
+        const size_t want = bytes < (256u << 10) ? (256u << 10) : bytes;
+        GRX_CHECK_HIP(hipHostMalloc(&g_pinned, want, hipHostMallocDefault));
+        g_pinned_bytes = want;
+    }
+    *out = g_pinned;
+    return GRX_OK;
+}
+
+#define GRX_TRY(expr) do { int rc__ = (expr); if (rc__ != GRX_OK) return rc__; } while (0)
+
+// prune.py:76-130 on the distance matrix of the working set: indices (into `work`) to drop
+std::vector<int> prune(const std::vector<Column> &cols, const std::vector<int> &work, const int32_t *dist, int thresh,
+                       const std::vector<std::vector<int>> &recorded)
+{
+    const int F = (int)work.size();
+    std::vector<std::vector<int>> adj(F);
+    for (int p = 0; p < F; ++p)
+        for (int q = p + 1; q < F; ++q)
+            if (dist[(size_t)p * F + q] <= thresh) { adj[p].push_back(q); adj[q].push_back(p); }
+    std::vector<int> comp(F, -1), drop;
+    std::vector<int> stack, members;
+    for (int s = 0; s < F; ++s) {
+        if (comp[s] >= 0 || adj[s].empty()) continue;             // isolated features are never pruned
+        members.clear();
+        stack.assign(1, s);
+        comp[s] = s;
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            members.push_back(v);
+            for (int u : adj[v])
+                if (comp[u] < 0) { comp[u] = s; stack.push_back(u); }
+        }
+        // the member recorded in the earliest generation survives; ties and never-recorded members by name
+        int keep = -1;
+        for (size_t gen = 0; gen < recorded.size() && keep < 0; ++gen)
+            for (int m : members) {
+                const int c = work[m];
+                if (std::find(recorded[gen].begin(), recorded[gen].end(), c) == recorded[gen].end()) continue;
+                if (keep < 0 || cols[c].name < cols[work[keep]].name) keep = m;
+            }
+        if (keep < 0)
+            for (int m : members)
+                if (keep < 0 || cols[work[m]].name < cols[work[keep]].name) keep = m;
+        for (int m : members)
+            if (m != keep) drop.push_back(m);
+    }
+    return drop;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
+                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
+                  int n_aggs, const int *h_aggs, void *d_arena, size_t arena_bytes, int max_columns,
+                  grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
+                  int *generation_count, size_t *arena_needed, void *stream)
+{
+    GRX_REQUIRE(plan && d_row_ptr && d_agg_col && n >= 1 && f0 >= 1 && h_gen0_cols && h_gen0_names,
+                "grx_refex_run: bad graph / generation-0 arguments");
+    GRX_REQUIRE(n_aggs >= 1 && h_aggs && h_columns && n_columns && h_gens && generation_count && max_columns >= f0 &&
+                max_gens >= 1, "grx_refex_run: bad output arguments");
+    bool has[N_AGG_KINDS] = {false, false, false, false, false, false};
+    for (int a = 0; a < n_aggs; ++a) {
+        GRX_REQUIRE(h_aggs[a] >= 0 && h_aggs[a] < N_AGG_KINDS, "grx_refex_run: unknown aggregation id %d", h_aggs[a]);
+        has[h_aggs[a]] = true;
+    }
+    hipStream_t st = grx_stream(stream);
+    Arena arena{reinterpret_cast<char *>(d_arena), d_arena ? arena_bytes : 0};
+    std::vector<Column> cols;
+    std::vector<int> work;                                   // working set, insertion order (extract.py:128-133)
+    std::vector<std::vector<int>> recorded;                  // generation -> recorded columns (_final_features)
+    int n_out = 0;
+    bool table_full = false;
+
+    // add the new columns to the working set, bin them, prune across the set, record what survives
+    // (extract.py:121-142); `block` = the new columns as one contiguous [count, n] block
+    auto update = [&](int first_new, int count, const double *block, int generation) -> int {
+        const size_t scratch_mark = arena.top;
+        uint8_t *bins = nullptr;
+        if (count) {
+            // bins are cached for the life of a column: re-binning is result-identical (prune.py:101-104)
+            arena.top = scratch_mark;
+            bins = reinterpret_cast<uint8_t *>(arena.take((size_t)count * n));
+        }
+        const size_t persistent_top = arena.top;
+        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, count);
+        void *ws = count ? arena.take(ws_bytes) : nullptr;
+        for (int j = 0; j < count; ++j) work.push_back(first_new + j);
+        const int F = (int)work.size();
+        int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take((size_t)F * F * 4));
+        std::vector<int> drop_idx;
+        if (!arena.overflow) {
+            if (count) {
+                GRX_TRY(grx_vertical_log_bin(n, count, block, n, 0.5, bins, n, nullptr, ws, ws_bytes, stream));
+                for (int j = 0; j < count; ++j) cols[first_new + j].bins = bins + (size_t)j * n;
+            }
+            if (F >= 2) {
+                std::vector<const uint8_t *> ptrs(F);
+                for (int j = 0; j < F; ++j) ptrs[j] = cols[work[j]].bins;
+                GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, (size_t)F * F * 4, st));
+                // the pruner only asks "distance <= generation number?" (prune.py:110-113)
+                GRX_TRY(grx_chebyshev(0, n, F, 0, ptrs.data(), d_dist, generation, stream));
+                void *host = nullptr;
+                GRX_TRY(pinned((size_t)F * F * 4, &host));
+                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, (size_t)F * F * 4, hipMemcpyDeviceToHost, st));
+                GRX_CHECK_HIP(hipStreamSynchronize(st));
+                drop_idx = prune(cols, work, reinterpret_cast<const int32_t *>(host), generation, recorded);
+            }
+        }
+        arena.top = persistent_top;                           // workspace and distance matrix are scratch
+        std::vector<char> dropped(cols.size(), 0);
+        for (int m : drop_idx) dropped[work[m]] = 1;
+        const int working_before = F;
+        work.erase(std::remove_if(work.begin(), work.end(), [&](int c) { return dropped[c] != 0; }), work.end());
+        std::vector<int> kept;
+        for (int j = 0; j < count; ++j)
+            if (!dropped[first_new + j]) kept.push_back(first_new + j);
+        // extract.py:140 Index.difference: name-sorted iff the drop list is non-empty (pandas 2)
+        if (!drop_idx.empty())
+            std::stable_sort(kept.begin(), kept.end(), [&](int a, int b) { return cols[a].name < cols[b].name; });
+        for (int c : kept) {
+            if (n_out >= max_columns) { table_full = true; break; }
+            cols[c].record_index = n_out;
+            grx_refex_column &o = h_columns[n_out++];
+            o.generation = generation;
+            o.parent = cols[c].parent >= 0 ? cols[cols[c].parent].record_index : -1;
+            o.agg = cols[c].agg;
+            o.gen0_index = cols[c].generation == 0 ? c : -1;
+            o.work_position = -1;
+            o.d_col = cols[c].data;
+        }
+        recorded.push_back(kept);
+        if (generation < max_gens) {
+            grx_refex_generation &g = h_gens[generation];
+            g.candidates = count;
+            g.working = working_before;
+            g.dropped = (int)drop_idx.size();
+            g.retained = (int)kept.size();
+        }
+        return GRX_OK;
+    };
+
+    // ---- generation 0: the neighbourhood features the caller computed (base.py:18-26)
+    for (int j = 0; j < f0; ++j) {
+        GRX_REQUIRE(h_gen0_cols[j] && h_gen0_names[j], "grx_refex_run: generation-0 column %d is NULL", j);
+        cols.push_back({h_gen0_names[j], 0, -1, -1, h_gen0_cols[j], nullptr, -1});
+    }
+    {
+        // binning wants one contiguous block: a scratch copy of the (separately allocated) input columns
+        const size_t mark = arena.top;
+        double *copy = reinterpret_cast<double *>(arena.take((size_t)f0 * n * 8));
+        if (!arena.overflow) GRX_TRY(grx_gather_columns(n, f0, h_gen0_cols, copy, n, stream));
+        (void)mark;
+        // (the copy stays below the bins in the arena: a few columns, once per run)
+        GRX_TRY(update(0, f0, copy, 0));
+    }
+    int generation = 0;
+    for (int g = 1; g < max_generations && !arena.overflow && !table_full; ++g) {
+        generation = g;
+        const std::vector<int> &prev = recorded[g - 1];
+        const int f = (int)prev.size();
+        const int count = n_aggs * f;
+        const int first_new = (int)cols.size();
+        double *block = count ? reinterpret_cast<double *>(arena.take((size_t)count * n * 8)) : nullptr;
+        if (count) {
+            // candidate order: every column under the first aggregation, then the second, ... (extract.py:158-162)
+            for (int a = 0; a < n_aggs; ++a)
+                for (int j = 0; j < f; ++j) {
+                    const Column &p = cols[prev[j]];
+                    cols.push_back({p.name + "(" + AGG_NAMES[h_aggs[a]] + ")", g, prev[j], h_aggs[a],
+                                    block ? block + ((size_t)a * f + j) * n : nullptr, nullptr, -1});
+                }
+            const size_t mark = arena.top;
+            const int ldr = grx_aggregate_ldr(f);
+            double *rows = reinterpret_cast<double *>(arena.take((size_t)n * ldr * 8));
+            const bool need_var = has[GRX_AGG_VAR] || has[GRX_AGG_STD];
+            double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
+                                                                    : nullptr;
+            if (!arena.overflow) {
+                auto out_of = [&](int agg) -> double * {
+                    for (int a = 0; a < n_aggs; ++a)
+                        if (h_aggs[a] == agg) return block + (size_t)a * f * n;
+                    return nullptr;
+                };
+                std::vector<const double *> ptrs(f);
+                for (int j = 0; j < f; ++j) ptrs[j] = cols[prev[j]].data;
+                GRX_TRY(grx_pack_rows(n, f, ptrs.data(), rows, ldr, stream));
+                double *d_mean = has[GRX_AGG_MEAN] ? out_of(GRX_AGG_MEAN) : mean_scratch;
+                if (has[GRX_AGG_SUM] || d_mean)
+                    GRX_TRY(grx_aggregate(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, out_of(GRX_AGG_SUM), d_mean, n, stream));
+                if (need_var)
+                    GRX_TRY(grx_aggregate_var(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, d_mean, out_of(GRX_AGG_VAR),
+                                              out_of(GRX_AGG_STD), n, stream));
+                if (has[GRX_AGG_MIN] || has[GRX_AGG_MAX])
+                    GRX_TRY(grx_aggregate_minmax(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, out_of(GRX_AGG_MIN),
+                                                 out_of(GRX_AGG_MAX), n, stream));
+            }
+            arena.top = mark;                                 // the gather source is scratch
+        }
+        GRX_TRY(update(first_new, count, block, g));
+        if (recorded[g].empty()) break;                       // extract.py:86-87
+    }
+    if (arena_needed) *arena_needed = arena.peak;
+    if (arena.overflow) {
+        grx_set_error("grx_refex_run: arena of %zu bytes is too small (needs at least %zu so far)", arena.cap, arena.peak);
+        return GRX_ERR_WORKSPACE;
+    }
+    if (table_full) {
+        grx_set_error("grx_refex_run: more than %d recorded columns", max_columns);
+        return GRX_ERR_WORKSPACE;
+    }
+    for (size_t pos = 0; pos < work.size(); ++pos)
+        if (cols[work[pos]].record_index >= 0) h_columns[cols[work[pos]].record_index].work_position = (int)pos;
+    *n_columns = n_out;
+    *generation_count = generation;
+    GRX_CHECK_HIP(hipStreamSynchronize(st));
+    return GRX_OK;
+}
+
+}  // extern "C"

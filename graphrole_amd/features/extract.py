@@ -59,11 +59,14 @@ class RecursiveFeatureExtractor:
         :param G: graph object from a supported graph package (networkx, graphrole_amd.CSRGraph)
         :param max_generations: maximum levels of recursion
         :param aggs: optional list of aggregations for each recursive generation
-          ('sum' / 'mean' in any spelling pandas accepts; others raise NotImplementedError)
+          ('sum', 'mean', 'min', 'max', 'std', 'var', 'prod' in any spelling pandas accepts; others raise
+          NotImplementedError)
         :kwargs: attributes / attributes_include / attributes_exclude for the graph interface;
-          distributed=True|ProcessGroup shards node ranges over the ranks of torch.distributed
+          distributed=True|ProcessGroup shards node ranges over the ranks of torch.distributed;
+          native_loop=False drives the generations from Python even on one GPU (tests)
         """
         distributed = kwargs.pop('distributed', None)
+        kwargs_native = bool(kwargs.pop('native_loop', True))
         graph_class = interface.get_interface(G)
         if graph_class is None:
             raise TypeError(f'Input graph G must be from one of the following '
@@ -91,6 +94,9 @@ class RecursiveFeatureExtractor:
         self._final_cols: Dict[str, object] = {}                   # recorded name -> fp64 column
         self._plan = None
         self._plan_ready = False
+        self._arena = None            # device memory of grx_refex_run, reused by later runs of this instance
+        #: False drives the generation loop from Python, kernel by kernel (the path a ShardPlan uses)
+        self._native_loop = kwargs_native
         #: per-generation statistics (candidates, retained, widths) for benchmarks
         self.stats: List[Dict] = []
 
@@ -143,11 +149,16 @@ class RecursiveFeatureExtractor:
         """
         if self._final_names:
             return
-        self._agg_names()
+        aggs = self._agg_names()
         self._shard()
 
         # generation 0: neighbourhood (local + ego-net) features
         names, cols, dtypes = self.graph.neighborhood_feature_columns()
+        if self._plan is None and self._native_loop and 'prod' not in aggs and len(set(aggs)) == len(aggs) \
+                and hasattr(self._K(), 'refex_run'):
+            # one GPU: the whole generation loop runs below the ABI (grx_refex_run)
+            self._run_native(names, cols, dtypes, aggs)
+            return
         self._update_columns(names, cols, dtypes)
 
         for generation in range(1, self.max_generations):
@@ -161,6 +172,46 @@ class RecursiveFeatureExtractor:
             # stop if an iteration results in no features retained
             if not self._final_names[generation]:
                 break
+
+    def _run_native(self, names0, cols0, dtypes0, aggs) -> None:
+        """grx_refex_run + the bookkeeping the DataFrame views need: names from the lineage table, pandas
+        dtypes, the final working set, per-generation statistics."""
+        K = self._K()
+        _, dev_graph, _ = self.graph._device_graph()
+        columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
+                                                                   aggs, self._arena)
+        host = self.graph._device_graph()[0]
+        no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
+        names: List[str] = []
+        for c in columns:
+            if c['gen0_index'] >= 0:
+                nm = names0[c['gen0_index']]
+                self._dtypes[nm] = dtypes0[c['gen0_index']]
+            else:
+                parent = names[c['parent']]
+                nm = f"{parent}({c['agg']})"
+                self._dtypes[nm] = self._candidate_dtype(self._dtypes[parent], aggs, no_empty_rows)
+            names.append(nm)
+            self._final_names.setdefault(c['generation'], []).append(nm)
+            self._final_cols[nm] = c['col']
+        for g in range(gen_count + 1):
+            self._final_names.setdefault(g, [])
+        in_work = sorted((c['work_position'], nm) for c, nm in zip(columns, names) if c['work_position'] >= 0)
+        for _, nm in in_work:
+            self._work[nm] = self._final_cols[nm]
+        self.generation_count = gen_count
+        self._feature_group_thresh = gen_count
+        self.stats = generations
+
+    @staticmethod
+    def _candidate_dtype(parent_dtype, aggs, no_empty_rows: bool):
+        """pandas dtype of a candidate column in the reference's frame (extract.py:104-119): the per-node
+        agg frame of an integer column stays integer unless 'mean' / 'std' / 'var' is among the aggs or a
+        node without neighbours turns min / max into NaN -> 0.0 (sum and prod of nothing are the integers 0
+        and 1); one float value makes the column float64."""
+        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum', 'prod'})
+        f64 = np.dtype('float64')
+        return np.dtype('int64') if keeps_int and np.dtype(parent_dtype).kind in 'iu' else f64
 
     def reset(self) -> None:
         """Forget all computed features (the graph stays resident in HBM)."""
@@ -245,15 +296,10 @@ class RecursiveFeatureExtractor:
         self._partial_block = sub if (plan is not None and not complete) else None
         cols = [sub[j] for j in range(len(picked))]
         names = [f'{c}({a})' for a in aggs for c in prev]
-        # pandas dtype of the reference's frame (extract.py:104-119): the per-node agg frame of an
-        # integer column stays integer unless 'mean' / 'std' / 'var' is among the aggs or a node
-        # without neighbours turns min / max into NaN -> 0.0 (sum and prod of nothing are the integers 0
-        # and 1); one float value makes the column float64
         host = self.graph._device_graph()[0]
         no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
-        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum', 'prod'})
-        f64, i64 = np.dtype('float64'), np.dtype('int64')
-        dtypes = [i64 if keeps_int and self._dtypes.get(c, f64).kind in 'iu' else f64 for a in aggs for c in prev]
+        f64 = np.dtype('float64')
+        dtypes = [self._candidate_dtype(self._dtypes.get(c, f64), aggs, no_empty_rows) for a in aggs for c in prev]
         return names, cols, dtypes, sub
 
     def _update_columns(self, names: Sequence[str], cols: Sequence, dtypes: Sequence[np.dtype],

@@ -391,6 +391,60 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
     return dist
 
 
+# ------------------------------------------------------------------------------- whole ReFeX loop
+def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
+              aggs: Sequence[str], arena: Optional[torch.Tensor] = None):
+    """
+    grx_refex_run: the generation loop of RecursiveFeatureExtractor below the ABI (one call, one GPU).
+    Returns (columns, generations, generation_count, arena): `columns` = one dict per RECORDED feature in
+    record order {generation, parent, agg (name or None), gen0_index, work_position, col (fp64[n] tensor --
+    a view into `arena`, or the caller's generation-0 column)}; `generations` = per-generation counts.
+    The arena (uint8 tensor) is grown until the run fits; pass it back in to reuse it.
+    """
+    n = csr.n
+    f0 = len(gen0_cols)
+    agg_ids = (ctypes.c_int * len(aggs))(*[_lib.AGG_IDS[a] for a in aggs])
+    names = (ctypes.c_char_p * f0)(*[nm.encode('utf-8') for nm in gen0_names])
+    col_ptrs = ptr_array(list(gen0_cols))
+    max_gens = max(int(max_generations), 1)
+    if arena is None:
+        arena = torch.empty(max(n, 1) * 8 * 96 + (32 << 20), dtype=torch.uint8, device=device())
+    max_columns = 256
+    while True:
+        table = (_lib.RefexColumn * max_columns)()
+        gens = (_lib.RefexGeneration * max_gens)()
+        n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
+        lib = _lib.load()
+        rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names,
+                               int(max_generations), len(aggs), agg_ids, _ptr(arena), arena.numel(), max_columns, table,
+                               ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),
+                               _stream())
+        if rc == -3:                                    # GRX_ERR_WORKSPACE: arena or column table too small
+            if needed.value > arena.numel():
+                del arena
+                arena = torch.empty(int(needed.value * 1.5) + (32 << 20), dtype=torch.uint8, device=device())
+            else:
+                max_columns *= 4
+            continue
+        _lib.check(rc, 'grx_refex_run')
+        break
+    base = arena.data_ptr()
+    agg_names = {v: k for k, v in _lib.AGG_IDS.items()}
+    columns = []
+    for i in range(n_cols.value):
+        c = table[i]
+        if c.gen0_index >= 0:
+            col = gen0_cols[c.gen0_index]
+        else:
+            off = int(c.d_col) - base
+            col = arena[off:off + n * 8].view(torch.float64)
+        columns.append(dict(generation=c.generation, parent=c.parent, agg=agg_names.get(c.agg), gen0_index=c.gen0_index,
+                            work_position=c.work_position, col=col))
+    generations = [dict(generation=g, candidates=gens[g].candidates, working=gens[g].working, dropped=gens[g].dropped,
+                        retained=gens[g].retained) for g in range(gen_count.value + 1)]
+    return columns, generations, int(gen_count.value), arena
+
+
 # ------------------------------------------------------------------------------- NMF
 def gather_columns(cols: Sequence[torch.Tensor], n: int) -> torch.Tensor:
     F = len(cols)
@@ -500,14 +554,20 @@ def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
 
 
 class NmfState:
-    """Device buffers of one multiplicative-update run (X, W feature-major; H r x F)."""
+    """Device buffers of one multiplicative-update run (X, W feature-major; H r x F).
+    H: host array or device tensor [r, F]; x_sq_norm: ||X||_F^2 when known (lets the convergence
+    checks use the trace identity of the W-pass outputs instead of a pass over X)."""
 
-    def __init__(self, X: torch.Tensor, n: int, W: torch.Tensor, H: np.ndarray):
+    def __init__(self, X: torch.Tensor, n: int, W: torch.Tensor, H, x_sq_norm: Optional[float] = None):
         self.X, self.n, self.W = X, n, W
-        self.x_sq_norm = None          # ||X||_F^2 when known (roles/factor.py uses it for cheap residuals)
+        self.x_sq_norm = x_sq_norm
+        self.info = None               # NmfInfo of the last grx_nmf_mu / grx_nmf_fit on this state
         self.F, self.r = X.shape[0], W.shape[0]
         dev = device()
-        self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)
+        if isinstance(H, torch.Tensor):
+            self.H = H.to(dev).contiguous()
+        else:
+            self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)
         self.AB = torch.zeros(self.r * self.F + self.r * self.r, dtype=torch.float64, device=dev)
         self.err = torch.zeros(1, dtype=torch.float64, device=dev)
         self.ws_bytes = _lib.load().grx_nmf_workspace_bytes(n, self.F, self.r)
@@ -541,3 +601,57 @@ class NmfState:
         _lib.call('grx_nmf_iterate', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),
                   _ld(self.W), _ptr(self.H), _ptr(self.AB), _ptr(self.err) if with_residual else None,
                   int(iters), _ptr(self.ws), self.ws_bytes, _stream())
+
+
+# ---- the whole factorisation below the ABI (grx.h: grx_nmf_init / grx_nmf_mu / grx_nmf_fit) ----
+def _fit_workspace(n: int, F: int, r: int) -> Tuple[torch.Tensor, int]:
+    ws_bytes = _lib.load().grx_nmf_fit_workspace_bytes(n, F, r)
+    return torch.empty(ws_bytes, dtype=torch.uint8, device=device()), ws_bytes
+
+
+def _omega_arg(omega: np.ndarray, F: int) -> np.ndarray:
+    omega = np.ascontiguousarray(omega, dtype=np.float64)
+    if omega.ndim != 2 or omega.shape[0] != F:
+        raise _lib.GrxInvalid(f'omega must be [F, r + 10] with F = {F}, got {omega.shape}')
+    return omega
+
+
+def nmf_init(X: torch.Tensor, n: int, r: int, omega: np.ndarray):
+    """NNDSVDa start of the feature-major device matrix X [F, ld] (n valid rows, n >= F) in one call:
+    (W0 [r, ld] device, H0 [r, F] device, ||X||_F^2)."""
+    F = X.shape[0]
+    omega = _omega_arg(omega, F)
+    W = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+    H = torch.empty((r, F), dtype=torch.float64, device=device())
+    ws, ws_bytes = _fit_workspace(n, F, r)
+    xx = ctypes.c_double(0.0)
+    _lib.call('grx_nmf_init', n, F, r, _ptr(X), _ld(X), _hptr(omega), omega.shape[1], _ptr(W), _ld(W), _ptr(H),
+              ctypes.byref(xx), _ptr(ws), ws_bytes, _stream())
+    return W, H, float(xx.value)
+
+
+def nmf_mu(state: NmfState, tol: float, max_iter: int) -> int:
+    """Multiplicative updates with sklearn's stopping rule on the state's W, H in place; returns n_iter."""
+    ws, ws_bytes = _fit_workspace(state.n, state.F, state.r)
+    info = _lib.NmfInfo()
+    xx = state.x_sq_norm if state.x_sq_norm is not None else -1.0
+    _lib.call('grx_nmf_mu', state.n, state.F, state.r, _ptr(state.X), _ld(state.X), _ptr(state.W), _ld(state.W),
+              _ptr(state.H), float(xx), float(tol), int(max_iter), ctypes.byref(info), _ptr(ws), ws_bytes, _stream())
+    state.info = info
+    return int(info.n_iter)
+
+
+def nmf_fit(X: torch.Tensor, n: int, r: int, omega: np.ndarray, tol: float, max_iter: int):
+    """grx_nmf_fit: NNDSVDa + multiplicative updates in ONE call; returns (NmfState, n_iter)."""
+    F = X.shape[0]
+    omega = _omega_arg(omega, F)
+    W = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+    H = torch.empty((r, F), dtype=torch.float64, device=device())
+    ws, ws_bytes = _fit_workspace(n, F, r)
+    info = _lib.NmfInfo()
+    _lib.call('grx_nmf_fit', n, F, r, _ptr(X), _ld(X), _hptr(omega), omega.shape[1], float(tol), int(max_iter),
+              _ptr(W), _ld(W), _ptr(H), ctypes.byref(info), _ptr(ws), ws_bytes, _stream())
+    del ws
+    state = NmfState(X, n, W, H, x_sq_norm=float(info.x_sq_norm))
+    state.info = info
+    return state, int(info.n_iter)

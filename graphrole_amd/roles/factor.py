@@ -12,10 +12,11 @@ init='nndsvda')`` (factor.py:19) with every O(N) pass on the GPU:
         (same Gaussian test matrix, drawn from numpy's global RNG exactly as sklearn does), so the
         singular triplets agree to rounding.  U = X Z, the svd_flip signs and the +/- part norms of
         NNDSVD come from one projection pass (grx_project); the element-wise NNDSVDa transform is
-        grx_nndsvd_apply.  All k x F algebra (k, F <= ~100) is numpy on the host.
+        grx_nndsvd_apply.  All k x F algebra is the library's own host code (grx_host_*).
   loop  (_nmf.py:815-885)  grx_nmf_iterate: fused W-update + W^T X / W^T W reduction pass,
-        H-update kernel, residual pass every 10 iterations; the host only reads one scalar per
-        convergence check.
+        H-update kernel; the host reads one small block per convergence check.
+  On one GPU both halves run below the ABI in one call (grx_nmf_fit, csrc/grx_fit.hip); with a ShardPlan
+  the same sequence is driven from here, kernel by kernel, with the exchanges between the passes.
 
 ``encode`` (factor.py:29-49: 1-D Lloyd-Max quantiser, sklearn KMeans in the reference) runs on the
 GPU as well (grx_lloyd_max, csrc/grx_quant.hip): SURVEY.md section 8(f) rank 1.
@@ -25,14 +26,12 @@ from __future__ import annotations
 from typing import Tuple
 
 import numpy as np
-from scipy import linalg
 
 from graphrole_amd.types import FactorTuple
 
 NMF_TOL = 1e-4          # sklearn NMF defaults (_nmf.py:1538-1553)
 NMF_MAX_ITER = 200
 NNDSVD_EPS = 1e-6
-NATIVE_SMALL_SPACE_MAX_F = 64   # Jacobi eigen / SVD of libgrx.so's host routines (O(F^3) per sweep)
 
 
 def _kernels():
@@ -40,86 +39,38 @@ def _kernels():
     return backend.get()
 
 
-# ------------------------------------------------------------------------------------------
-# small-space algebra of the initialisation (host, k x F matrices)
-# ------------------------------------------------------------------------------------------
-def _range_finder_svd(M: np.ndarray, r: int, omega: np.ndarray, shape: Tuple[int, int]):
-    """
-    sklearn's randomized_svd (extmath.py:531-604, n_oversamples=10, n_iter='auto',
-    normalizer 'auto' = LU) applied to the k x F matrix M that stands for X = Q M.
-    Returns (Us [k x r], S [r], Vt [r x F]) with X ~= (Q Us) diag(S) Vt, before svd_flip.
-    """
-    n_iter = 7 if r < 0.1 * min(shape) else 4                    # extmath.py:557-560
+def _host():
+    """The library's HOST routines for the k x F algebra of the initialisation (grx_host_*; no device
+    work, usable without a GPU)."""
+    from graphrole_amd import kernels
+    return kernels
+
+
+def _host_init(X: np.ndarray, r: int, omega: np.ndarray):
+    """N < F (fewer nodes than features): every matrix of the initialisation is small -- numpy / scipy
+    on the host, sklearn's transposed branch (extmath.py:565-569, 587-604)."""
+    from scipy import linalg
 
     def lu_norm(a):
         return linalg.lu(a, permute_l=True, check_finite=False)[0]
 
+    n, F = X.shape
+    M = X.T                                                          # F x n, more rows than columns
+    n_iter = 7 if r < 0.1 * min(X.shape) else 4                      # extmath.py:557-560
     Qs = omega
-    for _ in range(n_iter):                                        # extmath.py:349-351
+    for _ in range(n_iter):                                          # extmath.py:349-351
         Qs = lu_norm(M @ Qs)
         Qs = lu_norm(M.T @ Qs)
     Qs, _ = linalg.qr(M @ Qs, mode='economic', check_finite=False)
-    B = Qs.T @ M
-    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver='gesdd')
-    Us = Qs @ Uhat
-    k = Us.shape[1]
-    if k < r:                                                       # rank(X) < r: pad with zeros
-        Us = np.hstack([Us, np.zeros((Us.shape[0], r - k))])
-        s = np.concatenate([s, np.zeros(r - k)])
-        Vt = np.vstack([Vt, np.zeros((r - k, Vt.shape[1]))])
-    return Us[:, :r], s[:r], Vt[:r]
-
-
-def _nndsvd_plan(S, Vt, stats):
-    """
-    Column choices of NNDSVD (_nmf.py:324-352) from per-column statistics of the raw U = X Z:
-    stats[j] = (signed max-|.| entry, row, sum sq of positive part, sum sq of negative part).
-    Returns (sign[r], scale[r]) for grx_nndsvd_apply and the H matrix before thresholding.
-    """
-    r, F = Vt.shape
-    flip = np.sign(stats[:, 0])                                     # svd_flip, u-based (extmath.py:935-943)
-    flip[flip == 0] = 1.0
-    sign = np.zeros(r)
-    scale = np.zeros(r)
-    H = np.zeros((r, F))
-    scale[0] = np.sqrt(S[0])
-    H[0] = np.sqrt(S[0]) * np.abs(Vt[0])
-    for j in range(1, r):
-        y = Vt[j] * flip[j]
-        # positive / negative part norms of x = flip * u
-        x_p_nrm = np.sqrt(stats[j, 2] if flip[j] > 0 else stats[j, 3])
-        x_n_nrm = np.sqrt(stats[j, 3] if flip[j] > 0 else stats[j, 2])
-        y_p, y_n = np.maximum(y, 0), np.abs(np.minimum(y, 0))
-        y_p_nrm, y_n_nrm = linalg.norm(y_p), linalg.norm(y_n)
-        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
-        with np.errstate(invalid='ignore', divide='ignore'):
-            if m_p > m_n:
-                x_nrm, v, sigma, part = x_p_nrm, y_p / y_p_nrm, m_p, 1.0
-            else:
-                x_nrm, v, sigma, part = x_n_nrm, y_n / y_n_nrm, m_n, -1.0
-        lbd = np.sqrt(S[j] * sigma)
-        if not np.isfinite(lbd) or x_nrm == 0:
-            sign[j], scale[j] = 1.0, 0.0                             # degenerate component -> all fill
-            continue
-        sign[j] = flip[j] * part                                     # W_j = lbd * max(sign*u, 0) / x_nrm
-        scale[j] = lbd / x_nrm
-        H[j] = lbd * v
-    return sign, scale, H
-
-
-def _host_init(X: np.ndarray, r: int, omega: np.ndarray):
-    """N < F (fewer nodes than features): every matrix is small, the whole initialisation is the
-    k x F algebra above with Q = I."""
-    n, F = X.shape
-    Us, S, Vt = _range_finder_svd(X.T, r, omega, X.shape)           # transposed branch of sklearn
+    Uhat, S, Vt = linalg.svd(Qs.T @ M, full_matrices=False, lapack_driver='gesdd')
+    Us = (Qs @ Uhat)[:, :r]
+    S, Vt = S[:r], Vt[:r]
     # X^T ~= Us S Vt  ->  X ~= Vt^T S Us^T ; sklearn flips on the rows of its "Vt" = our Us^T
     U, V = Vt.T, Us.T
     idx = np.argmax(np.abs(U), axis=0)
-    flip = np.sign(U[idx, np.arange(r)])
-    flip[flip == 0] = 1.0
     stats = np.stack([U[idx, np.arange(r)], idx.astype(float), (np.maximum(U, 0) ** 2).sum(0),
                       (np.minimum(U, 0) ** 2).sum(0)], axis=1)
-    sign, scale, H = _nndsvd_plan(S, V, stats)
+    sign, scale, H = _host().host_nndsvd_plan(S, V, stats)
     W = np.empty_like(U)
     for j in range(r):
         col = np.abs(U[:, j]) if sign[j] == 0 else np.maximum(sign[j] * U[:, j], 0)
@@ -144,19 +95,15 @@ def _merge_project_stats(per_rank: np.ndarray) -> np.ndarray:
     return out
 
 
-# side channel from nndsvda_init_device to the state built from its result: ||X||_F^2 of the matrix the
-# factors were initialised for (NmfState.x_sq_norm; None = unknown -> residuals by the direct kernel)
-_LAST_INIT = {'x_sq_norm': None}
-
-
-def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
+def _init_orchestrated(Xd, n: int, r: int, omega: np.ndarray, plan=None):
     """
-    NNDSVDa start (W0 on the device, feature-major r x ld; H0 on the host) for the feature-major
-    device matrix Xd [F, ld] with n valid rows.  N >= F.
-    With a ShardPlan every rank scans only its rows: the two Gram matrices are summed over the
-    ranks, the projection statistics merged, and W0 is filled for the rank's own rows only.
+    The initialisation as a sequence of per-kernel calls with the exchanges of a ShardPlan between them
+    (the multi-GPU path): every rank scans only its rows, the two Gram matrices are summed over the ranks,
+    the projection statistics merged, and W0 is filled for the rank's own rows only.  On one GPU the
+    same sequence runs inside libgrx.so (grx_nmf_init).
     """
     K = _kernels()
+    H_ = _host()
     F = Xd.shape[0]
     rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
 
@@ -169,38 +116,32 @@ def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
 
     G1, xsum = gram()
     x_mean = xsum / (n * F)
-    _LAST_INIT['x_sq_norm'] = float(np.trace(G1))                    # ||X||_F^2, used by run_mu_loop
+    x_sq_norm = float(np.trace(G1))                                  # ||X||_F^2
     n_iter = 7 if r < 0.1 * min(n, F) else 4                          # extmath.py:557-560
-    native = F <= NATIVE_SMALL_SPACE_MAX_F and getattr(K, 'host_whiten', None) is not None
-    if native:
-        # the k x F algebra in libgrx.so's host routines (grx_host_*): same mathematics as below,
-        # without ~25 numpy / LAPACK wrapper round trips (0.6 ms per fit)
-        T1, lam_keep, V_keep = K.host_whiten(G1)
-        if T1.shape[1] == 0:
-            raise ValueError('NMF initialisation: the feature matrix is numerically zero')
-        G2, _ = gram(T1)
-        Z, S, Vt = K.host_range_finder(T1, lam_keep, V_keep, G2, omega, r, n_iter)
-    else:
-        lam, V1 = linalg.eigh(G1)
-        floor = max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
-        keep = lam > floor
-        if not keep.any():
-            raise ValueError('NMF initialisation: the feature matrix is numerically zero')
-        T1 = V1[:, keep] / np.sqrt(lam[keep])
-        G2, _ = gram(T1)
-        lam2, V2 = linalg.eigh(G2)
-        T = (T1 @ V2) / np.sqrt(lam2)                                # X T = Q, orthonormal columns
-        M = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)   # Q^T X
-        Us, S, Vt = _range_finder_svd(M, r, omega, (n, F))
-        Z = T @ Us                                                   # U = X Z
+    T1, lam_keep, V_keep = H_.host_whiten(G1)
+    if T1.shape[1] == 0:
+        raise ValueError('NMF initialisation: the feature matrix is numerically zero')
+    G2, _ = gram(T1)
+    Z, S, Vt = H_.host_range_finder(T1, lam_keep, V_keep, G2, omega, r, n_iter)
     U, stats = K.project(Xd, n, Z, rb, re)
     if plan is not None:
         stats = _merge_project_stats(plan.all_gather_host(stats))
-    sign, scale, H = K.host_nndsvd_plan(S, Vt, stats) if native else _nndsvd_plan(S, Vt, stats)
+    sign, scale, H = H_.host_nndsvd_plan(S, Vt, stats)
     K.nndsvd_apply(U, n, sign, scale, NNDSVD_EPS, x_mean, rb, re)    # W[W < eps] = 0; W[W == 0] = mean
     H[H < NNDSVD_EPS] = 0
     H[H == 0] = x_mean
-    return U, H
+    return U, H, x_sq_norm
+
+
+def nndsvda_init_device(Xd, n: int, r: int, omega: np.ndarray, plan=None):
+    """
+    NNDSVDa start for the feature-major device matrix Xd [F, ld] with n valid rows (N >= F):
+    (W0 on the device, feature-major r x ld; H0 [r, F]; ||X||_F^2).  One GPU: a single call below the
+    ABI (grx_nmf_init).  With a ShardPlan: the per-kernel sequence with its exchanges.
+    """
+    if plan is None:
+        return _kernels().nmf_init(Xd, n, r, omega)
+    return _init_orchestrated(Xd, n, r, omega, plan)
 
 
 def draw_omega(shape: Tuple[int, int], n_roles: int) -> np.ndarray:
@@ -210,26 +151,25 @@ def draw_omega(shape: Tuple[int, int], n_roles: int) -> np.ndarray:
     return np.random.normal(size=(n if n < F else F, n_roles + 10))
 
 
-def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=None):
+def _mu_orchestrated(state, tol: float, max_iter: int, plan=None) -> int:
     """
-    sklearn's _fit_multiplicative_update driver (_nmf.py:815-885): iterations are enqueued ten
-    at a time (grx_nmf_iterate); the host reads ||X - WH||_F once per block and applies the
-    reference's stopping rule (prev_err - err) / err_init < tol.
-    With a ShardPlan the per-iteration partial sums are all-reduced across ranks.
+    sklearn's _fit_multiplicative_update driver (_nmf.py:815-885) over the per-kernel entry points, with
+    the per-iteration all-reduce of a ShardPlan: ||X - WH||_F is read once per ten iterations and the
+    reference's stopping rule (prev_err - err) / err_init < tol applied.  On one GPU the same loop runs
+    inside libgrx.so (grx_nmf_mu).
     """
     K = _kernels()
 
     def residual_norm():
-        if plan is None:
-            return float(np.sqrt(K.to_host(state.err)[0]))
-        plan.all_reduce_sum_(state.err)
+        if plan is not None:
+            plan.all_reduce_sum_(state.err)
         return float(np.sqrt(K.to_host(state.err)[0]))
 
     def residual_from_identity():
         """||X - W H||_F from the W-pass outputs A = W^T X, B = W^T W (already summed over the ranks)
         and the updated H:  ||X||^2 - 2 <A, H> + <B, H H^T>.  No pass over X.  The identity cancels
-        when the fit is nearly exact, so it is only trusted for a relative residual above 1e-4
-        (its error is then below 1e-8 of the value, far under the 1e-4 stopping tolerance)."""
+        when the fit is nearly exact, so it is only trusted for a relative squared residual above 1e-8
+        (its rounding error is then far under the 1e-4 stopping tolerance)."""
         xx = getattr(state, 'x_sq_norm', None)
         if xx is None or xx <= 0.0:
             return None
@@ -264,17 +204,26 @@ def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=
             if (prev - err) / err_init < tol:
                 break
             prev = err
-    return state, n_iter
+    return n_iter
+
+
+def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=None):
+    """Multiplicative updates on an NmfState until sklearn's stopping rule fires; (state, n_iter)."""
+    if plan is None:
+        return state, _kernels().nmf_mu(state, tol, max_iter)
+    return state, _mu_orchestrated(state, tol, max_iter, plan)
 
 
 def nmf_device(Xd, n: int, n_roles: int, omega: np.ndarray,
-               tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER):
-    """NNDSVDa + multiplicative updates on a device matrix; returns (NmfState, n_iter)."""
+               tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=None):
+    """NNDSVDa + multiplicative updates on a device matrix; returns (NmfState, n_iter).  One GPU: ONE
+    call below the ABI (grx_nmf_fit)."""
     K = _kernels()
-    W0, H0 = nndsvda_init_device(Xd, n, n_roles, omega)
-    state = K.NmfState(Xd, n, W0, H0)
-    state.x_sq_norm = _LAST_INIT['x_sq_norm']
-    return run_mu_loop(state, tol, max_iter)
+    if plan is None:
+        return K.nmf_fit(Xd, n, n_roles, omega, tol, max_iter)
+    W0, H0, xx = _init_orchestrated(Xd, n, n_roles, omega, plan)
+    state = K.NmfState(Xd, n, W0, H0, x_sq_norm=xx)
+    return run_mu_loop(state, tol, max_iter, plan)
 
 
 def get_nmf_decomposition(X: np.ndarray, n_roles: int) -> FactorTuple:
@@ -310,6 +259,7 @@ def nmf_state(Xd, X: np.ndarray, n_roles: int):
     if n < F:
         # fewer nodes than features: every matrix of the initialisation is small (k x F algebra)
         W0h, H0 = _host_init(X, n_roles, omega)
+        H0 = H0.copy()
         W0h[W0h < NNDSVD_EPS] = 0
         H0[H0 < NNDSVD_EPS] = 0
         W0h[W0h == 0] = X.mean()

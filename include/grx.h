@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 100          /* 0.1.0 */
+#define GRX_VERSION 200          /* 0.2.0: whole-loop entry points (grx_refex_run, grx_nmf_fit) */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 16         /* NMF rank limit of the device kernels */
 #define GRX_MAX_NMF_FEATURES 480 /* NMF feature-count limit of the device kernels (fast paths: 120) */
@@ -42,7 +42,8 @@ typedef enum {
     GRX_ERR_INVALID = -1,        /* bad argument */
     GRX_ERR_HIP = -2,            /* HIP runtime error (message has hipGetErrorString) */
     GRX_ERR_WORKSPACE = -3,      /* workspace too small */
-    GRX_ERR_UNSUPPORTED = -4     /* shape outside the compiled limits */
+    GRX_ERR_UNSUPPORTED = -4,    /* shape outside the compiled limits */
+    GRX_ERR_DEGENERATE = -5      /* numerically degenerate input (e.g. an all-zero feature matrix) */
 } grx_status;
 
 /* ------------------------------------------------------------------ runtime helpers ---- */
@@ -189,6 +190,42 @@ int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_pt
 int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, const double *d_rows, int ldr,
                        int64_t row_begin, int64_t row_end, double *d_prod, int64_t ld, void *stream);
 
+/*
+ * The whole generation loop below the ABI (single GPU).  Replaces RecursiveFeatureExtractor.extract_features /
+ * _get_next_features / _update (graphrole/features/extract.py:65-142) together with FeaturePruner
+ * (graphrole/features/prune.py:76-139) and the feature graph's components (graphrole/graph/graph.py:7-57):
+ * generation 0 = the caller's neighbourhood-feature columns (grx_row_sums / grx_egonet_* outputs and
+ * attribute columns; names as the reference spells them), then per generation: pack the retained columns,
+ * aggregate over the neighbours (every aggregation of h_aggs, in that order: the candidate '<parent>(<agg>)'
+ * columns are ordered aggregation-major like extract.py:158-162), bin the new columns, Chebyshev distances
+ * over the working set with threshold = generation number, drop every member of a feature group but its
+ * oldest, record what this generation retains (name-sorted iff something was dropped), stop when a
+ * generation retains nothing or at max_generations.
+ *
+ * d_arena / arena_bytes: caller-provided device memory all columns, bins and scratch buffers are carved
+ * from (no allocation inside); too small -> GRX_ERR_WORKSPACE with *arena_needed = bytes needed up to the
+ * generation that failed (grow and call again; the run is deterministic).
+ * h_columns (capacity max_columns): the RECORDED columns in record order -- generation 0's first;
+ * `parent` indexes this table, names are rebuilt by the caller as name[parent] + '(' + agg + ')'.
+ * h_gens (capacity max_gens >= max_generations): per-generation counts.  *generation_count = the last
+ * executed generation (the reference's generation_count).  Synchronises `stream` before returning.
+ */
+typedef enum { GRX_AGG_SUM = 0, GRX_AGG_MEAN = 1, GRX_AGG_MIN = 2, GRX_AGG_MAX = 3, GRX_AGG_VAR = 4, GRX_AGG_STD = 5 } grx_agg;
+typedef struct {
+    int generation;            /* generation that recorded the column */
+    int parent;                /* index of the parent column in this table, -1 for generation 0 */
+    int agg;                   /* grx_agg, -1 for generation 0 */
+    int gen0_index;            /* index into h_gen0_cols for generation-0 columns, else -1 */
+    int work_position;         /* position in the final working set (extract.py:135-141), -1 if pruned from it */
+    const double *d_col;       /* fp64[n]: inside the arena, or the caller's generation-0 column */
+} grx_refex_column;
+typedef struct { int candidates, working, dropped, retained; } grx_refex_generation;
+int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
+                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
+                  int n_aggs, const int *h_aggs, void *d_arena, size_t arena_bytes, int max_columns,
+                  grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
+                  int *generation_count, size_t *arena_needed, void *stream);
+
 /* ------------------------------------------------------------------ pruning ------------- */
 /*
  * Vertical logarithmic binning of ncols columns.  Replaces vertical_log_binning
@@ -229,8 +266,8 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
  * HOST-side small dense algebra of the NNDSVDa initialisation (no device work; plain pointers to host
  * arrays, row-major).  Between its device passes (grx_gram twice, grx_project) sklearn's
  * initialisation (_nmf.py:324-359 via randomized_svd, extmath.py:531-604) only touches k x F matrices
- * with k <= F <= a few dozen; these three calls replace ~25 numpy / LAPACK wrapper calls (0.6 ms per
- * fit).  Cyclic-Jacobi eigen / singular value decompositions: meant for F <= 64.
+ * with k <= F; these three calls replace ~25 numpy / LAPACK wrapper calls (0.6 ms per fit).  Any
+ * F <= GRX_MAX_NMF_FEATURES: cyclic Jacobi up to 64 columns, tridiagonal QL above.
  *   grx_host_whiten        G1 = X^T X -> eigen-pairs above the numerical floor: lam_keep [k],
  *                          V_keep [F x k], T1 = V_keep / sqrt(lam_keep) [F x k]; *k = 0: X is zero
  *   grx_host_range_finder  G2 = (X T1)^T (X T1) -> T (X T orthonormal), M = (X T)^T X, randomized_svd of
@@ -239,6 +276,10 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
  *   grx_host_nndsvd_plan   per-column choices of NNDSVD from the grx_project statistics -> sign [r],
  *                          scale [r] for grx_nndsvd_apply and H [r x F] before thresholding
  */
+ /* grx_host_eigh: the symmetric eigen-solver behind the two calls below (cyclic Jacobi up to 64 columns,
+  * Householder tridiagonalisation + implicit QL above); h_A n x n row-major, h_w ascending, eigenvectors in
+  * the columns of h_V.  Exposed for tests. */
+int grx_host_eigh(int n, const double *h_A, double *h_w, double *h_V);
 int grx_host_whiten(int F, const double *h_G1, double *h_T1, double *h_lam_keep, double *h_V_keep, int *k);
 int grx_host_range_finder(int F, int k, const double *h_T1, const double *h_lam_keep, const double *h_V_keep,
                           const double *h_G2, const double *h_omega, int n_over, int r, int n_iter,
@@ -322,6 +363,43 @@ int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, con
 int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
                     int64_t ldw, double *d_H, double *d_AB, double *d_err, int iters,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The whole factorisation below the ABI.  Replaces get_nmf_decomposition (graphrole/roles/factor.py:10-26),
+ * i.e. sklearn NMF(n_components=r, solver='mu', init='nndsvda').fit_transform(X) with its defaults
+ * (tol 1e-4, max_iter 200; sklearn/decomposition/_nmf.py:1538-1553), on a feature-major device matrix:
+ *   grx_nmf_init  NNDSVDa start (_nmf.py:316-359 via randomized_svd, extmath.py:531-604): two Gram
+ *                 passes, the k x F host algebra (grx_host_*), one projection pass, the element-wise
+ *                 transform.  h_omega: the F x n_over Gaussian test matrix the caller drew exactly like
+ *                 sklearn does (global numpy RNG, n_over = r + 10).  Needs n >= F >= r.  Writes W0 to d_W
+ *                 (r x ldw), H0 to d_H (r x F, device) and ||X||_F^2 to *x_sq_norm.
+ *                 GRX_ERR_DEGENERATE: X is numerically zero.
+ *   grx_nmf_mu    multiplicative updates from the W, H in place with sklearn's stopping rule
+ *                 (_nmf.py:815-885: error every 10 iterations, stop when (prev - err) / err_init < tol).
+ *                 x_sq_norm > 0 lets the convergence checks use ||X||^2 - 2<W^T X, H> + <W^T W, H H^T>
+ *                 from the W-pass outputs whenever the relative squared residual exceeds 1e-8 (direct pass
+ *                 over X otherwise; x_sq_norm <= 0: always direct).
+ *   grx_nmf_fit   both.
+ * Kernels are enqueued on `stream`; the calls synchronise it at every small read-back (three in the
+ * initialisation, one per ten iterations) and return with the results complete in d_W / d_H.
+ */
+typedef struct {
+    int n_iter;               /* executed iterations: sklearn's n_iter_ */
+    int direct_residuals;     /* convergence checks that needed the direct ||X - W H|| pass */
+    double err_init;          /* ||X - W0 H0||_F */
+    double err_last;          /* error at the last convergence check */
+    double x_sq_norm;         /* ||X||_F^2 as used by the checks */
+} grx_nmf_info;
+size_t grx_nmf_fit_workspace_bytes(int64_t n, int F, int r);
+int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
+                 double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, void *d_workspace,
+                 size_t workspace_bytes, void *stream);
+int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw, double *d_H,
+               double x_sq_norm, double tol, int max_iter, grx_nmf_info *info, void *d_workspace,
+               size_t workspace_bytes, void *stream);
+int grx_nmf_fit(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
+                double tol, int max_iter, double *d_W, int64_t ldw, double *d_H, grx_nmf_info *info,
+                void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ RolX encode --------- */
 /*

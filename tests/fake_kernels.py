@@ -220,9 +220,11 @@ def lloyd_max(values, n_bins, max_iter=300):
 
 
 class NmfState:
-    def __init__(self, X, n, W, H):
+    def __init__(self, X, n, W, H, x_sq_norm=None):
         self.X, self.n, self.W = X, n, W
+        self.x_sq_norm = x_sq_norm
         self.F, self.r = X.shape[0], W.shape[0]
+        H = H.numpy() if isinstance(H, torch.Tensor) else H
         self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64).copy())
         self.AB = torch.zeros(self.r * self.F + self.r * self.r, dtype=torch.float64)
         self.err = torch.zeros(1, dtype=torch.float64)
@@ -267,3 +269,22 @@ class NmfState:
             self.h_update()
         if with_residual:
             self.residual_sq()
+
+
+# ---- whole-loop entry points: the test double runs the per-kernel sequence of roles/factor.py (the
+# sharded product path) without exchanges, on the fake kernels above
+def nmf_init(X, n, r, omega):
+    from graphrole_amd.roles import factor
+    W0, H0, xx = factor._init_orchestrated(X, n, r, omega, None)
+    return W0, torch.from_numpy(H0.copy()), xx
+
+
+def nmf_mu(state, tol, max_iter):
+    from graphrole_amd.roles import factor
+    return factor._mu_orchestrated(state, tol, max_iter, None)
+
+
+def nmf_fit(X, n, r, omega, tol, max_iter):
+    W0, H0, xx = nmf_init(X, n, r, omega)
+    state = NmfState(X, n, W0, H0, x_sq_norm=xx)
+    return state, nmf_mu(state, tol, max_iter)

@@ -52,11 +52,16 @@ def _graph_for(name, g):
     return G, g.js('kwargs')
 
 
+@pytest.mark.parametrize('native', [True, False], ids=['grx_refex_run', 'per_kernel'])
 @pytest.mark.parametrize('name', util.REFEX_CASES)
-def test_extract_features_matches_reference(name):
+def test_extract_features_matches_reference(name, native):
+    """Both drivers of the generation loop against the reference's golden tables: the whole loop below the
+    ABI (grx_refex_run, the one-GPU product path) and the per-kernel sequence from Python (the path a
+    ShardPlan uses)."""
     from graphrole_amd import RecursiveFeatureExtractor
     g = util.load_refex(name)
     G, kwargs = _graph_for(name, g)
+    kwargs = dict(kwargs, native_loop=native)
     aggs = util.golden_aggs(g)
     if aggs == ['sum', 'mean']:
         fe = RecursiveFeatureExtractor(G, **kwargs)          # default aggs, like the reference's example
@@ -72,7 +77,18 @@ def test_extract_features_matches_reference(name):
     _check_values(X.values.astype(np.float64), g['final_values'], weighted=bool(len(g['w'])))
     for gen in range(int(g['n_generations_recorded'])):
         assert fe._final_names[gen] == g.js(f'g{gen}_retained'), f'generation {gen}'
+    # the working set after the last generation (extract.py:135-141), in the reference's order
+    last = int(g['n_generations_recorded']) - 1
+    assert list(fe._features.columns) == g.js(f'g{last}_working_after')
+    # per-generation counts
+    for gen in range(int(g['n_generations_recorded'])):
+        st = fe.stats[gen]
+        assert st['candidates'] == len(g.js(f'g{gen}_cand_names')) and st['retained'] == len(g.js(f'g{gen}_retained'))
+        assert st['working'] == len(g.js(f'g{gen}_working_before')) and st['dropped'] == len(g.js(f'g{gen}_dropped'))
     # memoised second call is identical (reference test_extract_features_back_to_back)
+    pd.testing.assert_frame_equal(X, fe.extract_features())
+    # a second run of the same instance reuses its arena and reproduces the table bit for bit
+    fe.reset()
     pd.testing.assert_frame_equal(X, fe.extract_features())
 
 

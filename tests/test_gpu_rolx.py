@@ -44,9 +44,14 @@ def test_nndsvda_init_matches_reference_golden(name):
     X, r = g['X'], int(g['r'])
     n = X.shape[0]
     Xd = K.to_device(np.ascontiguousarray(X.T))
-    W0, H0 = factor.nndsvda_init_device(Xd, n, r, g['omega'])
+    W0, H0, xx = factor.nndsvda_init_device(Xd, n, r, g['omega'])          # one call below the ABI
     assert _relmax(K.to_host(W0)[:, :n].T, g['W0']) < 1e-9
-    assert _relmax(H0, g['H0']) < 1e-9
+    assert _relmax(K.to_host(H0), g['H0']) < 1e-9
+    assert abs(xx - float((X * X).sum())) <= 1e-12 * xx
+    # the per-kernel sequence the sharded path drives (same kernels, host algebra, no exchanges)
+    W0o, H0o, xxo = factor._init_orchestrated(Xd, n, r, g['omega'])
+    assert _relmax(K.to_host(W0o)[:, :n].T, g['W0']) < 1e-9
+    assert _relmax(H0o, g['H0']) < 1e-9 and abs(xxo - xx) <= 1e-12 * xx
 
 
 def test_nmf_consumes_global_rng_like_sklearn():

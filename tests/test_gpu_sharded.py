@@ -55,8 +55,7 @@ def _worker(rank, port, kind, out_dir):
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
-        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        state, n_iter = factor.nmf_device(Xd, G.n, 4, omega, plan=plan)
         out = dict(X=X.values.astype(float), cols=np.array(list(X.columns)), gen=fe.generation_count,
                    W=K.to_host(state.W)[:, :G.n], H=K.to_host(state.H), n_iter=n_iter,
                    rb=plan.row_begin, re=plan.row_end)
@@ -65,8 +64,7 @@ def _worker(rank, port, kind, out_dir):
             fe1 = RecursiveFeatureExtractor(G, max_generations=4)
             X1 = fe1.extract_features()
             Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
-            W1, H1 = factor.nndsvda_init_device(Xd1, G.n, 4, omega)
-            s1, it1 = factor.run_mu_loop(K.NmfState(Xd1, G.n, W1, H1))
+            s1, it1 = factor.nmf_device(Xd1, G.n, 4, omega)
             out.update(X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), W1=K.to_host(s1.W)[:, :G.n],
                        H1=K.to_host(s1.H), it1=it1)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
@@ -86,7 +84,8 @@ def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
     np.testing.assert_allclose(r0['H'], r0['H1'], rtol=1e-9)       # partial sums combine in another order
     for r in (r0, r1):
         rb, re = int(r['rb']), int(r['re'])
-        np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-15)
+        # entries far below the factor's scale carry the absolute error of the re-ordered partial sums
+        np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-12 * np.abs(r0['W1']).max())
 
 
 def _worker_rccl(rank, port, kind, out_dir):
@@ -112,14 +111,12 @@ def _worker_rccl(rank, port, kind, out_dir):
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
-        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        state, n_iter = factor.nmf_device(Xd, G.n, 4, omega, plan=plan)
         os.environ['GRX_FORCE_COLLECTIVES'] = '0'
         fe1 = RecursiveFeatureExtractor(G, max_generations=4, aggs=['sum', 'mean', 'max'])
         X1 = fe1.extract_features()
         Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
-        W1, H1 = factor.nndsvda_init_device(Xd1, G.n, 4, omega)
-        s1, it1 = factor.run_mu_loop(K.NmfState(Xd1, G.n, W1, H1))
+        s1, it1 = factor.nmf_device(Xd1, G.n, 4, omega)
         np.savez(os.path.join(out_dir, 'rccl.npz'), X=X.values.astype(float), cols=np.array(list(X.columns)),
                  X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), n_iter=n_iter, it1=it1,
                  H=K.to_host(state.H), H1=K.to_host(s1.H), W=K.to_host(state.W)[:, :G.n], W1=K.to_host(s1.W)[:, :G.n])
@@ -135,4 +132,4 @@ def test_rccl_collectives_one_rank(kind, tmp_path):
     assert np.array_equal(r['X'], r['X1'])
     assert int(r['n_iter']) == int(r['it1'])
     np.testing.assert_allclose(r['H'], r['H1'], rtol=1e-9)
-    np.testing.assert_allclose(r['W'], r['W1'], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(r['W'], r['W1'], rtol=1e-9, atol=1e-12 * np.abs(r['W1']).max())

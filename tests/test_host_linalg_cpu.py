@@ -1,7 +1,7 @@
 """
 -m "not gpu": the host-side small dense algebra of libgrx.so (grx_host_whiten, grx_host_range_finder,
 grx_host_nndsvd_plan; no device work) against the numpy / scipy formulation it replaces
-(graphrole_amd/roles/factor.py::_range_finder_svd, _nndsvd_plan) and against sklearn's randomized_svd.
+(restated below with scipy) and against sklearn's randomized_svd; the symmetric eigen-solver against numpy.
 """
 import ctypes
 
@@ -14,12 +14,65 @@ def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _range_finder_svd(M, r, omega, shape):
+    """sklearn's randomized_svd (extmath.py:531-604, n_oversamples=10, n_iter='auto', normalizer 'auto' = LU)
+    applied to the k x F matrix M that stands for X = Q M -- the scipy formulation grx_host_range_finder
+    replaces.  Returns (Us [k x r], S [r], Vt [r x F]) before svd_flip."""
+    n_iter = 7 if r < 0.1 * min(shape) else 4
+
+    def lu_norm(a):
+        return linalg.lu(a, permute_l=True, check_finite=False)[0]
+
+    Qs = omega
+    for _ in range(n_iter):
+        Qs = lu_norm(M @ Qs)
+        Qs = lu_norm(M.T @ Qs)
+    Qs, _ = linalg.qr(M @ Qs, mode='economic', check_finite=False)
+    Uhat, s, Vt = linalg.svd(Qs.T @ M, full_matrices=False, lapack_driver='gesdd')
+    Us = Qs @ Uhat
+    k = Us.shape[1]
+    if k < r:
+        Us = np.hstack([Us, np.zeros((Us.shape[0], r - k))])
+        s = np.concatenate([s, np.zeros(r - k)])
+        Vt = np.vstack([Vt, np.zeros((r - k, Vt.shape[1]))])
+    return Us[:, :r], s[:r], Vt[:r]
+
+
+def _nndsvd_plan(S, Vt, stats):
+    """Column choices of NNDSVD (_nmf.py:324-352) in numpy -- what grx_host_nndsvd_plan replaces."""
+    r, F = Vt.shape
+    flip = np.sign(stats[:, 0])
+    flip[flip == 0] = 1.0
+    sign, scale, H = np.zeros(r), np.zeros(r), np.zeros((r, F))
+    scale[0] = np.sqrt(S[0])
+    H[0] = np.sqrt(S[0]) * np.abs(Vt[0])
+    for j in range(1, r):
+        y = Vt[j] * flip[j]
+        x_p_nrm = np.sqrt(stats[j, 2] if flip[j] > 0 else stats[j, 3])
+        x_n_nrm = np.sqrt(stats[j, 3] if flip[j] > 0 else stats[j, 2])
+        y_p, y_n = np.maximum(y, 0), np.abs(np.minimum(y, 0))
+        y_p_nrm, y_n_nrm = linalg.norm(y_p), linalg.norm(y_n)
+        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+        with np.errstate(invalid='ignore', divide='ignore'):
+            if m_p > m_n:
+                x_nrm, v, sigma, part = x_p_nrm, y_p / y_p_nrm, m_p, 1.0
+            else:
+                x_nrm, v, sigma, part = x_n_nrm, y_n / y_n_nrm, m_n, -1.0
+        lbd = np.sqrt(S[j] * sigma)
+        if not np.isfinite(lbd) or x_nrm == 0:
+            sign[j], scale[j] = 1.0, 0.0
+            continue
+        sign[j] = flip[j] * part
+        scale[j] = lbd / x_nrm
+        H[j] = lbd * v
+    return sign, scale, H
+
+
 @pytest.mark.parametrize('n,F,r,deficient', [(5000, 20, 6, False), (3000, 12, 6, True), (4000, 40, 4, False),
                                              (2000, 7, 3, False), (3000, 9, 2, False), (800, 64, 8, False),
-                                             (500, 5, 5, True)])
+                                             (500, 5, 5, True), (1500, 115, 6, False), (1200, 200, 6, True)])
 def test_native_small_space_equals_scipy_formulation(n, F, r, deficient):
     from graphrole_amd import kernels as K
-    from graphrole_amd.roles import factor
     rng = np.random.RandomState(n + F)
     X = np.abs(rng.randn(n, F)) * np.linspace(1, 50, F)
     if deficient:
@@ -39,7 +92,7 @@ def test_native_small_space_equals_scipy_formulation(n, F, r, deficient):
     lam2, V2 = linalg.eigh(Yp.T @ Yp)
     Tp = (T1p @ V2) / np.sqrt(lam2)
     Mp = (np.sqrt(lam2)[:, None] * V2.T) @ (np.sqrt(lam[keep])[:, None] * V1[:, keep].T)
-    Usp, Sp, Vtp = factor._range_finder_svd(Mp, r, omega, (n, F))
+    Usp, Sp, Vtp = _range_finder_svd(Mp, r, omega, (n, F))
     n_iter = 7 if r < 0.1 * min(n, F) else 4
     Z, S, Vt = K.host_range_finder(T1, lam_keep, V_keep, Y.T @ Y, omega, r, n_iter)
     U, Up = X @ Z, X @ (Tp @ Usp)
@@ -63,7 +116,7 @@ def test_native_small_space_equals_scipy_formulation(n, F, r, deficient):
     idx = np.argmax(np.abs(U), axis=0)
     stats = np.stack([U[idx, np.arange(r)], idx.astype(float), (np.maximum(U, 0) ** 2).sum(0),
                       (np.minimum(U, 0) ** 2).sum(0)], axis=1)
-    sign_p, scale_p, H_p = factor._nndsvd_plan(S, Vt, stats)
+    sign_p, scale_p, H_p = _nndsvd_plan(S, Vt, stats)
     sign, scale, H = K.host_nndsvd_plan(S, Vt, stats)
     assert np.array_equal(sign, sign_p)
     np.testing.assert_allclose(scale, scale_p, rtol=1e-14)
@@ -76,3 +129,23 @@ def test_host_routines_validate_arguments():
     assert lib.grx_host_whiten(0, None, None, None, None, None) == -1
     assert lib.grx_host_range_finder(4, 5, None, None, None, None, None, 3, 2, 4, None, None, None) == -1   # k > F
     assert lib.grx_host_nndsvd_plan(2, 3, None, None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 33, 64, 65, 130, 257])
+def test_host_eigh_matches_numpy(n):
+    """grx_host_eigh: cyclic Jacobi up to 64 columns, Householder tridiagonalisation + implicit QL above."""
+    from graphrole_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(n)
+    X = np.abs(rng.randn(3 * n + 5, n)) * np.linspace(1, 30, n)
+    if n > 4:
+        X[:, n - 1] = X[:, 0] - 2 * X[:, 1]                      # rank deficient
+    A = X.T @ X
+    w, V = np.empty(n), np.empty((n, n))
+    assert lib.grx_host_eigh(n, _vp(A), _vp(w), _vp(V)) == 0
+    we = np.linalg.eigvalsh(A)
+    scale = max(we.max(), 1e-300)
+    assert np.all(np.diff(w) >= 0)
+    np.testing.assert_allclose(w, we, atol=1e-13 * scale * n)
+    np.testing.assert_allclose(A @ V, V * w, atol=1e-13 * scale * n)
+    np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12)

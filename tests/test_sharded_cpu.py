@@ -47,8 +47,7 @@ def _worker(rank, port, case, out_dir, WORLD):
         K = backend.get()
         Xd = K.to_device(np.ascontiguousarray(X.values.astype(float).T))
         omega = np.random.RandomState(5).normal(size=(X.shape[1], 4 + 10))
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 4, omega, plan=plan)
-        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        state, n_iter = factor.nmf_device(Xd, G.n, 4, omega, plan=plan)
         W = K.to_host(state.W)[:, :G.n]
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), X=X.values.astype(float), cols=np.array(list(X.columns)),
                  gen=fe.generation_count, W=W, H=K.to_host(state.H), n_iter=n_iter,
@@ -86,8 +85,7 @@ def test_sharded_pipeline_equals_single_process(case, WORLD, tmp_path):
         X = r0['X']
         Xd = K.to_device(np.ascontiguousarray(X.T))
         omega = np.random.RandomState(5).normal(size=(X.shape[1], 14))
-        W0, H0 = factor.nndsvda_init_device(Xd, X.shape[0], 4, omega)
-        state, n_iter = factor.run_mu_loop(K.NmfState(Xd, X.shape[0], W0, H0))
+        state, n_iter = factor.nmf_device(Xd, X.shape[0], 4, omega)
         Wref, Href = K.to_host(state.W), K.to_host(state.H)
     finally:
         backend.use(None)

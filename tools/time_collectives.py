@@ -63,8 +63,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        W0, H0 = factor.nndsvda_init_device(Xd, G.n, 6, omega, plan=plan)
-        factor.run_mu_loop(K.NmfState(Xd, G.n, W0, H0), plan=plan)
+        factor.nmf_device(Xd, G.n, 6, omega, plan=plan)
     torch.cuda.synchronize()
     print(f'nmf {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step')
     for k in sorted(acc, key=acc.get, reverse=True):

@@ -27,9 +27,9 @@ for trial in range(3):
     t0 = time.perf_counter()
     lam, V1 = linalg.eigh(G1); t['eigh1'] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    W0, H0 = factor.nndsvda_init_device(Xd, n, r, omega); sync(); t['init total'] = time.perf_counter() - t0
+    W0, H0, xx = factor.nndsvda_init_device(Xd, n, r, omega); sync(); t['init total'] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    st = K.NmfState(Xd, n, W0, H0); sync(); t['state'] = time.perf_counter() - t0
+    st = K.NmfState(Xd, n, W0, H0, x_sq_norm=xx); sync(); t['state'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     state, it = factor.run_mu_loop(st); sync(); t['mu loop'] = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -40,6 +40,6 @@ import cProfile, pstats
 pr = cProfile.Profile()
 sync(); pr.enable()
 for _ in range(20):
-    W0, H0 = factor.nndsvda_init_device(Xd, n, r, omega)
+    W0, H0, xx = factor.nndsvda_init_device(Xd, n, r, omega)
 sync(); pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(18)
