@@ -352,6 +352,516 @@ __global__ __launch_bounds__(64) void bin_threshold_kernel(const double *__restr
     if (lane == 0) nbins[blockIdx.x] = nb;
 }
 
+// =======================================================================================
+// Binning-specific sort ("window" sort).  The threshold walk of prune.py:33-54 needs ~20 order
+// statistics and the ends of their tie runs, not a fully sorted column, and most columns vary in few
+// of their 64 key bits.  One light pass finds which key bytes vary over each column
+// (key_bits_kernel -> bin_plan_kernel); with lo / hi the lowest / highest varying byte:
+//   NARROW (hi - lo < 4)  the column is sorted as 32-bit keys (key >> 8 lo): exact, 4-byte elements,
+//                          one LSD round per varying byte (integer-valued columns below 2^20 take 2-4
+//                          rounds of 12 bytes per key instead of 5 of 24);
+//   WIDE   (otherwise)     64-bit keys sorted by their top four window bytes only (bytes hi-3 .. hi):
+//                          at most four rounds; keys that agree in those bytes form short runs whose
+//                          order is resolved lazily, only where a bin threshold lands
+//                          (bin_threshold2_kernel: shuffle ranking for runs up to 64 keys, workgroup
+//                          radix selection for longer ones).
+// Exactly four rounds are launched whatever the columns need (a round a column does not use returns at
+// once): 13 launches per call instead of 24, and about half the key bytes moved.
+// =======================================================================================
+struct BinPlanCol {
+    uint64_t const_bits;      // NARROW: the (constant) key bits below the window
+    uint8_t narrow;
+    uint8_t npass;            // rounds this column takes part in (0: every key equal)
+    uint8_t lo_shift;         // NARROW: bit offset of the window; WIDE: bit offset of the sorted part
+    uint8_t pad0;
+    uint8_t dshift[4];        // per round: shift of the stored key that exposes the round's digit
+};
+
+constexpr int BITS_TILE = 256 * 32;
+
+__global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                       int ntiles, uint64_t *__restrict__ bits)
+{
+    const int col = blockIdx.y, tile = blockIdx.x;
+    const double *x = cols + (size_t)col * ld;
+    const int64_t base = (int64_t)tile * BITS_TILE;
+    uint64_t o = 0, z = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
+        if (idx < n) {
+            const uint64_t k = f64_to_key(x[idx] + 0.0);      // + 0.0: -0.0 and 0.0 are one value (np.unique)
+            o |= k;
+            z |= ~k;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        o |= __shfl_xor(o, off, 64);
+        z |= __shfl_xor(z, off, 64);
+    }
+    __shared__ uint64_t wb[4][2];
+    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6][0] = o; wb[threadIdx.x >> 6][1] = z; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        bits[((size_t)col * ntiles + tile) * 2 + threadIdx.x] =
+            wb[0][threadIdx.x] | wb[1][threadIdx.x] | wb[2][threadIdx.x] | wb[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void bin_plan_kernel(const uint64_t *__restrict__ bits, int ntiles,
+                                                      BinPlanCol *__restrict__ plan)
+{
+    const int col = blockIdx.x, lane = threadIdx.x;
+    uint64_t o = 0, z = 0;
+    for (int t = lane; t < ntiles; t += 64) {
+        o |= bits[((size_t)col * ntiles + t) * 2];
+        z |= bits[((size_t)col * ntiles + t) * 2 + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        o |= __shfl_xor(o, off, 64);
+        z |= __shfl_xor(z, off, 64);
+    }
+    if (lane != 0) return;
+    const uint64_t varying = o & z;                           // a bit varies iff set in one key and clear in another
+    BinPlanCol p;
+    p.const_bits = 0;
+    p.narrow = 1; p.npass = 0; p.lo_shift = 0; p.pad0 = 0;
+    for (int j = 0; j < 4; ++j) p.dshift[j] = 0;
+    int lo = -1, hi = -1;
+    for (int b = 0; b < 8; ++b)
+        if ((varying >> (8 * b)) & 0xFF) { if (lo < 0) lo = b; hi = b; }
+    if (lo >= 0) {
+        if (hi - lo < 4) {
+            p.narrow = 1;
+            p.lo_shift = (uint8_t)(8 * lo);
+            p.const_bits = lo ? (o & ((1ull << (8 * lo)) - 1)) : 0ull;
+            for (int b = lo; b <= hi; ++b)
+                if ((varying >> (8 * b)) & 0xFF) p.dshift[p.npass++] = (uint8_t)(8 * (b - lo));
+        } else {
+            p.narrow = 0;
+            p.lo_shift = (uint8_t)(8 * (hi - 3));
+            for (int b = hi - 3; b <= hi; ++b)
+                if ((varying >> (8 * b)) & 0xFF) p.dshift[p.npass++] = (uint8_t)(8 * b);
+        }
+    }
+    plan[col] = p;
+}
+
+// keys of one thread (wave-contiguous slices like load_keys); round 0 converts the fp64 input
+template <typename KeyT>
+__device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool from_f64, int lo_shift, int64_t n,
+                                           int64_t tile_base, KeyT (&keys)[SORT_ITEMS], uint32_t &valid_mask)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = tile_base + (int64_t)wave * 64 * SORT_ITEMS + lane;
+    valid_mask = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * 64;
+        if (idx < n) {
+            valid_mask |= 1u << i;
+            if (from_f64) keys[i] = (KeyT)(f64_to_key(reinterpret_cast<const double *>(src)[idx] + 0.0) >> lo_shift);
+            else keys[i] = reinterpret_cast<const KeyT *>(src)[idx];
+        } else {
+            keys[i] = (KeyT)~(KeyT)0;
+        }
+    }
+}
+
+template <typename KeyT>
+__device__ __forceinline__ void count_body(const void *src, bool from_f64, int lo_shift, int dshift, int64_t n,
+                                           int tile, uint32_t *cnt)
+{
+    KeyT keys[SORT_ITEMS];
+    uint32_t vm;
+    if (from_f64) load_keys2<KeyT>(src, true, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys2<KeyT>(src, false, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool valid = (vm >> i) & 1u;
+        const uint32_t d = (uint32_t)(keys[i] >> dshift) & 0xFF;
+        const uint64_t active = __ballot(valid);
+        if (active == 0) continue;
+        const int leader = __ffsll((long long)active) - 1;
+        const uint32_t d0 = __shfl(d, leader, 64);
+        if (__ballot(valid && d != d0) == 0) {
+            if (lane == leader) atomicAdd(&cnt[d0], (uint32_t)__popcll(active));
+        } else if (valid) {
+            atomicAdd(&cnt[d], 1u);
+        }
+    }
+}
+
+// source / destination of round `round` for a column: round 0 reads the fp64 input and writes buffer A,
+// then A -> B -> A -> B (each column has an n * 8 byte slot in both buffers; NARROW uses half of it)
+__device__ __forceinline__ const void *round_src(int round, int col, const double *cols, int64_t ld, int64_t n,
+                                                 const uint64_t *buf_a, const uint64_t *buf_b)
+{
+    if (round == 0) return cols + (size_t)col * ld;
+    return ((round & 1) ? buf_a : buf_b) + (size_t)col * n;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_count2_kernel(const double *__restrict__ cols, int64_t ld,
+                                                                   int64_t n, int round, int ntiles,
+                                                                   const BinPlanCol *__restrict__ plan,
+                                                                   const uint64_t *buf_a, const uint64_t *buf_b,
+                                                                   uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t cnt[RADIX];
+    const int col = blockIdx.y, tile = blockIdx.x;
+    if (round >= plan[col].npass) return;
+    const int narrow = plan[col].narrow, lo_shift = plan[col].lo_shift, dshift = plan[col].dshift[round];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const void *src = round_src(round, col, cols, ld, n, buf_a, buf_b);
+    if (narrow) count_body<uint32_t>(src, round == 0, lo_shift, dshift, n, tile, cnt);
+    else count_body<uint64_t>(src, round == 0, 0, dshift, n, tile, cnt);
+    __syncthreads();
+    hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void scan_rows2_kernel(uint32_t *__restrict__ hist, int ntiles,
+                                                        uint32_t *__restrict__ tot,
+                                                        const BinPlanCol *__restrict__ plan, int round)
+{
+    const int d = blockIdx.x, col = blockIdx.y, lane = threadIdx.x;
+    if (round >= plan[col].npass) return;
+    uint32_t *row = hist + ((size_t)col * RADIX + d) * ntiles;
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 64 * 4) {
+        uint32_t x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * 64 + lane;
+            x[j] = (t < ntiles) ? row[t] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * 64 + lane;
+            uint32_t inc = x[j];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += y;
+            }
+            if (t < ntiles) row[t] = carry + inc - x[j];
+            carry += __shfl(inc, 63, 64);
+        }
+    }
+    if (lane == 0) tot[(size_t)col * RADIX + d] = carry;
+}
+
+template <typename KeyT>
+__device__ __forceinline__ void scatter_body(const void *src, bool from_f64, int lo_shift, int dshift, void *dst,
+                                             int64_t n, int tile, int ntiles, const uint32_t *offsets_col,
+                                             const uint32_t *digit_tot_col, uint32_t (*cnt)[RADIX], uint32_t *gdelta,
+                                             uint32_t *wsum, KeyT *stage)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    KeyT keys[SORT_ITEMS];
+    uint32_t vm;
+    if (from_f64) load_keys2<KeyT>(src, true, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys2<KeyT>(src, false, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t rank[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool valid = (vm >> i) & 1u;
+        const uint32_t d = (uint32_t)(keys[i] >> dshift) & 0xFF;
+        uint64_t peers = __ballot(valid);
+        const uint32_t d0 = __shfl(d, peers ? __ffsll((long long)peers) - 1 : 0, 64);
+        if (__ballot(valid && d != d0) != 0) {
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const uint64_t m = __ballot(set);
+                peers &= set ? m : ~m;
+            }
+        }
+        uint32_t r = 0;
+        if (valid) {
+            const uint32_t before = cnt[wave][d];
+            const uint32_t in_group = (uint32_t)__popcll(peers & lt_mask);
+            r = before + in_group;
+            __builtin_amdgcn_wave_barrier();
+            if (in_group == 0) cnt[wave][d] = before + (uint32_t)__popcll(peers);
+        }
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = r;
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        const uint32_t total = c0 + c1 + c2 + c3;
+        const uint32_t gtot = digit_tot_col[d];
+        uint32_t inc = total, ginc = gtot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(inc, off, 64), gy = __shfl_up(ginc, off, 64);
+            if (lane >= off) { inc += y; ginc += gy; }
+        }
+        if (lane == 63) { wsum[wave] = inc; wsum[4 + wave] = ginc; }
+        __syncthreads();
+        uint32_t lp = inc - total, gbase = ginc - gtot;
+        for (int w = 0; w < wave; ++w) { lp += wsum[w]; gbase += wsum[4 + w]; }
+        const uint32_t g = offsets_col[(size_t)d * ntiles + tile] + gbase;
+        gdelta[d] = g - lp;
+        cnt[0][d] = lp;
+        cnt[1][d] = lp + c0;
+        cnt[2][d] = lp + c0 + c1;
+        cnt[3][d] = lp + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        if ((vm >> i) & 1u) {
+            const uint32_t d = (uint32_t)(keys[i] >> dshift) & 0xFF;
+            stage[cnt[wave][d] + rank[i]] = keys[i];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)tile * SORT_TILE;
+    const int nv = (int)(left < SORT_TILE ? left : SORT_TILE);
+    for (int j = threadIdx.x; j < nv; j += SORT_THREADS) {
+        const KeyT key = stage[j];
+        const uint32_t pos = gdelta[(uint32_t)(key >> dshift) & 0xFF] + (uint32_t)j;
+        reinterpret_cast<KeyT *>(dst)[pos] = key;
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void scatter2_kernel(const double *__restrict__ cols, int64_t ld,
+                                                                int64_t n, int round, int ntiles,
+                                                                const BinPlanCol *__restrict__ plan, uint64_t *buf_a,
+                                                                uint64_t *buf_b, const uint32_t *__restrict__ offsets,
+                                                                const uint32_t *__restrict__ digit_tot)
+{
+    __shared__ uint32_t cnt[4][RADIX];
+    __shared__ uint32_t gdelta[RADIX];
+    __shared__ uint32_t wsum[8];
+    __shared__ uint64_t stage[SORT_TILE];
+    const int col = blockIdx.y, tile = blockIdx.x;
+    if (round >= plan[col].npass) return;
+    const int narrow = plan[col].narrow, lo_shift = plan[col].lo_shift, dshift = plan[col].dshift[round];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const void *src = round_src(round, col, cols, ld, n, buf_a, buf_b);
+    void *dst = ((round & 1) ? buf_b : buf_a) + (size_t)col * n;
+    const uint32_t *off_col = offsets + (size_t)col * RADIX * ntiles;
+    const uint32_t *tot_col = digit_tot + (size_t)col * RADIX;
+    if (narrow)
+        scatter_body<uint32_t>(src, round == 0, lo_shift, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum,
+                               reinterpret_cast<uint32_t *>(stage));
+    else
+        scatter_body<uint64_t>(src, round == 0, 0, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum, stage);
+}
+
+// ---- threshold walk on a window-sorted column --------------------------------------------------
+// One workgroup per column.  prune.py:33-54: repeat { size = max(int(frac * unbinned), 1); hi = value at
+// sorted position done + size - 1; the bin ends at the end of hi's tie run }.  The searches are executed by
+// every wavefront alike (their loads hit the same lines); only the scan of a long unresolved run is split
+// over the waves.
+template <typename KeyT>
+struct KeyArray {
+    const KeyT *k;
+    __device__ __forceinline__ KeyT operator[](int64_t i) const { return k[i]; }
+};
+
+// first index in [L, R) whose key's high part differs from h, given that keys are sorted by high part,
+// that the high part at L - 1 equals h and that every key in [L, R) has a high part >= h
+template <typename KeyT>
+__device__ __forceinline__ int64_t run_end(const KeyArray<KeyT> s, int shift, uint64_t h, int64_t L, int64_t R)
+{
+    const int lane = threadIdx.x & 63;
+    // most runs end within a few keys: probe the next 64 positions with one load per lane
+    {
+        const int64_t idx = L + lane;
+        const bool eq = (idx < R) && (((uint64_t)s[idx] >> shift) == h);
+        const uint64_t m = __ballot(eq);
+        const int c = (m == ~0ull) ? 64 : __ffsll((long long)~m) - 1;       // leading lanes that still match
+        if (c < 64 || L + 64 >= R) return (L + c < R) ? L + c : R;
+        L += 64;
+    }
+    while (L < R) {
+        const int64_t len = R - L;
+        const int64_t step = (len + 63) >> 6;
+        const int64_t idx = L + (int64_t)lane * step;
+        const bool eq = (idx < R) && (((uint64_t)s[idx] >> shift) == h);
+        const int c = __popcll(__ballot(eq));
+        if (c == 0) {
+            R = L;
+        } else {
+            const int64_t nL = L + (int64_t)(c - 1) * step + 1;
+            const int64_t cap = L + (int64_t)c * step;
+            R = (cap < R) ? cap : R;
+            L = nL;
+        }
+    }
+    return L;
+}
+
+// first index in [L, R] whose high part equals h, given that it does at R and keys are sorted by high part
+template <typename KeyT>
+__device__ __forceinline__ int64_t run_begin(const KeyArray<KeyT> s, int shift, uint64_t h, int64_t L, int64_t R)
+{
+    const int lane = threadIdx.x & 63;
+    {
+        const int64_t idx = R - 1 - lane;
+        const bool eq = (idx >= L) && (((uint64_t)s[idx] >> shift) == h);
+        const uint64_t m = __ballot(eq);
+        const int c = (m == ~0ull) ? 64 : __ffsll((long long)~m) - 1;
+        if (c < 64 || R - 64 <= L) return (R - c > L) ? R - c : L;
+        R -= 64;
+    }
+    while (L < R) {
+        const int64_t len = R - L;
+        const int64_t step = (len + 63) >> 6;
+        const int64_t idx = L + (int64_t)lane * step;
+        const bool below = (idx < R) && (((uint64_t)s[idx] >> shift) < h);
+        const int c = __popcll(__ballot(below));                          // the first c sample points are below
+        if (c == 0) {
+            R = L;
+        } else {
+            const int64_t nL = L + (int64_t)(c - 1) * step + 1;
+            const int64_t cap = L + (int64_t)c * step;
+            R = (cap < R) ? cap : R;
+            L = nL;
+        }
+    }
+    return L;
+}
+
+__global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                             double frac, const BinPlanCol *__restrict__ plan,
+                                                             const uint64_t *__restrict__ buf_a,
+                                                             const uint64_t *__restrict__ buf_b,
+                                                             double *__restrict__ thr, int32_t *__restrict__ nbins)
+{
+    const int col = blockIdx.x;
+    const BinPlanCol p = plan[col];
+    double *t = thr + (size_t)col * GRX_MAX_BINS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.npass == 0) {                                       // every value equal: one bin
+        if (threadIdx.x == 0) { t[0] = cols[(size_t)col * ld]; nbins[col] = 1; }
+        return;
+    }
+    const uint64_t *buf = ((p.npass & 1) ? buf_a : buf_b) + (size_t)col * n;
+    __shared__ uint64_t s_red[8];
+    __shared__ uint32_t s_hist[RADIX];
+    __shared__ uint64_t s_pick[2];
+    int64_t done = 0;
+    int nb = 0;
+    if (p.narrow) {
+        const KeyArray<uint32_t> s{reinterpret_cast<const uint32_t *>(buf)};
+        while (done < n && nb < GRX_MAX_BINS) {
+            int64_t size = (int64_t)(frac * (double)(n - done));
+            if (size < 1) size = 1;
+            const int64_t pos = done + size - 1;
+            const uint32_t k = s[pos];
+            const int64_t end = run_end<uint32_t>(s, 0, (uint64_t)k, pos + 1, n);
+            if (threadIdx.x == 0) t[nb] = key_to_f64(((uint64_t)k << p.lo_shift) | p.const_bits);
+            ++nb;
+            done = end;
+        }
+    } else {
+        const KeyArray<uint64_t> s{buf};
+        const int shift = p.lo_shift;
+        while (done < n && nb < GRX_MAX_BINS) {
+            int64_t size = (int64_t)(frac * (double)(n - done));
+            if (size < 1) size = 1;
+            const int64_t pos = done + size - 1;
+            const uint64_t kpos = s[pos];
+            const uint64_t h = kpos >> shift;
+            const int64_t b = run_end<uint64_t>(s, shift, h, pos + 1, n);
+            const int64_t a = run_begin<uint64_t>(s, shift, h, done, pos);
+            const int64_t len = b - a, q = pos - a;           // the q-th smallest key of the run is the threshold
+            uint64_t tk;
+            int64_t end;
+            if (len == 1) {
+                tk = kpos;
+                end = b;
+            } else if (len <= 64) {
+                // rank every key of the run against the others (one key per lane, 64-bit shuffles)
+                const uint64_t mine = (lane < len) ? s[a + lane] : ~0ull;
+                int lt = 0, le = 0;
+                for (int j = 0; j < (int)len; ++j) {
+                    const uint64_t other = __shfl(mine, j, 64);
+                    lt += other < mine;
+                    le += other <= mine;
+                }
+                const uint64_t hit = __ballot(lane < len && lt <= q && q < le);
+                const int src = __ffsll((long long)hit) - 1;
+                tk = __shfl(mine, src, 64);
+                end = a + __shfl(le, src, 64);
+            } else {
+                // long run: all keys equal (heavy ties)?  min / max over the run, split over the workgroup
+                uint64_t mn = ~0ull, mx = 0;
+                for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+                    const uint64_t v = s[i];
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint64_t o1 = __shfl_xor(mn, off, 64), o2 = __shfl_xor(mx, off, 64);
+                    mn = o1 < mn ? o1 : mn;
+                    mx = o2 > mx ? o2 : mx;
+                }
+                __syncthreads();
+                if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+                __syncthreads();
+                mn = s_red[0]; mx = s_red[4];
+                for (int w = 1; w < 4; ++w) { mn = s_red[w] < mn ? s_red[w] : mn; mx = s_red[4 + w] > mx ? s_red[4 + w] : mx; }
+                if (mn == mx) {
+                    tk = mn;
+                    end = b;
+                } else {
+                    // radix selection of the q-th smallest key over the unsorted low bytes, most significant first
+                    uint64_t prefix = h << shift;
+                    int64_t below = 0, qrem = q, equal = len;
+                    for (int byte = shift / 8 - 1; byte >= 0; --byte) {
+                        __syncthreads();
+                        s_hist[threadIdx.x] = 0;
+                        __syncthreads();
+                        const int hs = 8 * (byte + 1);
+                        for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+                            const uint64_t v = s[i];
+                            if ((v >> hs) == (prefix >> hs)) atomicAdd(&s_hist[(uint32_t)(v >> (8 * byte)) & 0xFF], 1u);
+                        }
+                        __syncthreads();
+                        if (threadIdx.x == 0) {
+                            int64_t cum = 0;
+                            int d = 0;
+                            for (; d < 255; ++d) {
+                                if (cum + (int64_t)s_hist[d] > qrem) break;
+                                cum += s_hist[d];
+                            }
+                            s_pick[0] = (uint64_t)d;
+                            s_pick[1] = (uint64_t)cum;
+                        }
+                        __syncthreads();
+                        const int d = (int)s_pick[0];
+                        prefix |= (uint64_t)d << (8 * byte);
+                        below += (int64_t)s_pick[1];
+                        qrem -= (int64_t)s_pick[1];
+                        equal = (int64_t)s_hist[d];
+                    }
+                    tk = prefix;
+                    end = a + below + equal;
+                }
+            }
+            if (threadIdx.x == 0) t[nb] = key_to_f64(tk);
+            ++nb;
+            done = end;
+        }
+    }
+    // more than GRX_MAX_BINS bins (only reachable with a tiny frac): reported as a negative count
+    if (threadIdx.x == 0) nbins[col] = (done < n) ? -nb : nb;
+}
+
 __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restrict__ cols, int64_t ld,
                                                          int64_t n, const double *__restrict__ thr,
                                                          const int32_t *__restrict__ nbins,
@@ -359,7 +869,8 @@ __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restric
 {
     __shared__ double t[GRX_MAX_BINS];
     const int col = blockIdx.y;
-    const int nb = nbins[col];
+    int nb = nbins[col];
+    if (nb < 0) nb = GRX_MAX_BINS;                    // more than GRX_MAX_BINS bins: labels saturate, the caller is told
     if (threadIdx.x < GRX_MAX_BINS)
         t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0.0;
     __syncthreads();
@@ -592,7 +1103,7 @@ size_t grx_log_bin_workspace_bytes(int64_t n, int ncols)
     // keysA + sorted + hist + thresholds + nbins + pass-skipping state (key bits, flags)
     return 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
            grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 16, 256) +
-           grx_align_up((size_t)ncols * 9, 256);
+           grx_align_up((size_t)ncols * sizeof(BinPlanCol), 256);
 }
 
 int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, double *d_sorted,
@@ -628,25 +1139,42 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
     hipStream_t st = grx_stream(stream);
     const SortPlan p = make_plan(n, ncols);
     char *ws = reinterpret_cast<char *>(d_workspace);
-    uint64_t *keysA = reinterpret_cast<uint64_t *>(ws);
-    double *sorted = reinterpret_cast<double *>(ws + p.keys_bytes);
+    uint64_t *buf_a = reinterpret_cast<uint64_t *>(ws);
+    uint64_t *buf_b = reinterpret_cast<uint64_t *>(ws + p.keys_bytes);
     uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 2 * p.keys_bytes);
+    uint32_t *tot = hist + grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) / 4;
     double *thr = reinterpret_cast<double *>(ws + 2 * p.keys_bytes + p.hist_bytes);
     int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
-    char *skip_ws = reinterpret_cast<char *>(nb_ws) + grx_align_up((size_t)ncols * 4, 256);
-    SkipCtl ctl;
-    ctl.bits = reinterpret_cast<uint64_t *>(skip_ws);
-    ctl.flags = reinterpret_cast<uint8_t *>(skip_ws + grx_align_up((size_t)ncols * p.ntiles * 16, 256));
-    ctl.cols = d_cols;
-    ctl.cols_ld = ld;
-    ctl.buf_a = keysA;
-    ctl.buf_b = reinterpret_cast<uint64_t *>(sorted);
-    ctl.ncols = ncols;
-    int rc = sort_columns(n, ncols, d_cols, ld, sorted, n, keysA, hist, st, ctl);
-    if (rc != GRX_OK) return rc;
+    char *plan_ws = reinterpret_cast<char *>(nb_ws) + grx_align_up((size_t)ncols * 4, 256);
+    uint64_t *bits = reinterpret_cast<uint64_t *>(plan_ws);
+    BinPlanCol *plan = reinterpret_cast<BinPlanCol *>(plan_ws + grx_align_up((size_t)ncols * p.ntiles * 16, 256));
+    // which key bytes vary -> per-column plan (NARROW 32-bit keys / WIDE top-four-bytes sort)
+    const int nbt = (int)grx_ceil_div(n, BITS_TILE);
+    {
+        GRX_PROF(GRX_K_KEY_BITS, st);
+        key_bits_kernel<<<dim3(nbt, ncols), 256, 0, st>>>(d_cols, ld, n, nbt, bits);
+        bin_plan_kernel<<<ncols, 64, 0, st>>>(bits, nbt, plan);
+    }
+    GRX_LAUNCH_CHECK();
+    const dim3 sgrid(p.ntiles, ncols);
+    for (int round = 0; round < 4; ++round) {
+        {
+            GRX_PROF(GRX_K_SORT_COUNT, st);
+            tile_count2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist);
+        }
+        {
+            GRX_PROF(GRX_K_SORT_SCAN, st);
+            scan_rows2_kernel<<<dim3(RADIX, ncols), 64, 0, st>>>(hist, p.ntiles, tot, plan, round);
+        }
+        {
+            GRX_PROF(GRX_K_SORT_SCATTER, st);
+            scatter2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist, tot);
+        }
+        GRX_LAUNCH_CHECK();
+    }
     { GRX_PROF(GRX_K_BIN_THRESHOLD, st);
-    bin_threshold_kernel<<<ncols, 64, 0, st>>>(sorted, n, n, frac, thr, nb_ws, ctl);
+    bin_threshold2_kernel<<<ncols, 256, 0, st>>>(d_cols, ld, n, frac, plan, buf_a, buf_b, thr, nb_ws);
     }
     GRX_LAUNCH_CHECK();
     const int64_t want = grx_ceil_div(n, 256 * 4);

@@ -25,7 +25,8 @@ namespace {
 
 constexpr int Q_TILE = 2048;            // elements per scan workgroup (256 threads x 8)
 constexpr int Q_CELLS = 1024;           // micro-cells of the DP stage
-constexpr int Q_MAX_BINS = 256;
+constexpr int Q_MAX_BINS = 256;          // exact-DP start + one-thread-per-cluster Lloyd kernel
+constexpr int Q_BIG_MAX_BINS = 65536;    // above Q_MAX_BINS: companding start, strided Lloyd kernel, tables in global memory
 
 // ---- three fused prefix sums over the sorted values: s, s^2, cbrt(s[i+1]-s[i])^2 -----------
 __device__ __forceinline__ void q_terms(const double *__restrict__ s, int64_t m, int64_t i, double &a, double &b,
@@ -296,10 +297,119 @@ __global__ __launch_bounds__(256) void q_assign_kernel(const double *__restrict_
     }
 }
 
+// ---- more than Q_MAX_BINS levels (n_bits = int(log2(n_roles * min(shape))) reaches 9-12 bits on wide feature
+// tables, roles/extract.py:72) ---------------------------------------------------------------------------------
+// The exact DP over micro-cells costs O(k cells^2) and its tables live in LDS; with this many levels the
+// high-resolution approximation is already close to optimal, so the start is the companding partition itself --
+// k cells of equal cbrt-density mass (Panter-Dite) -- refined by the same Lloyd iterations.  One workgroup,
+// clusters strided over its threads, all tables in global memory.
+__global__ __launch_bounds__(1024) void q_cells_big_kernel(const double *__restrict__ Gp, int64_t m, int k,
+                                                           int64_t *__restrict__ raw, int64_t *__restrict__ edges)
+{
+    const int t = threadIdx.x;
+    const double total = Gp[m];
+    for (int b = t; b <= k; b += blockDim.x) {
+        int64_t e;
+        if (b == 0) e = 0;
+        else if (b == k) e = m;
+        else if (m <= k) e = b < m ? b : m;               // no more values than levels: one value per cell
+        else {
+            const double target = total * (double)b / (double)k;
+            int64_t lo = 0, hi = m;                       // first i with Gp[i] >= target
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (Gp[mid] < target) lo = mid + 1; else hi = mid; }
+            e = lo < 1 ? 1 : (lo > m - 1 ? m - 1 : lo);
+        }
+        raw[b] = e;
+    }
+    __syncthreads();
+    // monotone edges (duplicates = empty clusters, which inherit the centre below them in the Lloyd kernel)
+    for (int b = t; b <= k; b += blockDim.x) edges[b] = raw[b];
+    __syncthreads();
+    if (t == 0)
+        for (int b = 1; b <= k; ++b)
+            if (edges[b] < edges[b - 1]) edges[b] = edges[b - 1];
+}
+
+__global__ __launch_bounds__(1024) void q_lloyd_big_kernel(const double *__restrict__ s, int64_t m,
+                                                           const double *__restrict__ P, int k, int max_iter,
+                                                           const int64_t *__restrict__ edges, double *__restrict__ c,
+                                                           int64_t *__restrict__ hi, int64_t *__restrict__ nh,
+                                                           double *__restrict__ bounds, int32_t *__restrict__ info)
+{
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int j = t; j < k; j += nt) {
+        const int64_t a = edges[j], b = edges[j + 1];
+        hi[j + 1] = b;
+        c[j] = (b > a) ? (P[b] - P[a]) / (double)(b - a) : -1e308;      // marker: empty
+    }
+    if (t == 0) hi[0] = 0;
+    __syncthreads();
+    if (t == 0) {                                          // empty clusters inherit the centre below them
+        double last = 0.0;
+        bool have = false;
+        for (int j = 0; j < k; ++j) {
+            if (c[j] == -1e308) c[j] = have ? last : 0.0;
+            else { last = c[j]; have = true; }
+        }
+    }
+    __syncthreads();
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        int changed = 0;
+        for (int j = t; j < k; j += nt) {
+            int64_t e = m;
+            if (j < k - 1) {
+                const double bnd = 0.5 * (c[j] + c[j + 1]);
+                int64_t lo = 0, up = m;                   // first index with s > bnd
+                while (lo < up) { const int64_t mid = (lo + up) >> 1; if (s[mid] <= bnd) lo = mid + 1; else up = mid; }
+                e = lo;
+            }
+            nh[j] = e;
+            changed |= (e != hi[j + 1]);
+        }
+        if (!__syncthreads_or(changed)) break;
+        for (int j = t; j < k; j += nt) hi[j + 1] = nh[j];
+        __syncthreads();
+        for (int j = t; j < k; j += nt) {
+            const int64_t a = hi[j], b = hi[j + 1];
+            if (b > a) c[j] = (P[b] - P[a]) / (double)(b - a);
+        }
+        __syncthreads();
+    }
+    for (int j = t; j < k - 1; j += nt) bounds[j] = 0.5 * (c[j] + c[j + 1]);
+    if (t == 0) {
+        info[0] = it;
+        int nonempty = 0, distinct = 0;
+        double last = 0.0;
+        for (int q = 0; q < k; ++q) {
+            if (hi[q + 1] > hi[q]) {
+                ++nonempty;
+                if (distinct == 0 || c[q] != last) { ++distinct; last = c[q]; }
+            }
+        }
+        info[1] = nonempty;
+        info[2] = distinct;
+    }
+}
+
+__global__ __launch_bounds__(256) void q_assign_big_kernel(const double *__restrict__ x, int64_t m, int k,
+                                                           const double *__restrict__ centers,
+                                                           const double *__restrict__ bounds, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const double v = x[i];
+        int lo = 0, up = k - 1;                           // first boundary >= v  -> cluster index (tables are L2 hits)
+        while (lo < up) { const int mid = (lo + up) >> 1; if (bounds[mid] < v) lo = mid + 1; else up = mid; }
+        out[i] = centers[lo];
+    }
+}
+
 struct QuantPlan {
     int64_t ntiles;
     size_t off_sorted, off_P, off_P2, off_G, off_tsum, off_ce, off_arg, off_edges, off_bounds, off_nb, off_cell, off_D,
-        off_sort_ws, total;
+        off_big, off_sort_ws, total;
+    int64_t kmax;
 };
 
 QuantPlan q_plan(int64_t m)
@@ -313,10 +423,14 @@ QuantPlan q_plan(int64_t m)
     p.off_P2 = take((size_t)(m + 1) * 8);
     p.off_G = take((size_t)(m + 1) * 8);
     p.off_tsum = take((size_t)p.ntiles * 3 * 8);
+    // tables of the many-level path are sized by the largest admissible level count (n_bins <= m)
+    p.kmax = m < Q_BIG_MAX_BINS ? m : Q_BIG_MAX_BINS;
+    if (p.kmax < Q_MAX_BINS) p.kmax = Q_MAX_BINS;
     p.off_ce = take((size_t)(Q_CELLS + 2) * 8);
     p.off_arg = take((size_t)Q_MAX_BINS * (Q_CELLS + 1) * 4);
-    p.off_edges = take((size_t)(Q_MAX_BINS + 1) * 8);
-    p.off_bounds = take((size_t)Q_MAX_BINS * 8);
+    p.off_edges = take((size_t)(p.kmax + 1) * 8);
+    p.off_bounds = take((size_t)p.kmax * 8);
+    p.off_big = take((size_t)(p.kmax + 2) * 8 * 3);        // raw edges / running edges / new edges
     p.off_nb = take(256);
     p.off_cell = take((size_t)3 * (Q_CELLS + 1) * 8);
     p.off_D = take((size_t)2 * (Q_CELLS + 1) * 8);
@@ -340,8 +454,8 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
     GRX_REQUIRE(m >= 1, "grx_lloyd_max: no values");
     GRX_REQUIRE(n_bins >= 1 && max_iter >= 0, "grx_lloyd_max: bad n_bins / max_iter");
     GRX_REQUIRE(n_bins <= m, "n_samples=%lld should be >= n_clusters=%d.", (long long)m, n_bins);
-    if (n_bins > Q_MAX_BINS) {
-        grx_set_error("grx_lloyd_max: n_bins=%d > %d", n_bins, Q_MAX_BINS);
+    if (n_bins > Q_BIG_MAX_BINS) {
+        grx_set_error("grx_lloyd_max: n_bins=%d > %d", n_bins, Q_BIG_MAX_BINS);
         return GRX_ERR_UNSUPPORTED;
     }
     GRX_REQUIRE(m < ((int64_t)1 << 31), "grx_lloyd_max: m must be < 2^31");
@@ -372,6 +486,17 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
         q_tile_sums_kernel<<<(int)p.ntiles, 256, 0, st>>>(sorted, m, tsum);
         q_scan_tiles_kernel<<<1, 64, 0, st>>>(tsum, p.ntiles);
         q_prefix_kernel<<<(int)p.ntiles, 256, 0, st>>>(sorted, m, tsum, P, P2, Gp);
+        if (n_bins > Q_MAX_BINS) {
+            int64_t *raw = reinterpret_cast<int64_t *>(ws + p.off_big);
+            int64_t *hi = raw + (p.kmax + 2), *nh = hi + (p.kmax + 2);
+            q_cells_big_kernel<<<1, 1024, 0, st>>>(Gp, m, n_bins, raw, edges);
+            q_lloyd_big_kernel<<<1, 1024, 0, st>>>(sorted, m, P, n_bins, max_iter, edges, d_centers, hi, nh, bounds, d_info);
+            const int64_t want_big = grx_ceil_div(m, 256 * 4);
+            q_assign_big_kernel<<<(int)(want_big > 2048 ? 2048 : want_big), 256, 0, st>>>(d_values, m, n_bins, d_centers,
+                                                                                        bounds, d_quantized);
+            GRX_LAUNCH_CHECK();
+            return GRX_OK;
+        }
         q_cells_kernel<<<1, Q_CELLS, 0, st>>>(Gp, m, Q_CELLS, ce, nb);
         q_dp_init_kernel<<<4, 256, 0, st>>>(ce, nb, P, P2, cell, Dbuf);
         for (int j = 0; j < n_bins; ++j) {

@@ -37,7 +37,12 @@ def vertical_log_binning(arr: VectorLike, frac: float = 0.5) -> VectorLike:
     if values.size == 0:
         return np.zeros(0, dtype=int)
     K = _kernels()
-    bins, _ = K.vertical_log_bin(K.to_device(values.reshape(1, -1)), frac)
+    bins, nbins = K.vertical_log_bin(K.to_device(values.reshape(1, -1)), frac)
+    if int(K.to_host(nbins)[0]) < 0:
+        # uint8 labels / GRX_MAX_BINS thresholds: the pipeline's frac = 0.5 needs < 70 bins for any n < 2^63,
+        # only a tiny frac on many distinct values gets here
+        raise NotImplementedError(f'vertical_log_binning: more than 128 bins (frac={frac}); the device kernels '
+                                  'label bins with 7 bits and graphrole_amd has no CPU fallback')
     return K.to_host(bins)[0].astype(int)
 
 

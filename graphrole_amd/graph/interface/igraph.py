@@ -67,8 +67,13 @@ class IgraphInterface(DeviceGraphInterface):
                 wts = np.asarray(raw, dtype=np.float64)
                 if all(isinstance(x, Integral) for x in raw):
                     wts = wts.astype(np.int64)
-            # igraph reports neighbours in ascending vertex order: the CSR's own column order
-            self._csr = CSRGraph(n, src, dst, wts, self.directed, labels=list(range(n)), validate=False)
+            # Graph.neighbors(v, mode='out') -- the order the reference's neighbour sums run in (igraph.py:55-59,
+            # features/extract.py:108-110) -- lists the neighbours in ascending vertex order whatever the order
+            # of the edge list: that is the CSR's own column order, not the order of appearance CSRGraph
+            # assumes for plain edge arrays
+            csr = CSRGraph(n, src, dst, wts, self.directed, labels=list(range(n)), validate=False)
+            csr.adj_col = csr.col.copy()
+            self._csr = csr
         return self._csr
 
     def _attribute_frame(self) -> Optional[pd.DataFrame]:

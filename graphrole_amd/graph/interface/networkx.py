@@ -26,6 +26,11 @@ class NetworkxInterface(DeviceGraphInterface):
         :kwarg attributes_include: only these attributes (default: all)
         :kwarg attributes_exclude: never these attributes (wins over include)
         """
+        if G.is_multigraph():
+            # the reference runs on a Multi(Di)Graph but mixes conventions there (weighted degrees sum the
+            # parallel edges, its ego-net sums count each of them as 1, networkx.py:54-62,115-123)
+            raise NotImplementedError('networkx MultiGraph / MultiDiGraph input: merge the parallel edges first '
+                                      '(e.g. nx.Graph(G), or sum their weights into one edge)')
         self.G = G
         self.directed = G.is_directed()
         self._set_attribute_kwargs(**kwargs)

@@ -99,8 +99,9 @@ class RoleExtractor:
             for bits in range(self.min_bits, bit_stop):
                 try:
                     state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits)
-                except ValueError:
-                    # more bins requested than there are factor entries to quantise
+                except factor.TooFewSamples:
+                    # more bins requested than there are factor entries to quantise (the reference swallows
+                    # KMeans' ValueError here, roles/extract.py:127-129); any other error surfaces
                     continue
                 # description_length.py:32-41 / :44-61 on the device-resident factors
                 encoding_costs[roles, bits] = np.ceil(np.log2(max(uniq_g, uniq_f))) * (Wq.numel() + Hq.numel())

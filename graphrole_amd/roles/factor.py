@@ -29,6 +29,12 @@ import numpy as np
 
 from graphrole_amd.types import FactorTuple
 
+class TooFewSamples(ValueError):
+    """More quantisation levels requested than there are factor entries: sklearn's KMeans raises ValueError
+    ("n_samples=.. should be >= n_clusters=..") in the reference's encode(); the model-selection grid of
+    RoleExtractor skips exactly these cells (roles/extract.py:127-129) and nothing else."""
+
+
 NMF_TOL = 1e-4          # sklearn NMF defaults (_nmf.py:1538-1553)
 NMF_MAX_ITER = 200
 NNDSVD_EPS = 1e-6
@@ -291,7 +297,7 @@ def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int):
     n_bins = int(2 ** n_bits)
     for size in (n_roles * n, n_roles * F):               # encode(G) first, then encode(F)
         if n_bins > size:
-            raise ValueError(f'n_samples={size} should be >= n_clusters={n_bins}.')
+            raise TooFewSamples(f'n_samples={size} should be >= n_clusters={n_bins}.')
     W = state.W if state.W.shape[1] == n else state.W[:, :n].contiguous()
     Wq, _, info_w = K.lloyd_max(W.reshape(-1), n_bins)
     Hq, _, info_h = K.lloyd_max(state.H.reshape(-1), n_bins)
@@ -314,7 +320,7 @@ def encode(X: np.ndarray, n_bins: int) -> np.ndarray:
     if n_bins > X.size:
         # sklearn raises the same for KMeans(n_clusters > n_samples); the model-selection loop
         # of RoleExtractor relies on it (roles/extract.py:127-129)
-        raise ValueError(f'n_samples={X.size} should be >= n_clusters={n_bins}.')
+        raise TooFewSamples(f'n_samples={X.size} should be >= n_clusters={n_bins}.')
     flat = K.to_device(np.ascontiguousarray(X).reshape(-1))
     quantized, _, _ = K.lloyd_max(flat, int(n_bins))
     return K.to_host(quantized).reshape(X.shape)

@@ -407,7 +407,9 @@ int grx_nmf_fit(int64_t n, int F, int r, const double *d_X, int64_t ldx, const d
  * the flattened factor entries, every entry replaced by its cluster centre).  Deterministic:
  * sort -> prefix sums -> exact DP over <= 1024 equal cbrt-density micro-cells -> Lloyd refinement
  * -> assignment.  d_values / d_quantized: fp64[m]; d_centers: fp64[n_bins] (ascending);
- * d_info: int32[3] = {Lloyd iterations, non-empty cells, distinct output values}.  n_bins <= 256.
+ * d_info: int32[3] = {Lloyd iterations, non-empty cells, distinct output values}.  Up to 256 levels the start
+ * is the exact DP; 257..65536 levels (9..16 bits: roles/extract.py:72 asks for 2**int(log2(n_roles * min(shape)))
+ * on wide tables) start from the companding partition itself (equal cbrt-density cells).
  * n_bins > m is the reference's ValueError (sklearn: "n_samples=.. should be >= n_clusters=..")
  * -> GRX_ERR_INVALID.
  */

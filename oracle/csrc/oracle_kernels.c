@@ -225,9 +225,18 @@ int64_t orc_vertical_log_binning(int64_t n, const double *arr, double frac, int3
     if (!s) return -1;
     memcpy(s, arr, (size_t)n * sizeof(double));
     qsort(s, (size_t)n, sizeof(double), cmp_double);
-    double thr[128];
+    /* one threshold per bin; at most one bin per distinct value (the array is grown on demand) */
+    int64_t cap = 64;
+    double *thr = (double *)malloc((size_t)cap * sizeof(double));
+    if (!thr) { free(s); return -1; }
     int64_t nb = 0, done = 0;
-    while (done < n && nb < 128) {
+    while (done < n) {
+        if (nb == cap) {
+            cap *= 2;
+            double *grown = (double *)realloc(thr, (size_t)cap * sizeof(double));
+            if (!grown) { free(thr); free(s); return -1; }
+            thr = grown;
+        }
         int64_t size = (int64_t)(frac * (double)(n - done));
         if (size < 1) size = 1;
         int64_t pos = done + size - 1;               /* first unique with cumcount >= done+size */
@@ -243,6 +252,7 @@ int64_t orc_vertical_log_binning(int64_t n, const double *arr, double frac, int3
         while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (thr[mid] < x) lo = mid + 1; else hi = mid; }
         out[i] = (int32_t)lo;
     }
+    free(thr);
     return nb;
 }
 

@@ -40,6 +40,11 @@ def _datasets():
         ('few_distinct', rng.randint(0, 20, 5000).astype(float), 8),
         ('signed', rng.randn(20000) * 3, 16),
         ('k256', rng.gamma(2.0, 1.0, 100000), 256),
+        # more than 256 levels (n_bits = int(log2(n_roles * min(shape))) = 9..12 on wide feature tables,
+        # roles/extract.py:72): companding start + strided Lloyd kernel
+        ('k512', rng.gamma(2.0, 1.0, 100000), 512),
+        ('k512_of_690', rng.gamma(0.8, 3.0, 690), 512),          # the r x F factor of a 115-feature table, r = 6
+        ('k4096', rng.lognormal(0, 2, 300000), 4096),
     ]
 
 
@@ -64,8 +69,12 @@ def test_lloyd_max_properties_and_error_vs_sklearn(case):
     assert np.all(np.diff(q[order]) >= 0)
     # error not above the reference quantiser's
     inertia = float(((data - q) ** 2).sum())
+    if k > 1024:
+        return                                                     # sklearn needs minutes here; fixed-point checks above
     ref = _sklearn_inertia(data, k)
-    assert inertia <= ref * (1 + 1e-6) + 1e-12, (name, inertia, ref)
+    # up to 256 levels the exact-DP start guarantees <= sklearn; above, the companding start is near-optimal
+    slack = 1e-6 if k <= 256 else 0.05
+    assert inertia <= ref * (1 + slack) + 1e-12, (name, inertia, ref)
 
 
 def test_lloyd_max_small_input_is_the_exact_optimum():
@@ -118,3 +127,18 @@ def test_encode_at_rolx_scale():
     assert enc.shape == G.shape and len(np.unique(enc)) <= 64
     rel = np.sqrt(((G - enc) ** 2).mean()) / G.std()
     assert rel < 0.05
+
+
+def test_role_extractor_many_levels():
+    """RoleExtractor(n_roles=k) on a wide table asks for 2**int(log2(k * F)) >= 512 levels
+    (roles/extract.py:69-72); the reference works there, so must this."""
+    import pandas as pd
+    from graphrole_amd import RoleExtractor
+    rng = np.random.RandomState(5)
+    X = pd.DataFrame(np.abs(rng.randn(4000, 125)) * np.linspace(1, 20, 125))
+    np.random.seed(0)
+    rx = RoleExtractor(n_roles=5)                                 # 5 * 125 = 625 -> 9 bits -> 512 levels
+    rx.extract_role_factors(X)
+    assert rx.node_role_factor.shape == (4000, 5) and rx.role_feature_factor.shape == (5, 125)
+    assert len(np.unique(rx.node_role_factor.values)) <= 512
+    assert len(np.unique(rx.role_feature_factor.values)) <= 512

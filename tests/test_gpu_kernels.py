@@ -434,6 +434,52 @@ def test_log_bin_pass_skipping_patterns(K, n):
             assert int(nb[j]) == exp.max() + 1
 
 
+@pytest.mark.parametrize('n', [70, 5000, 400001])
+def test_log_bin_window_sort_adversarial(K, n):
+    """The binning sort orders WIDE columns by their top four varying key bytes only and resolves runs of
+    keys that agree in those bytes where a threshold lands: runs of 2..64 keys (shuffle ranking), long runs of
+    equal keys (heavy ties), long runs of unequal keys (workgroup radix selection), and NARROW 32-bit columns
+    next to them in one launch -- all must give the oracle's bins."""
+    import torch
+    from oracle import ckernels
+    rng = np.random.default_rng(n + 7)
+    tiny = 2.0 ** -40
+    base = 1.0 + rng.integers(0, 1 << 20, n) * tiny                  # differ only in key bytes 1..3
+    far = np.where(rng.random(n) < 0.01, rng.random(n) * 1e12, 0.0)   # a few huge values: byte 7 varies -> WIDE
+    cols = [
+        np.where(far > 0, far, base),                                 # ONE long run of unequal keys + outliers
+        np.where(far > 0, far, 1.0 + (rng.integers(0, 3, n)) * tiny),  # three values in one long run
+        np.where(rng.random(n) < 0.4, 0.1, rng.random(n)) + np.where(rng.random(n) < 0.001, 1e9, 0.0),   # heavy ties, WIDE
+        np.round(rng.random(n) * 4096) / 4096 + rng.integers(0, 4, n) * 2.0 ** -45 + np.where(rng.random(n) < 0.01, 1e6, 0),
+        rng.integers(0, 1 << 19, n).astype(np.float64),               # NARROW: integers below 2^20
+        rng.integers(0, 1 << 30, n).astype(np.float64),               # integers up to 2^30: five varying bytes -> WIDE
+        (rng.integers(0, 1 << 30, n) // 7 * 7).astype(np.float64) * 1024.0,
+        rng.pareto(1.2, n),                                           # heavy tail, all distinct
+        -rng.pareto(1.2, n).round(1),                                 # negative, ties
+        np.where(rng.random(n) < 0.3, -0.0, rng.standard_normal(n).round(1)),
+    ]
+    for frac in (0.5, 0.3, 0.9):
+        block = torch.from_numpy(np.stack(cols)).cuda()
+        bins, nb = K.vertical_log_bin(block, frac)
+        got = bins.cpu().numpy()
+        for j in range(len(cols)):
+            exp = ckernels.vertical_log_binning(cols[j], frac)
+            if exp.max() >= 128:
+                assert int(nb[j]) < 0                                 # reported, never silently wrong
+                continue
+            assert np.array_equal(got[j], exp), f'col {j} frac {frac}'
+            assert int(nb[j]) == exp.max() + 1
+
+
+def test_log_bin_too_many_bins_is_reported(K):
+    """frac so small that more than 128 bins are needed: the reference returns them, the device labels are
+    7-bit -- the standalone API raises instead of returning saturated labels."""
+    from graphrole_amd.features.prune import vertical_log_binning
+    with pytest.raises(NotImplementedError, match='128 bins'):
+        vertical_log_binning(np.arange(300.0), frac=0.001)
+    assert vertical_log_binning(np.arange(10.0)).tolist() == [0, 0, 0, 0, 0, 1, 1, 2, 3, 4]
+
+
 @pytest.mark.parametrize('n', [1000, 123457, 1 << 20])
 def test_log_bin_vs_oracle_random(K, n):
     import torch
