@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void bin_threshold_kernel(const double *__restr
 // once): 13 launches per call instead of 24, and about half the key bytes moved.
 // =======================================================================================
 struct BinPlanCol {
-    uint64_t const_bits;      // NARROW: the (constant) key bits below the window
+    uint64_t const_bits;      // NARROW: the (constant) key bits outside the 32 sorted ones
     uint8_t narrow;
     uint8_t npass;            // rounds this column takes part in (0: every key equal)
     uint8_t lo_shift;         // NARROW: bit offset of the window; WIDE: bit offset of the sorted part
@@ -435,7 +435,9 @@ __global__ __launch_bounds__(64) void bin_plan_kernel(const uint64_t *__restrict
         if (hi - lo < 4) {
             p.narrow = 1;
             p.lo_shift = (uint8_t)(8 * lo);
-            p.const_bits = lo ? (o & ((1ull << (8 * lo)) - 1)) : 0ull;
+            // the 32 key bits from the window's lowest byte upwards are carried in the sorted key; every other
+            // bit of the key is constant over the column and kept aside (o holds its value)
+            p.const_bits = o & ~(0xFFFFFFFFull << (8 * lo));
             for (int b = lo; b <= hi; ++b)
                 if ((varying >> (8 * b)) & 0xFF) p.dshift[p.npass++] = (uint8_t)(8 * (b - lo));
         } else {
@@ -769,6 +771,8 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
     } else {
         const KeyArray<uint64_t> s{buf};
         const int shift = p.lo_shift;
+        uint64_t prev_h = 0;
+        int64_t prev_a = 0;
         while (done < n && nb < GRX_MAX_BINS) {
             int64_t size = (int64_t)(frac * (double)(n - done));
             if (size < 1) size = 1;
@@ -776,7 +780,11 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
             const uint64_t kpos = s[pos];
             const uint64_t h = kpos >> shift;
             const int64_t b = run_end<uint64_t>(s, shift, h, pos + 1, n);
-            const int64_t a = run_begin<uint64_t>(s, shift, h, done, pos);
+            // a run is unordered inside: positions do not tell which of its keys earlier bins took, so a
+            // threshold that lands in the run of the previous one is ranked against the WHOLE run again
+            const int64_t a = (nb > 0 && h == prev_h) ? prev_a : run_begin<uint64_t>(s, shift, h, done, pos);
+            prev_h = h;
+            prev_a = a;
             const int64_t len = b - a, q = pos - a;           // the q-th smallest key of the run is the threshold
             uint64_t tk;
             int64_t end;

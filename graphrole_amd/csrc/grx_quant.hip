@@ -26,6 +26,7 @@ namespace {
 constexpr int Q_TILE = 2048;            // elements per scan workgroup (256 threads x 8)
 constexpr int Q_CELLS = 1024;           // micro-cells of the DP stage
 constexpr int Q_MAX_BINS = 256;          // exact-DP start + one-thread-per-cluster Lloyd kernel
+constexpr int QC_BIG = 8192;             // exact DP with one cell per value up to this many values
 constexpr int Q_BIG_MAX_BINS = 65536;    // above Q_MAX_BINS: companding start, strided Lloyd kernel, tables in global memory
 
 // ---- three fused prefix sums over the sorted values: s, s^2, cbrt(s[i+1]-s[i])^2 -----------
@@ -156,14 +157,14 @@ __global__ __launch_bounds__(Q_CELLS) void q_cells_kernel(const double *__restri
 // argmin butterfly), so a layer is spread over the whole chip instead of one workgroup.
 __global__ __launch_bounds__(256) void q_dp_init_kernel(const int64_t *__restrict__ ce, const int *__restrict__ nb_ptr,
                                                         const double *__restrict__ P, const double *__restrict__ P2,
-                                                        double *__restrict__ cell, double *__restrict__ D0)
+                                                        double *__restrict__ cell, double *__restrict__ D0, int cs)
 {
     const int nb = *nb_ptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) {
         const int64_t e = ce[i];
         cell[i] = P[e];
-        cell[(Q_CELLS + 1) + i] = P2[e];
-        cell[2 * (Q_CELLS + 1) + i] = (double)e;
+        cell[cs + i] = P2[e];
+        cell[2 * cs + i] = (double)e;
         D0[i] = (i == 0) ? 0.0 : 1e300;
     }
 }
@@ -171,11 +172,11 @@ __global__ __launch_bounds__(256) void q_dp_init_kernel(const int64_t *__restric
 __global__ __launch_bounds__(256) void q_dp_layer_kernel(const int *__restrict__ nb_ptr, int j, int k,
                                                          const double *__restrict__ cell,
                                                          const double *__restrict__ Dprev, double *__restrict__ Dcur,
-                                                         int32_t *__restrict__ arg)
+                                                         int32_t *__restrict__ arg, int cs)
 {
     const int nb = *nb_ptr;
     if (j >= (k < nb ? k : nb)) return;                 // surplus layers (more bins than cells)
-    const double *cp = cell, *cp2 = cell + (Q_CELLS + 1), *cn = cell + 2 * (Q_CELLS + 1);
+    const double *cp = cell, *cp2 = cell + cs, *cn = cell + 2 * cs;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per i
     if (i > nb) return;
@@ -201,12 +202,12 @@ __global__ __launch_bounds__(256) void q_dp_layer_kernel(const int *__restrict__
     }
     if (lane == 0) {
         Dcur[i] = (i == 0) ? 1e300 : best;
-        arg[(size_t)j * (Q_CELLS + 1) + i] = (bm == 0x7fffffff) ? j : bm;
+        arg[(size_t)j * cs + i] = (bm == 0x7fffffff) ? j : bm;
     }
 }
 
 __global__ void q_dp_backtrack_kernel(const int64_t *__restrict__ ce, const int *__restrict__ nb_ptr, int k,
-                                      const int32_t *__restrict__ arg, int64_t *__restrict__ edges)
+                                      const int32_t *__restrict__ arg, int64_t *__restrict__ edges, int cs)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int nb = *nb_ptr;
@@ -214,7 +215,7 @@ __global__ void q_dp_backtrack_kernel(const int64_t *__restrict__ ce, const int 
     int i = nb;
     edges[kk] = ce[nb];
     for (int j = kk - 1; j >= 0; --j) {
-        i = arg[(size_t)j * (Q_CELLS + 1) + i];
+        i = arg[(size_t)j * cs + i];
         edges[j] = ce[i];
     }
     for (int j = kk + 1; j <= k; ++j) edges[j] = ce[nb];      // surplus clusters stay empty
@@ -410,6 +411,7 @@ struct QuantPlan {
     size_t off_sorted, off_P, off_P2, off_G, off_tsum, off_ce, off_arg, off_edges, off_bounds, off_nb, off_cell, off_D,
         off_big, off_sort_ws, total;
     int64_t kmax;
+    int cell_cap;          // micro-cells of the DP stage: Q_CELLS, or QC_BIG when every one of <= QC_BIG values is a cell
 };
 
 QuantPlan q_plan(int64_t m)
@@ -426,14 +428,18 @@ QuantPlan q_plan(int64_t m)
     // tables of the many-level path are sized by the largest admissible level count (n_bins <= m)
     p.kmax = m < Q_BIG_MAX_BINS ? m : Q_BIG_MAX_BINS;
     if (p.kmax < Q_MAX_BINS) p.kmax = Q_MAX_BINS;
-    p.off_ce = take((size_t)(Q_CELLS + 2) * 8);
-    p.off_arg = take((size_t)Q_MAX_BINS * (Q_CELLS + 1) * 4);
+    // exact start whenever every value can be its own cell: the r x F factor has m/2 < k <= m levels
+    // (k = 2**int(log2(m))) and r x F <= 16 x 480 values, where no density-based start is any good
+    p.cell_cap = (m > Q_CELLS && m <= QC_BIG) ? QC_BIG : Q_CELLS;
+    const size_t layers = (p.cell_cap == QC_BIG) ? (size_t)m : (size_t)Q_CELLS;
+    p.off_ce = take((size_t)(p.cell_cap + 2) * 8);
+    p.off_arg = take(layers * (size_t)(p.cell_cap + 1) * 4);
     p.off_edges = take((size_t)(p.kmax + 1) * 8);
     p.off_bounds = take((size_t)p.kmax * 8);
     p.off_big = take((size_t)(p.kmax + 2) * 8 * 3);        // raw edges / running edges / new edges
     p.off_nb = take(256);
-    p.off_cell = take((size_t)3 * (Q_CELLS + 1) * 8);
-    p.off_D = take((size_t)2 * (Q_CELLS + 1) * 8);
+    p.off_cell = take((size_t)3 * (p.cell_cap + 1) * 8);
+    p.off_D = take((size_t)2 * (p.cell_cap + 1) * 8);
     p.off_sort_ws = take(grx_sort_workspace_bytes(m, 1));
     p.total = o;
     return p;
@@ -486,10 +492,23 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
         q_tile_sums_kernel<<<(int)p.ntiles, 256, 0, st>>>(sorted, m, tsum);
         q_scan_tiles_kernel<<<1, 64, 0, st>>>(tsum, p.ntiles);
         q_prefix_kernel<<<(int)p.ntiles, 256, 0, st>>>(sorted, m, tsum, P, P2, Gp);
-        if (n_bins > Q_MAX_BINS) {
-            int64_t *raw = reinterpret_cast<int64_t *>(ws + p.off_big);
-            int64_t *hi = raw + (p.kmax + 2), *nh = hi + (p.kmax + 2);
+        int64_t *raw = reinterpret_cast<int64_t *>(ws + p.off_big);
+        int64_t *hi = raw + (p.kmax + 2), *nh = hi + (p.kmax + 2);
+        if (n_bins <= Q_MAX_BINS || m <= QC_BIG) {
+            // exact start: dynamic programming over the micro-cells (every value its own cell when m <= 8192)
+            const int cs = p.cell_cap + 1;
+            q_cells_kernel<<<1, Q_CELLS, 0, st>>>(Gp, m, p.cell_cap, ce, nb);
+            q_dp_init_kernel<<<(p.cell_cap + 256) / 256, 256, 0, st>>>(ce, nb, P, P2, cell, Dbuf, cs);
+            for (int j = 0; j < n_bins; ++j) {
+                double *Dprev = Dbuf + (size_t)(j & 1) * cs;
+                double *Dcur = Dbuf + (size_t)((j + 1) & 1) * cs;
+                q_dp_layer_kernel<<<(cs + 3) / 4, 256, 0, st>>>(nb, j, n_bins, cell, Dprev, Dcur, arg, cs);
+            }
+            q_dp_backtrack_kernel<<<1, 64, 0, st>>>(ce, nb, n_bins, arg, edges, cs);
+        } else {
             q_cells_big_kernel<<<1, 1024, 0, st>>>(Gp, m, n_bins, raw, edges);
+        }
+        if (n_bins > Q_MAX_BINS) {
             q_lloyd_big_kernel<<<1, 1024, 0, st>>>(sorted, m, P, n_bins, max_iter, edges, d_centers, hi, nh, bounds, d_info);
             const int64_t want_big = grx_ceil_div(m, 256 * 4);
             q_assign_big_kernel<<<(int)(want_big > 2048 ? 2048 : want_big), 256, 0, st>>>(d_values, m, n_bins, d_centers,
@@ -497,14 +516,6 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
             GRX_LAUNCH_CHECK();
             return GRX_OK;
         }
-        q_cells_kernel<<<1, Q_CELLS, 0, st>>>(Gp, m, Q_CELLS, ce, nb);
-        q_dp_init_kernel<<<4, 256, 0, st>>>(ce, nb, P, P2, cell, Dbuf);
-        for (int j = 0; j < n_bins; ++j) {
-            double *Dprev = Dbuf + (size_t)(j & 1) * (Q_CELLS + 1);
-            double *Dcur = Dbuf + (size_t)((j + 1) & 1) * (Q_CELLS + 1);
-            q_dp_layer_kernel<<<(Q_CELLS + 1 + 3) / 4, 256, 0, st>>>(nb, j, n_bins, cell, Dprev, Dcur, arg);
-        }
-        q_dp_backtrack_kernel<<<1, 64, 0, st>>>(ce, nb, n_bins, arg, edges);
         q_lloyd_kernel<<<1, Q_MAX_BINS, 0, st>>>(sorted, m, P, n_bins, max_iter, edges, d_centers, bounds, d_info);
         const int64_t want = grx_ceil_div(m, 256 * 4);
         q_assign_kernel<<<(int)(want > 2048 ? 2048 : want), 256, 0, st>>>(d_values, m, n_bins, d_centers, bounds,
