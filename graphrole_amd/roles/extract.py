@@ -41,6 +41,7 @@ class RoleExtractor:
 
         self.node_role_factor: Optional[pd.DataFrame] = None
         self.role_feature_factor: Optional[pd.DataFrame] = None
+        self.model_selection_ = None
 
     @property
     def roles(self) -> Optional[Dict[Node, float]]:
@@ -110,6 +111,9 @@ class RoleExtractor:
 
         costs = self._rescale_costs(encoding_costs) + self._rescale_costs(error_costs)
         best_roles, best_bits = np.argwhere(costs == np.nanmin(costs))[0]
+        #: diagnostics of the last grid search: both cost grids and the selected (n_roles, n_bits) cell
+        self.model_selection_ = {'encoding_costs': encoding_costs, 'error_costs': error_costs,
+                                 'selected': (int(best_roles), int(best_bits))}
         Wq, Hq = factors[best_roles][best_bits]
         return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 

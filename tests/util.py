@@ -11,6 +11,7 @@ REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'lo
                'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000',
                'karate_minmax', 'ba300_maxsum', 'dw200_minmax', 'loops_dangling150_minmax', 'ba300_stdvar',
                'karate_sumstd', 'iface7_prod', 'dw200_prod', 'path4_prod']
+ROLES_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'directed120', 'loops_dangling150']
 NMF_CASES = ['rand20x30_r3', 'rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'karate_r4', 'er2000_r6',
              'ba2000_r6', 'dw200_r5']
 
@@ -36,6 +37,10 @@ def golden_aggs(g):
 
 def load_refex(name):
     return Golden(os.path.join(GOLDEN, f'refex_{name}.npz'))
+
+
+def load_roles(name):
+    return Golden(os.path.join(GOLDEN, f'roles_{name}.npz'))
 
 
 def load_nmf(name):

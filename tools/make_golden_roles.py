@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""
+tools/make_golden_roles.py -- model-selection fixtures (tests/golden/roles_<name>.npz) by RUNNING THE
+REFERENCE's RoleExtractor in the build container on feature tables that tools/make_golden.py already captured
+(the final ReFeX tables of tests/golden/refex_<name>.npz).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden_roles.py
+
+Per table: the MDL grid of RoleExtractor._select_model (graphrole/roles/extract.py:98-142) -- encoding and
+error costs of every (n_roles, n_bits) cell as the reference computes them (its quantiser is sklearn
+KMeans(random_state=1), graphrole/roles/factor.py:41-48) with numpy's global RNG seeded once before the grid --
+the selected cell, the selected factors, and the fixed-rank result for n_roles = 3.
+The reference is imported here and only here; the fixtures are data.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+warnings.simplefilter('ignore')
+
+import pandas as pd                                              # noqa: E402
+from graphrole import RoleExtractor                              # noqa: E402
+from graphrole.roles.description_length import get_description_length_costs   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'tests', 'golden')
+CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'directed120', 'loops_dangling150']
+SEED = 0
+
+
+def main():
+    for name in CASES:
+        z = np.load(os.path.join(OUT, f'refex_{name}.npz'))
+        cols = json.loads(str(z['final_columns_json']))
+        labels = json.loads(str(z['labels_json']))
+        X = pd.DataFrame(z['final_values'], index=labels, columns=cols)
+        # the grid exactly as RoleExtractor._select_model walks it (one RNG stream for the whole grid)
+        rx = RoleExtractor()
+        bit_stop = rx.max_bits + 1
+        role_stop = min(min(X.shape), rx.max_roles) + 1
+        enc = np.full((role_stop, bit_stop), np.nan)
+        err = np.full((role_stop, bit_stop), np.nan)
+        np.random.seed(SEED)
+        for roles in range(rx.min_roles, role_stop):
+            for bits in range(rx.min_bits, bit_stop):
+                try:
+                    model = rx._get_encoded_role_factors(X, roles, bits)
+                    e, r = get_description_length_costs(X, model)
+                except ValueError:
+                    continue
+                enc[roles, bits], err[roles, bits] = e, r
+        costs = rx._rescale_costs(enc) + rx._rescale_costs(err)
+        sel = np.argwhere(costs == np.nanmin(costs))[0]
+        # the public call must pick the same cell
+        np.random.seed(SEED)
+        rx2 = RoleExtractor()
+        rx2.extract_role_factors(X)
+        assert rx2.node_role_factor.shape[1] == int(sel[0]), (name, rx2.node_role_factor.shape, sel)
+        # fixed rank
+        np.random.seed(SEED)
+        rx3 = RoleExtractor(n_roles=3)
+        rx3.extract_role_factors(X)
+        np.savez_compressed(
+            os.path.join(OUT, f'roles_{name}.npz'), seed=SEED, encoding_costs=enc, error_costs=err,
+            selected=np.array(sel, dtype=np.int64), node_role_factor=rx2.node_role_factor.values,
+            role_feature_factor=rx2.role_feature_factor.values, fixed3_node_role_factor=rx3.node_role_factor.values,
+            fixed3_role_feature_factor=rx3.role_feature_factor.values,
+            fixed3_n_bits=int(np.log2(3 * min(X.shape))))
+        print(f'roles_{name}: table {X.shape} -> selected (n_roles, n_bits) = {tuple(int(v) for v in sel)}')
+
+
+if __name__ == '__main__':
+    main()
