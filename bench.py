@@ -300,6 +300,20 @@ def main():
     elapsed = time.perf_counter() - t_start
     lib.grx_profile_enable(0)
     prof = profile_totals(lib)
+    # N > 1: one more (untimed) step with HIP events around every exchange -> exchange share of a step
+    exchange = None
+    if plan is not None:
+        plan.reset_timing()
+        plan.timing = True
+        barrier()
+        t_x = time.perf_counter()
+        step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
+        barrier()
+        t_x = time.perf_counter() - t_x
+        plan.timing = False
+        stats = plan.collect_timing()
+        exchange = {'step_ms': t_x * 1e3, 'ms': sum(v[1] for v in stats.values()), 'calls': sum(v[0] for v in stats.values()),
+                    'by_kind': {k: {'calls': v[0], 'ms': v[1]} for k, v in stats.items()}}
 
     # max over ranks
     red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64,
@@ -322,6 +336,18 @@ def main():
         encode_info = {'ms': (time.perf_counter() - t0) * 1e3, 'values': int(flat.numel()), 'n_bins': n_bins,
                        'lloyd_iterations': int(info[0]), 'what': 'grx_lloyd_max on the N x r node-role factor'}
 
+    # per-rank figures (N > 1): every rank's aggregation launch time and exchange time, gathered on rank 0
+    per_rank = None
+    if multi:
+        agg_ms_r, agg_cnt_r = prof.get('aggregate_kernel', (0.0, 0))
+        hub_ms_r, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
+        w_ms_r, w_cnt_r = prof.get('nmf_w_pass_kernel', (0.0, 0))
+        mine = {'rank': rank, 'rows': (plan.row_end - plan.row_begin) if plan is not None else G.n,
+                'aggregate_avg_launch_ms': (agg_ms_r + hub_ms_r) / agg_cnt_r if agg_cnt_r else None,
+                'w_pass_avg_launch_ms': w_ms_r / w_cnt_r if w_cnt_r else None, 'exchange': exchange}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     if rank == 0:
         gens = state['gens']
         edges_per_step = G.nnz * gens
@@ -400,6 +426,17 @@ def main():
             'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
             'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
         }
+        if per_rank is not None:
+            # per-rank roofline of the aggregation kernel (each rank owns ~1/N of the rows and of the nnz) and the
+            # share of a step spent in exchanges: what a scaling curve has to be read against
+            for pr in per_rank:
+                if pr['aggregate_avg_launch_ms'] and launches:
+                    ach = alg_bytes / launches / (pr['aggregate_avg_launch_ms'] * 1e-3) / 1e9
+                    pr['aggregate_achieved_gbs'] = ach
+                    pr['aggregate_frac_of_hbm_peak'] = ach / HBM_PEAK_GBS
+                if pr['exchange']:
+                    pr['exchange_share_of_step'] = pr['exchange']['ms'] / pr['exchange']['step_ms']
+            line['per_rank'] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             Xh = K.to_host(state['Xd'])[:, :G.n].T.copy() if args.cpu_nmf else None
             base, extra = cpu_baseline(G, args, Xh)

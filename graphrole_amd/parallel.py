@@ -53,6 +53,48 @@ class ShardPlan:
         # real RCCL calls, dtypes and split sizes on a one-GPU box, tests/test_gpu_sharded.py)
         self._solo = self.world == 1 and not _force_collectives()
         self._perm_cache: dict = {}
+        #: exchange timing (bench.py --gpus N): name -> [calls, device ms]; off by default
+        self.timing = False
+        self._timed_events: list = []
+        self.exchange_stats: dict = {}
+
+    # ------------------------------------------------------------------ exchange timing
+    def _time(self, name: str):
+        """Context manager: HIP events around one exchange on the current stream (device time of the packing
+        kernels + the collective); a no-op unless self.timing."""
+        plan = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.on = plan.timing and torch.cuda.is_available()
+                if self_inner.on:
+                    self_inner.start = torch.cuda.Event(enable_timing=True)
+                    self_inner.stop = torch.cuda.Event(enable_timing=True)
+                    self_inner.start.record()
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                if self_inner.on:
+                    self_inner.stop.record()
+                    plan._timed_events.append((name, self_inner.start, self_inner.stop))
+                return False
+
+        return _Scope()
+
+    def collect_timing(self) -> dict:
+        """Synchronise and fold the recorded events into exchange_stats {name: [calls, ms]}."""
+        if self._timed_events:
+            torch.cuda.synchronize()
+            for name, start, stop in self._timed_events:
+                cell = self.exchange_stats.setdefault(name, [0, 0.0])
+                cell[0] += 1
+                cell[1] += start.elapsed_time(stop)
+            self._timed_events = []
+        return self.exchange_stats
+
+    def reset_timing(self) -> None:
+        self._timed_events = []
+        self.exchange_stats = {}
 
     # ------------------------------------------------------------------ collectives
     def _staged(self, t: torch.Tensor) -> bool:
@@ -68,6 +110,10 @@ class ShardPlan:
         ncols = block.shape[0]
         if ncols == 0 or self.n == 0:
             return block
+        with self._time('all_gather_block'):
+            return self._all_gather_block(block, ncols)
+
+    def _all_gather_block(self, block: torch.Tensor, ncols: int) -> torch.Tensor:
         send = torch.zeros((ncols, self.max_rows), dtype=block.dtype, device=block.device)
         send[:, :self.row_end - self.row_begin] = block[:, self.row_begin:self.row_end]
         if self._staged(block):
@@ -99,6 +145,10 @@ class ShardPlan:
     def columns_to_owners(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> the WHOLE columns this rank owns
         (columns rank, rank + world, ...) as a [n_owned, n] tensor."""
+        with self._time('columns_to_owners'):
+            return self._columns_to_owners(block)
+
+    def _columns_to_owners(self, block: torch.Tensor) -> torch.Tensor:
         ncols = block.shape[0]
         rb, re = self.row_begin, self.row_end
         counts, perm = self._owner_order(ncols, block.device)
@@ -122,6 +172,10 @@ class ShardPlan:
     def owned_to_rows(self, owned: torch.Tensor, ncols: int) -> torch.Tensor:
         """Inverse direction for per-column results (uint8 bins): owned [n_owned, n] whole columns ->
         [ncols, n] with this rank's row slice of EVERY column valid (other rows zero)."""
+        with self._time('owned_to_rows'):
+            return self._owned_to_rows(owned, ncols)
+
+    def _owned_to_rows(self, owned: torch.Tensor, ncols: int) -> torch.Tensor:
         rb, re = self.row_begin, self.row_end
         n_owned = owned.shape[0]
         counts, perm = self._owner_order(ncols, owned.device)
@@ -201,10 +255,12 @@ class ShardPlan:
         return (K.to_host(out) if out.is_cuda else out.numpy()).reshape((self.world,) + a.shape)
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
-        return self._all_reduce_(t, dist.ReduceOp.MAX)
+        with self._time('all_reduce_max'):
+            return self._all_reduce_(t, dist.ReduceOp.MAX)
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
-        return self._all_reduce_(t, dist.ReduceOp.SUM)
+        with self._time('all_reduce_sum'):
+            return self._all_reduce_(t, dist.ReduceOp.SUM)
 
 
 def _force_collectives() -> bool:

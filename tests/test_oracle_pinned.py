@@ -232,3 +232,21 @@ def test_reference_path_nmf_equals_golden():
     assert n_iter == int(g['n_iter'])
     np.testing.assert_allclose(W, g['W'], rtol=1e-12, atol=0)
     np.testing.assert_allclose(H, g['H'], rtol=1e-12, atol=0)
+
+
+def test_environment_of_the_bit_exact_pin():
+    """The "bit for bit" claims are about the reference AS IT RUNS IN THIS IMAGE: pandas without the optional
+    `bottleneck` package adds a float64 column with ndarray.sum(), i.e. numpy's pairwise summation, which the
+    oracle (and the HIP kernels) restate.  With bottleneck installed pandas would add sequentially and the
+    reference's own bits would change -- this test says so instead of letting the goldens drift silently."""
+    import importlib.util
+    import pandas as pd
+    assert importlib.util.find_spec('bottleneck') is None, \
+        'bottleneck is installed: pandas sums sequentially, regenerate tests/golden with tools/make_golden.py'
+    assert tuple(int(v) for v in np.__version__.split('.')[:2]) >= (1, 22)
+    rng = np.random.default_rng(0)
+    for m in (1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 70001):
+        x = rng.standard_normal(m) * 10.0 ** rng.integers(-3, 6, m)
+        want = float(x.sum())                                        # numpy: pairwise, 8192-element ufunc buffer
+        assert float(pd.Series(x).sum()) == want                     # pandas: the same bits (no bottleneck)
+        assert float(refex.ndarray_sum(x.reshape(-1, 1))[0]) == want   # the oracle's restatement
