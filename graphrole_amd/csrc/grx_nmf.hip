@@ -813,71 +813,6 @@ __global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, double 
     }
 }
 
-// reduce_partials_kernel + nmf_h_update_kernel in ONE launch (single-GPU loop, grx_nmf_iterate): every
-// workgroup reduces its four outputs, the workgroup that finishes last (ticket counter) then applies the H
-// update.  Same arithmetic in the same order as the two separate kernels -- what is saved is one dependent
-// launch per iteration (~5 us of a 60 us iteration on the 1 M-node graph, a quarter of a 20 us iteration on a
-// 100 k-node one).  The release / acquire pair around the ticket makes the other workgroups' sums visible.
-__global__ __launch_bounds__(256) void reduce_h_update_kernel(const double *__restrict__ partial, int nb, int P,
-                                                              double *__restrict__ AB, int F, int r,
-                                                              double *__restrict__ H, unsigned int *__restrict__ ticket)
-{
-    __shared__ double sB[MAX_R * MAX_R];
-    __shared__ int s_last;
-    {
-        const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
-        if (p < P) {
-            const double *src = partial + (size_t)p * nb;
-            double s = 0.0;
-            for (int b0 = lane; b0 < nb; b0 += 64 * 16) {
-                double v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int b = b0 + 64 * j;
-                    v[j] = (b < nb) ? src[b] : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) s += v[j];
-            }
-            s = grx_group_sum<64>(s);
-            if (lane == 0) AB[p] = s;
-        }
-    }
-    __threadfence();                                           // release this workgroup's sums
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                           // acquire everybody else's
-    if (threadIdx.x == 0) *ticket = 0;                         // ready for the next iteration
-    const double *ABv = AB;
-    for (int idx = threadIdx.x; idx < r * r; idx += 256)
-        sB[idx] = __hip_atomic_load(&ABv[r * F + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    constexpr int PER = (MAX_R * MAX_F_WIDE + 255) / 256;
-    double hnew[PER];
-#pragma unroll
-    for (int s = 0; s < PER; ++s) {
-        const int idx = threadIdx.x + 256 * s;
-        hnew[s] = 0.0;
-        if (idx < r * F) {
-            const int k = idx / F, c = idx % F;
-            double denom = 0.0;
-            for (int l = 0; l < r; ++l) denom += sB[k * r + l] * H[l * F + c];
-            if (denom == 0.0) denom = NMF_EPSILON;
-            const double a = __hip_atomic_load(&ABv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hnew[s] = H[idx] * (a / denom);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < PER; ++s) {
-        const int idx = threadIdx.x + 256 * s;
-        if (idx < r * F) H[idx] = hnew[s];
-    }
-}
-
 __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                            const double *__restrict__ X, int64_t ldx,
                                                            const double *__restrict__ W, int64_t ldw,
@@ -1323,14 +1258,12 @@ size_t grx_nmf_workspace_bytes(int64_t n, int F, int r)
     const size_t P = (size_t)r * F + (size_t)r * r;
     const size_t a = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256);
     const size_t b = grx_align_up((size_t)RES_GRID * 8, 256);
-    return a + b + 256;                                        // + the ticket counter of the fused reduce / H update
+    return a + b;
 }
 
-// fuse_h: the reduction of the partial sums also applies the H update (reduce_h_update_kernel); d_H is then
-// written and `ticket` (zeroed device counter) is used
-static int w_pass_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
-                       int64_t row_begin, int64_t row_end, double *d_H, double *d_AB, void *d_workspace,
-                       size_t workspace_bytes, void *stream, bool fuse_h, unsigned int *ticket)
+int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                   int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
+                   void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldw >= n,
                 "grx_nmf_w_pass: bad row range");
@@ -1370,19 +1303,10 @@ static int w_pass_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, 
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
-    if (fuse_h) reduce_h_update_kernel<<<(P + 3) / 4, 256, 0, st>>>(partial, grid, P, d_AB, F, r, d_H, ticket);
-    else reduce_partials_kernel<<<(P + 3) / 4, 256, 0, st>>>(partial, grid, P, d_AB);
+    reduce_partials_kernel<<<(P + 3) / 4, 256, 0, st>>>(partial, grid, P, d_AB);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
-}
-
-int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
-                   int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
-                   void *d_workspace, size_t workspace_bytes, void *stream)
-{
-    return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, const_cast<double *>(d_H), d_AB, d_workspace,
-                       workspace_bytes, stream, false, nullptr);
 }
 
 int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream)
@@ -1463,21 +1387,11 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
                     size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(iters >= 0, "grx_nmf_iterate: iters < 0");
-    if (iters > 0) {
-        if (workspace_bytes < grx_nmf_workspace_bytes(n, F, r)) {
-            grx_set_error("grx_nmf_iterate: workspace too small");
-            return GRX_ERR_WORKSPACE;
-        }
-        GRX_REQUIRE(d_workspace != nullptr, "grx_nmf_iterate: NULL workspace");
-        // ticket counter of the fused reduce / H-update launch: the last 256 bytes of the workspace
-        unsigned int *ticket = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(d_workspace) +
-                                                                grx_nmf_workspace_bytes(n, F, r) - 256);
-        GRX_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, grx_stream(stream)));
-        for (int it = 0; it < iters; ++it) {
-            int rc = w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream, true,
-                                 ticket);
-            if (rc != GRX_OK) return rc;
-        }
+    for (int it = 0; it < iters; ++it) {
+        int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream);
+        if (rc != GRX_OK) return rc;
+        rc = grx_nmf_h_update(F, r, d_H, d_AB, stream);
+        if (rc != GRX_OK) return rc;
     }
     if (d_err)
         return grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err, d_workspace, workspace_bytes, stream);
