@@ -124,6 +124,10 @@ _SIGNATURES = {
     'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                               c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p, POINTER(c_int),
                               POINTER(c_size_t), c_void_p]),
+    'grx_kmeans1d_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'grx_kmeans1d': (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_transpose': (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'grx_host_eigh': (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_fit_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'grx_nmf_init': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p,

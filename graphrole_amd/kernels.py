@@ -553,6 +553,56 @@ def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
     return out, centers, info
 
 
+# ---- the reference's quantiser: sklearn KMeans(n_clusters, random_state=1) reproduced (grx_kmeans1d) ----
+_KMEANS_DRAWS: dict = {}
+
+
+def kmeans_draws(m: int, n_bins: int):
+    """The random numbers sklearn's KMeans(random_state=1) consumes for m samples and n_bins clusters -- they do
+    not depend on the data: (index of the first seed, (n_bins - 1) x n_trials uniforms).
+    _kmeans_plusplus: center_id = random_state.choice(n_samples, p=sample_weight / sample_weight.sum()), i.e.
+    searchsorted(cumsum(p) / cumsum(p)[-1], random_sample(), side='right') with p = 1/m (what numpy's choice
+    does, without its argument checks); then random_state.uniform(size=2 + int(log(k))) per further seed."""
+    key = (int(m), int(n_bins))
+    hit = _KMEANS_DRAWS.get(key)
+    if hit is None:
+        rs = np.random.RandomState(1)
+        u = rs.random_sample()
+        cdf = np.cumsum(np.full(m, 1.0 / m))
+        cdf /= cdf[-1]
+        first = int(np.searchsorted(cdf, u, side='right'))
+        trials = 2 + int(np.log(n_bins))
+        uniform = rs.uniform(size=(max(n_bins - 1, 0), trials))
+        hit = (first, np.ascontiguousarray(uniform), trials)
+        if len(_KMEANS_DRAWS) > 64:
+            _KMEANS_DRAWS.clear()
+        _KMEANS_DRAWS[key] = hit
+    return hit
+
+
+def kmeans1d(values: torch.Tensor, n_bins: int, max_iter: int = 300, rel_tol: float = 1e-4):
+    """encode() as the reference computes it: `values` flat fp64 device tensor IN THE REFERENCE'S FLATTEN ORDER ->
+    (quantised tensor, centres [n_bins] in seed order, info int32[3] = {n_iter_, non-empty clusters, distinct
+    output values})."""
+    m = values.numel()
+    first, uniform, trials = kmeans_draws(m, int(n_bins))
+    out = torch.empty_like(values)
+    centers = torch.empty(max(int(n_bins), 1), dtype=torch.float64, device=device())
+    info = torch.zeros(3, dtype=torch.int32, device=device())
+    ws_bytes = _lib.load().grx_kmeans1d_workspace_bytes(m, int(n_bins))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_kmeans1d', m, _ptr(values), int(n_bins), first, _hptr(uniform), trials, int(max_iter), float(rel_tol),
+              _ptr(out), _ptr(centers), _ptr(info), _ptr(ws), ws_bytes, _stream())
+    return out, centers, info
+
+
+def transpose(src: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """[rows, >= cols] row-major (leading dimension src.stride(0)) -> contiguous [cols, rows]."""
+    out = torch.empty((cols, rows), dtype=torch.float64, device=device())
+    _lib.call('grx_transpose', rows, cols, _ptr(src), _ld(src), _ptr(out), rows, _stream())
+    return out
+
+
 class NmfState:
     """Device buffers of one multiplicative-update run (X, W feature-major; H r x F).
     H: host array or device tensor [r, F]; x_sq_norm: ||X||_F^2 when known (lets the convergence

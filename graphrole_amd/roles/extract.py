@@ -22,6 +22,10 @@ class RoleExtractor:
 
     N_ROLE_RANGE = (2, 8)
     N_BIT_RANGE = (1, 8)
+    #: 'kmeans' = the reference's quantiser reproduced (sklearn KMeans(random_state=1), grx_kmeans1d);
+    #: 'lloyd_max' = the deterministic Lloyd-Max solver (lower error, other numbers).  Class attribute: set it
+    #: on the class or on an instance before fitting.
+    quantizer = 'kmeans'
 
     def __init__(
         self,
@@ -67,7 +71,7 @@ class RoleExtractor:
             # the two factors hold n_roles * (n_nodes + n_features) values; encode them with
             # about log2(n_roles * min(shape)) bits (:69-72)
             n_bits = int(np.log2(self.n_roles * min(features.shape)))
-            node_role, role_feature = self._get_encoded_role_factors(features, self.n_roles, n_bits)
+            node_role, role_feature = self._get_encoded_role_factors(features, self.n_roles, n_bits, self.quantizer)
         else:
             node_role, role_feature = self._select_model(features)
 
@@ -99,7 +103,7 @@ class RoleExtractor:
         for roles in range(self.min_roles, role_stop):
             for bits in range(self.min_bits, bit_stop):
                 try:
-                    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits)
+                    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits, self.quantizer)
                 except factor.TooFewSamples:
                     # more bins requested than there are factor entries to quantise (the reference swallows
                     # KMeans' ValueError here, roles/extract.py:127-129); any other error surfaces
@@ -118,13 +122,14 @@ class RoleExtractor:
         return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 
     @staticmethod
-    def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int) -> FactorTuple:
+    def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int,
+                                  quantizer: Optional[str] = None) -> FactorTuple:
         """NMF of the feature matrix with both factors quantised to 2**n_bits levels (:144-161)"""
         from graphrole_amd import backend
         K = backend.get()
         V = factor._checked_matrix(features.values)
         Vd = K.to_device(np.ascontiguousarray(V.T))
-        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits)
+        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer)
         return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 
     @staticmethod

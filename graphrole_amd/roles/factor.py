@@ -18,8 +18,9 @@ init='nndsvda')`` (factor.py:19) with every O(N) pass on the GPU:
   On one GPU both halves run below the ABI in one call (grx_nmf_fit, csrc/grx_fit.hip); with a ShardPlan
   the same sequence is driven from here, kernel by kernel, with the exchanges between the passes.
 
-``encode`` (factor.py:29-49: 1-D Lloyd-Max quantiser, sklearn KMeans in the reference) runs on the
-GPU as well (grx_lloyd_max, csrc/grx_quant.hip): SURVEY.md section 8(f) rank 1.
+``encode`` (factor.py:29-49: sklearn KMeans(n_clusters, random_state=1) on the flattened entries) runs on the
+GPU as the same procedure (grx_kmeans1d, csrc/grx_kmeans.hip); the deterministic Lloyd-Max solver
+grx_lloyd_max (csrc/grx_quant.hip) is available as quantizer='lloyd_max' (SURVEY.md section 8(f) rank 1).
 """
 from __future__ import annotations
 
@@ -284,12 +285,29 @@ def nmf_with_info(X: np.ndarray, n_roles: int):
     return K.to_host(state.W)[:, :n].T.copy(), K.to_host(state.H).copy(), n_iter
 
 
-def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int):
+QUANTIZERS = ('kmeans', 'lloyd_max')
+
+
+def _quantize_flat(flat, n_bins: int, quantizer: str):
+    """Quantise a flat device tensor (reference flatten order) -> (quantised, distinct output values)."""
+    K = _kernels()
+    if quantizer == 'kmeans':
+        q, _, info = K.kmeans1d(flat, n_bins)
+    elif quantizer == 'lloyd_max':
+        q, _, info = K.lloyd_max(flat, n_bins)
+    else:
+        raise ValueError(f'quantizer must be one of {QUANTIZERS}, got {quantizer!r}')
+    return q, info
+
+
+def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantizer: str = 'kmeans'):
     """
     NMF of X followed by the quantisation of both factors with 2**n_bits levels, without leaving
     HBM (roles/extract.py:144-161).  Returns (state, Wq [r, n], Hq [r, F], distinct values of Wq,
-    distinct values of Hq); raises ValueError like the reference when there are fewer factor
-    entries than levels.
+    distinct values of Hq); raises TooFewSamples (a ValueError, like the reference) when there are fewer
+    factor entries than levels.
+    quantizer='kmeans' reproduces the reference's sklearn KMeans(random_state=1) (grx_kmeans1d);
+    'lloyd_max' is the deterministic optimum-seeking quantiser (grx_lloyd_max): lower error, other numbers.
     """
     K = _kernels()
     n, F = X.shape
@@ -298,20 +316,24 @@ def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int):
     for size in (n_roles * n, n_roles * F):               # encode(G) first, then encode(F)
         if n_bins > size:
             raise TooFewSamples(f'n_samples={size} should be >= n_clusters={n_bins}.')
-    W = state.W if state.W.shape[1] == n else state.W[:, :n].contiguous()
-    Wq, _, info_w = K.lloyd_max(W.reshape(-1), n_bins)
-    Hq, _, info_h = K.lloyd_max(state.H.reshape(-1), n_bins)
+    # the reference quantises G.reshape(G.size, 1) with G = W as an n x r row-major matrix: that order is the
+    # order of its cumulative sums, so the feature-major device factor is transposed first
+    G_flat = K.transpose(state.W, n_roles, n).reshape(-1)
+    Gq_flat, info_w = _quantize_flat(G_flat, n_bins, quantizer)
+    Wq = K.transpose(Gq_flat.view(n, n_roles), n, n_roles)
+    Hq, info_h = _quantize_flat(state.H.reshape(-1), n_bins, quantizer)
     info_w, info_h = K.to_host(info_w), K.to_host(info_h)
-    return state, Wq.view(n_roles, n), Hq.view(n_roles, F), int(info_w[2]), int(info_h[2])
+    return state, Wq, Hq.view(n_roles, F), int(info_w[2]), int(info_h[2])
 
 
-def encode(X: np.ndarray, n_bins: int) -> np.ndarray:
+def encode(X: np.ndarray, n_bins: int, quantizer: str = 'kmeans') -> np.ndarray:
     """
-    Encode (quantize) a matrix X using a specified number of bins: every entry is replaced by
-    the centre of its cell of a 1-D Lloyd-Max quantiser over all entries (factor.py:29-49, where
-    the quantiser is sklearn KMeans(n_clusters=n_bins, random_state=1)).  Here the quantiser is
-    grx_lloyd_max on the GPU: deterministic (exact DP start on equal cbrt-density micro-cells, then
-    Lloyd iterations), same fixed-point conditions as k-means, error not above sklearn's.
+    Encode (quantize) a matrix X using a specified number of bins: every entry is replaced by the centre of its
+    cluster (factor.py:29-49).  quantizer='kmeans' (default): the reference's quantiser itself,
+    sklearn KMeans(n_clusters=n_bins, random_state=1) on the flattened entries, reproduced on the GPU
+    (grx_kmeans1d: same seeding draws, same Lloyd iterations and stopping rule; centres equal sklearn's to ~1e-12).
+    quantizer='lloyd_max': grx_lloyd_max, a deterministic 1-D Lloyd-Max solver (exact DP start + Lloyd
+    iterations) -- the same fixed-point conditions with an error not above KMeans', but other numbers.
     :param X: matrix to encode
     :param n_bins: number of bins for encoding
     """
@@ -322,5 +344,5 @@ def encode(X: np.ndarray, n_bins: int) -> np.ndarray:
         # of RoleExtractor relies on it (roles/extract.py:127-129)
         raise TooFewSamples(f'n_samples={X.size} should be >= n_clusters={n_bins}.')
     flat = K.to_device(np.ascontiguousarray(X).reshape(-1))
-    quantized, _, _ = K.lloyd_max(flat, int(n_bins))
+    quantized, _ = _quantize_flat(flat, int(n_bins), quantizer)
     return K.to_host(quantized).reshape(X.shape)

@@ -418,6 +418,29 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
                   double *d_centers, int32_t *d_info, void *d_workspace, size_t workspace_bytes,
                   void *stream);
 
+/*
+ * The reference's quantiser itself.  Replaces encode() (graphrole/roles/factor.py:29-49) with the SAME procedure
+ * sklearn runs there: KMeans(n_clusters=k, random_state=1) on the flattened entries -- k-means++ seeding driven by
+ * the caller's random numbers (drawn exactly as RandomState(1) hands them to sklearn: they do not depend on the
+ * data), Lloyd iterations with sklearn's stopping rule (labels unchanged, or total squared centre shift <=
+ * 1e-4 * var), empty-cluster relocation, every entry replaced by its cluster centre.  Centres agree with sklearn's
+ * to ~1e-12 (sums are reduced in another order); the model selection of RolX then picks the reference's cell.
+ *   d_values      fp64[m] in the order the reference flattens the matrix (row-major n x r for the node-role
+ *                 factor: grx_transpose from the feature-major device layout)
+ *   first_seed    RandomState(1).choice(m, p = uniform)            (sklearn _kmeans_plusplus, first centre)
+ *   h_uniform     (k - 1) x n_trials doubles, n_trials = 2 + int(log(k)): RandomState.uniform(size=n_trials) per seed
+ *   max_iter, rel_tol   sklearn defaults 300, 1e-4
+ *   d_centers     fp64[k] in seed order;  d_info int32[3] = {Lloyd iterations (n_iter_), non-empty clusters,
+ *                 distinct output values}.   k <= 8192 (GRX_ERR_UNSUPPORTED above), k <= m (GRX_ERR_INVALID).
+ * grx_transpose: out[c * ld_out + r] = in[r * ld_in + c].
+ */
+size_t grx_kmeans1d_workspace_bytes(int64_t m, int k);
+int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, const double *h_uniform, int n_trials,
+                 int max_iter, double rel_tol, double *d_quantized, double *d_centers, int32_t *d_info,
+                 void *d_workspace, size_t workspace_bytes, void *stream);
+int grx_transpose(int64_t rows, int64_t cols, const double *d_in, int64_t ld_in, double *d_out, int64_t ld_out,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

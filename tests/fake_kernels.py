@@ -219,6 +219,15 @@ def lloyd_max(values, n_bins, max_iter=300):
                                                                   dtype=torch.int32)
 
 
+def kmeans1d(values, n_bins, max_iter=300, rel_tol=1e-4):
+    """The reference's quantiser: sklearn KMeans(random_state=1) on the flat values."""
+    return lloyd_max(values, n_bins)
+
+
+def transpose(src, rows, cols):
+    return src[:rows, :cols].t().contiguous()
+
+
 class NmfState:
     def __init__(self, X, n, W, H, x_sq_norm=None):
         self.X, self.n, self.W = X, n, W

@@ -1,10 +1,11 @@
 """
--m gpu: RolX `encode` on the GPU (grx_lloyd_max) against the reference's quantiser
-(graphrole/roles/factor.py:29-49 = sklearn KMeans(n_clusters, random_state=1) on the flattened
-entries).  k-means++ seeding is not reproducible on a device, so parity is by property
-(SURVEY.md 8f-1): <= n_bins distinct values; Lloyd-Max fixed-point conditions (every output is the
-mean of its cell; every input sits in the cell of its nearest centre); quantisation error not
-above sklearn's; the exact optimum when there are <= 1024 values.
+-m gpu: RolX `encode` on the GPU against the reference's quantiser (graphrole/roles/factor.py:29-49 = sklearn
+KMeans(n_clusters, random_state=1) on the flattened entries).
+  * quantizer='kmeans' (default, grx_kmeans1d): the same procedure -- seeding draws of RandomState(1), Lloyd
+    iterations, stopping rule, empty-cluster relocation -- compared NUMERICALLY with sklearn run here: equal
+    iteration count, equal number of distinct levels, every quantised value within 1e-9.
+  * quantizer='lloyd_max' (grx_lloyd_max): parity by property: <= n_bins distinct values;
+    Lloyd-Max fixed-point conditions; quantisation error not above sklearn's; the exact optimum on small inputs.
 """
 import warnings
 
@@ -53,7 +54,7 @@ def _datasets():
 def test_lloyd_max_properties_and_error_vs_sklearn(case):
     from graphrole_amd.roles import factor
     name, data, k = case
-    q = factor.encode(data.reshape(-1, 1), k).ravel()
+    q = factor.encode(data.reshape(-1, 1), k, quantizer='lloyd_max').ravel()
     centres = np.unique(q)
     assert len(centres) <= k
     # centroid condition: each output value is the mean of the inputs mapped to it
@@ -85,7 +86,7 @@ def test_lloyd_max_small_input_is_the_exact_optimum():
     rng = np.random.RandomState(3)
     for m, k in [(12, 3), (60, 32), (200, 7), (1000, 16)]:
         data = np.sort(rng.lognormal(0, 1.5, m))
-        q = factor.encode(data.reshape(1, -1), k).ravel()
+        q = factor.encode(data.reshape(1, -1), k, quantizer='lloyd_max').ravel()
         got = float(((data - q) ** 2).sum())
         # brute-force DP over the sorted values
         P = np.concatenate([[0.0], np.cumsum(data)])
@@ -107,17 +108,20 @@ def test_encode_shape_errors_and_determinism():
     from graphrole_amd.roles import factor
     rng = np.random.RandomState(0)
     X = rng.rand(20, 30)
-    for n_bins in range(1, 8):                                   # reference test_factor.py:27-31
-        enc = factor.encode(X, n_bins)
-        assert enc.shape == X.shape
-        assert len(np.unique(enc)) <= n_bins
-    with pytest.raises(ValueError, match='n_clusters'):          # sklearn's error, relied on by _select_model
-        factor.encode(rng.rand(3, 2), 8)
-    a = factor.encode(X, 5)
-    b = factor.encode(X, 5)
-    assert np.array_equal(a, b)
-    # constant input: a single level
-    assert np.unique(factor.encode(np.full((10, 3), 2.5), 4)).tolist() == [2.5]
+    for quantizer in ('kmeans', 'lloyd_max'):
+        for n_bins in range(1, 8):                               # reference test_factor.py:27-31
+            enc = factor.encode(X, n_bins, quantizer=quantizer)
+            assert enc.shape == X.shape
+            assert len(np.unique(enc)) <= n_bins
+        with pytest.raises(ValueError, match='n_clusters'):      # sklearn's error, relied on by _select_model
+            factor.encode(rng.rand(3, 2), 8, quantizer=quantizer)
+        a = factor.encode(X, 5, quantizer=quantizer)
+        b = factor.encode(X, 5, quantizer=quantizer)
+        assert np.array_equal(a, b)
+        # constant input: a single level
+        assert np.unique(factor.encode(np.full((10, 3), 2.5), 4, quantizer=quantizer)).tolist() == [2.5]
+    with pytest.raises(ValueError, match='quantizer'):
+        factor.encode(X, 4, quantizer='median-cut')
 
 
 def test_encode_at_rolx_scale():
@@ -144,3 +148,62 @@ def test_role_extractor_many_levels():
     assert rx.node_role_factor.shape == (4000, 5) and rx.role_feature_factor.shape == (5, 125)
     assert len(np.unique(rx.node_role_factor.values)) <= 512
     assert len(np.unique(rx.role_feature_factor.values)) <= 512
+
+
+# ---------------------------------------------------------------- the reference's quantiser, numerically
+def _kmeans_cases():
+    rng = np.random.RandomState(0)
+    from oracle import rolx
+    X = np.abs(rng.randn(20000, 10)) * np.linspace(1, 30, 10)
+    np.random.seed(0)
+    W, H, _ = rolx.nmf(X, 6)
+    return [
+        ('u600_k8', rng.rand(600), 8),
+        ('u600_k64', rng.rand(600), 64),
+        ('gamma20k_k64', rng.gamma(0.5, 2.0, 20000), 64),
+        ('spike_k32', np.concatenate([rng.exponential(1, 3000), np.full(1000, 1e-3)]), 32),
+        ('ints_k8', rng.randint(0, 20, 5000).astype(float), 8),
+        ('ints_k30_more_levels_than_values', rng.randint(0, 20, 500).astype(float), 30),
+        ('k_eq_m', rng.rand(40), 40),
+        ('k512_of_690', rng.gamma(0.8, 3.0, 690), 512),
+        ('signed_k16', rng.randn(20000) * 3, 16),
+        ('lognormal200k_k128', rng.lognormal(0, 2, 200000), 128),
+        ('nmf_W_k64', W.ravel(), 64),
+        ('nmf_H_k32', H.ravel(), 32),
+        ('k1', rng.rand(50), 1),
+        ('k2_two_values', np.where(rng.rand(1000) < 0.3, 1.0, 4.0), 2),
+        ('k256_1m', rng.gamma(2.0, 1.0, 1000000), 256),
+    ]
+
+
+@pytest.mark.parametrize('case', _kmeans_cases(), ids=lambda c: c[0])
+def test_kmeans_quantizer_equals_sklearn(case):
+    """grx_kmeans1d against sklearn.cluster.KMeans(n_clusters=k, random_state=1) -- the reference's quantiser
+    (graphrole/roles/factor.py:41-48) -- run here on the same values: same n_iter_, same number of distinct
+    levels, every entry's level within 1e-9 (relative to the data's scale)."""
+    from sklearn.cluster import KMeans
+    from graphrole_amd import kernels as K
+    name, data, k = case
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        km = KMeans(n_clusters=k, random_state=1).fit(data.reshape(-1, 1))
+    ref = km.cluster_centers_[km.labels_].ravel()
+    q, centres, info = K.kmeans1d(K.to_device(data), k)
+    q, info = K.to_host(q), K.to_host(info)
+    scale = max(np.abs(data).max(), 1e-300)
+    assert int(info[0]) == km.n_iter_, (name, int(info[0]), km.n_iter_)
+    assert np.abs(q - ref).max() <= 1e-9 * scale, (name, np.abs(q - ref).max())
+    assert int(info[2]) == len(np.unique(ref)) == len(np.unique(q))
+    # centres in seed order, like cluster_centers_
+    np.testing.assert_allclose(K.to_host(centres), km.cluster_centers_[:, 0], rtol=0, atol=1e-9 * scale)
+
+
+def test_kmeans_quantizer_equals_the_oracle_restatement():
+    from graphrole_amd.roles import factor
+    from oracle import kmeans1d
+    rng = np.random.RandomState(9)
+    X = rng.gamma(0.7, 2.0, size=(3000, 5))
+    for n_bins in (4, 16, 100):
+        enc = factor.encode(X, n_bins)                           # default quantizer = 'kmeans'
+        ref, _, _ = kmeans1d.kmeans_quantize(X, n_bins)
+        assert np.abs(enc - ref).max() <= 1e-9 * np.abs(X).max()

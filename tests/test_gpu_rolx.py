@@ -340,7 +340,7 @@ def test_model_selection_on_a_larger_matrix_runs_in_hbm():
 
 
 # ---------------------------------------------------------------- model selection vs the reference (fixtures)
-def _selection_record(name):
+def _selection_record(name, quantizer):
     """(reference grid + selection, ours) for one golden feature table."""
     from graphrole_amd import RoleExtractor
     ref = util.load_roles(name)
@@ -348,48 +348,68 @@ def _selection_record(name):
     X = pd.DataFrame(g['final_values'], index=g.js('labels'), columns=g.js('final_columns'))
     np.random.seed(int(ref['seed']))
     rx = RoleExtractor()
+    rx.quantizer = quantizer
     rx.extract_role_factors(X)
-    return ref, rx
+    return ref, rx, X
 
 
 @pytest.mark.parametrize('name', util.ROLES_CASES)
-def test_model_selection_grid_vs_reference(name):
-    """RoleExtractor(n_roles=None) against the MDL grid the reference computed for the same table
-    (tools/make_golden_roles.py; graphrole/roles/extract.py:98-142).  The NMF of every cell is the reference's
-    (same RNG stream); the quantiser is not (grx_lloyd_max instead of sklearn KMeans(random_state=1)), so:
-      * the same cells are skipped (more levels than factor entries);
-      * the encoding cost never exceeds the reference's (at most 2**bits distinct values per factor);
-      * the KL error cost of a cell differs from the reference's in either direction (the quantisers minimise
-        squared error, the MDL error cost is a KL divergence), typically by a percent, by tens of percent in
-        cells with very few levels;
-      * the selected cell is recorded next to the reference's in gpurun_out/model_selection.json (copied to
-        profiles/): it differs by one role on some tables where neighbouring cells are close in total cost."""
-    import json
-    import os
-    ref, rx = _selection_record(name)
+def test_model_selection_equals_reference(name):
+    """RoleExtractor(n_roles=None) with the reference's quantiser reproduced (quantizer='kmeans', the default)
+    against the MDL grid the reference computed for the same table (tools/make_golden_roles.py;
+    graphrole/roles/extract.py:98-142): the same cells are skipped, every cell's encoding cost is equal, every
+    cell's error cost agrees to 1e-6, the SAME (n_roles, n_bits) cell is selected and the selected factors agree."""
+    ref, rx, X = _selection_record(name, 'kmeans')
     ours = rx.model_selection_
     enc_r, err_r = ref['encoding_costs'], ref['error_costs']
     enc_o, err_o = ours['encoding_costs'], ours['error_costs']
-    assert enc_o.shape == enc_r.shape
+    assert np.array_equal(np.isnan(enc_o), np.isnan(enc_r)) and np.array_equal(np.isnan(err_o), np.isnan(err_r))
+    live = ~np.isnan(enc_r)
+    assert np.array_equal(enc_o[live], enc_r[live])
+    np.testing.assert_allclose(err_o[live], err_r[live], rtol=1e-6)
+    assert list(ours['selected']) == [int(v) for v in ref['selected']]
+    assert rx.node_role_factor.shape == ref['node_role_factor'].shape
+    scale = np.abs(ref['node_role_factor']).max()
+    assert np.abs(rx.node_role_factor.values - ref['node_role_factor']).max() <= 1e-7 * scale
+    assert np.abs(rx.role_feature_factor.values - ref['role_feature_factor']).max() <= 1e-7 * np.abs(ref['role_feature_factor']).max()
+    # fixed rank (roles/extract.py:69-77): n_roles = 3
+    from graphrole_amd import RoleExtractor
+    np.random.seed(int(ref['seed']))
+    rx3 = RoleExtractor(n_roles=3)
+    rx3.extract_role_factors(X)
+    assert np.abs(rx3.node_role_factor.values - ref['fixed3_node_role_factor']).max() <= 1e-7 * np.abs(ref['fixed3_node_role_factor']).max()
+    assert np.abs(rx3.role_feature_factor.values - ref['fixed3_role_feature_factor']).max() <= \
+        1e-7 * np.abs(ref['fixed3_role_feature_factor']).max()
+
+
+@pytest.mark.parametrize('name', util.ROLES_CASES)
+def test_model_selection_with_the_lloyd_max_quantizer(name):
+    """quantizer='lloyd_max' (the deterministic Lloyd-Max solver) is NOT the reference's quantiser: the same
+    cells are skipped and the encoding cost never exceeds the reference's, but the KL error cost of a cell
+    differs in either direction and the selected cell can move by one role.  The table is recorded in
+    gpurun_out/model_selection_lloyd_max.json (copied to profiles/)."""
+    import json
+    import os
+    ref, rx, _ = _selection_record(name, 'lloyd_max')
+    ours = rx.model_selection_
+    enc_r, err_r = ref['encoding_costs'], ref['error_costs']
+    enc_o, err_o = ours['encoding_costs'], ours['error_costs']
     assert np.array_equal(np.isnan(enc_o), np.isnan(enc_r)) and np.array_equal(np.isnan(err_o), np.isnan(err_r))
     live = ~np.isnan(enc_r)
     assert np.all(enc_o[live] <= enc_r[live])
     rel = (err_o[live] - err_r[live]) / np.abs(err_r[live])
     record = {'table': name, 'reference_selected': [int(v) for v in ref['selected']],
-              'ours_selected': list(ours['selected']), 'error_cost_rel_diff_max': float(rel.max()),
+              'lloyd_max_selected': list(ours['selected']), 'error_cost_rel_diff_max': float(rel.max()),
               'error_cost_rel_diff_min': float(rel.min()), 'error_cost_rel_diff_median': float(np.median(rel)),
-              'encoding_cost_cells_lower': int((enc_o[live] < enc_r[live]).sum()), 'cells': int(live.sum())}
+              'cells': int(live.sum())}
     out_dir = os.path.join(os.environ.get('GRAFT_REPO_ROOT', util.ROOT), 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, 'model_selection.json')
+    path = os.path.join(out_dir, 'model_selection_lloyd_max.json')
     table = json.load(open(path)) if os.path.exists(path) else {}
     table[name] = record
     json.dump(table, open(path, 'w'), indent=1, sort_keys=True)
-    print(record)
     assert abs(float(np.median(rel))) < 0.05, record
     assert abs(ours['selected'][0] - int(ref['selected'][0])) <= 1 and abs(ours['selected'][1] - int(ref['selected'][1])) <= 1
-    k = rx.node_role_factor.shape[1]
-    assert k == ours['selected'][0] and rx.role_feature_factor.shape[0] == k
 
 
 # ---------------------------------------------------------------- stopping rule under adversarial margins

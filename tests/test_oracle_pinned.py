@@ -250,3 +250,27 @@ def test_environment_of_the_bit_exact_pin():
         want = float(x.sum())                                        # numpy: pairwise, 8192-element ufunc buffer
         assert float(pd.Series(x).sum()) == want                     # pandas: the same bits (no bottleneck)
         assert float(refex.ndarray_sum(x.reshape(-1, 1))[0]) == want   # the oracle's restatement
+
+
+def test_oracle_kmeans1d_equals_sklearn():
+    """oracle/kmeans1d.py restates sklearn.cluster.KMeans(n_clusters=k, random_state=1) for one feature column (the
+    quantiser of the reference's encode(), graphrole/roles/factor.py:41-48): same n_iter_, same levels."""
+    import warnings
+    from sklearn.cluster import KMeans
+    from oracle import kmeans1d
+    rng = np.random.RandomState(0)
+    cases = [(rng.rand(600), 8), (rng.rand(600), 64), (rng.gamma(0.5, 2, 20000), 64),
+             (np.concatenate([rng.exponential(1, 3000), np.full(1000, 1e-3)]), 32),
+             (rng.randint(0, 20, 5000).astype(float), 8), (rng.randint(0, 20, 500).astype(float), 30),
+             (rng.rand(40), 40), (rng.gamma(0.8, 3, 690), 512), (rng.randn(20000) * 3, 16), (rng.rand(50), 1)]
+    for data, k in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            km = KMeans(n_clusters=k, random_state=1).fit(data.reshape(-1, 1))
+        ref = km.cluster_centers_[km.labels_].ravel()
+        q, centres, n_iter = kmeans1d.kmeans_quantize(data, k)
+        assert n_iter == km.n_iter_
+        assert np.abs(q - ref).max() <= 1e-12 * max(np.abs(data).max(), 1.0)
+        assert len(np.unique(q)) == len(np.unique(ref))
+    with pytest.raises(ValueError, match='n_clusters'):
+        kmeans1d.kmeans_quantize(np.arange(3.0), 8)
