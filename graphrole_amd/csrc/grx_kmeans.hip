@@ -19,7 +19,8 @@
 //     a last E step when the labels had not settled.
 // What cannot be bit-identical: sums are reduced in another order than numpy's cumsum / BLAS / OpenMP partials
 // (relative 1e-13), so a uniform draw that lands within that distance of a boundary of the cumulative sum picks a
-// neighbouring point (probability ~1e-6 per draw at 6 M values).  Centres agree with sklearn to ~1e-12 otherwise.
+// neighbouring point (probability ~1e-6 per draw at 6 M values), and tied candidate potentials are recognised
+// with a 1e-12 tolerance (see km_choose_kernel).  Centres agree with sklearn to ~1e-12 otherwise.
 #include "grx_common.h"
 
 int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
@@ -226,9 +227,14 @@ __global__ __launch_bounds__(64) void km_choose_kernel(const double *__restrict_
     }
     __syncthreads();
     if (j == 0) {
+        // np.argmin: first minimum.  Exact ties are COMMON on small inputs -- two isolated candidates that each
+        // capture only themselves and each other give the same potential, the same numbers summed in swapped
+        // positions -- and BLAS returns bit-equal sums for them where another summation order may not: potentials
+        // within 1e-12 of the minimum count as tied, the first of them wins
+        double lowest = pots[0];
+        for (int q = 1; q < n_trials; ++q) lowest = pots[q] < lowest ? pots[q] : lowest;
         int best = 0;
-        for (int q = 1; q < n_trials; ++q)
-            if (pots[q] < pots[best]) best = q;                 // np.argmin: first minimum
+        while (best < n_trials - 1 && pots[best] > lowest + 1e-12 * lowest) ++best;
         st->pot = pots[best];
         st->best_x = st->cand_x[best];
         st->best_id = st->cand_id[best];
@@ -583,7 +589,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                  int max_iter, double rel_tol, double *d_quantized, double *d_centers, int32_t *d_info,
                  void *d_workspace, size_t workspace_bytes, void *stream)
 {
-    GRX_REQUIRE(m >= 1 && k >= 1 && max_iter >= 1, "grx_kmeans1d: bad m / k / max_iter");
+    GRX_REQUIRE(m >= 1 && k >= 1 && max_iter >= 0, "grx_kmeans1d: bad m / k / max_iter");   // max_iter = 0: seeding only
     GRX_REQUIRE(k <= m, "n_samples=%lld should be >= n_clusters=%d.", (long long)m, k);
     GRX_REQUIRE(m < ((int64_t)1 << 31), "grx_kmeans1d: m must be < 2^31");
     if (k > KM_MAX_K) {

