@@ -322,19 +322,24 @@ def main():
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
 
-    # RolX encode (1-D Lloyd-Max quantiser of the node-role factor), outside the timed steps
+    # RolX encode of the node-role factor, outside the timed steps: the reference's quantiser reproduced
+    # (grx_kmeans1d, the default of RoleExtractor) and the Lloyd-Max solver (quantizer='lloyd_max')
     encode_info = None
     if rank == 0 and world == 1:
         Wd = state['W']
-        n_bins = min(256, 2 ** int(np.log2(N_ROLES * min(G.n, state['F']))))   # roles/extract.py:72; 8 bits = default range
-        flat = Wd[:, :G.n].contiguous().reshape(-1)
-        K.lloyd_max(flat, n_bins)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        _, _, info = K.lloyd_max(flat, n_bins)
-        torch.cuda.synchronize()
-        encode_info = {'ms': (time.perf_counter() - t0) * 1e3, 'values': int(flat.numel()), 'n_bins': n_bins,
-                       'lloyd_iterations': int(info[0]), 'what': 'grx_lloyd_max on the N x r node-role factor'}
+        n_bins = 2 ** int(np.log2(N_ROLES * min(G.n, state['F'])))          # roles/extract.py:72
+        flat = K.transpose(Wd, N_ROLES, G.n).reshape(-1)                      # the reference's flatten order (n x r)
+        encode_info = {'values': int(flat.numel()), 'n_bins': n_bins}
+        for label, fn in (('kmeans', K.kmeans1d), ('lloyd_max', K.lloyd_max)):
+            fn(flat, n_bins)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, info = fn(flat, n_bins)
+            torch.cuda.synchronize()
+            encode_info[label] = {'ms': (time.perf_counter() - t0) * 1e3, 'iterations': int(info[0]),
+                                  'distinct_levels': int(info[2])}
+        encode_info['what'] = ('encode() of the N x r node-role factor: kmeans = sklearn KMeans(random_state=1) reproduced '
+                               '(grx_kmeans1d), lloyd_max = grx_lloyd_max')
 
     # per-rank figures (N > 1): every rank's aggregation launch time and exchange time, gathered on rank 0
     per_rank = None

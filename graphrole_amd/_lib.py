@@ -128,6 +128,13 @@ _SIGNATURES = {
     'grx_kmeans1d': (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_transpose': (c_int, [c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    'grx_ingest_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
+    'grx_ingest': (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_orient_workspace_bytes': (c_size_t, [c_int64]),
+    'grx_orient_count': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_orient_fill': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_void_p]),
     'grx_host_eigh': (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_fit_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'grx_nmf_init': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p,

@@ -1042,7 +1042,7 @@ SortPlan make_plan(int64_t n, int ncols)
 
 // sort ncols columns; keysA/hist are scratch; result (fp64 ascending) in out (column stride out_ld)
 int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
-                 uint64_t *keysA, uint32_t *hist, hipStream_t st, SkipCtl ctl = SkipCtl{})
+                 uint64_t *keysA, uint32_t *hist, hipStream_t st, SkipCtl ctl = SkipCtl{}, bool raw_u64 = false)
 {
     const SortPlan p = make_plan(n, ncols);
     const bool skipping = ctl.flags != nullptr;             // then out is a key buffer with stride n
@@ -1062,7 +1062,7 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         else { dst = keysA; dld = n; }
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist, ctl);
+            if (pass == 0 && !raw_u64) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist, ctl);
             else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, sld, n, shift, p.ntiles, hist, ctl);
         }
         GRX_LAUNCH_CHECK();
@@ -1073,8 +1073,8 @@ int sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *o
         GRX_LAUNCH_CHECK();
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            if (pass == 0) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
-            else if (pass == 7 && !skipping) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
+            if (pass == 0 && !raw_u64) scatter_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
+            else if (pass == 7 && !skipping && !raw_u64) scatter_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
             else scatter_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, sld, dst, dld, n, shift, p.ntiles, hist, tot, ctl);
         }
         GRX_LAUNCH_CHECK();
@@ -1093,6 +1093,16 @@ int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t 
     char *ws = reinterpret_cast<char *>(workspace);
     return sort_columns(n, ncols, cols, ld, out, out_ld, reinterpret_cast<uint64_t *>(ws),
                         reinterpret_cast<uint32_t *>(ws + p.keys_bytes), st);
+}
+
+// raw 64-bit keys (graph ingest: (row, column) / (row, edge sequence) pairs), ascending; same workspace
+int grx_internal_sort_u64(int64_t n, const uint64_t *keys, uint64_t *out, void *workspace, hipStream_t st)
+{
+    if (n <= 0) return GRX_OK;
+    const SortPlan p = make_plan(n, 1);
+    char *ws = reinterpret_cast<char *>(workspace);
+    return sort_columns(n, 1, reinterpret_cast<const double *>(keys), n, reinterpret_cast<double *>(out), n,
+                        reinterpret_cast<uint64_t *>(ws), reinterpret_cast<uint32_t *>(ws + p.keys_bytes), st, SkipCtl{}, true);
 }
 
 extern "C" {

@@ -93,23 +93,16 @@ class CSRGraph:
         self.labels = list(range(n)) if labels is None else list(labels)
         if len(self.labels) != n:
             raise ValueError('labels must have n entries')
-        if directed:
-            self.row_ptr, self.col, self.w = _csr_from_coo(n, src, dst, w)
-            self.t_row_ptr, self.t_col, self.t_w = _csr_from_coo(n, dst, src, w)
-        else:
-            off = src != dst
-            s2 = np.concatenate([src, dst[off]])
-            d2 = np.concatenate([dst, src[off]])
-            w2 = None if w is None else np.concatenate([w, w[off]])
-            self.row_ptr, self.col, self.w = _csr_from_coo(n, s2, d2, w2)
-            self.t_row_ptr = self.t_col = self.t_w = None
-        if adjacency is None:
-            self.adj_col = adjacency_order(n, src, dst, directed)
-        else:
-            self.adj_col = np.ascontiguousarray(adjacency, dtype=np.int32)
-        if self.adj_col.shape != self.col.shape:
+        # The host CSR is built on first use: the device path ingests the edge arrays directly
+        # (grx_ingest, graphrole_amd/kernels.py::device_ingest) and never needs it.
+        self._edges = (src, dst, w)
+        self._adjacency = None if adjacency is None else np.ascontiguousarray(adjacency, dtype=np.int32)
+        self._host = None
+        n_loops = int(np.count_nonzero(src == dst))
+        self._nnz = int(len(src)) if directed else 2 * int(len(src)) - n_loops
+        if self._adjacency is not None and self._adjacency.shape != (self._nnz,):
             raise ValueError('adjacency must list every neighbour of every row exactly once')
-        if validate and len(self.col):
+        if validate and self._adjacency is not None and self._nnz:
             rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(self.row_ptr))
             if not np.array_equal(np.sort(rows * n + self.adj_col), rows * n + self.col):
                 raise ValueError('adjacency rows must be permutations of the neighbour sets')
@@ -120,9 +113,50 @@ class CSRGraph:
                 raise ValueError(f'attribute {name!r} must have shape ({n},)')
             self.attributes[name] = values
 
+    # ------------------------------------------------------------------ host CSR (lazy)
+    def _build_host(self) -> dict:
+        if self._host is None:
+            n, (src, dst, w) = self.n, self._edges
+            h = {}
+            if self.directed:
+                h['row_ptr'], h['col'], h['w'] = _csr_from_coo(n, src, dst, w)
+                h['t_row_ptr'], h['t_col'], h['t_w'] = _csr_from_coo(n, dst, src, w)
+            else:
+                off = src != dst
+                s2 = np.concatenate([src, dst[off]])
+                d2 = np.concatenate([dst, src[off]])
+                w2 = None if w is None else np.concatenate([w, w[off]])
+                h['row_ptr'], h['col'], h['w'] = _csr_from_coo(n, s2, d2, w2)
+                h['t_row_ptr'] = h['t_col'] = h['t_w'] = None
+            h['adj_col'] = self._adjacency if self._adjacency is not None else adjacency_order(n, src, dst, self.directed)
+            self._host = h
+        return self._host
+
+    row_ptr = property(lambda self: self._build_host()['row_ptr'])
+    col = property(lambda self: self._build_host()['col'])
+    w = property(lambda self: self._build_host()['w'])
+    t_row_ptr = property(lambda self: self._build_host()['t_row_ptr'])
+    t_col = property(lambda self: self._build_host()['t_col'])
+    t_w = property(lambda self: self._build_host()['t_w'])
+
+    @property
+    def adj_col(self) -> np.ndarray:
+        return self._build_host()['adj_col']
+
+    @adj_col.setter
+    def adj_col(self, value) -> None:
+        value = np.ascontiguousarray(value, dtype=np.int32)
+        self._build_host()['adj_col'] = value
+        self._adjacency = value                       # an explicit order: the device ingest must not assume appearance order
+
+    def edge_arrays(self):
+        """(src, dst, weights or None) as given -- what the device ingest consumes -- or None when an explicit
+        neighbour order was supplied (then the host CSR is the source of truth)."""
+        return None if self._adjacency is not None else self._edges
+
     @property
     def nnz(self) -> int:
-        return int(self.row_ptr[-1])
+        return self._nnz
 
     def neighbors(self, row: int) -> np.ndarray:
         return self.col[self.row_ptr[row]:self.row_ptr[row + 1]]
@@ -222,7 +256,7 @@ class InternalGraph:
 
     @property
     def nnz(self) -> int:
-        return int(self.row_ptr[-1])
+        return self._nnz
 
     def to_internal(self, values: np.ndarray) -> np.ndarray:
         """label-order per-node array -> internal order"""
@@ -230,4 +264,27 @@ class InternalGraph:
 
     def to_label_order(self, values: np.ndarray) -> np.ndarray:
         """internal-order per-node array -> label order"""
+        return np.ascontiguousarray(np.asarray(values)[..., self.inv])
+
+
+class DeviceBuiltGraph:
+    """
+    Host view of a graph whose CSR was built in HBM (kernels.device_ingest): the same attributes the engine
+    reads from an InternalGraph -- shape, flags, labels, the internal order and the row pointers -- without the
+    column arrays, which exist on the device only.
+    """
+
+    def __init__(self, g: CSRGraph, perm: np.ndarray, inv: np.ndarray, row_ptr: np.ndarray) -> None:
+        self.perm, self.inv, self.row_ptr = perm, inv, row_ptr
+        self.n, self.directed, self.weighted, self.integral = g.n, g.directed, g.weighted, g.integral
+        self.labels, self.num_edges = g.labels, g.num_edges
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def to_internal(self, values: np.ndarray) -> np.ndarray:
+        return np.ascontiguousarray(np.asarray(values)[self.perm])
+
+    def to_label_order(self, values: np.ndarray) -> np.ndarray:
         return np.ascontiguousarray(np.asarray(values)[..., self.inv])

@@ -14,7 +14,7 @@ from typing import Iterable, List, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from graphrole_amd.graph.csr import CSRGraph, InternalGraph
+from graphrole_amd.graph.csr import CSRGraph, DeviceBuiltGraph, InternalGraph
 from graphrole_amd.types import Node
 
 
@@ -83,11 +83,23 @@ class DeviceGraphInterface(BaseGraphInterface):
         (degree-descending) order -- see graphrole_amd.graph.csr.InternalGraph."""
         if getattr(self, '_dev', None) is None:
             K = self._K()
-            host = InternalGraph(self.to_csr())
-            out = K.DeviceCSR(host.row_ptr, host.col, host.w, agg_col=host.agg_col)
-            tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
+            g = self.to_csr()
+            edges = g.edge_arrays() if hasattr(K, 'device_ingest') else None
+            if edges is not None and g.num_edges > 0 and self._device_ingest:
+                # the whole construction -- degree-descending relabelling, CSR in adjacency and in ascending
+                # column order, weights, transposed CSR -- in HBM (grx_ingest); no host CSR is ever built
+                src, dst, w = edges
+                perm, inv, row_ptr, out, tr = K.device_ingest(g.n, src, dst, w, g.directed, g.nnz)
+                host = DeviceBuiltGraph(g, perm, inv, row_ptr)
+            else:
+                host = InternalGraph(g)
+                out = K.DeviceCSR(host.row_ptr, host.col, host.w, agg_col=host.agg_col)
+                tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
             self._dev = (host, out, tr)
         return self._dev
+
+    #: False forces the host-side construction (InternalGraph + upload); tests compare the two
+    _device_ingest = True
 
     def _row_range(self) -> Tuple[int, int]:
         """Rows this rank computes (whole graph unless a ShardPlan was attached)."""

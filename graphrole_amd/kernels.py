@@ -156,13 +156,55 @@ class DeviceCSR:
         self._plan = None
         self.degree_sorted = bool(self.n < 2 or np.all(deg[1:] <= deg[:-1]))
 
+    @classmethod
+    def from_device(cls, row_ptr: torch.Tensor, col: torch.Tensor, w: Optional[torch.Tensor],
+                    agg_col: Optional[torch.Tensor], host_row_ptr: np.ndarray) -> 'DeviceCSR':
+        """A CSR that is already in HBM (device_ingest); only the row pointers exist on the host."""
+        self = cls.__new__(cls)
+        host_row_ptr = np.ascontiguousarray(host_row_ptr, dtype=np.int64)
+        self.n = int(len(host_row_ptr) - 1)
+        self.nnz = int(host_row_ptr[-1])
+        self.row_ptr, self.col, self.w = row_ptr, col, w
+        avg = self.nnz / max(self.n, 1)
+        self.lanes_per_row = 4 if avg < 12 else 8 if avg < 24 else 16 if avg < 48 else 32
+        deg = np.diff(host_row_ptr)
+        hubs = np.nonzero(deg > HUB_FACTOR * self.lanes_per_row)[0].astype(np.int32)
+        self.n_hubs = int(len(hubs))
+        self.hub_rows = torch.from_numpy(hubs).to(device()) if self.n_hubs else None
+        self._host = (host_row_ptr, None)
+        self._oriented = None
+        self.agg_col = col if agg_col is None else agg_col
+        self._plan = None
+        self.degree_sorted = bool(self.n < 2 or np.all(deg[1:] <= deg[:-1]))
+        return self
+
     def plan(self) -> AggregatePlan:
         if self._plan is None:
             self._plan = AggregatePlan(self._host[0])
         return self._plan
 
+    def _oriented_on_device(self) -> 'DeviceCSR':
+        """grx_orient_count / grx_orient_fill: the orientation without a host copy of the columns."""
+        n = self.n
+        lib = _lib.load()
+        ws_bytes = lib.grx_orient_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+        o_ptr = torch.empty(n + 1, dtype=torch.int64, device=device())
+        _lib.call('grx_orient_count', n, _ptr(self.row_ptr), _ptr(self.col), _ptr(o_ptr), _ptr(ws), ws_bytes, _stream())
+        h_ptr = o_ptr.cpu().numpy()
+        o_nnz = int(h_ptr[-1])
+        o_col = torch.empty(max(o_nnz, 1), dtype=torch.int32, device=device())
+        arc = torch.empty(max(o_nnz, 1), dtype=torch.int64, device=device())
+        _lib.call('grx_orient_fill', n, _ptr(self.row_ptr), _ptr(self.col), _ptr(o_ptr), o_nnz, _ptr(o_col), _ptr(arc),
+                  _ptr(ws), ws_bytes, _stream())
+        o = DeviceCSR.from_device(o_ptr, o_col, None, None, h_ptr)
+        o.arc = arc
+        return o
+
     def oriented(self) -> 'DeviceCSR':
         """Degree-oriented copy (arc u->v iff (d'(u),u) < (d'(v),v)) for grx_triangle_counts."""
+        if self._oriented is None and self._host[1] is None:
+            self._oriented = self._oriented_on_device()
         if self._oriented is None:
             row_ptr, col = self._host
             n = self.n
@@ -190,6 +232,44 @@ class DeviceCSR:
         cuts = [0] + [int(np.searchsorted(work, total * p / world, side='left')) for p in range(1, world)] + [self.n]
         cuts = np.maximum.accumulate(np.array(cuts, dtype=np.int64))
         return int(cuts[rank]), int(cuts[rank + 1])
+
+
+def device_ingest(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarray], directed: bool, nnz: int):
+    """
+    grx_ingest: edge arrays -> (perm, inv, host row pointers [, host transposed row pointers], DeviceCSR of the
+    out-adjacency, DeviceCSR of the in-adjacency or None) with rows in the internal (degree-descending) order --
+    what InternalGraph + DeviceCSR build on the host, without the host.
+    """
+    dev = device()
+    m = int(len(src))
+    d_src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)).to(dev)
+    d_dst = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int32)).to(dev)
+    d_w = None if w is None else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64)).to(dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, dtype=torch.int32, device=dev)
+    row_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    wcol = None if w is None else torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    agg_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    t_row_ptr = t_col = t_w = None
+    if directed:
+        t_row_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        t_col = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        t_w = None if w is None else torch.empty(max(m, 1), dtype=torch.float64, device=dev)
+    ws_bytes = _lib.load().grx_ingest_workspace_bytes(n, m, int(directed))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call('grx_ingest', n, m, _ptr(d_src), _ptr(d_dst), _ptr(d_w), int(directed), int(nnz), _ptr(perm), _ptr(inv),
+              _ptr(row_ptr), _ptr(col), _ptr(wcol), _ptr(agg_col), _ptr(t_row_ptr), _ptr(t_col), _ptr(t_w), _ptr(ws),
+              ws_bytes, _stream())
+    del ws
+    h_perm = perm.cpu().numpy().astype(np.int64)
+    h_inv = inv.cpu().numpy().astype(np.int64)
+    h_row_ptr = row_ptr.cpu().numpy()
+    out = DeviceCSR.from_device(row_ptr, col, wcol, agg_col, h_row_ptr)
+    tr = None
+    if directed:
+        tr = DeviceCSR.from_device(t_row_ptr, t_col, t_w, None, t_row_ptr.cpu().numpy())
+    return h_perm, h_inv, h_row_ptr, out, tr
 
 
 def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: Optional[int] = None,

@@ -78,6 +78,36 @@ int grx_profile_kernel_count(void);
 const char *grx_profile_kernel_name(int id);
 int grx_profile_read(int id, double *total_ms, long long *launches);
 
+/* ------------------------------------------------------------------ graph ingest -------- */
+/*
+ * Edge list -> the CSR structures of this library, on the device.  Replaces the host-side construction the
+ * adapters need before anything can run (graphrole/graph/interface/networkx.py:36-46 get_nodes / get_neighbors,
+ * base.py:18-26 row order): ~1 s of numpy per 10 M edges against milliseconds here.
+ *   d_src / d_dst  int32[m] row indices (0..n-1 = sorted node labels); every edge once (undirected: either
+ *                  orientation; a self-loop once); d_w fp64[m] or NULL.
+ *   internal order: rows sorted by out-degree descending, ties by label (hub rows become a prefix):
+ *                  d_perm[i] = label row of internal row i, d_inv its inverse.
+ *   d_row_ptr int64[n+1], d_col int32[nnz] ascending per row, d_wcol fp64[nnz] (aligned with d_col, NULL if
+ *                  unweighted), d_agg_col int32[nnz] = the same rows with the neighbours in ADJACENCY order (the
+ *                  order the incident edges appear in the edge list = G[node] order of a graph built by
+ *                  add_edge in that order): the summation order of grx_aggregate.
+ *   nnz            2m - #self-loops (undirected) or m (directed): the caller counts the loops.
+ *   directed:      d_t_row_ptr / d_t_col / d_t_w = the transposed (in-) adjacency, ascending (weighted in-degree).
+ * grx_orient_count / grx_orient_fill: the degree-oriented copy for grx_triangle_counts (arc u -> v kept iff
+ * (d'(u), u) < (d'(v), v), d' = degree without the self-loop) and its per-arc table; count first (o_row_ptr,
+ * o_nnz = o_row_ptr[n] read back by the caller), then fill with the same workspace.
+ */
+size_t grx_ingest_workspace_bytes(int64_t n, int64_t m, int directed);
+int grx_ingest(int64_t n, int64_t m, const int32_t *d_src, const int32_t *d_dst, const double *d_w, int directed,
+               int64_t nnz, int32_t *d_perm, int32_t *d_inv, int64_t *d_row_ptr, int32_t *d_col, double *d_wcol,
+               int32_t *d_agg_col, int64_t *d_t_row_ptr, int32_t *d_t_col, double *d_t_w, void *d_workspace,
+               size_t workspace_bytes, void *stream);
+size_t grx_orient_workspace_bytes(int64_t n);
+int grx_orient_count(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int64_t *d_o_row_ptr, void *d_workspace,
+                     size_t workspace_bytes, void *stream);
+int grx_orient_fill(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, const int64_t *d_o_row_ptr, int64_t o_nnz,
+                    int32_t *d_o_col, uint64_t *d_o_arc, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ generation 0 -------- */
 /*
  * Weighted row sums of a CSR.  Replaces NetworkxInterface._get_local_features
