@@ -256,7 +256,7 @@ class InternalGraph:
 
     @property
     def nnz(self) -> int:
-        return self._nnz
+        return int(self.row_ptr[-1])
 
     def to_internal(self, values: np.ndarray) -> np.ndarray:
         """label-order per-node array -> internal order"""
