@@ -131,6 +131,7 @@ _SIGNATURES = {
     'grx_ingest_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'grx_ingest': (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_permute_columns': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_orient_workspace_bytes': (c_size_t, [c_int64]),
     'grx_orient_count': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_orient_fill': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,

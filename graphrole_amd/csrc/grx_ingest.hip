@@ -260,6 +260,17 @@ __global__ __launch_bounds__(256) void orient_arc_kernel(int64_t o_nnz, const in
     arc[k] = b | (len << 40);
 }
 
+// out[c][i] = col_c[idx[i]]: feature columns from the internal row order back to label order, all columns of the
+// result table in one launch (the host then needs a single copy instead of a fancy-index gather per column)
+__global__ __launch_bounds__(256) void permute_columns_kernel(int64_t n, GrxPtrTable ptr_tab, const int32_t *__restrict__ idx,
+                                                              double *__restrict__ out, int64_t ld)
+{
+    const double *src = reinterpret_cast<const double *>(ptr_tab.p[blockIdx.y]);
+    double *dst = out + (size_t)blockIdx.y * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
 struct IngestPlan {
     size_t off_deg, off_deg_in, off_keys_n, off_sorted_n, off_cnt, off_cnt_in, off_tsum, off_key_a, off_key_b, off_out, off_sort,
         total;
@@ -363,6 +374,24 @@ int grx_ingest(int64_t n, int64_t m, const int32_t *d_src, const int32_t *d_dst,
         if (rc != GRX_OK) return rc;
         ing_low32_kernel<<<(int)grx_ceil_div(m, 256), 256, 0, st>>>(m, out, d_t_col);
         if (d_w) ing_weights_kernel<<<egrid, 256, 0, st>>>(m, d_src, d_dst, d_w, d_inv, 2, d_t_row_ptr, d_t_col, d_t_w);
+        GRX_LAUNCH_CHECK();
+    }
+    return GRX_OK;
+}
+
+int grx_permute_columns(int64_t n, int F, const double *const *h_col_ptrs, const int32_t *d_index, double *d_out,
+                        int64_t ld, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && F >= 0 && ld >= n, "grx_permute_columns: bad shape");
+    if (n == 0 || F == 0) return GRX_OK;
+    GRX_REQUIRE(h_col_ptrs && d_index && d_out, "grx_permute_columns: NULL pointer");
+    const int64_t want = grx_ceil_div(n, 256 * 4);
+    for (int c0 = 0; c0 < F; c0 += GRX_MAX_PTRS) {
+        const int fc = (F - c0 < GRX_MAX_PTRS) ? F - c0 : GRX_MAX_PTRS;
+        GrxPtrTable tab;
+        for (int c = 0; c < fc; ++c) tab.p[c] = h_col_ptrs[c0 + c];
+        const dim3 grid((unsigned)(want > 1024 ? 1024 : want), fc);
+        permute_columns_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, tab, d_index, d_out + (size_t)c0 * ld, ld);
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;

@@ -379,26 +379,41 @@ class RecursiveFeatureExtractor:
         return K.gather_columns(list(cols), n)[:, :n] if n else K.zeros((len(cols), 0))
 
     def _finalize_features(self) -> DataFrameLike:
-        """DataFrame of every recorded feature, latest generation first (extract.py:91-96)."""
-        K = self._K()
-        order = self._order()
+        """DataFrame of every recorded feature, latest generation first (extract.py:91-96): the columns are put
+        back into label order on the device (one permutation kernel for the whole table), copied out as one
+        block, and wrapped without another copy."""
         columns = self.final_columns()
-        data = {nm: order.to_label_order(K.to_host(self._final_cols[nm])).astype(self._dtypes.get(nm, np.dtype('float64')))
-                for nm in columns}
-        return pd.DataFrame(data, index=pd.Index(self._labels()), columns=columns)
+        frame = self._frame_of(columns, [self._final_cols[nm] for nm in columns])
+        return frame
+
+    def _frame_of(self, names: Sequence[str], cols: Sequence) -> pd.DataFrame:
+        K = self._K()
+        n = self._n()
+        labels = pd.Index(self._labels())
+        if not names:
+            return pd.DataFrame(index=labels)
+        block = K.to_host(K.permute_columns(list(cols), self._inv_device(), n))           # [F, n], label order
+        frame = pd.DataFrame(block.T, index=labels, columns=list(names), copy=False)
+        for nm in names:                                   # the few integer columns (generation 0 of unweighted graphs)
+            dt = np.dtype(self._dtypes.get(nm, 'float64'))
+            if dt.kind in 'iu':
+                frame[nm] = frame[nm].to_numpy().astype(dt)
+        return frame
+
+    def _inv_device(self):
+        """inv (label row -> internal row) as an int32 device tensor, uploaded once."""
+        if getattr(self, '_inv_dev', None) is None:
+            self._inv_dev = self._K().to_device(self._order().inv.astype(np.int32))
+        return self._inv_dev
 
     # ------------------------------------------------------------------ reference-compatible internals
     # The reference's tests drive these private members with DataFrames / dicts of dicts
     # (tests/test_features/test_extract.py:87-214).  They are thin views over the device store.
     @property
     def _features(self) -> pd.DataFrame:
-        K = self._K()
-        order = self._order()
-        data = {nm: order.to_label_order(K.to_host(col)).astype(self._dtypes.get(nm, np.dtype('float64')))
-                for nm, col in self._work.items()}
-        if not data:
+        if not self._work:
             return pd.DataFrame()
-        return pd.DataFrame(data, index=pd.Index(self._labels()), columns=list(data))
+        return self._frame_of(list(self._work), list(self._work.values()))
 
     @_features.setter
     def _features(self, frame: pd.DataFrame) -> None:
@@ -410,15 +425,9 @@ class RecursiveFeatureExtractor:
 
     @property
     def _final_features(self) -> Dict[int, DataFrameDict]:
-        K = self._K()
-        order = self._order()
-        labels = self._labels()
         out: Dict[int, DataFrameDict] = {}
         for gen, names in self._final_names.items():
-            frame = pd.DataFrame(
-                {nm: order.to_label_order(K.to_host(self._final_cols[nm])).astype(self._dtypes.get(nm, np.dtype('float64')))
-                 for nm in names}, index=pd.Index(labels), columns=list(names))
-            out[gen] = frame.to_dict()
+            out[gen] = self._frame_of(list(names), [self._final_cols[nm] for nm in names]).to_dict()
         return out
 
     @_final_features.setter

@@ -676,6 +676,15 @@ def kmeans1d(values: torch.Tensor, n_bins: int, max_iter: int = 300, rel_tol: fl
     return out, centers, info
 
 
+def permute_columns(cols: Sequence[torch.Tensor], index: torch.Tensor, n: int) -> torch.Tensor:
+    """[F, n] block with out[c][i] = cols[c][index[i]] (index int32 on the device)."""
+    F = len(cols)
+    out = torch.empty((F, max(n, 1)), dtype=torch.float64, device=device())
+    if F and n:
+        _lib.call('grx_permute_columns', n, F, ptr_array(cols), _ptr(index), _ptr(out), _ld(out), _stream())
+    return out[:, :n]
+
+
 def transpose(src: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     """[rows, >= cols] row-major (leading dimension src.stride(0)) -> contiguous [cols, rows]."""
     out = torch.empty((cols, rows), dtype=torch.float64, device=device())

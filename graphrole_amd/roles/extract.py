@@ -93,7 +93,7 @@ class RoleExtractor:
         from graphrole_amd import backend
         K = backend.get()
         V = factor._checked_matrix(features.values)
-        Vd = K.to_device(np.ascontiguousarray(V.T))
+        Vd = factor.feature_major(V)
         bit_stop = self.max_bits + 1
         role_stop = min(min(features.shape), self.max_roles) + 1
         encoding_costs = np.full((role_stop, bit_stop), np.nan)
@@ -128,7 +128,7 @@ class RoleExtractor:
         from graphrole_amd import backend
         K = backend.get()
         V = factor._checked_matrix(features.values)
-        Vd = K.to_device(np.ascontiguousarray(V.T))
+        Vd = factor.feature_major(V)
         _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer)
         return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 

@@ -247,7 +247,7 @@ def _checked_matrix(X) -> np.ndarray:
     X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
     if X.ndim != 2:
         raise ValueError('X must be 2-dimensional')
-    if (X < 0).any():
+    if X.size and X.min() < 0:
         raise ValueError('Negative values in data passed to NMF (input X)')        # _nmf.py:283
     return X
 
@@ -275,12 +275,20 @@ def nmf_state(Xd, X: np.ndarray, n_roles: int):
     return nmf_device(Xd, n, n_roles, omega)
 
 
+def feature_major(X: np.ndarray):
+    """The n x F host table as the feature-major device matrix [F, n] the NMF kernels read: uploaded as it is
+    (row-major) and transposed in HBM -- a strided host transpose of a multi-GB table costs seconds."""
+    K = _kernels()
+    n, F = X.shape
+    return K.transpose(K.to_device(X), n, F)
+
+
 def nmf_with_info(X: np.ndarray, n_roles: int):
     """(G, F, n_iter); G = W (n x r), F = H (r x n_features)."""
     K = _kernels()
     X = _checked_matrix(X)
     n = X.shape[0]
-    Xd = K.to_device(np.ascontiguousarray(X.T))
+    Xd = feature_major(X)
     state, n_iter = nmf_state(Xd, X, n_roles)
     return K.to_host(state.W)[:, :n].T.copy(), K.to_host(state.H).copy(), n_iter
 

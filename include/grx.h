@@ -102,6 +102,10 @@ int grx_ingest(int64_t n, int64_t m, const int32_t *d_src, const int32_t *d_dst,
                int64_t nnz, int32_t *d_perm, int32_t *d_inv, int64_t *d_row_ptr, int32_t *d_col, double *d_wcol,
                int32_t *d_agg_col, int64_t *d_t_row_ptr, int32_t *d_t_col, double *d_t_w, void *d_workspace,
                size_t workspace_bytes, void *stream);
+/* out[c * ld + i] = col_c[d_index[i]] for F columns (host table of device pointers): the result table from the
+ * internal row order back to label order (d_index = inv), one contiguous F x ld block for a single copy out. */
+int grx_permute_columns(int64_t n, int F, const double *const *h_col_ptrs, const int32_t *d_index, double *d_out,
+                        int64_t ld, void *stream);
 size_t grx_orient_workspace_bytes(int64_t n);
 int grx_orient_count(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, int64_t *d_o_row_ptr, void *d_workspace,
                      size_t workspace_bytes, void *stream);

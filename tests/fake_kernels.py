@@ -224,6 +224,11 @@ def kmeans1d(values, n_bins, max_iter=300, rel_tol=1e-4):
     return lloyd_max(values, n_bins)
 
 
+def permute_columns(cols, index, n):
+    idx = index.long()
+    return torch.stack([c[idx] for c in cols]) if len(cols) else torch.zeros((0, n), dtype=torch.float64)
+
+
 def transpose(src, rows, cols):
     return src[:rows, :cols].t().contiguous()
 
