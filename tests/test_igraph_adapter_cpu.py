@@ -150,3 +150,60 @@ def test_empty_graph_raises_like_the_reference(fake_backend):
     Graph = _stand_in_graph_class()
     with pytest.raises(ValueError, match='at least one edge'):    # features/extract.py:42-43
         RecursiveFeatureExtractor(Graph(3, []))
+
+
+def test_reference_expected_tables_through_the_igraph_adapter(fake_backend):
+    """The reference runs ONE set of expected tables against both of its adapters
+    (tests/test_graph/test_interface.py:124-221: the 7-node graph, its directed weighted variant, its node
+    attributes).  They are library-independent data, so they pin this adapter without igraph: edges, neighbours,
+    generation-0 features, dtypes."""
+    import pandas as pd
+    from graphrole_amd.graph.interface import IgraphInterface
+    from tests.graphs import IFACE7_ATTRS, IFACE7_EDGES, IFACE7_WEIGHTS
+    Graph = _stand_in_graph_class()
+    # (:85-123) edges, nodes, neighbours
+    ig = Graph(7, IFACE7_EDGES)
+    a = IgraphInterface(ig)
+    assert a.get_num_edges() == 7 and set(a.get_nodes()) == set(range(7))
+    expect_nbrs = {0: {1, 2, 3}, 1: {0}, 2: {0}, 3: {0, 6}, 4: {5, 6}, 5: {4, 6}, 6: {3, 4, 5}}
+    for node, nbrs in expect_nbrs.items():
+        assert set(a.get_neighbors(node)) == nbrs
+    # (:124-148) undirected, unweighted
+    got = a.get_neighborhood_features()
+    exp = pd.DataFrame({'degree': [3, 1, 1, 2, 2, 2, 3], 'internal_edges': [3, 1, 1, 2, 3, 3, 4],
+                        'external_edges': [1, 2, 2, 4, 1, 1, 1]})
+    pd.testing.assert_frame_equal(got, exp)
+    # (:150-186) directed, weighted
+    igd = Graph(7, IFACE7_EDGES, directed=True, weights=IFACE7_WEIGHTS)
+    got = IgraphInterface(igd).get_neighborhood_features()
+    exp = pd.DataFrame({'in_degree': [0.00, 2.00, 1.50, 3.00, 0.00, 0.75, 3.75],
+                        'out_degree': [6.50, 0.00, 0.00, 0.25, 3.25, 1.00, 0.00],
+                        'total_degree': [6.50, 2.00, 1.50, 3.25, 3.25, 1.75, 3.75],
+                        'internal_edges': [6.50, 0.00, 0.00, 0.25, 4.25, 1.00, 0.00],
+                        'external_edges': [0.25, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00]})
+    pd.testing.assert_frame_equal(got, exp)
+    # (:188-221) node attributes: attr1 only on node 0, attr2 everywhere; include / exclude lists
+    attrs = {'attr1': [IFACE7_ATTRS[i].get('attr1') for i in range(7)],
+             'attr2': [IFACE7_ATTRS[i].get('attr2') for i in range(7)]}
+    iga = Graph(7, IFACE7_EDGES, vertex_attrs=attrs)
+    got = IgraphInterface(iga, attributes=True).get_neighborhood_features()
+    exp = pd.DataFrame({'degree': [3, 1, 1, 2, 2, 2, 3],
+                        'attribute_attr1': [1.00, 0, 0, 0, 0, 0, 0],
+                        'attribute_attr2': [0.00, 1.00, 2.00, 3.00, 4.00, 5.00, 6.00],
+                        'internal_edges': [3, 1, 1, 2, 3, 3, 4], 'external_edges': [1, 2, 2, 4, 1, 1, 1]})
+    pd.testing.assert_frame_equal(got, exp)
+    got = IgraphInterface(iga, attributes=True, attributes_include=['attr1', 'attr2'],
+                          attributes_exclude=['attr2']).get_neighborhood_features()
+    assert list(got.columns) == ['degree', 'attribute_attr1', 'internal_edges', 'external_edges']
+
+
+def test_igraph_neighbour_order_is_ascending_whatever_the_edge_list_order(fake_backend):
+    """Graph.neighbors lists neighbours in ascending vertex order: the summation order handed to the engine must
+    not depend on the order of get_edgelist()."""
+    from graphrole_amd.graph.interface import IgraphInterface
+    Graph = _stand_in_graph_class()
+    edges = [(4, 0), (0, 9), (3, 0), (0, 1), (7, 0), (2, 9)]
+    csr = IgraphInterface(Graph(10, edges)).to_csr()
+    assert csr.adj_col.tolist() == csr.col.tolist()
+    assert csr.adj_col[csr.row_ptr[0]:csr.row_ptr[1]].tolist() == [1, 3, 4, 7, 9]
+    assert csr.edge_arrays() is None                      # explicit order: not ingested from the edge arrays
