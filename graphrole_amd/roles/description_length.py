@@ -1,7 +1,9 @@
 """
 Minimum-description-length costs for RolX model selection (reference:
-graphrole/roles/description_length.py).  Only used when ``n_roles=None``; it acts on the small
-encoded factors on the host (device version is a "next" row).
+graphrole/roles/description_length.py) for callers that hold the encoded factors as HOST arrays.
+RoleExtractor's grid search computes the same two costs in HBM (roles/extract.py::_select_model: code-book
+sizes from the quantiser, masked KL error by grx_nmf_kl_cost -- SURVEY.md section 8f rank 2) and does not
+come through here; tests/test_gpu_rolx.py checks the device costs against these formulas.
 """
 from typing import Tuple
 
