@@ -54,7 +54,9 @@ def to_device(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(device())
 
 
-_PINNED: dict = {}
+import threading
+
+_PINNED = threading.local()          # per-thread staging buffers: distinct extractor instances may run in distinct threads
 _PINNED_MAX_BYTES = 1 << 20
 
 
@@ -68,10 +70,13 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     nbytes = t.numel() * t.element_size()
     if not t.is_cuda or nbytes == 0 or nbytes > _PINNED_MAX_BYTES:
         return t.cpu().numpy()
-    buf = _PINNED.get(t.dtype)
+    bufs = getattr(_PINNED, 'bufs', None)
+    if bufs is None:
+        bufs = _PINNED.bufs = {}
+    buf = bufs.get(t.dtype)
     if buf is None or buf.numel() < t.numel():
         buf = torch.empty(max(t.numel(), 4096), dtype=t.dtype, pin_memory=True)
-        _PINNED[t.dtype] = buf
+        bufs[t.dtype] = buf
     view = buf[:t.numel()]
     view.copy_(t.contiguous().view(-1), non_blocking=True)
     torch.cuda.current_stream().synchronize()
