@@ -438,6 +438,132 @@ __global__ __launch_bounds__(256) void gram_pairs_mfma_kernel(int64_t row_begin,
     }
 }
 
+// ---- full-width Gram for 48 < k <= 128 output columns: X is read ONCE ----------------------------------
+// The group-pair kernel above reads every 48-column group once per pair (3.75 x the matrix at k = 115) in 32-byte
+// pieces (MFMA A layout straight from global memory: 16 columns x 4 rows per load) -- 10 ms per Gram matrix at
+// 5 M x 115.  Here a workgroup owns 16-row sub-tiles: the (transformed) tile Y^T [k][16] is built once in LDS --
+// no transform: coalesced 128-byte loads of X; with T: Y^T = T^T X^T on the matrix cores, T as A operand from L2,
+// X as B operand straight from global memory in 128-byte segments -- and the KT (KT + 1) / 2 output tiles are
+// split over the four waves (<= 9 accumulator tiles each, kept in registers over all sub-tiles).  Two LDS tiles
+// alternate so that one barrier per sub-tile suffices.
+constexpr int GF_LD = 17;
+constexpr int GF_MAX_KT = 8;
+
+// the MFMAs of one K step for wave W: every index is a compile-time constant (accumulators stay in registers)
+template <int KT, int W>
+__device__ __forceinline__ void gram_full_step(const double (&op)[KT], gv4d (&acc)[(KT * (KT + 1) / 2 + 3) / 4])
+{
+    int m = 0, m2 = 0;
+#pragma unroll
+    for (int pp = 0; pp < KT * (KT + 1) / 2; ++pp) {
+        if ((pp & 3) == W) acc[pp >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[m], op[m2], acc[pp >> 2], 0, 0, 0);
+        if (++m2 == KT) { ++m; m2 = m; }
+    }
+}
+
+template <int PW>
+__device__ __forceinline__ gv4d gram_full_pick(const gv4d (&acc)[PW], int idx)
+{
+    gv4d out = acc[0];
+#pragma unroll
+    for (int p = 1; p < PW; ++p)
+        if (idx == p) out = acc[p];
+    return out;
+}
+
+template <int KT, bool HAS_T>
+__global__ __launch_bounds__(256) void gram_full_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int k,
+                                                             const double *__restrict__ X, int64_t ldx,
+                                                             const double *__restrict__ T, double *__restrict__ partial)
+{
+    constexpr int NP = KT * (KT + 1) / 2;                       // output tile pairs (m <= m2)
+    constexpr int PW = (NP + 3) / 4;                            // pairs per wave
+    constexpr int TILE = 16 * KT * GF_LD;
+    extern __shared__ __attribute__((aligned(16))) double gfs[];    // 2 tiles, later the reduction buffer
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    gv4d acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) acc[p] = (gv4d){0.0, 0.0, 0.0, 0.0};
+    const int nq = (F + 3) / 4;
+    const int64_t nsub = (row_end - row_begin + 15) / 16;
+    int buf = 0;
+    for (int64_t sidx = blockIdx.x; sidx < nsub; sidx += gridDim.x, buf ^= 1) {
+        double *yT = gfs + buf * TILE;                          // [j][i]
+        const int64_t row0 = row_begin + sidx * 16;
+        if (!HAS_T) {
+            // Y = X: thread (column group t >> 4, row t & 15): 16 consecutive rows of a column per 16 lanes
+            for (int c = t >> 4; c < 16 * KT; c += 16) {
+                const int64_t row = row0 + (t & 15);
+                yT[c * GF_LD + (t & 15)] = (c < F && row < row_end) ? X[(size_t)c * ldx + row] : 0.0;
+            }
+        } else {
+            // Y^T = T^T X^T: this wave's output tiles jt = wave, wave + 4, ...
+            const int64_t row = row0 + li;
+            const bool valid = row < row_end;
+            const int64_t rowc = valid ? row : row_end - 1;
+            gv4d y[(KT + 3) / 4];
+#pragma unroll
+            for (int u = 0; u < (KT + 3) / 4; ++u) y[u] = (gv4d){0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < nq; ++q) {
+                const int c = 4 * q + lq;
+                const double xv = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
+                const double x = (valid && c < F) ? xv : 0.0;
+#pragma unroll
+                for (int u = 0; u < (KT + 3) / 4; ++u) {
+                    const int jt = wave + 4 * u;
+                    if (jt < KT) {
+                        const int j = 16 * jt + li;
+                        const double a = (c < F && j < k) ? T[(size_t)c * k + j] : 0.0;
+                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x, y[u], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < (KT + 3) / 4; ++u) {
+                const int jt = wave + 4 * u;
+                if (jt < KT) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) yT[(16 * jt + lq + 4 * g) * GF_LD + li] = y[u][g];
+                }
+            }
+        }
+        __syncthreads();
+        // this wave's pairs: pair number pp (order (0,0),(0,1),...,(0,KT-1),(1,1),...) belongs to wave pp & 3
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int i = 4 * st + lq;
+            double op[KT];
+#pragma unroll
+            for (int m = 0; m < KT; ++m) op[m] = yT[(16 * m + li) * GF_LD + i];
+            switch (wave) {
+            case 0: gram_full_step<KT, 0>(op, acc); break;
+            case 1: gram_full_step<KT, 1>(op, acc); break;
+            case 2: gram_full_step<KT, 2>(op, acc); break;
+            default: gram_full_step<KT, 3>(op, acc); break;
+            }
+        }
+        // the other tile is written next: its last readers passed the barrier above one iteration ago
+    }
+    __syncthreads();
+    // per-workgroup partials: each pair tile belongs to exactly one wave
+    {
+        int m = 0, m2 = 0;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            if ((pp & 3) == wave) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j = 16 * m + lq + 4 * g, j2 = 16 * m2 + li;
+                    if (j < k && j2 < k && j <= j2)
+                        partial[(size_t)((size_t)j2 * (j2 + 1) / 2 + j) * gridDim.x + blockIdx.x] = gram_full_pick<PW>(acc, pp >> 2)[g];
+                }
+            }
+            if (++m2 == KT) { ++m; m2 = m; }
+        }
+    }
+}
+
 // sum of X[:, ja .. ja+na) over the row range: per-workgroup partials (fixed order)
 __global__ __launch_bounds__(256) void column_sum_kernel(int64_t row_begin, int64_t row_end,
                                                          const double *__restrict__ X, int64_t ldx, int ja, int na,
@@ -1168,6 +1294,32 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
                                             grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256));
     if (h_T) GRX_CHECK_HIP(hipMemcpyAsync(dTw, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
     const int pgrid = gram_pairs_grid(row_end - row_begin, k);
+    if (k <= 16 * GF_MAX_KT && (h_T != nullptr || F == k)) {
+        // 49..128 output columns: the full-width kernel reads X once
+        const int KT = (k + 15) / 16;
+        const size_t lds = (size_t)2 * 16 * KT * GF_LD * 8;
+        {
+            GRX_PROF(GRX_K_GRAM, st);
+            const dim3 g(pgrid), b(256);
+#define GRX_GRAM_FULL(KTV)                                                                                              \
+    if (h_T) gram_full_mfma_kernel<KTV, true><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dTw, partial);       \
+    else gram_full_mfma_kernel<KTV, false><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial)
+            switch (KT) {
+            case 4: GRX_GRAM_FULL(4); break;
+            case 5: GRX_GRAM_FULL(5); break;
+            case 6: GRX_GRAM_FULL(6); break;
+            case 7: GRX_GRAM_FULL(7); break;
+            default: GRX_GRAM_FULL(8); break;
+            }
+#undef GRX_GRAM_FULL
+            if (!h_T) column_sum_kernel<<<pgrid, 256, 0, st>>>(row_begin, row_end, d_X, ldx, 0, k,
+                                                               partial + (size_t)(npairs_all - 1) * pgrid);
+        }
+        GRX_LAUNCH_CHECK();
+        gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, pgrid, k, d_out, k, 0, k, 0, h_T ? 0 : 1);
+        GRX_LAUNCH_CHECK();
+        return GRX_OK;
+    }
     const double *src = d_X;
     int64_t lds_src = ldx;
     {
