@@ -471,15 +471,22 @@ __device__ __forceinline__ gv4d gram_full_pick(const gv4d (&acc)[PW], int idx)
     return out;
 }
 
+__device__ __forceinline__ double gram_full_keep(double v, bool keep)
+{
+    return __longlong_as_double(__double_as_longlong(v) & (keep ? -1ll : 0ll));
+}
+
 template <int KT, bool HAS_T>
-__global__ __launch_bounds__(256) void gram_full_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int k,
+__global__ __launch_bounds__(256, (HAS_T && KT <= 5) ? 2 : 1) void gram_full_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int k,
                                                              const double *__restrict__ X, int64_t ldx,
-                                                             const double *__restrict__ T, double *__restrict__ partial)
+                                                             const double *__restrict__ T, double *__restrict__ partial,
+                                                             double *__restrict__ sum_partial)
 {
     constexpr int NP = KT * (KT + 1) / 2;                       // output tile pairs (m <= m2)
     constexpr int PW = (NP + 3) / 4;                            // pairs per wave
-    constexpr int TILE = 16 * KT * GF_LD;
-    extern __shared__ __attribute__((aligned(16))) double gfs[];    // 2 tiles, later the reduction buffer
+    constexpr int XT = 8;                                       // X tile: up to 128 feature columns (F <= 128)
+    constexpr int XTILE = 16 * XT * GF_LD;
+    extern __shared__ __attribute__((aligned(16))) double gfs[];    // xbuf[2][XTILE] (+ ypart[4][16 KT LD] with T)
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lq = lane >> 4;
     gv4d acc[PW];
@@ -487,55 +494,83 @@ __global__ __launch_bounds__(256) void gram_full_mfma_kernel(int64_t row_begin, 
     for (int p = 0; p < PW; ++p) acc[p] = (gv4d){0.0, 0.0, 0.0, 0.0};
     const int nq = (F + 3) / 4;
     const int64_t nsub = (row_end - row_begin + 15) / 16;
-    int buf = 0;
-    for (int64_t sidx = blockIdx.x; sidx < nsub; sidx += gridDim.x, buf ^= 1) {
-        double *yT = gfs + buf * TILE;                          // [j][i]
-        const int64_t row0 = row_begin + sidx * 16;
-        if (!HAS_T) {
-            // Y = X: thread (column group t >> 4, row t & 15): 16 consecutive rows of a column per 16 lanes
-            for (int c = t >> 4; c < 16 * KT; c += 16) {
-                const int64_t row = row0 + (t & 15);
-                yT[c * GF_LD + (t & 15)] = (c < F && row < row_end) ? X[(size_t)c * ldx + row] : 0.0;
-            }
-        } else {
-            // Y^T = T^T X^T: this wave's output tiles jt = wave, wave + 4, ...
-            const int64_t row = row0 + li;
-            const bool valid = row < row_end;
-            const int64_t rowc = valid ? row : row_end - 1;
-            gv4d y[(KT + 3) / 4];
+    // thread (column t >> 4 + 16 u, row t & 15): 16 lanes read 16 consecutive rows of one column (128 bytes).
+    // Two sub-tiles of loads stay in flight (register sets pa / pb) while a third is multiplied from LDS.
+    double pa[XT], pb[XT];
+    // issue() only loads (clamped addresses); the padding mask is applied in stash(), the first use -- a mask or
+    // select next to the load makes the compiler wait for it there
+    auto issue = [&](double (&pre)[XT], int64_t sidx) {
+        const int64_t row = row_begin + sidx * 16 + (t & 15);
+        const int64_t rowc = row < row_end ? row : row_end - 1;
 #pragma unroll
-            for (int u = 0; u < (KT + 3) / 4; ++u) y[u] = (gv4d){0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < nq; ++q) {
-                const int c = 4 * q + lq;
-                const double xv = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
-                const double x = (valid && c < F) ? xv : 0.0;
-#pragma unroll
-                for (int u = 0; u < (KT + 3) / 4; ++u) {
-                    const int jt = wave + 4 * u;
-                    if (jt < KT) {
-                        const int j = 16 * jt + li;
-                        const double a = (c < F && j < k) ? T[(size_t)c * k + j] : 0.0;
-                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x, y[u], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < (KT + 3) / 4; ++u) {
-                const int jt = wave + 4 * u;
-                if (jt < KT) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) yT[(16 * jt + lq + 4 * g) * GF_LD + li] = y[u][g];
-                }
-            }
+        for (int u = 0; u < XT; ++u) {
+            const int c = (t >> 4) + 16 * u;
+            pre[u] = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    double xsum = 0.0;                                          // this thread's share of sum(X) (padding is zero)
+    auto stash = [&](const double (&pre)[XT], int64_t sidx, double *xb) {
+        __builtin_amdgcn_sched_barrier(0);
+        const bool row_ok = row_begin + sidx * 16 + (t & 15) < row_end;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int c = (t >> 4) + 16 * u;
+            const double v = gram_full_keep(pre[u], row_ok && c < F);
+            xb[c * GF_LD + (t & 15)] = v;
+            xsum += v;
+        }
+    };
+    // With T: the transform Y^T = T^T X^T is split over the feature (K) dimension -- wave w owns feature rows
+    // [4 q_lo, 4 (q_lo + q_n)) and keeps its slice of T in registers for the whole kernel, so the loop has no
+    // loads but the X stream. The four partial Y^T tiles are summed (fixed order) when they are read back.
+    constexpr int QW = 8;                                       // K steps per wave (nq <= 32)
+    constexpr int YPLANE = 16 * KT * GF_LD;
+    double *ypart = gfs + 2 * XTILE;                            // [4][YPLANE]
+    const int qw = (nq + 3) / 4, q_lo = wave * qw;
+    const int q_n = nq - q_lo < qw ? nq - q_lo : qw;            // may be <= 0: the wave contributes zeros
+    double treg[HAS_T ? KT : 1][QW];
+    if (HAS_T) {
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq) {
+                const int c = 4 * (q_lo + qq) + lq, j = 16 * jt + li;
+                treg[jt][qq] = (qq < q_n && c < F && j < k) ? T[(size_t)c * k + j] : 0.0;
+            }
+    }
+    auto compute = [&](const double *xT) {
+        if (HAS_T) {
+            gv4d y[KT];
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) y[jt] = (gv4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq) {
+                if (qq < q_n) {                                 // uniform over the wave
+                    const double x = xT[(4 * (q_lo + qq) + lq) * GF_LD + li];   // tile rows c >= F are zero
+#pragma unroll
+                    for (int jt = 0; jt < KT; ++jt)
+                        y[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(treg[jt][qq], x, y[jt], 0, 0, 0);
+                }
+            }
+            double *yp = ypart + wave * YPLANE;
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yp[(16 * jt + lq + 4 * g) * GF_LD + li] = y[jt][g];
+            __syncthreads();
+        }
         // this wave's pairs: pair number pp (order (0,0),(0,1),...,(0,KT-1),(1,1),...) belongs to wave pp & 3
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int i = 4 * st + lq;
             double op[KT];
 #pragma unroll
-            for (int m = 0; m < KT; ++m) op[m] = yT[(16 * m + li) * GF_LD + i];
+            for (int m = 0; m < KT; ++m) {
+                const int a = (16 * m + li) * GF_LD + i;
+                if (HAS_T) op[m] = (ypart[a] + ypart[YPLANE + a]) + (ypart[2 * YPLANE + a] + ypart[3 * YPLANE + a]);
+                else op[m] = xT[a];
+            }
             switch (wave) {
             case 0: gram_full_step<KT, 0>(op, acc); break;
             case 1: gram_full_step<KT, 1>(op, acc); break;
@@ -543,9 +578,36 @@ __global__ __launch_bounds__(256) void gram_full_mfma_kernel(int64_t row_begin, 
             default: gram_full_step<KT, 3>(op, acc); break;
             }
         }
-        // the other tile is written next: its last readers passed the barrier above one iteration ago
+    };
+    const int64_t G = gridDim.x;
+    int64_t sidx = blockIdx.x;
+    if (nsub > 0) {
+        issue(pa, sidx);
+        stash(pa, sidx, gfs);
+        issue(pa, sidx + G);
     }
     __syncthreads();
+    // invariant at the top: buffer 0 holds sub-tile sidx, pa carries sidx + G (in flight), pb is free
+    while (sidx < nsub) {
+        issue(pb, sidx + 2 * G);
+        compute(gfs);
+        stash(pa, sidx + G, gfs + XTILE);
+        __syncthreads();                                        // next X tile visible; ybuf free again
+        sidx += G;
+        if (sidx >= nsub) break;
+        issue(pa, sidx + 2 * G);
+        compute(gfs + XTILE);
+        stash(pb, sidx + G, gfs);
+        __syncthreads();
+        sidx += G;
+    }
+    if (sum_partial) {
+        __syncthreads();
+        xsum = grx_group_sum<64>(xsum);
+        if (lane == 0) gfs[wave] = xsum;
+        __syncthreads();
+        if (t == 0) sum_partial[blockIdx.x] = ((gfs[0] + gfs[1]) + gfs[2]) + gfs[3];
+    }
     // per-workgroup partials: each pair tile belongs to exactly one wave
     {
         int m = 0, m2 = 0;
@@ -1294,16 +1356,20 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
                                             grx_align_up((size_t)MAX_F_WIDE * (size_t)(k > MAX_F ? k : MAX_F) * 8, 256));
     if (h_T) GRX_CHECK_HIP(hipMemcpyAsync(dTw, h_T, (size_t)F * k * 8, hipMemcpyHostToDevice, st));
     const int pgrid = gram_pairs_grid(row_end - row_begin, k);
-    if (k <= 16 * GF_MAX_KT && (h_T != nullptr || F == k)) {
-        // 49..128 output columns: the full-width kernel reads X once
+    if (k <= 16 * GF_MAX_KT && F <= 128 && (h_T != nullptr || F == k)) {
+        // 49..128 output columns of at most 128 feature columns: the full-width kernel reads X once
         const int KT = (k + 15) / 16;
-        const size_t lds = (size_t)2 * 16 * KT * GF_LD * 8;
+        const size_t lds = ((size_t)2 * 16 * 8 * GF_LD + (h_T ? (size_t)4 * 16 * KT * GF_LD : 0)) * 8;
         {
             GRX_PROF(GRX_K_GRAM, st);
             const dim3 g(pgrid), b(256);
 #define GRX_GRAM_FULL(KTV)                                                                                              \
-    if (h_T) gram_full_mfma_kernel<KTV, true><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dTw, partial);       \
-    else gram_full_mfma_kernel<KTV, false><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial)
+    if (h_T && lds > 64 * 1024)                                                                                         \
+        GRX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_full_mfma_kernel<KTV, true>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+    if (h_T) gram_full_mfma_kernel<KTV, true><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, dTw, partial, nullptr); \
+    else gram_full_mfma_kernel<KTV, false><<<g, b, lds, st>>>(row_begin, row_end, F, k, d_X, ldx, nullptr, partial,       \
+                                                              partial + (size_t)(npairs_all - 1) * pgrid)
             switch (KT) {
             case 4: GRX_GRAM_FULL(4); break;
             case 5: GRX_GRAM_FULL(5); break;
@@ -1312,8 +1378,6 @@ int grx_gram(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_begin
             default: GRX_GRAM_FULL(8); break;
             }
 #undef GRX_GRAM_FULL
-            if (!h_T) column_sum_kernel<<<pgrid, 256, 0, st>>>(row_begin, row_end, d_X, ldx, 0, k,
-                                                               partial + (size_t)(npairs_all - 1) * pgrid);
         }
         GRX_LAUNCH_CHECK();
         gram_finalize_kernel<<<(k * k + 1 + 3) / 4, 256, 0, st>>>(partial, pgrid, k, d_out, k, 0, k, 0, h_T ? 0 : 1);
