@@ -507,6 +507,40 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ld
     }
 }
 
+// The same for ldr a multiple of 16 (rows of whole 128-byte lines): a 64-row x 16-column tile goes through LDS so
+// that both sides are coalesced -- columns are read 64 rows (512 bytes) at a time, rows written a line at a time.
+constexpr int PK_LD = 65;
+__global__ __launch_bounds__(256) void pack_rows_tiled_kernel(int64_t n, int f, int ldr, GrxPtrTable cols_tab,
+                                                              double *__restrict__ rows, int c_off, int pad_from)
+{
+    __shared__ double tile[16 * PK_LD];
+    const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int c_end = pad_from < ldr ? ldr : c_off + f;          // the last launch also zeroes the pad columns
+    const int64_t ntiles = (n + 63) / 64;
+    for (int64_t tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+        const int64_t row0 = tile_i * 64;
+        for (int cb = c_off; cb < c_end; cb += 16) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + wave + 4 * u - c_off;         // column of this launch's table
+                const int64_t i = row0 + lane;
+                v[u] = (c < f && i < n) ? cols[c][i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tile[(wave + 4 * u) * PK_LD + lane] = v[u];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = (t >> 4) + 16 * u, c = t & 15;
+                if (row0 + r < n && cb + c < c_end) rows[(row0 + r) * ldr + cb + c] = tile[c * PK_LD + r];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void add_columns_kernel(int64_t n, const double *__restrict__ a,
                                                           const double *__restrict__ b,
                                                           double *__restrict__ out)
@@ -1121,7 +1155,13 @@ int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_r
         for (int c = 0; c < fc; ++c) tab.p[c] = h_col_ptrs[c0 + c];
         {
             GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
-            pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
+            if (ldr % 16 == 0) {
+                const int64_t tiles = grx_ceil_div(n, 64);
+                const int tgrid = (int)(tiles > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : tiles);
+                pack_rows_tiled_kernel<<<tgrid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
+            } else {
+                pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
+            }
         }
         GRX_LAUNCH_CHECK();
         if (last) break;

@@ -659,3 +659,19 @@ def test_unsupported_shapes_fail_loudly(K):
     X = torch.zeros((481, 10), dtype=torch.float64, device='cuda')          # GRX_MAX_NMF_FEATURES = 480
     with pytest.raises(GrxError):
         K.gram(X, 10)
+
+
+@pytest.mark.parametrize('f', [1, 3, 8, 9, 16, 23, 48, 130])
+@pytest.mark.parametrize('n', [1, 63, 64, 1000 + 37])
+def test_pack_rows_every_width(K, f, n):
+    """grx_pack_rows: the thread-per-row kernel (rows of 16 / 32 / 64 bytes) and the LDS-tiled one (whole
+    lines, pointer table split at 128 columns) give the zero-padded row-major block."""
+    import torch
+    X = np.random.default_rng(100 * f + n).standard_normal((f, n))
+    Xd = torch.from_numpy(X).cuda()
+    rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n)
+    torch.cuda.synchronize()
+    got = rows.cpu().numpy()
+    assert got.shape == (n, ldr) and ldr >= f
+    assert np.array_equal(got[:, :f], X.T)
+    assert np.all(got[:, f:] == 0.0)
