@@ -254,6 +254,17 @@ class ShardPlan:
         from graphrole_amd import kernels as K
         return (K.to_host(out) if out.is_cuda else out.numpy()).reshape((self.world,) + a.shape)
 
+    #: set to the exception text when a HIP-graph capture of the MU block failed (the loop then runs eagerly)
+    capture_error: Optional[str] = None
+
+    def graph_capturable(self) -> bool:
+        """Collectives of this plan can be recorded into a HIP graph: device-to-device RCCL only (a solo plan has
+        no collectives and uses the single-GPU driver instead)."""
+        import os
+        if self._solo or os.environ.get('GRX_NO_GRAPHS') == '1' or not torch.cuda.is_available():
+            return False
+        return dist.get_backend(self.group) == 'nccl'
+
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         with self._time('all_reduce_max'):
             return self._all_reduce_(t, dist.ReduceOp.MAX)

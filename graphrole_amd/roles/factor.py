@@ -198,10 +198,7 @@ def _mu_orchestrated(state, tol: float, max_iter: int, plan=None) -> int:
         if plan is None:
             state.iterate(step, with_residual=False)
         else:
-            for _ in range(step):
-                state.w_pass(rb, re)
-                plan.all_reduce_sum_(state.AB)
-                state.h_update()
+            _sharded_mu_block(state, plan, rb, re, step)
         n_iter += step
         if check:                                                     # _nmf.py:872-885
             err = residual_from_identity()
@@ -212,6 +209,42 @@ def _mu_orchestrated(state, tol: float, max_iter: int, plan=None) -> int:
                 break
             prev = err
     return n_iter
+
+
+def _sharded_mu_block(state, plan, rb: int, re: int, steps: int) -> None:
+    """`steps` multiplicative updates of a row shard: W pass over the own rows, ONE all-reduce of the fused
+    [W^T X ; W^T W] buffer, H update.  Over RCCL the block is captured once as a HIP graph (kernels and
+    collective on the capture stream) and replayed, so an iteration costs no host calls; backends that stage
+    through the host (gloo) and any capture failure run the same sequence eagerly."""
+    def eager():
+        for _ in range(steps):
+            state.w_pass(rb, re)
+            plan.all_reduce_sum_(state.AB)
+            state.h_update()
+
+    if not plan.graph_capturable():
+        return eager()
+    import torch
+    graphs = state.__dict__.setdefault('_mu_graphs', {})
+    key = (steps, rb, re)
+    g = graphs.get(key)
+    if g is None:
+        try:
+            g = torch.cuda.CUDAGraph()
+            was_timing, plan.timing = plan.timing, False         # no event records inside a capture
+            try:
+                with torch.cuda.graph(g):
+                    eager()
+            finally:
+                plan.timing = was_timing
+        except Exception as exc:                                 # pragma: no cover - depends on the RCCL build
+            plan.capture_error = repr(exc)
+            g = False
+        graphs[key] = g
+    if g is False:
+        return eager()
+    with plan._time('mu_block_graph'):
+        g.replay()
 
 
 def run_mu_loop(state, tol: float = NMF_TOL, max_iter: int = NMF_MAX_ITER, plan=None):
