@@ -38,6 +38,7 @@ enum GrxKernelId {
     GRX_K_NNDSVD_APPLY, GRX_K_NMF_W_PASS, GRX_K_REDUCE_PARTIALS, GRX_K_NMF_H_UPDATE,
     GRX_K_NMF_RESIDUAL, GRX_K_ADD_COLUMNS, GRX_K_TRIANGLES, GRX_K_EGONET_FINISH, GRX_K_QUANT, GRX_K_KEY_BITS, GRX_K_COUNT
 };
+bool grx_prof_is_on();
 void grx_prof_begin(int id, hipStream_t st);
 void grx_prof_end(int id, hipStream_t st);
 struct GrxProfScope {

@@ -51,7 +51,10 @@ __device__ __forceinline__ int ilog2_i64(int64_t x) { return 63 - __clzll((unsig
 // ---------------------------------------------------------------------------------------
 // weighted row sums
 // ---------------------------------------------------------------------------------------
-template <int G>
+// G lanes per row, R rows per group in flight (rows v, v + ngroups, ...): the dependent row_ptr -> weights chain
+// of one short row leaves the memory system idle, R independent chains keep it busy.  Per row the additions run
+// in the same order whatever R is: lane-strided partial sums, then the butterfly.
+template <int G, int R>
 __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict__ row_ptr,
                                                        const int32_t *__restrict__ col,
                                                        const double *__restrict__ w, int add_loop,
@@ -61,22 +64,49 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
     const int lane = threadIdx.x % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
-        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+    for (int64_t v0 = row_begin + group; v0 < row_end; v0 += ngroups * R) {
+        int64_t b[R], e[R];
+        int64_t longest = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int64_t v = v0 + ngroups * i;
+            const bool live = v < row_end;
+            b[i] = live ? row_ptr[v] : 0;
+            e[i] = live ? row_ptr[v + 1] : 0;
+            longest = e[i] - b[i] > longest ? e[i] - b[i] : longest;
+        }
         if (w == nullptr) {                                 // implicit weight 1: degree from row_ptr
-            if (lane == 0)
-                out[v] = (double)((e - b) + ((add_loop && find_in_row(col, b, e, (int32_t)v) >= 0) ? 1 : 0));
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int64_t v = v0 + ngroups * i;
+                    if (v < row_end)
+                        out[v] = (double)((e[i] - b[i]) + ((add_loop && find_in_row(col, b[i], e[i], (int32_t)v) >= 0) ? 1 : 0));
+                }
+            }
             continue;
         }
-        double s = 0.0, loop = 0.0;
-        for (int64_t k = b + lane; k < e; k += G) {
-            const double x = w ? w[k] : 1.0;
-            s += x;
-            if (add_loop && col[k] == v) loop = x;
+        double s[R], loop[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) s[i] = loop[i] = 0.0;
+        for (int64_t off = lane; off < longest; off += G) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int64_t k = b[i] + off;
+                if (k < e[i]) {
+                    const double x = w[k];
+                    s[i] += x;
+                    if (add_loop && col[k] == v0 + ngroups * i) loop[i] = x;
+                }
+            }
         }
-        s = grx_group_sum<G>(s);
-        loop = grx_group_sum<G>(loop);
-        if (lane == 0) out[v] = s + loop;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const double si = grx_group_sum<G>(s[i]);
+            const double li = grx_group_sum<G>(loop[i]);
+            const int64_t v = v0 + ngroups * i;
+            if (lane == 0 && v < row_end) out[v] = si + li;
+        }
     }
 }
 
@@ -1029,7 +1059,7 @@ int grx_row_sums(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, cons
     const int64_t want = grx_ceil_div(nrows * 8, 256);
     const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
     { GRX_PROF(GRX_K_ROW_SUMS, grx_stream(stream));
-    row_sums_kernel<8><<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, add_self_loop,
+    row_sums_kernel<8, 4><<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, add_self_loop,
                                                             row_begin, row_end, d_out);
     }
     GRX_LAUNCH_CHECK();

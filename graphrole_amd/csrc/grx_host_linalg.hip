@@ -54,18 +54,19 @@ void jacobi_eigh(int n, double *A, double *w, double *V)
 {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
-    double total = 0.0;
-    for (int i = 0; i < n * n; ++i) total += A[i] * A[i];
+    // A pair is converged when |a_pq| <= eps sqrt(|a_pp a_qq|) (rotating it would not move either eigenvalue in
+    // double precision; the relative criterion keeps the small eigenvalues of a graded Gram matrix accurate);
+    // the iteration ends with the first sweep that rotates nothing.  A bound on the off-diagonal NORM far below
+    // eps ||A|| is never met once n is a few dozen: rounding noise alone keeps it up and all 64 sweeps run.
+    const double eps = 2.220446049250313e-16;
     for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
-        if (off <= total * 1e-34 || off == 0.0) break;
+        bool rotated = false;
         for (int p = 0; p < n; ++p) {
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[(size_t)p * n + q];
-                if (apq == 0.0) continue;
                 const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                if (apq == 0.0 || std::fabs(apq) <= eps * std::sqrt(std::fabs(app * aqq))) continue;
+                rotated = true;
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
@@ -86,6 +87,7 @@ void jacobi_eigh(int n, double *A, double *w, double *V)
                 }
             }
         }
+        if (!rotated) break;
     }
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
@@ -102,13 +104,13 @@ void jacobi_eigh(int n, double *A, double *w, double *V)
 
 // Symmetric eigen-decomposition in O(n^3): Householder reduction to tridiagonal form with the
 // transformations accumulated in place, then implicit-shift QL sweeps on the tridiagonal (the classical
-// EISPACK pair).  Used above 64 columns, where the ~10 Jacobi sweeps (9 n^3 flops each) would cost tens of
+// EISPACK pair).  Used above 32 columns, where the ~10 Jacobi sweeps (9 n^3 flops each) would cost tens of
 // milliseconds; same interface as jacobi_eigh (A destroyed, w ascending, eigenvectors in the columns of V).
 // Absolute accuracy eps * ||A|| like LAPACK's tridiagonal drivers; the second Gram pass of the
 // initialisation re-orthogonalises, so small eigenvalues need no more than that.
 bool tridiagonal_eigh(int n, double *A, double *w, double *V)
 {
-    std::vector<double> e(n, 0.0);
+    std::vector<double> e(n, 0.0), gv(n, 0.0);
     double *a = A, *d = w;
     auto at = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
     for (int i = n - 1; i >= 1; --i) {
@@ -126,19 +128,29 @@ bool tridiagonal_eigh(int n, double *A, double *w, double *V)
                 e[i] = scale * g;
                 h -= f * g;
                 at(i, l) = f - g;
+                // p = A u over the stored lower triangle, rows only (contiguous): the k <= j terms row by row, then
+                // row k adds its share to every p_j, j < k -- per p_j the additions run in the same order as the
+                // textbook column walk
                 f = 0.0;
                 for (int j = 0; j <= l; ++j) {
                     at(j, i) = at(i, j) / h;
-                    g = 0.0;
+                    double g = 0.0;
                     for (int k = 0; k <= j; ++k) g += at(j, k) * at(i, k);
-                    for (int k = j + 1; k <= l; ++k) g += at(k, j) * at(i, k);
-                    e[j] = g / h;
+                    e[j] = g;
+                }
+                for (int k = 1; k <= l; ++k) {
+                    const double uk = at(i, k);
+                    const double *rowk = &at(k, 0);
+                    for (int j = 0; j < k; ++j) e[j] += rowk[j] * uk;
+                }
+                for (int j = 0; j <= l; ++j) {
+                    e[j] /= h;
                     f += e[j] * at(i, j);
                 }
                 const double hh = f / (h + h);
                 for (int j = 0; j <= l; ++j) {
                     f = at(i, j);
-                    e[j] = g = e[j] - hh * f;
+                    const double g = e[j] = e[j] - hh * f;
                     for (int k = 0; k <= j; ++k) at(j, k) -= f * e[k] + g * at(i, k);
                 }
             }
@@ -151,17 +163,28 @@ bool tridiagonal_eigh(int n, double *A, double *w, double *V)
     e[0] = 0.0;
     for (int i = 0; i < n; ++i) {
         if (d[i] != 0.0) {
-            for (int j = 0; j < i; ++j) {
-                double g = 0.0;
-                for (int k = 0; k < i; ++k) g += at(i, k) * at(k, j);
-                for (int k = 0; k < i; ++k) at(k, j) -= g * at(k, i);
+            // g_j = sum_k a(i,k) a(k,j), then a(k,j) -= g_j a(k,i): rows of the block, k outermost
+            std::fill(gv.begin(), gv.begin() + i, 0.0);
+            for (int k = 0; k < i; ++k) {
+                const double uk = at(i, k);
+                const double *rowk = &at(k, 0);
+                for (int j = 0; j < i; ++j) gv[j] += uk * rowk[j];
+            }
+            for (int k = 0; k < i; ++k) {
+                const double vk = at(k, i);
+                double *rowk = &at(k, 0);
+                for (int j = 0; j < i; ++j) rowk[j] -= gv[j] * vk;
             }
         }
         d[i] = at(i, i);
         at(i, i) = 1.0;
         for (int j = 0; j < i; ++j) at(j, i) = at(i, j) = 0.0;
     }
-    // QL with implicit shifts on (d, e); the rotations are applied to the columns of a
+    // QL with implicit shifts on (d, e); the rotations mix two eigenvector columns -- held as the ROWS of zt so
+    // that the update streams through contiguous memory
+    Mat zt((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) zt[(size_t)j * n + i] = at(i, j);
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     bool ok = true;
@@ -195,10 +218,11 @@ bool tridiagonal_eigh(int n, double *A, double *w, double *V)
                     p = s * r;
                     d[i + 1] = g + p;
                     g = c * r - b;
+                    double *z0 = &zt[(size_t)i * n], *z1 = z0 + n;
                     for (int k = 0; k < n; ++k) {
-                        f = at(k, i + 1);
-                        at(k, i + 1) = s * at(k, i) + c * f;
-                        at(k, i) = c * at(k, i) - s * f;
+                        const double hi = z1[k], lo = z0[k];
+                        z1[k] = s * lo + c * hi;
+                        z0[k] = c * lo - s * hi;
                     }
                 }
                 if (r == 0.0 && i >= l) continue;
@@ -215,12 +239,12 @@ bool tridiagonal_eigh(int n, double *A, double *w, double *V)
     std::vector<double> ds(d, d + n);
     for (int j = 0; j < n; ++j) {
         w[j] = ds[order[j]];
-        for (int i = 0; i < n; ++i) V[(size_t)i * n + j] = a[(size_t)i * n + order[j]];
+        for (int i = 0; i < n; ++i) V[(size_t)i * n + j] = zt[(size_t)order[j] * n + i];
     }
     return ok;
 }
 
-constexpr int JACOBI_MAX_N = 64;
+constexpr int JACOBI_MAX_N = 32;
 
 // eigen-decomposition used by the initialisation: Jacobi for small matrices, tridiagonal QL above
 void sym_eigh(int n, double *A, double *w, double *V)
@@ -306,34 +330,38 @@ void qr_q(int m, int k, double *a, double *Q)
 // columns of A = B^T.  U m x m, Vt m x n.
 void jacobi_svd(int m, int n, const double *B, double *U, double *s, double *Vt)
 {
-    Mat A((size_t)n * m), R((size_t)m * m);
+    // the m vectors being orthogonalised are the ROWS of A (= B) and of Rt (= R^T): contiguous streams
+    Mat A(B, B + (size_t)m * n), Rt((size_t)m * m);
     for (int i = 0; i < m; ++i)
-        for (int j = 0; j < n; ++j) A[(size_t)j * m + i] = B[(size_t)i * n + j];
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j) R[(size_t)i * m + j] = (i == j) ? 1.0 : 0.0;
+        for (int j = 0; j < m; ++j) Rt[(size_t)i * m + j] = (i == j) ? 1.0 : 0.0;
+    const double tol = std::sqrt((double)m) * 2.220446049250313e-16;
     for (int sweep = 0; sweep < 64; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < m; ++p) {
             for (int q = p + 1; q < m; ++q) {
+                double *ap = &A[(size_t)p * n], *aq = &A[(size_t)q * n];
                 double app = 0.0, aqq = 0.0, apq = 0.0;
                 for (int k = 0; k < n; ++k) {
-                    const double x = A[(size_t)k * m + p], y = A[(size_t)k * m + q];
+                    const double x = ap[k], y = aq[k];
                     app += x * x; aqq += y * y; apq += x * y;
                 }
-                if (apq == 0.0 || std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
+                // converged pair: |cos| below sqrt(m) eps (the dgesvj criterion).  A tighter bound never fires for
+                // the noise-level columns of a rank-deficient B and burns all 64 sweeps.
+                if (apq == 0.0 || std::fabs(apq) <= tol * std::sqrt(app * aqq)) continue;
                 rotated = true;
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
                 for (int k = 0; k < n; ++k) {
-                    const double x = A[(size_t)k * m + p], y = A[(size_t)k * m + q];
-                    A[(size_t)k * m + p] = c * x - sn * y;
-                    A[(size_t)k * m + q] = sn * x + c * y;
+                    const double x = ap[k], y = aq[k];
+                    ap[k] = c * x - sn * y;
+                    aq[k] = sn * x + c * y;
                 }
+                double *rp = &Rt[(size_t)p * m], *rq = &Rt[(size_t)q * m];
                 for (int k = 0; k < m; ++k) {
-                    const double x = R[(size_t)k * m + p], y = R[(size_t)k * m + q];
-                    R[(size_t)k * m + p] = c * x - sn * y;
-                    R[(size_t)k * m + q] = sn * x + c * y;
+                    const double x = rp[k], y = rq[k];
+                    rp[k] = c * x - sn * y;
+                    rq[k] = sn * x + c * y;
                 }
             }
         }
@@ -342,7 +370,7 @@ void jacobi_svd(int m, int n, const double *B, double *U, double *s, double *Vt)
     std::vector<double> nrm(m);
     for (int j = 0; j < m; ++j) {
         double v = 0.0;
-        for (int k = 0; k < n; ++k) v += A[(size_t)k * m + j] * A[(size_t)k * m + j];
+        for (int k = 0; k < n; ++k) v += A[(size_t)j * n + k] * A[(size_t)j * n + k];
         nrm[j] = std::sqrt(v);
     }
     std::vector<int> order(m);
@@ -351,8 +379,8 @@ void jacobi_svd(int m, int n, const double *B, double *U, double *s, double *Vt)
     for (int j = 0; j < m; ++j) {
         const int o = order[j];
         s[j] = nrm[o];
-        for (int i = 0; i < m; ++i) U[(size_t)i * m + j] = R[(size_t)i * m + o];
-        for (int k = 0; k < n; ++k) Vt[(size_t)j * n + k] = nrm[o] > 0.0 ? A[(size_t)k * m + o] / nrm[o] : 0.0;
+        for (int i = 0; i < m; ++i) U[(size_t)i * m + j] = Rt[(size_t)o * m + i];
+        for (int k = 0; k < n; ++k) Vt[(size_t)j * n + k] = nrm[o] > 0.0 ? A[(size_t)o * n + k] / nrm[o] : 0.0;
     }
 }
 

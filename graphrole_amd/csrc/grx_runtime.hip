@@ -49,6 +49,8 @@ static hipEvent_t prof_get_event()
     return ev;
 }
 
+bool grx_prof_is_on() { return g_prof_on; }
+
 void grx_prof_begin(int id, hipStream_t st)
 {
     if (!g_prof_on || !((g_prof_mask >> id) & 1ull)) return;

@@ -181,7 +181,7 @@ class RecursiveFeatureExtractor:
         columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
                                                                    aggs, self._arena)
         host = self.graph._device_graph()[0]
-        no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
+        no_empty_rows = self._no_empty_rows(host)
         names: List[str] = []
         for c in columns:
             if c['gen0_index'] >= 0:
@@ -202,6 +202,15 @@ class RecursiveFeatureExtractor:
         self.generation_count = gen_count
         self._feature_group_thresh = gen_count
         self.stats = generations
+
+    @staticmethod
+    def _no_empty_rows(host) -> bool:
+        """Every node has a neighbour -- a property of the graph, computed once (np.diff over millions of rows
+        costs milliseconds per call)."""
+        hit = host.__dict__.get('_no_empty_rows')
+        if hit is None:
+            hit = host.__dict__['_no_empty_rows'] = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
+        return hit
 
     @staticmethod
     def _candidate_dtype(parent_dtype, aggs, no_empty_rows: bool):
@@ -297,7 +306,7 @@ class RecursiveFeatureExtractor:
         cols = [sub[j] for j in range(len(picked))]
         names = [f'{c}({a})' for a in aggs for c in prev]
         host = self.graph._device_graph()[0]
-        no_empty_rows = bool(host.n == 0 or np.diff(host.row_ptr).min() > 0)
+        no_empty_rows = self._no_empty_rows(host)
         f64 = np.dtype('float64')
         dtypes = [self._candidate_dtype(self._dtypes.get(c, f64), aggs, no_empty_rows) for a in aggs for c in prev]
         return names, cols, dtypes, sub

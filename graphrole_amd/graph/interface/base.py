@@ -128,6 +128,8 @@ class DeviceGraphInterface(BaseGraphInterface):
             outd = K.row_sums(out, False, rb, re)
             ind = K.row_sums(tr, False, rb, re)
             outd, ind = self._finish_columns([outd, ind])
+            # the ego-net kernel wants the same out-weight sums: hand them over instead of a second pass
+            self._out_rowsum = outd if host.weighted else None
             names = ['in_degree', 'out_degree', 'total_degree']
             cols = [ind, outd, K.add_columns(outd, ind)]
         else:
@@ -160,7 +162,9 @@ class DeviceGraphInterface(BaseGraphInterface):
         K = self._K()
         host, out, _ = self._device_graph()
         rb, re = self._row_range()
-        rowsum = K.row_sums(out, False) if host.weighted else None
+        rowsum = self.__dict__.pop('_out_rowsum', None) if host.weighted else None
+        if rowsum is None and host.weighted:
+            rowsum = K.row_sums(out, False)
         internal, external = K.egonet_features(out, host.directed, rowsum, rb, re,
                                                shard=getattr(self, '_shard_plan', None))
         internal, external = self._finish_columns([internal, external])

@@ -301,7 +301,7 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
  * arrays, row-major).  Between its device passes (grx_gram twice, grx_project) sklearn's
  * initialisation (_nmf.py:324-359 via randomized_svd, extmath.py:531-604) only touches k x F matrices
  * with k <= F; these three calls replace ~25 numpy / LAPACK wrapper calls (0.6 ms per fit).  Any
- * F <= GRX_MAX_NMF_FEATURES: cyclic Jacobi up to 64 columns, tridiagonal QL above.
+ * F <= GRX_MAX_NMF_FEATURES: cyclic Jacobi up to 32 columns, tridiagonal QL above.
  *   grx_host_whiten        G1 = X^T X -> eigen-pairs above the numerical floor: lam_keep [k],
  *                          V_keep [F x k], T1 = V_keep / sqrt(lam_keep) [F x k]; *k = 0: X is zero
  *   grx_host_range_finder  G2 = (X T1)^T (X T1) -> T (X T orthonormal), M = (X T)^T X, randomized_svd of
@@ -310,7 +310,7 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
  *   grx_host_nndsvd_plan   per-column choices of NNDSVD from the grx_project statistics -> sign [r],
  *                          scale [r] for grx_nndsvd_apply and H [r x F] before thresholding
  */
- /* grx_host_eigh: the symmetric eigen-solver behind the two calls below (cyclic Jacobi up to 64 columns,
+ /* grx_host_eigh: the symmetric eigen-solver behind the two calls below (cyclic Jacobi up to 32 columns,
   * Householder tridiagonalisation + implicit QL above); h_A n x n row-major, h_w ascending, eigenvectors in
   * the columns of h_V.  Exposed for tests. */
 int grx_host_eigh(int n, const double *h_A, double *h_w, double *h_V);

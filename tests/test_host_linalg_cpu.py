@@ -133,7 +133,7 @@ def test_host_routines_validate_arguments():
 
 @pytest.mark.parametrize('n', [1, 2, 7, 33, 64, 65, 130, 257])
 def test_host_eigh_matches_numpy(n):
-    """grx_host_eigh: cyclic Jacobi up to 64 columns, Householder tridiagonalisation + implicit QL above."""
+    """grx_host_eigh: cyclic Jacobi up to 32 columns, Householder tridiagonalisation + implicit QL above."""
     from graphrole_amd import _lib
     lib = _lib.load()
     rng = np.random.RandomState(n)

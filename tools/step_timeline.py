@@ -1,0 +1,20 @@
+"""Kernel timeline of the LAST bench step from a rocprofv3 --kernel-trace csv: start (ms), idle gap before the
+kernel, duration, name.  Usage: python tools/step_timeline.py <kernel_trace.csv> <out.txt> [first-kernel-substring]"""
+import csv
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+anchor = sys.argv[3] if len(sys.argv) > 3 else 'row_sums_kernel'
+rows = list(csv.DictReader(open(src)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# the step starts with the generation-0 degree kernels: take the last run of them
+idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
+start = idx[-1]
+while start - 1 in idx:
+    start -= 1
+t0 = prev_end = int(rows[start]['Start_Timestamp'])
+with open(dst, 'w') as out:
+    for r in rows[start:]:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        out.write('%9.3f gap %7.3f dur %8.3f  %s\n' % ((s - t0) / 1e6, (s - prev_end) / 1e6, (e - s) / 1e6, r['Kernel_Name'][:100]))
+        prev_end = e
