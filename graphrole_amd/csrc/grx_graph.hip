@@ -626,6 +626,22 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
     const double *base = rows + 2 * part;
     double res0 = 0.0, res1 = 0.0;
     const int c8 = cnt & ~7;
+    // The cnt % 8 trailing neighbours are ADDED last, one by one, but nothing stops their loads from being issued
+    // first: indices, then rows, all in flight with the main part's gathers (inside `if (idx < cnt)` each index
+    // load was waited for before its gather, and each gather before the next index: up to 2 A round trips in a
+    // row).  Clamped indices re-read the last neighbour; the mask is applied where the values are used.
+    const int rem = cnt - c8;
+    double2 xt[A];
+    if (rem) {                                            // uniform over the lane group
+        int64_t ut[A];
+#pragma unroll
+        for (int t = 0; t < A; ++t) {
+            const int idx = c8 + slot + t * S;
+            ut[t] = col[b + (idx < cnt ? idx : cnt - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < A; ++t) xt[t] = *reinterpret_cast<const double2 *>(base + ut[t] * row_stride);
+    }
     if (c8) {
         double r0[A], r1[A];
 #pragma unroll
@@ -677,17 +693,13 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
         }
         res0 = r0[0]; res1 = r1[0];
     }
-    const int rem = cnt - c8;
-    if (rem) {                                            // uniform over the lane group
+    if (rem) {
         double2 x[A];
 #pragma unroll
         for (int t = 0; t < A; ++t) {
             const int idx = c8 + slot + t * S;
-            x[t] = make_double2(0.0, 0.0);
-            if (idx < cnt) {
-                const int64_t u = col[b + idx];
-                x[t] = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
-            }
+            const double2 v = tr(xt[t]);
+            x[t] = idx < cnt ? v : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {

@@ -1018,13 +1018,25 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
         double w[MAX_R];
 #pragma unroll
         for (int k = 0; k < MAX_R; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
-        for (int c = 0; c < F; ++c) {
-            double wh = 0.0;
+        // eight columns of X in flight per row (a load-use loop waits for every load in turn); the squares are
+        // added in column order as before
+        for (int c0 = 0; c0 < F; c0 += 8) {
+            double x[8];
 #pragma unroll
-            for (int k = 0; k < MAX_R; ++k)
-                if (k < r) wh += w[k] * sH[k * F + c];
-            const double d = X[(size_t)c * ldx + i] - wh;
-            s += d * d;
+            for (int j = 0; j < 8; ++j) x[j] = X[(size_t)(c0 + j < F ? c0 + j : F - 1) * ldx + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j;
+                if (c < F) {
+                    double wh = 0.0;
+#pragma unroll
+                    for (int k = 0; k < MAX_R; ++k)
+                        if (k < r) wh += w[k] * sH[k * F + c];
+                    const double d = x[j] - wh;
+                    s += d * d;
+                }
+            }
         }
     }
     s = grx_group_sum<64>(s);

@@ -52,23 +52,30 @@ constexpr uint8_t PASS_SKIPPED = 0xFF;
 // Load the ITEMS keys of this thread.  Wave w of the tile owns the contiguous slice
 // [w*64*ITEMS, (w+1)*64*ITEMS); item i of lane l is element i*64 + l of that slice, so
 // (wave, item, lane) order == memory order (needed for LSD stability) and loads coalesce.
+// The loads are issued back to back from clamped addresses and converted / masked afterwards, behind a scheduling
+// barrier: a load inside `if (idx < n)` -- or a conversion next to it -- makes hipcc wait for every load before it
+// issues the next one (s_waitcnt vmcnt(0) sixteen times per thread; found in the ISA).
 template <bool from_f64>
 __device__ __forceinline__ void load_keys(const void *__restrict__ src, int64_t n, int64_t tile_base,
                                           uint64_t (&keys)[SORT_ITEMS], uint32_t &valid_mask)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = tile_base + (int64_t)wave * 64 * SORT_ITEMS + lane;
-    valid_mask = 0;
+    const int64_t last = n > 0 ? n - 1 : 0;
+    uint64_t raw[SORT_ITEMS];
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * 64;
-        if (idx < n) {
-            valid_mask |= 1u << i;
-            if (from_f64) keys[i] = f64_to_key(reinterpret_cast<const double *>(src)[idx]);
-            else keys[i] = reinterpret_cast<const uint64_t *>(src)[idx];
-        } else {
-            keys[i] = 0xFFFFFFFFFFFFFFFFull;
-        }
+        raw[i] = reinterpret_cast<const uint64_t *>(src)[idx < n ? idx : last];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    valid_mask = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool ok = base + (int64_t)i * 64 < n;
+        valid_mask |= ok ? 1u << i : 0u;
+        const uint64_t k = from_f64 ? f64_to_key(__longlong_as_double((long long)raw[i])) : raw[i];
+        keys[i] = ok ? k : 0xFFFFFFFFFFFFFFFFull;
     }
 }
 
@@ -386,13 +393,22 @@ __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict_
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)tile * BITS_TILE;
     uint64_t o = 0, z = 0;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
-        if (idx < n) {
-            const uint64_t k = f64_to_key(x[idx] + 0.0);      // + 0.0: -0.0 and 0.0 are one value (np.unique)
-            o |= k;
-            z |= ~k;
+    const int64_t last = n > 0 ? n - 1 : 0;
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+        // eight loads in flight (clamped addresses), then the conversions (see load_keys)
+        double raw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t idx = base + (int64_t)(i0 + j) * 256 + threadIdx.x;
+            raw[j] = x[idx < n ? idx : last];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t idx = base + (int64_t)(i0 + j) * 256 + threadIdx.x;
+            const uint64_t k = f64_to_key(raw[j] + 0.0);      // + 0.0: -0.0 and 0.0 are one value (np.unique)
+            o |= idx < n ? k : 0;
+            z |= idx < n ? ~k : 0;
         }
     }
 #pragma unroll
@@ -457,16 +473,36 @@ __device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool fr
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = tile_base + (int64_t)wave * 64 * SORT_ITEMS + lane;
+    const int64_t last = n > 0 ? n - 1 : 0;
     valid_mask = 0;
+    if (from_f64) {
+        // loads first, conversion behind a scheduling barrier (see load_keys)
+        double raw[SORT_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int64_t idx = base + (int64_t)i * 64;
-        if (idx < n) {
-            valid_mask |= 1u << i;
-            if (from_f64) keys[i] = (KeyT)(f64_to_key(reinterpret_cast<const double *>(src)[idx] + 0.0) >> lo_shift);
-            else keys[i] = reinterpret_cast<const KeyT *>(src)[idx];
-        } else {
-            keys[i] = (KeyT)~(KeyT)0;
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const int64_t idx = base + (int64_t)i * 64;
+            raw[i] = reinterpret_cast<const double *>(src)[idx < n ? idx : last];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const bool ok = base + (int64_t)i * 64 < n;
+            valid_mask |= ok ? 1u << i : 0u;
+            keys[i] = ok ? (KeyT)(f64_to_key(raw[i] + 0.0) >> lo_shift) : (KeyT)~(KeyT)0;
+        }
+    } else {
+        KeyT raw[SORT_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const int64_t idx = base + (int64_t)i * 64;
+            raw[i] = reinterpret_cast<const KeyT *>(src)[idx < n ? idx : last];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const bool ok = base + (int64_t)i * 64 < n;
+            valid_mask |= ok ? 1u << i : 0u;
+            keys[i] = ok ? raw[i] : (KeyT)~(KeyT)0;
         }
     }
 }
@@ -970,12 +1006,22 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
         const int rows = (int)((row_end - r0 < CH_ROWS) ? (row_end - r0) : CH_ROWS);
         __syncthreads();
         if (rows == CH_ROWS && ((r0 | align_or) & 3) == 0) {
-            // full tile, 4-byte aligned columns: element e = (column, dword) over all 256 lanes, so the
-            // loads of a tile are independent and issue back to back
-            for (int e = threadIdx.x; e < F * (CH_ROWS / 4); e += 256) {
-                const int c = e / (CH_ROWS / 4), w = e % (CH_ROWS / 4);
-                reinterpret_cast<uint32_t *>(tile + c * CH_STRIDE)[w] =
-                    reinterpret_cast<const uint32_t *>(ptrs[c] + r0)[w];
+            // full tile, 4-byte aligned columns: element e = (column, dword) over all 256 lanes; eight loads per
+            // thread are issued before the first LDS store (a load-store loop waits for every load in turn)
+            const int total = F * (CH_ROWS / 4);
+            for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 256 * j < total ? e0 + 256 * j : total - 1;
+                    v[j] = reinterpret_cast<const uint32_t *>(ptrs[e / (CH_ROWS / 4)] + r0)[e % (CH_ROWS / 4)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 256 * j;
+                    if (e < total) reinterpret_cast<uint32_t *>(tile + (e / (CH_ROWS / 4)) * CH_STRIDE)[e % (CH_ROWS / 4)] = v[j];
+                }
             }
         } else {
             for (int e = threadIdx.x; e < F * CH_ROWS; e += 256) {
