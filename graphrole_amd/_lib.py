@@ -65,6 +65,7 @@ _SIGNATURES = {
     'grx_event_record': (c_int, [c_void_p, c_void_p]),
     'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     'grx_profile_enable': (c_int, [c_int]),
+    'grx_profile_enabled': (c_int, []),
     'grx_profile_select': (c_int, [ctypes.c_uint64]),
     'grx_profile_reset': (c_int, []),
     'grx_profile_kernel_count': (c_int, []),

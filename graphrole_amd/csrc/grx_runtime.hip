@@ -79,6 +79,8 @@ int grx_profile_enable(int on)
     return GRX_OK;
 }
 
+int grx_profile_enabled(void) { return g_prof_on ? 1 : 0; }
+
 int grx_profile_select(uint64_t kernel_mask)
 {
     g_prof_mask = kernel_mask ? kernel_mask : ~0ull;

@@ -561,7 +561,8 @@ def test_chebyshev_cap_semantics_and_column_groups(K, F, n):
 # ------------------------------------------------------------------------------------- NMF
 @pytest.mark.parametrize('shape', [(1000, 7, 4), (50000, 12, 6), (3000, 40, 6), (2000, 64, 8), (700, 100, 16),
                                    (100, 3, 2), (4099, 48, 5), (1001, 17, 3), (333, 33, 2), (17, 1, 1), (5000, 49, 4),
-                                   (1200, 121, 4), (900, 200, 7), (600, 480, 16)])
+                                   (1200, 121, 4), (900, 200, 7), (600, 480, 16),
+                                   (777, 70, 5), (1500, 90, 3), (2049, 128, 6), (130, 113, 4)])
 def test_nmf_building_blocks_vs_numpy(K, shape):
     import torch
     from oracle import rolx

@@ -98,6 +98,7 @@ def _worker_rccl(rank, port, kind, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ['GRX_FORCE_COLLECTIVES'] = '1'
+    os.environ['GRX_SHARDED_GRAPHS'] = '1'                      # the replayed MU block (opt-in)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
