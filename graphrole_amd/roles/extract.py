@@ -32,13 +32,19 @@ class RoleExtractor:
         n_roles: Optional[int] = None,
         n_role_range: Optional[Tuple[int, int]] = None,
         n_bit_range: Optional[Tuple[int, int]] = None,
+        distributed=None,
     ) -> None:
         """
         n_roles fixes the rank of the factorisation; when it is None the rank and the code length are
         picked by minimum description length over the grid n_role_range x n_bit_range (inclusive
         (low, high) pairs, defaults N_ROLE_RANGE / N_BIT_RANGE).
+        distributed (new; the reference is single-process): True / a torch.distributed process group -- every rank
+        passes the SAME feature table and seeds numpy alike; the row passes of every factorisation (Gram matrices,
+        projection, multiplicative updates, residuals, the KL error cost of a grid cell) cover the rank's rows only
+        and are summed over the ranks, the small quantisation runs replicated; every rank ends with the same factors.
         """
         self.n_roles = n_roles
+        self.distributed = distributed
 
         self.min_roles, self.max_roles = n_role_range if n_role_range else self.N_ROLE_RANGE
         self.min_bits, self.max_bits = n_bit_range if n_bit_range else self.N_BIT_RANGE
@@ -71,7 +77,8 @@ class RoleExtractor:
             # the two factors hold n_roles * (n_nodes + n_features) values; encode them with
             # about log2(n_roles * min(shape)) bits (:69-72)
             n_bits = int(np.log2(self.n_roles * min(features.shape)))
-            node_role, role_feature = self._get_encoded_role_factors(features, self.n_roles, n_bits, self.quantizer)
+            node_role, role_feature = self._get_encoded_role_factors(features, self.n_roles, n_bits, self.quantizer,
+                                                                     self._plan(features.shape[0]))
         else:
             node_role, role_feature = self._select_model(features)
 
@@ -81,6 +88,13 @@ class RoleExtractor:
 
     def explain(self):
         raise NotImplementedError('Role explanation ("sense making") is not yet implemented.')
+
+    def _plan(self, n_rows: int):
+        """Row shards of the feature table (equal row counts: every row of the NMF passes costs the same)."""
+        if not self.distributed:
+            return None
+        from graphrole_amd import parallel
+        return parallel.maybe_plan(np.zeros(n_rows + 1, dtype=np.int64), self.distributed)
 
     def _select_model(self, features: pd.DataFrame) -> FactorTuple:
         """
@@ -94,6 +108,8 @@ class RoleExtractor:
         K = backend.get()
         V = factor._checked_matrix(features.values)
         Vd = factor.feature_major(V)
+        plan = self._plan(V.shape[0])
+        rb, re = (0, V.shape[0]) if plan is None else (plan.row_begin, plan.row_end)
         bit_stop = self.max_bits + 1
         role_stop = min(min(features.shape), self.max_roles) + 1
         encoding_costs = np.full((role_stop, bit_stop), np.nan)
@@ -103,14 +119,18 @@ class RoleExtractor:
         for roles in range(self.min_roles, role_stop):
             for bits in range(self.min_bits, bit_stop):
                 try:
-                    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits, self.quantizer)
+                    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, roles, bits, self.quantizer,
+                                                                                  plan)
                 except factor.TooFewSamples:
                     # more bins requested than there are factor entries to quantise (the reference swallows
                     # KMeans' ValueError here, roles/extract.py:127-129); any other error surfaces
                     continue
                 # description_length.py:32-41 / :44-61 on the device-resident factors
                 encoding_costs[roles, bits] = np.ceil(np.log2(max(uniq_g, uniq_f))) * (Wq.numel() + Hq.numel())
-                error_costs[roles, bits] = state.kl_cost(Wq, Hq)
+                cost = state.kl_cost(Wq, Hq, rb, re)
+                if plan is not None:
+                    cost = float(plan.all_reduce_sum_host(np.array([cost]))[0])
+                error_costs[roles, bits] = cost
                 factors[roles][bits] = (Wq, Hq)
 
         costs = self._rescale_costs(encoding_costs) + self._rescale_costs(error_costs)
@@ -123,13 +143,14 @@ class RoleExtractor:
 
     @staticmethod
     def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int,
-                                  quantizer: Optional[str] = None) -> FactorTuple:
+                                  quantizer: Optional[str] = None, plan=None) -> FactorTuple:
         """NMF of the feature matrix with both factors quantised to 2**n_bits levels (:144-161)"""
         from graphrole_amd import backend
         K = backend.get()
         V = factor._checked_matrix(features.values)
         Vd = factor.feature_major(V)
-        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer)
+        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer,
+                                                        plan)
         return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
 
     @staticmethod

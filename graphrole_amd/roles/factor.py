@@ -287,17 +287,23 @@ def _checked_matrix(X) -> np.ndarray:
     return X
 
 
-def nmf_state(Xd, X: np.ndarray, n_roles: int):
+def nmf_state(Xd, X: np.ndarray, n_roles: int, plan=None):
     """
     Run the factorisation of the host matrix X whose feature-major copy Xd [F, n] is already in
     HBM; returns (NmfState with W [r, n] and H [r, F] on the device, n_iter).  Consumes numpy's
-    global RNG exactly like sklearn (one Gaussian test matrix).
+    global RNG exactly like sklearn (one Gaussian test matrix).  With a ShardPlan the row passes cover the
+    rank's rows only (every rank must hold the same X and draw the same test matrix: seed numpy alike) and the
+    rows of W are gathered at the end, so that every rank returns the complete factor.
     """
     K = _kernels()
     n, F = X.shape
     if n_roles > min(n, F):
         raise ValueError("init = 'nndsvda' can only be used when n_components <= min(n_samples, n_features)")
     omega = draw_omega(X.shape, n_roles)
+    if plan is not None and n >= F:
+        state, n_iter = nmf_device(Xd, n, n_roles, omega, plan=plan)
+        plan.all_gather_block(state.W[:, :n])
+        return state, n_iter
     if n < F:
         # fewer nodes than features: every matrix of the initialisation is small (k x F algebra)
         W0h, H0 = _host_init(X, n_roles, omega)
@@ -343,7 +349,7 @@ def _quantize_flat(flat, n_bins: int, quantizer: str):
     return q, info
 
 
-def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantizer: str = 'kmeans'):
+def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantizer: str = 'kmeans', plan=None):
     """
     NMF of X followed by the quantisation of both factors with 2**n_bits levels, without leaving
     HBM (roles/extract.py:144-161).  Returns (state, Wq [r, n], Hq [r, F], distinct values of Wq,
@@ -354,7 +360,7 @@ def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantiz
     """
     K = _kernels()
     n, F = X.shape
-    state, _ = nmf_state(Xd, X, n_roles)
+    state, _ = nmf_state(Xd, X, n_roles, plan)
     n_bins = int(2 ** n_bits)
     for size in (n_roles * n, n_roles * F):               # encode(G) first, then encode(F)
         if n_bins > size:

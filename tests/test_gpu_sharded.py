@@ -140,3 +140,49 @@ def test_rccl_collectives_one_rank(kind, tmp_path):
     assert int(r['n_iter']) == int(r['it1'])
     np.testing.assert_allclose(r['H'], r['H1'], rtol=1e-9)
     np.testing.assert_allclose(r['W'], r['W1'], rtol=1e-9, atol=1e-12 * np.abs(r['W1']).max())
+
+
+def _roles_worker(rank, port, out_dir):
+    import pandas as pd
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from graphrole_amd import RecursiveFeatureExtractor, RoleExtractor
+        G = _graph('ba')
+        X = RecursiveFeatureExtractor(G, max_generations=3).extract_features()
+        out = {}
+        for tag, kwargs in (('grid', dict(n_role_range=(2, 4), n_bit_range=(2, 5))), ('fixed', dict(n_roles=4))):
+            for mode, distributed in (('sharded', True), ('single', None)):
+                if mode == 'single' and rank != 0:
+                    continue
+                np.random.seed(11)
+                rx = RoleExtractor(distributed=distributed, **kwargs)
+                rx.extract_role_factors(X)
+                out[f'{tag}_{mode}_G'] = rx.node_role_factor.values
+                out[f'{tag}_{mode}_F'] = rx.role_feature_factor.values
+                if tag == 'grid':
+                    out[f'{tag}_{mode}_sel'] = np.array(rx.model_selection_['selected'])
+                    out[f'{tag}_{mode}_err'] = rx.model_selection_['error_costs']
+        np.savez(os.path.join(out_dir, f'roles{rank}.npz'), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_role_extraction_two_ranks_one_gpu(tmp_path):
+    """RoleExtractor(distributed=True) on the real kernels: row-sharded factorisations and KL costs of the MDL grid
+    (grx_gram / grx_project / grx_nmf_w_pass / grx_nmf_kl_cost with row ranges + all-reduces), replicated KMeans
+    encode; both ranks end with the single-process factors and cost grid."""
+    mp.spawn(_roles_worker, args=(_free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = np.load(tmp_path / 'roles0.npz'), np.load(tmp_path / 'roles1.npz')
+    assert list(r0['grid_sharded_sel']) == list(r1['grid_sharded_sel']) == list(r0['grid_single_sel'])
+    np.testing.assert_allclose(r0['grid_sharded_err'], r0['grid_single_err'], rtol=1e-8, equal_nan=True)
+    for tag in ('grid', 'fixed'):
+        for part in ('G', 'F'):
+            a, b, s = r0[f'{tag}_sharded_{part}'], r1[f'{tag}_sharded_{part}'], r0[f'{tag}_single_{part}']
+            assert np.array_equal(a, b), 'ranks disagree'
+            np.testing.assert_allclose(a, s, rtol=1e-8, atol=1e-11 * np.abs(s).max())

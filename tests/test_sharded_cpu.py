@@ -115,3 +115,53 @@ def test_shard_plan_balances_edges_not_nodes():
         assert cuts[0] < 2500                            # first rank owns the hubs -> fewer rows
     finally:
         dist.destroy_process_group()
+
+
+def _roles_worker(rank, port, case, out_dir, WORLD):
+    import pandas as pd
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from graphrole_amd import RoleExtractor, backend
+        from tests import fake_kernels
+        backend.use(fake_kernels)
+        g = util.load_refex(case)
+        ref = util.load_roles(case)
+        X = pd.DataFrame(g['final_values'], index=g.js('labels'), columns=g.js('final_columns'))
+        out = {}
+        for tag, kwargs in (('grid', dict(n_role_range=(2, 4), n_bit_range=(1, 4))), ('fixed', dict(n_roles=3))):
+            for mode, distributed in (('sharded', True), ('single', None)):
+                if mode == 'single' and rank != 0:
+                    continue
+                np.random.seed(int(ref['seed']))
+                rx = RoleExtractor(distributed=distributed, **kwargs)
+                rx.extract_role_factors(X)
+                out[f'{tag}_{mode}_G'] = rx.node_role_factor.values
+                out[f'{tag}_{mode}_F'] = rx.role_feature_factor.values
+                if tag == 'grid':
+                    out[f'{tag}_{mode}_sel'] = np.array(rx.model_selection_['selected'])
+                    out[f'{tag}_{mode}_err'] = rx.model_selection_['error_costs']
+        np.savez(os.path.join(out_dir, f'roles{rank}.npz'), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case,WORLD', [('er300', 2), ('karate', 3)])
+def test_sharded_role_extraction_equals_single_process(case, WORLD, tmp_path):
+    """RoleExtractor(distributed=True): the row passes of every factorisation of the MDL grid and the KL error cost
+    of every cell run on the rank's rows and are summed over the ranks; every rank ends with the factors and the
+    cost grids of a single-process fit (same numpy seed on every rank)."""
+    mp.spawn(_roles_worker, args=(_free_port(), case, str(tmp_path), WORLD), nprocs=WORLD, join=True)
+    r0 = np.load(tmp_path / 'roles0.npz')
+    rl = np.load(tmp_path / f'roles{WORLD - 1}.npz')
+    for tag in ('grid', 'fixed'):
+        for part in ('G', 'F'):
+            a, b, s = r0[f'{tag}_sharded_{part}'], rl[f'{tag}_sharded_{part}'], r0[f'{tag}_single_{part}']
+            # (the CPU test double quantises with sklearn's threaded KMeans: centres are equal to an ulp, not bitwise)
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=0, err_msg='ranks disagree')
+            assert a.shape == s.shape
+            np.testing.assert_allclose(a, s, rtol=1e-9, atol=1e-12 * np.abs(s).max())
+    assert list(r0['grid_sharded_sel']) == list(rl['grid_sharded_sel']) == list(r0['grid_single_sel'])
+    np.testing.assert_allclose(r0['grid_sharded_err'], r0['grid_single_err'], rtol=1e-9, equal_nan=True)
