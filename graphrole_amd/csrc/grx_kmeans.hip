@@ -214,19 +214,31 @@ __global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__
     }
 }
 
-__global__ __launch_bounds__(64) void km_choose_kernel(const double *__restrict__ ppart, int nb, int n_trials, int seed_no,
-                                                       KmState *st, double *__restrict__ seeds_x,
-                                                       int64_t *__restrict__ seeds_id)
+// one wavefront per candidate: lane-strided partial sums (eight loads in flight), fixed butterfly -- a single
+// thread walking the thousands of block partials of its candidate was a 0.1 ms latency chain per seed
+__global__ __launch_bounds__(64 * KM_MAX_TRIALS) void km_choose_kernel(const double *__restrict__ ppart, int nb,
+                                                                       int n_trials, int seed_no, KmState *st,
+                                                                       double *__restrict__ seeds_x,
+                                                                       int64_t *__restrict__ seeds_id)
 {
     __shared__ double pots[KM_MAX_TRIALS];
-    const int j = threadIdx.x;
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (j < n_trials) {
+        const double *src = ppart + (size_t)j * nb;
         double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += ppart[(size_t)j * nb + b];
-        pots[j] = s;
+        for (int b0 = lane; b0 < nb; b0 += 64 * 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[b0 + 64 * q < nb ? b0 + 64 * q : nb - 1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += b0 + 64 * q < nb ? v[q] : 0.0;
+        }
+        s = grx_group_sum<64>(s);
+        if (lane == 0) pots[j] = s;
     }
     __syncthreads();
-    if (j == 0) {
+    if (threadIdx.x == 0) {
         // np.argmin: first minimum.  Exact ties are COMMON on small inputs -- two isolated candidates that each
         // capture only themselves and each other give the same potential, the same numbers summed in swapped
         // positions -- and BLAS returns bit-equal sums for them where another summation order may not: potentials
@@ -633,7 +645,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                                                                         d_uniform + (size_t)(c - 1) * n_trials, n_trials,
                                                                         c == 1, state);
         km_pots_kernel<<<p.nb, 256, 0, st>>>(x, d, m, n_trials, state, ppart);
-        km_choose_kernel<<<1, 64, 0, st>>>(ppart, p.nb, n_trials, c, state, seeds_x, seeds_id);
+        km_choose_kernel<<<1, 64 * n_trials, 0, st>>>(ppart, p.nb, n_trials, c, state, seeds_x, seeds_id);
         km_update_kernel<<<(int)p.ntiles, 256, 0, st>>>(x, d, m, state, tsum);
     }
     GRX_LAUNCH_CHECK();
