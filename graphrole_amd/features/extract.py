@@ -398,7 +398,8 @@ class RecursiveFeatureExtractor:
     def _frame_of(self, names: Sequence[str], cols: Sequence) -> pd.DataFrame:
         K = self._K()
         n = self._n()
-        labels = pd.Index(self._labels())
+        csr = self.graph.to_csr()
+        labels = csr.label_index() if hasattr(csr, 'label_index') else pd.Index(self._labels())
         if not names:
             return pd.DataFrame(index=labels)
         block = K.to_host(K.permute_columns(list(cols), self._inv_device(), n))           # [F, n], label order

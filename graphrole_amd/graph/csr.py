@@ -90,9 +90,12 @@ class CSRGraph:
         self.directed = bool(directed)
         self.weighted = w is not None
         self.num_edges = int(len(src))
-        self.labels = list(range(n)) if labels is None else list(labels)
+        # default labels stay a range: a million-entry list (and the pandas Index built from it for every result
+        # table) costs ~0.1 s that the rest of the pipeline no longer has
+        self.labels = range(int(n)) if labels is None else list(labels)
         if len(self.labels) != n:
             raise ValueError('labels must have n entries')
+        self._label_index = None
         # The host CSR is built on first use: the device path ingests the edge arrays directly
         # (grx_ingest, graphrole_amd/kernels.py::device_ingest) and never needs it.
         self._edges = (src, dst, w)
@@ -162,6 +165,16 @@ class CSRGraph:
         return self.col[self.row_ptr[row]:self.row_ptr[row + 1]]
 
     # ------------------------------------------------------------------ other array-native inputs
+    def label_index(self):
+        """pandas Index of the node labels (row order), built once."""
+        if self._label_index is None:
+            import pandas as pd
+            if isinstance(self.labels, range):
+                self._label_index = pd.Index(np.arange(self.n, dtype=np.int64))
+            else:
+                self._label_index = pd.Index(self.labels)
+        return self._label_index
+
     @classmethod
     def from_scipy_sparse(cls, A, directed: bool = False, weighted: Optional[bool] = None,
                           labels: Optional[Sequence] = None,

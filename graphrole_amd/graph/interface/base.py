@@ -180,7 +180,9 @@ class DeviceGraphInterface(BaseGraphInterface):
         K = self._K()
         host = self._device_graph()[0]
         data = {nm: host.to_label_order(K.to_host(c)).astype(dt) for nm, c, dt in zip(names, cols, dtypes)}
-        return pd.DataFrame(data, index=pd.Index(host.labels), columns=names)
+        csr = self.to_csr()
+        index = csr.label_index() if hasattr(csr, 'label_index') else pd.Index(host.labels)
+        return pd.DataFrame(data, index=index, columns=names)
 
     # -- reference API on top ------------------------------------------------------------
     def _get_local_features(self) -> pd.DataFrame:
