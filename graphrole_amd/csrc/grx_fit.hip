@@ -11,7 +11,6 @@
 #include "grx_common.h"
 
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -76,68 +75,6 @@ FitLayout fit_layout(int64_t n, int F, int r)
 
 }  // namespace
 
-namespace {
-
-// Ten multiplicative updates (30 small dependent launches) as ONE replayed HIP graph: captured on a private
-// stream the first time a full block runs, replayed for the later blocks of the fit.  The caller's stream is
-// joined by events on both sides.  Anything that prevents the capture (kernel profiling on, GRX_NO_GRAPHS=1, a
-// caller stream that is itself being captured, a runtime error) leaves the plain launch sequence.
-struct MuBlock {
-    int64_t n; int F, r; const double *d_X; int64_t ldx; double *d_W; int64_t ldw; double *d_H, *d_AB;
-    void *ws; size_t ws_bytes; hipStream_t caller;
-    hipStream_t side = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    bool off = false;
-
-    ~MuBlock()
-    {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (ev_in) (void)hipEventDestroy(ev_in);
-        if (ev_out) (void)hipEventDestroy(ev_out);
-        if (side) (void)hipStreamDestroy(side);
-    }
-
-    int eager(int steps) { return grx_nmf_iterate(n, F, r, d_X, ldx, d_W, ldw, d_H, d_AB, nullptr, steps, ws, ws_bytes, caller); }
-
-    bool capture()
-    {
-        const char *no = std::getenv("GRX_NO_GRAPHS");
-        if (grx_prof_is_on() || (no && no[0] == '1')) return false;
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipStreamBeginCapture(side, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
-        const int rc = grx_nmf_iterate(n, F, r, d_X, ldx, d_W, ldw, d_H, d_AB, nullptr, 10, ws, ws_bytes, side);
-        hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(side, &g);
-        bool ok = rc == GRX_OK && e == hipSuccess && g != nullptr &&
-                  hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
-        if (!ok) { exec = nullptr; (void)hipGetLastError(); }
-        return ok;
-    }
-
-    int run(int steps)
-    {
-        if (steps != 10 || off) return eager(steps);
-        if (!exec && !capture()) { off = true; return eager(steps); }
-        GRX_CHECK_HIP(hipEventRecord(ev_in, caller));
-        GRX_CHECK_HIP(hipStreamWaitEvent(side, ev_in, 0));
-        GRX_CHECK_HIP(hipGraphLaunch(exec, side));
-        GRX_CHECK_HIP(hipEventRecord(ev_out, side));
-        GRX_CHECK_HIP(hipStreamWaitEvent(caller, ev_out, 0));
-        return GRX_OK;
-    }
-};
-
-}  // namespace
-
 extern "C" {
 
 size_t grx_nmf_fit_workspace_bytes(int64_t n, int F, int r)
@@ -168,7 +105,6 @@ int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *
     double *host = nullptr;
     GRX_TRY(staging((nA + nB + nA + 8) * 8, &host));
 
-    MuBlock block{n, F, r, d_X, ldx, d_W, ldw, d_H, d_AB, mu_ws, mu_bytes, st};
     info->n_iter = 0;
     info->direct_residuals = 0;
     info->x_sq_norm = x_sq_norm;
@@ -183,7 +119,9 @@ int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *
     while (n_iter < max_iter) {
         const int step = (max_iter - n_iter) < 10 ? (max_iter - n_iter) : 10;
         const bool check = tol > 0.0 && (n_iter + step) % 10 == 0;
-        GRX_TRY(block.run(step));
+        // (a replayed HIP graph of the block was measured and removed: capture + instantiation cost 0.4 ms per fit,
+        // and even a cached executable graph replayed slower than these launches -- DESIGN.md section 3)
+        GRX_TRY(grx_nmf_iterate(n, F, r, d_X, ldx, d_W, ldw, d_H, d_AB, nullptr, step, mu_ws, mu_bytes, stream));
         n_iter += step;
         if (!check) continue;
         // _nmf.py:872-885.  ||X - W H||_F from the W-pass outputs A = W^T X, B = W^T W and the updated H:

@@ -63,6 +63,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (lane == 0) out[p] = s;
 }
 
+// One entry of the H update, H[k][c] * (A[k][c] / sum_l B[k][l] H[l][c]) with a zero denominator replaced by
+// EPSILON (_nmf.py:638-641).  The products are accumulated with explicit fused multiply-adds so that the
+// stand-alone kernel and the copy in the W-pass prologue give the same bits whatever the compiler contracts.
+__device__ __forceinline__ double h_update_value(const double *H, const double *sB, double a, int idx, int F, int r)
+{
+    const int k = idx / F, c = idx % F;
+    double denom = 0.0;
+    for (int l = 0; l < r; ++l) denom = __fma_rn(sB[k * r + l], H[l * F + c], denom);
+    if (denom == 0.0) denom = NMF_EPSILON;
+    return H[idx] * (a / denom);
+}
+
 // ---------------------------------------------------------------------------------------
 // Gram of the (optionally transformed) rows
 // ---------------------------------------------------------------------------------------
@@ -825,7 +837,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
                                                               const double *__restrict__ X, int64_t ldx,
                                                               double *__restrict__ W, int64_t ldw,
                                                               const double *__restrict__ H,
-                                                              double *__restrict__ partial)
+                                                              double *__restrict__ partial,
+                                                              const double *__restrict__ AB_prev,
+                                                              double *__restrict__ H_out)
 {
     constexpr int FT = (NQ + 3) / 4;                             // 16-column tiles of the A accumulator
     constexpr int F4 = NQ;                                       // K steps of 4 columns over c
@@ -834,10 +848,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
     double *sHH = fsm + 4 * WAVE_LDS;                            // 16 x 16
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lq = lane >> 4;
+    double *sH = fsm;                                            // r * F <= 16 * 120 doubles, aliases the wave slices
     // H H^T (r x r, zero padded to 16 x 16) through LDS
     {
-        double *sH = fsm;                                        // r * F <= 16 * 120 doubles, aliases the wave slices
         for (int idx = t; idx < r * F; idx += 256) sH[idx] = H[idx];
+        if (AB_prev != nullptr) {
+            // The H update of the PREVIOUS iteration, H <- H * A / (B H) from its reduced sums, recomputed by
+            // every workgroup (r F <= 1920 outputs, a microsecond) instead of a launch of its own between two
+            // W passes; workgroup 0 also stores it.  Same arithmetic as nmf_h_update_kernel (h_update_value).
+            double *sB = fsm + r * F;                            // r x r
+            for (int idx = t; idx < r * r; idx += 256) sB[idx] = AB_prev[r * F + idx];
+            __syncthreads();
+            constexpr int PER = (MAX_R * MAX_F + 255) / 256;     // 8 outputs per thread at most
+            double hn[PER];
+#pragma unroll
+            for (int s_ = 0; s_ < PER; ++s_) {
+                const int idx = t + 256 * s_;
+                hn[s_] = idx < r * F ? h_update_value(sH, sB, AB_prev[idx], idx, F, r) : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s_ = 0; s_ < PER; ++s_) {
+                const int idx = t + 256 * s_;
+                if (idx < r * F) {
+                    sH[idx] = hn[s_];
+                    if (blockIdx.x == 0 && H_out != nullptr) H_out[idx] = hn[s_];
+                }
+            }
+        }
         __syncthreads();
         {
             const int k = t >> 4, l = t & 15;
@@ -852,7 +890,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
 #pragma unroll
     for (int q = 0; q < F4; ++q) {
         const int c = 4 * q + lq;
-        hA[q] = (li < r && c < F) ? H[li * F + c] : 0.0;
+        hA[q] = (li < r && c < F) ? sH[li * F + c] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < R4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
@@ -971,9 +1009,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
     }
 }
 
-// H <- H * (A / (B H)), one workgroup; B (r x r) in LDS, A and H (r x F, a few KB, cache resident)
-// read in place: every H[l][c] is read before the barrier that precedes the writes.
-__global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, double *__restrict__ H,
+// H <- H * (A / (B H)), one workgroup; B (r x r) in LDS, A and H (r x F, a few KB, cache resident); every
+// H[l][c] is read before the barrier that precedes the writes, so H_out may be H_in.
+__global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, const double *H_in, double *H_out,
                                                            const double *__restrict__ AB)
 {
     __shared__ double sB[MAX_R * MAX_R];
@@ -984,20 +1022,13 @@ __global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, double 
 #pragma unroll
     for (int s = 0; s < PER; ++s) {
         const int idx = threadIdx.x + 256 * s;
-        hnew[s] = 0.0;
-        if (idx < r * F) {
-            const int k = idx / F, c = idx % F;
-            double denom = 0.0;
-            for (int l = 0; l < r; ++l) denom += sB[k * r + l] * H[l * F + c];
-            if (denom == 0.0) denom = NMF_EPSILON;
-            hnew[s] = H[idx] * (AB[idx] / denom);
-        }
+        hnew[s] = idx < r * F ? h_update_value(H_in, sB, AB[idx], idx, F, r) : 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < PER; ++s) {
         const int idx = threadIdx.x + 256 * s;
-        if (idx < r * F) H[idx] = hnew[s];
+        if (idx < r * F) H_out[idx] = hnew[s];
     }
 }
 
@@ -1212,7 +1243,7 @@ __global__ __launch_bounds__(256) void nmf_w_accum_wide_kernel(int64_t row_begin
 
 // launch table over (NQ, R4): function pointers of the instantiations
 using WPassKernel = void (*)(int64_t, int64_t, int, int, const double *, int64_t, double *, int64_t, const double *,
-                             double *);
+                             double *, const double *, double *);
 template <int R4, int... NQs>
 constexpr std::array<WPassKernel, sizeof...(NQs)> w_pass_table(std::integer_sequence<int, NQs...>)
 {
@@ -1486,12 +1517,24 @@ size_t grx_nmf_workspace_bytes(int64_t n, int F, int r)
     const size_t P = (size_t)r * F + (size_t)r * r;
     const size_t a = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256);
     const size_t b = grx_align_up((size_t)RES_GRID * 8, 256);
-    return a + b;
+    return a + b + 2 * grx_align_up((size_t)r * F * 8, 256);        // + the two H buffers of grx_nmf_iterate
 }
 
-int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
-                   int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
-                   void *d_workspace, size_t workspace_bytes, void *stream)
+// the two r x F scratch copies of H at the end of the workspace (grx_nmf_iterate)
+static double *nmf_h_scratch(void *d_workspace, int F, int r, int which)
+{
+    const size_t P = (size_t)r * F + (size_t)r * r;
+    const size_t off = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256) + grx_align_up((size_t)RES_GRID * 8, 256) +
+                       (size_t)which * grx_align_up((size_t)r * F * 8, 256);
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(d_workspace) + off);
+}
+
+// d_AB_prev / d_H_out (single-launch kernels only, F <= MAX_F): the kernel first applies the H update of the
+// previous iteration to d_H (from d_AB_prev) and stores the result in d_H_out -- see nmf_w_pass_mfma_kernel
+static int w_pass_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                       int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
+                       const double *d_AB_prev, double *d_H_out,
+                       void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ldx >= n && ldw >= n,
                 "grx_nmf_w_pass: bad row range");
@@ -1518,9 +1561,10 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
             const int cap = mfma_resident_grid(F, r, lds);
             grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
             hipLaunchKernelGGL(w_pass_kernel(F, r), dim3(grid), dim3(256), lds, st, row_begin, row_end, F, r, d_X,
-                               ldx, d_W, ldw, d_H, partial);
+                               ldx, d_W, ldw, d_H, partial, d_AB_prev, d_H_out);
         } else {
             (void)FT;
+            GRX_REQUIRE(d_AB_prev == nullptr, "w_pass_impl: the chunked kernels have no fused H update");
             const int cap = GRX_NUM_CU * 4;
             grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
             if (r <= 8) nmf_w_update_wide_kernel<2><<<grid, 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H);
@@ -1537,13 +1581,21 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
     return GRX_OK;
 }
 
+int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                   int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB,
+                   void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H, d_AB, nullptr, nullptr, d_workspace,
+                       workspace_bytes, stream);
+}
+
 int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream)
 {
     int rc = check_nmf_shape("grx_nmf_h_update", F, r);
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(d_H && d_AB, "grx_nmf_h_update: NULL pointer");
     { GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
-    nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H, d_AB);
+    nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H, d_H, d_AB);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -1615,11 +1667,31 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
                     size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(iters >= 0, "grx_nmf_iterate: iters < 0");
-    for (int it = 0; it < iters; ++it) {
-        int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream);
-        if (rc != GRX_OK) return rc;
-        rc = grx_nmf_h_update(F, r, d_H, d_AB, stream);
-        if (rc != GRX_OK) return rc;
+    if (F <= MAX_F && iters > 0) {
+        // two launches per iteration instead of three: the W pass of iteration i starts by applying the H update
+        // of iteration i - 1 (every workgroup recomputes the r x F entries; workgroup 0 stores them, ping-pong
+        // between two scratch copies so that no workgroup reads what another is writing); one stand-alone
+        // update closes the block
+        const double *h_in = d_H;
+        for (int it = 0; it < iters; ++it) {
+            double *h_out = nmf_h_scratch(d_workspace, F, r, it & 1);
+            int rc = w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, 0, n, h_in, d_AB, it ? d_AB : nullptr, it ? h_out : nullptr,
+                                 d_workspace, workspace_bytes, stream);
+            if (rc != GRX_OK) return rc;
+            if (it) h_in = h_out;
+        }
+        {
+            GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
+            nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, h_in, d_H, d_AB);
+        }
+        GRX_LAUNCH_CHECK();
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream);
+            if (rc != GRX_OK) return rc;
+            rc = grx_nmf_h_update(F, r, d_H, d_AB, stream);
+            if (rc != GRX_OK) return rc;
+        }
     }
     if (d_err)
         return grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err, d_workspace, workspace_bytes, stream);

@@ -254,26 +254,6 @@ class ShardPlan:
         from graphrole_amd import kernels as K
         return (K.to_host(out) if out.is_cuda else out.numpy()).reshape((self.world,) + a.shape)
 
-    #: set to the exception text when a HIP-graph capture of the MU block failed (the loop then runs eagerly)
-    capture_error: Optional[str] = None
-
-    def graph_capturable(self) -> bool:
-        """Collectives of this plan may be recorded into a HIP graph: asked for with GRX_SHARDED_GRAPHS=1,
-        device-to-device RCCL only (a solo plan has no collectives and uses the single-GPU driver instead), event
-        profiler off."""
-        import os
-        # opt-in (GRX_SHARDED_GRAPHS=1) until the captured collective has been seen working on more than one
-        # physical GPU: the only RCCL capture this code has run is the one-rank group of tests/test_gpu_sharded.py
-        if os.environ.get('GRX_SHARDED_GRAPHS') != '1':
-            return False
-        if self._solo or os.environ.get('GRX_NO_GRAPHS') == '1' or not torch.cuda.is_available():
-            return False
-        if dist.get_backend(self.group) != 'nccl':
-            return False
-        # the per-kernel event profiler records events around every launch: not inside a capture
-        from graphrole_amd import _lib
-        return not _lib.load().grx_profile_enabled()
-
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         with self._time('all_reduce_max'):
             return self._all_reduce_(t, dist.ReduceOp.MAX)

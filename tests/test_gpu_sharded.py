@@ -98,7 +98,6 @@ def _worker_rccl(rank, port, kind, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ['GRX_FORCE_COLLECTIVES'] = '1'
-    os.environ['GRX_SHARDED_GRAPHS'] = '1'                      # the replayed MU block (opt-in)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
@@ -113,9 +112,6 @@ def _worker_rccl(rank, port, kind, out_dir):
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
         state, n_iter = factor.nmf_device(Xd, G.n, 4, omega, plan=plan)
-        graphs = getattr(state, '_mu_graphs', {})
-        graph_used = bool(graphs) and all(g is not False for g in graphs.values())
-        capture_error = plan.capture_error or ''
         os.environ['GRX_FORCE_COLLECTIVES'] = '0'
         fe1 = RecursiveFeatureExtractor(G, max_generations=4, aggs=['sum', 'mean', 'max'])
         X1 = fe1.extract_features()
@@ -123,7 +119,6 @@ def _worker_rccl(rank, port, kind, out_dir):
         s1, it1 = factor.nmf_device(Xd1, G.n, 4, omega)
         np.savez(os.path.join(out_dir, 'rccl.npz'), X=X.values.astype(float), cols=np.array(list(X.columns)),
                  X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), n_iter=n_iter, it1=it1,
-                 graph_used=graph_used, capture_error=capture_error,
                  H=K.to_host(state.H), H1=K.to_host(s1.H), W=K.to_host(state.W)[:, :G.n], W1=K.to_host(s1.W)[:, :G.n])
     finally:
         dist.destroy_process_group()
@@ -133,8 +128,6 @@ def _worker_rccl(rank, port, kind, out_dir):
 def test_rccl_collectives_one_rank(kind, tmp_path):
     mp.spawn(_worker_rccl, args=(_free_port(), kind, str(tmp_path)), nprocs=1, join=True)
     r = np.load(tmp_path / 'rccl.npz')
-    # the MU block (W pass + RCCL all-reduce + H update, ten iterations) ran as a replayed HIP graph
-    assert bool(r['graph_used']), f"MU block was not captured: {str(r['capture_error'])}"
     assert list(r['cols']) == list(r['cols1'])
     assert np.array_equal(r['X'], r['X1'])
     assert int(r['n_iter']) == int(r['it1'])
