@@ -72,7 +72,7 @@ int grx_event_elapsed_ms(void *start, void *stop, float *ms_out);   /* synchroni
  * grx_profile_reset.
  */
 int grx_profile_enable(int on);
-int grx_profile_enabled(void);                  /* 1 while the event profiler is on (HIP graphs are not captured then) */
+int grx_profile_enabled(void);                  /* 1 while the event profiler is on */
 int grx_profile_select(uint64_t kernel_mask);   /* bit i = time kernel id i; 0 = all (default) */
 int grx_profile_reset(void);
 int grx_profile_kernel_count(void);
