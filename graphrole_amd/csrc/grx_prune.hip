@@ -385,6 +385,10 @@ struct BinPlanCol {
 };
 
 constexpr int BITS_TILE = 256 * 32;
+// INTEGER columns (every value a non-negative integer below 2^32: degrees, ego-net counts, their neighbour sums) may
+// be sorted by the integer itself instead of the fp64 bit pattern: a degree-like column below 2^16 varies in two
+// bytes of the integer but in four of the fp64 key (exponent + leading mantissa bits).  Marked by lo_shift.
+constexpr int LO_SHIFT_INT = 255;
 
 __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
                                                        int ntiles, uint64_t *__restrict__ bits)
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict_
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)tile * BITS_TILE;
     uint64_t o = 0, z = 0;
+    uint32_t oi = 0, zi = 0, notint = 0;
     const int64_t last = n > 0 ? n - 1 : 0;
     for (int i0 = 0; i0 < 32; i0 += 8) {
         // eight loads in flight (clamped addresses), then the conversions (see load_keys)
@@ -406,21 +411,33 @@ __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t idx = base + (int64_t)(i0 + j) * 256 + threadIdx.x;
-            const uint64_t k = f64_to_key(raw[j] + 0.0);      // + 0.0: -0.0 and 0.0 are one value (np.unique)
+            const double v = raw[j] + 0.0;                    // + 0.0: -0.0 and 0.0 are one value (np.unique)
+            const uint64_t k = f64_to_key(v);
             o |= idx < n ? k : 0;
             z |= idx < n ? ~k : 0;
+            const bool in_range = v >= 0.0 && v < 4294967296.0;  // false for NaN
+            const uint32_t iv = in_range ? (uint32_t)v : 0u;
+            const bool isint = in_range && (double)iv == v;
+            oi |= idx < n ? iv : 0u;
+            zi |= idx < n ? ~iv : 0u;
+            notint |= (idx < n && !isint) ? 1u : 0u;
         }
     }
+    uint64_t w2 = (uint64_t)oi | ((uint64_t)notint << 32), w3 = zi;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         o |= __shfl_xor(o, off, 64);
         z |= __shfl_xor(z, off, 64);
+        w2 |= __shfl_xor(w2, off, 64);
+        w3 |= __shfl_xor(w3, off, 64);
     }
-    __shared__ uint64_t wb[4][2];
-    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6][0] = o; wb[threadIdx.x >> 6][1] = z; }
+    __shared__ uint64_t wb[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        wb[threadIdx.x >> 6][0] = o; wb[threadIdx.x >> 6][1] = z; wb[threadIdx.x >> 6][2] = w2; wb[threadIdx.x >> 6][3] = w3;
+    }
     __syncthreads();
-    if (threadIdx.x < 2)
-        bits[((size_t)col * ntiles + tile) * 2 + threadIdx.x] =
+    if (threadIdx.x < 4)
+        bits[((size_t)col * ntiles + tile) * 4 + threadIdx.x] =
             wb[0][threadIdx.x] | wb[1][threadIdx.x] | wb[2][threadIdx.x] | wb[3][threadIdx.x];
 }
 
@@ -428,15 +445,19 @@ __global__ __launch_bounds__(64) void bin_plan_kernel(const uint64_t *__restrict
                                                       BinPlanCol *__restrict__ plan)
 {
     const int col = blockIdx.x, lane = threadIdx.x;
-    uint64_t o = 0, z = 0;
+    uint64_t o = 0, z = 0, w2 = 0, w3 = 0;
     for (int t = lane; t < ntiles; t += 64) {
-        o |= bits[((size_t)col * ntiles + t) * 2];
-        z |= bits[((size_t)col * ntiles + t) * 2 + 1];
+        o |= bits[((size_t)col * ntiles + t) * 4];
+        z |= bits[((size_t)col * ntiles + t) * 4 + 1];
+        w2 |= bits[((size_t)col * ntiles + t) * 4 + 2];
+        w3 |= bits[((size_t)col * ntiles + t) * 4 + 3];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         o |= __shfl_xor(o, off, 64);
         z |= __shfl_xor(z, off, 64);
+        w2 |= __shfl_xor(w2, off, 64);
+        w3 |= __shfl_xor(w3, off, 64);
     }
     if (lane != 0) return;
     const uint64_t varying = o & z;                           // a bit varies iff set in one key and clear in another
@@ -461,6 +482,21 @@ __global__ __launch_bounds__(64) void bin_plan_kernel(const uint64_t *__restrict
             p.lo_shift = (uint8_t)(8 * (hi - 3));
             for (int b = hi - 3; b <= hi; ++b)
                 if ((varying >> (8 * b)) & 0xFF) p.dshift[p.npass++] = (uint8_t)(8 * b);
+        }
+        // integer column: the integer key when it needs fewer rounds than the fp64 pattern
+        if (((w2 >> 32) & 1ull) == 0) {
+            const uint32_t vi = (uint32_t)w2 & (uint32_t)w3;
+            int rounds = 0;
+            for (int b = 0; b < 4; ++b) rounds += ((vi >> (8 * b)) & 0xFF) ? 1 : 0;
+            if (rounds < p.npass) {
+                p.narrow = 1;
+                p.lo_shift = (uint8_t)LO_SHIFT_INT;
+                p.const_bits = 0;
+                p.npass = 0;
+                for (int j = 0; j < 4; ++j) p.dshift[j] = 0;
+                for (int b = 0; b < 4; ++b)
+                    if ((vi >> (8 * b)) & 0xFF) p.dshift[p.npass++] = (uint8_t)(8 * b);
+            }
         }
     }
     plan[col] = p;
@@ -488,7 +524,9 @@ __device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool fr
         for (int i = 0; i < SORT_ITEMS; ++i) {
             const bool ok = base + (int64_t)i * 64 < n;
             valid_mask |= ok ? 1u << i : 0u;
-            keys[i] = ok ? (KeyT)(f64_to_key(raw[i] + 0.0) >> lo_shift) : (KeyT)~(KeyT)0;
+            const KeyT k = lo_shift == LO_SHIFT_INT ? (KeyT)(uint32_t)(raw[i] + 0.0)
+                                                    : (KeyT)(f64_to_key(raw[i] + 0.0) >> lo_shift);
+            keys[i] = ok ? k : (KeyT)~(KeyT)0;
         }
     } else {
         KeyT raw[SORT_ITEMS];
@@ -800,7 +838,8 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
             const int64_t pos = done + size - 1;
             const uint32_t k = s[pos];
             const int64_t end = run_end<uint32_t>(s, 0, (uint64_t)k, pos + 1, n);
-            if (threadIdx.x == 0) t[nb] = key_to_f64(((uint64_t)k << p.lo_shift) | p.const_bits);
+            if (threadIdx.x == 0)
+                t[nb] = p.lo_shift == LO_SHIFT_INT ? (double)k : key_to_f64(((uint64_t)k << p.lo_shift) | p.const_bits);
             ++nb;
             done = end;
         }
@@ -1166,7 +1205,7 @@ size_t grx_log_bin_workspace_bytes(int64_t n, int ncols)
     const SortPlan p = make_plan(n, ncols);
     // keysA + sorted + hist + thresholds + nbins + pass-skipping state (key bits, flags)
     return 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
-           grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 16, 256) +
+           grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 32, 256) +
            grx_align_up((size_t)ncols * sizeof(BinPlanCol), 256);
 }
 
@@ -1212,7 +1251,7 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
     char *plan_ws = reinterpret_cast<char *>(nb_ws) + grx_align_up((size_t)ncols * 4, 256);
     uint64_t *bits = reinterpret_cast<uint64_t *>(plan_ws);
-    BinPlanCol *plan = reinterpret_cast<BinPlanCol *>(plan_ws + grx_align_up((size_t)ncols * p.ntiles * 16, 256));
+    BinPlanCol *plan = reinterpret_cast<BinPlanCol *>(plan_ws + grx_align_up((size_t)ncols * p.ntiles * 32, 256));
     // which key bytes vary -> per-column plan (NARROW 32-bit keys / WIDE top-four-bytes sort)
     const int nbt = (int)grx_ceil_div(n, BITS_TILE);
     {

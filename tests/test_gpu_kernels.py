@@ -457,6 +457,14 @@ def test_log_bin_window_sort_adversarial(K, n):
         rng.pareto(1.2, n),                                           # heavy tail, all distinct
         -rng.pareto(1.2, n).round(1),                                 # negative, ties
         np.where(rng.random(n) < 0.3, -0.0, rng.standard_normal(n).round(1)),
+        # integer-key mode (non-negative integers below 2^32 sorted by the integer itself) and its boundaries
+        rng.integers(0, 300, n).astype(np.float64),                   # two varying bytes as integers, four as fp64
+        np.minimum(rng.pareto(1.1, n) * 50, 4294967295.0).round(),    # degree-like, up to the last admissible value
+        np.where(rng.random(n) < 0.001, 4294967296.0, rng.integers(0, 1 << 16, n).astype(np.float64)),   # 2^32: not admissible
+        np.where(rng.random(n) < 0.001, 0.5, rng.integers(0, 1 << 16, n).astype(np.float64)),            # one non-integer
+        np.where(rng.random(n) < 0.001, -3.0, rng.integers(0, 1 << 16, n).astype(np.float64)),           # one negative
+        np.where(rng.random(n) < 0.5, -0.0, rng.integers(0, 5, n).astype(np.float64)),                   # -0.0 is the integer 0
+        (rng.integers(0, 1 << 12, n) * 65536).astype(np.float64),     # integers varying in bytes 2..3 only
     ]
     for frac in (0.5, 0.3, 0.9):
         block = torch.from_numpy(np.stack(cols)).cuda()
