@@ -39,6 +39,15 @@ int staging(size_t bytes, double **out)
     return GRX_OK;
 }
 
+// one size for every driver of a fit: the buffer is then never reallocated while a copy of an earlier stage is
+// still in flight (init: F*F + 1 + 4 r doubles; MU loop: [A | B], H and two scalars)
+size_t staging_bytes(int F, int r)
+{
+    const size_t a = (size_t)F * F + 1 + (size_t)r * 4;
+    const size_t b = (size_t)2 * r * F + (size_t)r * r + 8;
+    return (a > b ? a : b) * 8;
+}
+
 // device -> pinned host, then wait for the stream: the values are valid on return
 int fetch(double *h_dst, const double *d_src, size_t count, hipStream_t st)
 {
@@ -103,18 +112,19 @@ int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *
     double *d_err = reinterpret_cast<double *>(ws + L.small);
     const size_t nA = (size_t)r * F, nB = (size_t)r * r;
     double *host = nullptr;
-    GRX_TRY(staging((nA + nB + nA + 8) * 8, &host));
+    GRX_TRY(staging(staging_bytes(F, r), &host));
 
     info->n_iter = 0;
     info->direct_residuals = 0;
     info->x_sq_norm = x_sq_norm;
     // initial error, _nmf.py:826 (always the direct pass: W0 H0 is far from X, but the identity's
-    // inputs A, B do not exist yet)
-    GRX_TRY(grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err, mu_ws, mu_bytes, stream));
-    GRX_TRY(fetch(host, d_err, 1, st));
-    const double err_init = std::sqrt(host[0]);
-    info->err_init = info->err_last = err_init;
-    double prev = err_init;
+    // inputs A, B do not exist yet).  It is only needed at the first convergence check: the scalar stays
+    // on the device (d_err[1]) and comes back with that check's block -- one synchronisation fewer per fit.
+    double *d_err_init = d_err + 1;
+    GRX_TRY(grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err_init, mu_ws, mu_bytes, stream));
+    double *h_err_init = host + nA + nB + nA;
+    bool have_init = false;
+    double err_init = 0.0, prev = 0.0;
     int n_iter = 0;
     while (n_iter < max_iter) {
         const int step = (max_iter - n_iter) < 10 ? (max_iter - n_iter) : 10;
@@ -129,6 +139,7 @@ int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *
         // exact, so it is only trusted for a relative squared residual above 1e-8 (its own rounding error
         // is then far under the 1e-4 stopping tolerance); otherwise the direct kernel runs.
         double err = -1.0;
+        if (!have_init) GRX_CHECK_HIP(hipMemcpyAsync(h_err_init, d_err_init, 8, hipMemcpyDeviceToHost, st));
         if (x_sq_norm > 0.0) {
             GRX_CHECK_HIP(hipMemcpyAsync(host, d_AB, (nA + nB) * 8, hipMemcpyDeviceToHost, st));
             GRX_TRY(fetch(host + nA + nB, d_H, nA, st));
@@ -151,17 +162,29 @@ int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *
             err = std::sqrt(host[0]);
             info->direct_residuals += 1;
         }
+        if (!have_init) {                                     // arrived with one of the fetches above
+            err_init = prev = std::sqrt(*h_err_init);
+            have_init = true;
+        }
         info->err_last = err;
         if ((prev - err) / err_init < tol) break;
         prev = err;
     }
+    if (!have_init) {                                         // no convergence check took place
+        GRX_TRY(fetch(h_err_init, d_err_init, 1, st));
+        err_init = std::sqrt(*h_err_init);
+        info->err_last = err_init;
+    }
+    info->err_init = err_init;
     info->n_iter = n_iter;
     return GRX_OK;
 }
 
-int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
-                 double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, void *d_workspace,
-                 size_t workspace_bytes, void *stream)
+// wait_for_upload = false (grx_nmf_fit): the caller goes on enqueueing on the same stream and does not touch the
+// staging buffer from the host before its next synchronisation
+static int nmf_init_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
+                         double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, void *d_workspace,
+                         size_t workspace_bytes, void *stream, bool wait_for_upload)
 {
     GRX_REQUIRE(n >= 1 && F >= 1 && r >= 1 && n >= F && r <= F, "grx_nmf_init: needs n >= F >= r >= 1 (n=%lld F=%d r=%d)",
                 (long long)n, F, r);
@@ -176,7 +199,7 @@ int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const 
     double *d_small = reinterpret_cast<double *>(ws + L.small);
     const size_t big_bytes = L.ab;
     double *host = nullptr;
-    GRX_TRY(staging(((size_t)F * F + 1 + (size_t)r * 4) * 8, &host));
+    GRX_TRY(staging(staging_bytes(F, r), &host));
 
     // X = Q M with orthonormal Q from two Gram passes: eigh(X^T X) whitens, the second pass
     // re-orthogonalises; sklearn's randomized_svd of X (extmath.py:531-604) then runs on the k x F
@@ -215,8 +238,16 @@ int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const 
     // through the pinned buffer: a pageable source would make the asynchronous copy synchronous anyway
     std::memcpy(host, H.data(), (size_t)r * F * 8);
     GRX_CHECK_HIP(hipMemcpyAsync(d_H, host, (size_t)r * F * 8, hipMemcpyHostToDevice, st));
-    GRX_CHECK_HIP(hipStreamSynchronize(st));                          // `host` is reused by the next call
+    if (wait_for_upload) GRX_CHECK_HIP(hipStreamSynchronize(st));     // `host` is reused by the next call
     return GRX_OK;
+}
+
+int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
+                 double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, void *d_workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    return nmf_init_impl(n, F, r, d_X, ldx, h_omega, n_over, d_W, ldw, d_H, x_sq_norm, d_workspace, workspace_bytes,
+                         stream, true);
 }
 
 int grx_nmf_fit(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
@@ -225,7 +256,8 @@ int grx_nmf_fit(int64_t n, int F, int r, const double *d_X, int64_t ldx, const d
 {
     GRX_REQUIRE(info != nullptr, "grx_nmf_fit: info is NULL");
     double xx = -1.0;
-    GRX_TRY(grx_nmf_init(n, F, r, d_X, ldx, h_omega, n_over, d_W, ldw, d_H, &xx, d_workspace, workspace_bytes, stream));
+    GRX_TRY(nmf_init_impl(n, F, r, d_X, ldx, h_omega, n_over, d_W, ldw, d_H, &xx, d_workspace, workspace_bytes, stream,
+                          false));
     return grx_nmf_mu(n, F, r, d_X, ldx, d_W, ldw, d_H, xx, tol, max_iter, info, d_workspace, workspace_bytes, stream);
 }
 
