@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
     int64_t row_begin, int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
 {
     constexpr int G = 8;
+    __shared__ unsigned long long ego_filter[256 / G][16];
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -151,6 +152,21 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
         const bool mine_v = (uu[0] == (int32_t)v) | (uu[1] == (int32_t)v) | (uu[2] == (int32_t)v) | (uu[3] == (int32_t)v);
         const bool v_in_row = ((__ballot(mine_v) >> gshift) & 0xFFull) != 0;
         const int members = (int)dv + (v_in_row ? 0 : 1);
+        // 1024-bit membership filter of ego(v) (one bit per id & 1023) in the group's LDS slice: an arc target is
+        // compared against the ego ids only when its bit is set -- with at most 33 bits set most 8-arc chunks of a
+        // member's row end after one LDS read, a bit test and a ballot (all outside) instead of the all-pairs
+        // shuffle compare
+        unsigned long long *flt = ego_filter[threadIdx.x / G];
+        __builtin_amdgcn_wave_barrier();                       // the previous node's readers are done
+        flt[lane] = 0ull;
+        flt[lane + G] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i <= EGO_SLOTS; ++i) {
+            const int32_t id = i < EGO_SLOTS ? uu[i < EGO_SLOTS ? i : 0] : (lane == 0 ? (int32_t)v : -2);
+            if (id >= 0) atomicOr(&flt[(id >> 6) & 15], 1ull << (id & 63));
+        }
+        __builtin_amdgcn_wave_barrier();
         double ins = 0.0, ext = 0.0;
         for (int m = 0; m < members; ++m) {
             int32_t a;
@@ -169,11 +185,14 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
                     const int32_t b = live ? col[j0 + lane] : -1;
                     const double x = live ? (w ? w[j0 + lane] : 1.0) : 0.0;
                     unsigned match = 0;
+                    const bool maybe = live && ((flt[(b >> 6) & 15] >> (b & 63)) & 1ull);
+                    if ((__ballot(maybe) >> gshift) & 0xFFull) {        // uniform over the group
 #pragma unroll
-                    for (int sidx = 0; sidx < G; ++sidx) {
-                        const int32_t bs = __shfl(b, sidx, G);
-                        const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
-                        if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
+                        for (int sidx = 0; sidx < G; ++sidx) {
+                            const int32_t bs = __shfl(b, sidx, G);
+                            const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
+                            if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
+                        }
                     }
                     if (live) {
                         const bool inside = ((match >> lane) & 1u) || b == (int32_t)v;
