@@ -886,20 +886,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
         }
         __syncthreads();
     }
-    double hA[F4], hhA[R4];
+    // SMALL (r <= 8): v_mfma_f64_4x4x4 (four independent 4x4x4 blocks per instruction, 19 cycles against
+    // 66 for the 16x16x4 form) with the roles padded to 8 instead of 16.  Lane = 16 k + 4 block + i: A[block][i][k],
+    // B[block][k][j] and D[block][i][j] at lane 16 i + 4 block + j (probed: tools/microbench/
+    // mfma_f64_4x4x4_probe.hip).  The four blocks of an instruction take the four 4-row groups of the sub-tile
+    // (phase 1) / four 4-column groups of a 16-column feature tile (phase 2), the A operand -- four roles -- is
+    // the same in every block; two instructions cover the eight roles.  The B operands and the result lanes are
+    // those of the 16x16x4 form (X as loaded; role = 4 rho + (lane >> 4), row / column = lane & 15).
+    constexpr bool SMALL = (R4 == 2);
+    const int l3 = lane & 3;
+    double hA[SMALL ? 1 : F4], hhA[SMALL ? 1 : R4];
+    double hA2[SMALL ? F4 : 1][2], hhA2[SMALL ? R4 : 1][2];
+    if constexpr (SMALL) {
 #pragma unroll
-    for (int q = 0; q < F4; ++q) {
-        const int c = 4 * q + lq;
-        hA[q] = (li < r && c < F) ? sH[li * F + c] : 0.0;
+        for (int q = 0; q < F4; ++q)
+#pragma unroll
+            for (int rho = 0; rho < 2; ++rho) {
+                const int k = 4 * rho + l3, c = 4 * q + lq;
+                hA2[q][rho] = (k < r && c < F) ? sH[k * F + c] : 0.0;
+            }
+#pragma unroll
+        for (int q = 0; q < R4; ++q)
+#pragma unroll
+            for (int rho = 0; rho < 2; ++rho) hhA2[q][rho] = sHH[(4 * rho + l3) * 16 + 4 * q + lq];
+    } else {
+#pragma unroll
+        for (int q = 0; q < F4; ++q) {
+            const int c = 4 * q + lq;
+            hA[q] = (li < r && c < F) ? sH[li * F + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < R4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
     }
-#pragma unroll
-    for (int q = 0; q < R4; ++q) hhA[q] = sHH[li * 16 + 4 * q + lq];
     __syncthreads();                                             // sH (aliased) is dead from here on
     double *xT = fsm + wave * WAVE_LDS;                          // [c][i], row stride MF_LD
     double *wT = xT + 16 * FT * MF_LD;                           // [k][i]
     v4d accA[FT], accB = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ct = 0; ct < FT; ++ct) accA[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double acc2[2][FT], accB2[2] = {0.0, 0.0};                   // SMALL: [rho][feature tile]
+#pragma unroll
+    for (int ct = 0; ct < FT; ++ct) acc2[0][ct] = acc2[1][ct] = 0.0;
     // When the last 16-column tile of A has r spare columns (F = 20, r = 6: columns 4..9 of tile 1),
     // W' rides along as extra "feature" columns F..F+r-1 of the LDS tile and B = W'^T W' comes out of
     // the same MFMAs as A: four matrix instructions fewer per sub-tile (12 -> 8 in phase 2).
@@ -930,15 +957,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
         const int64_t row = row_begin + sidx * 16 + li;
         const bool valid = row < row_end;
         v4d num = {0.0, 0.0, 0.0, 0.0}, den = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (SMALL) {
+            double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < F4; ++q) {
-            xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
-            num = __builtin_amdgcn_mfma_f64_16x16x4f64(hA[q], xb[q], num, 0, 0, 0);
-        }
+            for (int q = 0; q < F4; ++q) {
+                xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
+                n0 = __builtin_amdgcn_mfma_f64_4x4x4f64(hA2[q][0], xb[q], n0, 0, 0, 0);
+                n1 = __builtin_amdgcn_mfma_f64_4x4x4f64(hA2[q][1], xb[q], n1, 0, 0, 0);
+            }
 #pragma unroll
-        for (int q = 0; q < R4; ++q) {
-            wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
-            den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
+            for (int q = 0; q < R4; ++q) {
+                wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
+                d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(hhA2[q][0], wb[q], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(hhA2[q][1], wb[q], d1, 0, 0, 0);
+            }
+            num[0] = n0; num[1] = n1; den[0] = d0; den[1] = d1;
+        } else {
+#pragma unroll
+            for (int q = 0; q < F4; ++q) {
+                xb[q] = (valid && 4 * q + lq < F) ? xb[q] : 0.0;
+                num = __builtin_amdgcn_mfma_f64_16x16x4f64(hA[q], xb[q], num, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < R4; ++q) {
+                wb[q] = (valid && 4 * q + lq < r) ? wb[q] : 0.0;
+                den = __builtin_amdgcn_mfma_f64_16x16x4f64(hhA[q], wb[q], den, 0, 0, 0);
+            }
         }
         double wnew[R4];
 #pragma unroll
@@ -971,13 +1015,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int i = 4 * st + lq;
-            const double aW = wT[li * MF_LD + i];
+            if constexpr (SMALL) {
+                const double a0 = wT[l3 * MF_LD + i], a1 = wT[(4 + l3) * MF_LD + i];   // W'[row i][role rho * 4 + l3]
 #pragma unroll
-            for (int ct = 0; ct < FT; ++ct) {
-                const double bX = xT[(16 * ct + li) * MF_LD + i];
-                accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, bX, accA[ct], 0, 0, 0);
+                for (int ct = 0; ct < FT; ++ct) {
+                    const double bX = xT[(16 * ct + li) * MF_LD + i];
+                    acc2[0][ct] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bX, acc2[0][ct], 0, 0, 0);
+                    acc2[1][ct] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bX, acc2[1][ct], 0, 0, 0);
+                }
+                if (!fuse_b) {
+                    const double bW = wT[li * MF_LD + i];                          // rows k >= r of wT hold zeros
+                    accB2[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bW, accB2[0], 0, 0, 0);
+                    accB2[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bW, accB2[1], 0, 0, 0);
+                }
+            } else {
+                const double aW = wT[li * MF_LD + i];
+#pragma unroll
+                for (int ct = 0; ct < FT; ++ct) {
+                    const double bX = xT[(16 * ct + li) * MF_LD + i];
+                    accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, bX, accA[ct], 0, 0, 0);
+                }
+                if (!fuse_b) accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, aW, accB, 0, 0, 0);
             }
-            if (!fuse_b) accB = __builtin_amdgcn_mfma_f64_16x16x4f64(aW, aW, accB, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -986,12 +1045,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
     // fixed-order sum of the four waves' accumulators: red[wave][tile][g][lane]
     __syncthreads();
     double *red = fsm + wave * WAVE_LDS;                         // (FT + 1) * 256 doubles <= WAVE_LDS
+    if constexpr (SMALL) {                                       // g = rho: role (lane >> 4) + 4 g as in the other form
 #pragma unroll
-    for (int ct = 0; ct < FT; ++ct)
+        for (int ct = 0; ct < FT; ++ct)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) red[(ct * 4 + g) * 64 + lane] = accA[ct][g];
+            for (int g = 0; g < 4; ++g) red[(ct * 4 + g) * 64 + lane] = g < 2 ? acc2[g][ct] : 0.0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) red[(FT * 4 + g) * 64 + lane] = accB[g];
+        for (int g = 0; g < 4; ++g) red[(FT * 4 + g) * 64 + lane] = g < 2 ? accB2[g] : 0.0;
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < FT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[(ct * 4 + g) * 64 + lane] = accA[ct][g];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(FT * 4 + g) * 64 + lane] = accB[g];
+    }
     __syncthreads();
     for (int idx = t; idx < (FT + 1) * 256; idx += 256) {
         const int tile = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63;
