@@ -392,8 +392,10 @@ int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, con
                     int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H, double *d_out,
                     void *d_workspace, size_t workspace_bytes, void *stream);
 /*
- * Enqueue `iters` full single-GPU iterations (w_pass + h_update each) followed by one residual
- * evaluation into d_err[0]; no host synchronisation.  This is the unit bench.py times.
+ * Enqueue `iters` full single-GPU iterations followed (d_err != NULL) by one residual evaluation into
+ * d_err[0]; no host synchronisation.  Same results as `iters` x (grx_nmf_w_pass, grx_nmf_h_update), two
+ * launches per iteration instead of three: for F <= 120 the H update of an iteration runs in the prologue of the
+ * next W pass (two scratch copies of H at the end of the workspace), d_H holds the final H on completion.
  */
 int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
                     int64_t ldw, double *d_H, double *d_AB, double *d_err, int iters,
