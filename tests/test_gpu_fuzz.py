@@ -13,3 +13,13 @@ def test_refex_random_graphs_equal_oracle(seed):
     rng = np.random.default_rng(seed)
     done = sum(fuzz_refex.one(rng, case) != 'skip' for case in range(40))
     assert done >= 30
+
+
+@pytest.mark.parametrize('seed', [21, 22])
+def test_rolx_random_tables_equal_oracle(seed):
+    """tools/fuzz_rolx.py: random non-negative tables (F = 2..140, r = 2..8, dense / graded / sparse / rank-deficient):
+    the GPU factorisation stops at the oracle's iteration and gives its factors to 1e-7."""
+    from tools import fuzz_rolx
+    rng = np.random.default_rng(seed)
+    for case in range(25):
+        fuzz_rolx.one(rng, case)
