@@ -114,6 +114,8 @@ _SIGNATURES = {
     'grx_nmf_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'grx_nmf_w_pass': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_w_pass_next': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_h_update': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_residual': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

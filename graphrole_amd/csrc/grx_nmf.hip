@@ -1657,6 +1657,21 @@ int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, doub
                        workspace_bytes, stream);
 }
 
+int grx_nmf_w_pass_next(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                        int64_t row_begin, int64_t row_end, const double *d_H_prev, const double *d_AB_prev,
+                        double *d_H_out, double *d_AB, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(d_H_prev && d_AB_prev && d_H_out && d_H_prev != d_H_out, "grx_nmf_w_pass_next: needs distinct H buffers");
+    if (F > MAX_F) {                                            // chunked kernels: the update as a launch of its own
+        GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
+        nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H_prev, d_H_out, d_AB_prev);
+        return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H_out, d_AB, nullptr, nullptr, d_workspace,
+                           workspace_bytes, stream);
+    }
+    return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H_prev, d_AB, d_AB_prev, d_H_out, d_workspace,
+                       workspace_bytes, stream);
+}
+
 int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream)
 {
     int rc = check_nmf_shape("grx_nmf_h_update", F, r);

@@ -230,13 +230,17 @@ class DeviceCSR:
     def triangle_split(self, rank: int, world: int) -> Tuple[int, int]:
         """Source-row range of the oriented CSR that `rank` of `world` counts triangles for:
         cuts balance sum(d+ * (d+ + 1)), the size of the list intersections a source row starts."""
+        cache = self.__dict__.setdefault('_tri_split', {})
+        if (rank, world) in cache:                              # a property of the graph: computed once
+            return cache[(rank, world)]
         o = self.oriented()
         dplus = np.diff(o._host[0])
         work = np.cumsum(dplus * (dplus + 1) + 1)
         total = int(work[-1]) if len(work) else 0
         cuts = [0] + [int(np.searchsorted(work, total * p / world, side='left')) for p in range(1, world)] + [self.n]
         cuts = np.maximum.accumulate(np.array(cuts, dtype=np.int64))
-        return int(cuts[rank]), int(cuts[rank + 1])
+        cache[(rank, world)] = (int(cuts[rank]), int(cuts[rank + 1]))
+        return cache[(rank, world)]
 
 
 def device_ingest(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarray], directed: bool, nnz: int):
@@ -722,6 +726,18 @@ class NmfState:
         _lib.call('grx_nmf_w_pass', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W),
                   _ld(self.W), row_begin, row_end, _ptr(self.H), _ptr(self.AB), _ptr(self.ws),
                   self.ws_bytes, _stream())
+
+    def w_pass_next(self, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        """h_update() + w_pass() in one launch less (grx_nmf_w_pass_next): self.AB must hold the (all-reduced) sums
+        of the previous pass; afterwards self.H is the updated H and self.AB this rank's new partial sums."""
+        row_end = self.n if row_end is None else row_end
+        spare = self.__dict__.get('_H_spare')
+        if spare is None:
+            spare = self._H_spare = torch.empty_like(self.H)
+        _lib.call('grx_nmf_w_pass_next', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(self.W), _ld(self.W),
+                  row_begin, row_end, _ptr(self.H), _ptr(self.AB), _ptr(spare), _ptr(self.AB), _ptr(self.ws),
+                  self.ws_bytes, _stream())
+        self.H, self._H_spare = spare, self.H
 
     def h_update(self) -> None:
         _lib.call('grx_nmf_h_update', self.F, self.r, _ptr(self.H), _ptr(self.AB), _stream())

@@ -216,9 +216,15 @@ def _sharded_mu_block(state, plan, rb: int, re: int, steps: int) -> None:
     [W^T X ; W^T W] buffer, H update.  (Capturing the block -- kernels and the RCCL all-reduce -- as a HIP graph was
     measured on a one-rank RCCL group and removed: 8.80 ms per step against 8.00 for these plain calls, the
     capture per fit costs more than the launches it saves.)"""
-    for _ in range(steps):
-        state.w_pass(rb, re)
+    for it in range(steps):
+        # iterations after the first fold the H update of their predecessor into the W pass (one launch and one
+        # host call fewer); the update of the last one closes the block
+        if it == 0:
+            state.w_pass(rb, re)
+        else:
+            state.w_pass_next(rb, re)
         plan.all_reduce_sum_(state.AB)
+    if steps:
         state.h_update()
 
 

@@ -376,6 +376,13 @@ int grx_nndsvd_apply(int64_t n, int r, double *d_U, int64_t ldu, int64_t row_beg
  *                    (_beta_divergence, _nmf.py:120-133, before the square root).
  */
 size_t grx_nmf_workspace_bytes(int64_t n, int F, int r);
+/* grx_nmf_w_pass_next: the W pass of the NEXT iteration with the H update of the previous one folded in --
+ * H = d_H_prev * A / (B d_H_prev) from the (all-reduced) d_AB_prev is computed in the kernel's prologue, used for the
+ * pass and stored in d_H_out (a different buffer); equal to grx_nmf_h_update followed by grx_nmf_w_pass, one launch
+ * fewer per iteration.  d_AB_prev may be d_AB (it is read before the partial sums are reduced into d_AB). */
+int grx_nmf_w_pass_next(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                        int64_t row_begin, int64_t row_end, const double *d_H_prev, const double *d_AB_prev,
+                        double *d_H_out, double *d_AB, void *d_workspace, size_t workspace_bytes, void *stream);
 int grx_nmf_w_pass(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
                    int64_t ldw, int64_t row_begin, int64_t row_end, const double *d_H,
                    double *d_AB, void *d_workspace, size_t workspace_bytes, void *stream);

@@ -271,6 +271,10 @@ class NmfState:
         self.err[0] = float((R * R).sum())
         return self.err
 
+    def w_pass_next(self, row_begin=0, row_end=None):
+        self.h_update()
+        self.w_pass(row_begin, row_end)
+
     def kl_cost(self, W, H, row_begin=0, row_end=None):
         row_end = self.n if row_end is None else row_end
         V = self.X.numpy()[:, row_begin:row_end].T
