@@ -309,7 +309,7 @@ def main():
     lib.grx_profile_enable(0)
     prof = profile_totals(lib)
     # the same steps once more WITHOUT the per-launch events of the timed region (what a caller runs: no event
-    # records between the small launches, the MU block replayed as a HIP graph) -- reported next to `value`,
+    # records between the small launches) -- reported next to `value`,
     # never instead of it
     plain = dict(refex=0.0, nmf=0.0, nmf_iters=0)
     barrier()
