@@ -3,7 +3,8 @@ The igraph adapter (graphrole_amd/graph/interface/igraph.py).  python-igraph is 
 this image, so the reference's igraph path cannot be run: the adapter is driven with a duck-typed
 stand-in that offers the handful of Graph methods the adapter uses, and must give, on simple graphs,
 the table the networkx adapter gives for the same edges (both reference adapters define the same
-features there).  Parity of this adapter with the reference itself is UNPINNED.
+features there) and, with self-loops / parallel edges, the table of oracle/igraph_path.py -- the reference
+adapter restated line by line on igraph's DOCUMENTED conventions.  Parity with igraph itself is UNPINNED.
 """
 import sys
 import types
@@ -134,15 +135,72 @@ def test_weighted_integer_weights_keep_int_columns(fake_backend):
     assert frame['degree'].tolist() == [5, 3, 9, 3]
 
 
-def test_loops_and_parallel_edges_are_refused(fake_backend):
+def _random_multigraph(rng, n, m, directed, loops, parallels):
+    edges = []
+    while len(edges) < m:
+        a, b = (int(x) for x in rng.integers(0, n, 2))
+        if a == b and not loops:
+            continue
+        edges.append((a, b))
+        if parallels and rng.random() < 0.25:                      # a parallel edge (either orientation)
+            edges.append((b, a) if (not directed and rng.random() < 0.5) else (a, b))
+    return edges
+
+
+@pytest.mark.parametrize('directed', [False, True])
+@pytest.mark.parametrize('weights', [None, 'int', 'float'])
+@pytest.mark.parametrize('loops,parallels', [(True, False), (False, True), (True, True)])
+def test_loops_and_parallel_edges_follow_the_reference_igraph_conventions(fake_backend, directed, weights, loops,
+                                                                          parallels):
+    """Graphs with self-loops / parallel edges against oracle/igraph_path.py, the line-by-line restatement of the
+    reference adapter on igraph's documented conventions (multiset neighbours, loops twice in neighbors() and
+    degree(), the edge_weights dict with last-weight-wins): generation 0, the recursion, column order, dtypes."""
     from graphrole_amd import RecursiveFeatureExtractor
+    from oracle import igraph_path
+    rng = np.random.default_rng(11 + 4 * directed + 2 * loops + parallels + (0 if weights is None else len(weights)))
+    n = 40
+    edges = _random_multigraph(rng, n, 110, directed, loops, parallels)
+    w = None
+    if weights == 'int':
+        w = [int(x) for x in rng.integers(1, 6, len(edges))]
+    elif weights == 'float':
+        w = [float(x) for x in rng.integers(1, 40, len(edges)) / 8.0]   # dyadic: sums are exact in any order
     Graph = _stand_in_graph_class()
-    with pytest.raises(NotImplementedError, match='self-loops'):
-        RecursiveFeatureExtractor(Graph(3, [(0, 1), (1, 1)])).extract_features()
-    with pytest.raises(NotImplementedError, match='parallel'):
-        RecursiveFeatureExtractor(Graph(3, [(0, 1), (1, 0)])).extract_features()
-    # directed: a->b and b->a are different arcs
-    RecursiveFeatureExtractor(Graph(3, [(0, 1), (1, 0), (1, 2)], directed=True)).extract_features()
+    ig = Graph(n, edges, directed, w)
+    fe = RecursiveFeatureExtractor(ig, max_generations=4)
+    X = fe.extract_features()
+    ref = igraph_path.extract_features(n, edges, directed, w, max_generations=4)
+    assert list(X.columns) == ref.columns
+    assert fe.generation_count == ref.generation_count
+    assert np.array_equal(X.values.astype(float), ref.values)
+    names0, X0 = igraph_path.neighborhood_features(n, edges, directed, w)
+    want_int = weights != 'float'
+    for nm in names0:
+        if nm in X.columns:
+            assert (str(X[nm].dtype) == 'int64') == want_int, nm
+    # get_neighbors is Graph.neighbors(v, mode='out'): the multiset, ascending
+    iface = fe.graph
+    lists = igraph_path.neighbors(n, edges, directed)
+    assert all(list(iface.get_neighbors(v)) == lists[v] for v in range(n))
+
+
+def test_igraph_hand_checked_multigraph(fake_backend):
+    """Four nodes, a doubled edge and a loop, worked by hand from igraph.py: degree counts edge ENDS (the loop
+    twice, the doubled edge twice), the ego-net sums read the edge dict (the doubled edge once)."""
+    from graphrole_amd.graph.interface import IgraphInterface
+    Graph = _stand_in_graph_class()
+    edges = [(0, 1), (1, 2), (2, 0), (0, 1), (3, 3), (2, 3)]
+    frame = IgraphInterface(Graph(4, edges)).get_neighborhood_features()
+    assert frame['degree'].tolist() == [3, 3, 3, 3]
+    assert frame['internal_edges'].tolist() == [3, 3, 5, 2]
+    assert frame['external_edges'].tolist() == [1, 1, 0, 2]
+    # weighted + directed: the second (0, 1) overwrites the first weight; total degree counts a loop once
+    frame = IgraphInterface(Graph(4, edges, directed=True, weights=[1., 2., 3., 4., 5., 6.])).get_neighborhood_features()
+    assert frame['in_degree'].tolist() == [3., 4., 2., 11.]
+    assert frame['out_degree'].tolist() == [4., 2., 9., 5.]
+    assert frame['total_degree'].tolist() == [7., 6., 11., 11.]
+    assert frame['internal_edges'].tolist() == [4., 2., 14., 5.]
+    assert frame['external_edges'].tolist() == [2., 9., 4., 0.]
 
 
 def test_empty_graph_raises_like_the_reference(fake_backend):
