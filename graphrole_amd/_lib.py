@@ -47,6 +47,20 @@ class RefexGeneration(ctypes.Structure):
 
 AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5}       # grx_agg
 
+
+class P2pOp(ctypes.Structure):
+    """grx_p2p_op of include/grx.h."""
+    _fields_ = [('is_recv', c_int), ('peer', c_int), ('d_ptr', c_void_p), ('bytes', c_size_t)]
+
+
+# transport callbacks of grx_comm_create_callbacks
+ALL_REDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p)
+EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(P2pOp), c_void_p)
+COMM_ID_BYTES = 128
+COMM_SELF_VIA_TRANSPORT = 1
+DTYPE_IDS = {'float64': 0, 'int32': 1, 'int64': 2, 'uint8': 3}                 # grx_dtype
+COMM_KINDS = ('all_reduce', 'exchange', 'all_gather_rows', 'columns_to_owners', 'owned_to_rows')   # grx_comm_kind
+
 _lib = None
 
 # name -> (restype, argtypes); every entry mirrors include/grx.h
@@ -64,6 +78,7 @@ _SIGNATURES = {
     'grx_event_destroy': (c_int, [c_void_p]),
     'grx_event_record': (c_int, [c_void_p, c_void_p]),
     'grx_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'grx_trace_marker': (c_int, [c_int, c_void_p]),
     'grx_profile_enable': (c_int, [c_int]),
     'grx_profile_enabled': (c_int, []),
     'grx_profile_select': (c_int, [ctypes.c_uint64]),
@@ -71,6 +86,22 @@ _SIGNATURES = {
     'grx_profile_kernel_count': (c_int, []),
     'grx_profile_kernel_name': (c_char_p, [c_int]),
     'grx_profile_read': (c_int, [c_int, POINTER(c_double), POINTER(ctypes.c_longlong)]),
+    'grx_comm_rccl_unique_id': (c_int, [c_void_p]),
+    'grx_comm_create_rccl': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    'grx_comm_create_callbacks': (c_int, [c_int, c_int, ALL_REDUCE_FN, EXCHANGE_FN, c_void_p, POINTER(c_void_p)]),
+    'grx_comm_destroy': (c_int, [c_void_p]),
+    'grx_comm_rank': (c_int, [c_void_p]),
+    'grx_comm_world': (c_int, [c_void_p]),
+    'grx_comm_all_reduce': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'grx_comm_exchange': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'grx_comm_all_gather_rows': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'grx_comm_columns_to_owners': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                           c_void_p]),
+    'grx_comm_owned_to_rows': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                       c_void_p]),
+    'grx_comm_timing': (c_int, [c_void_p, c_int]),
+    'grx_comm_timing_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_longlong), POINTER(c_double)]),
+    'grx_comm_timing_reset': (c_int, [c_void_p]),
     'grx_row_sums': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_add_columns': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
@@ -125,8 +156,8 @@ _SIGNATURES = {
     'grx_nmf_kl_cost': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                              c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p, POINTER(c_int),
-                              POINTER(c_size_t), c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p,
+                              POINTER(c_int), POINTER(c_size_t), c_void_p]),
     'grx_kmeans1d_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_kmeans1d': (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -142,11 +173,13 @@ _SIGNATURES = {
     'grx_host_eigh': (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_fit_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'grx_nmf_init': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p,
-                             POINTER(c_double), c_void_p, c_size_t, c_void_p]),
+                             POINTER(c_double), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_mu': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_double, c_double,
-                           c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_fit': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_double, c_int, c_void_p,
-                            c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                            c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_nmf_iterate_rows': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }

@@ -1745,11 +1745,14 @@ int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, con
     return GRX_OK;
 }
 
-int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
-                    double *d_H, double *d_AB, double *d_err, int iters, void *d_workspace,
-                    size_t workspace_bytes, void *stream)
+// `iters` multiplicative updates over rows [row_begin, row_end); comm != NULL: the partial sums [W^T X | W^T W] of
+// every pass are all-reduced before the H update that consumes them (one small collective per iteration, enqueued
+// on the same stream between the launches -- the host does not wait)
+static int nmf_iterate_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                            int64_t row_begin, int64_t row_end, double *d_H, double *d_AB, int iters, grx_comm *comm,
+                            void *d_workspace, size_t workspace_bytes, void *stream)
 {
-    GRX_REQUIRE(iters >= 0, "grx_nmf_iterate: iters < 0");
+    const size_t nAB = (size_t)r * F + (size_t)r * r;
     if (F <= MAX_F && iters > 0) {
         // two launches per iteration instead of three: the W pass of iteration i starts by applying the H update
         // of iteration i - 1 (every workgroup recomputes the r x F entries; workgroup 0 stores them, ping-pong
@@ -1758,9 +1761,13 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
         const double *h_in = d_H;
         for (int it = 0; it < iters; ++it) {
             double *h_out = nmf_h_scratch(d_workspace, F, r, it & 1);
-            int rc = w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, 0, n, h_in, d_AB, it ? d_AB : nullptr, it ? h_out : nullptr,
-                                 d_workspace, workspace_bytes, stream);
+            int rc = w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, h_in, d_AB, it ? d_AB : nullptr,
+                                 it ? h_out : nullptr, d_workspace, workspace_bytes, stream);
             if (rc != GRX_OK) return rc;
+            if (comm) {
+                rc = grx_comm_all_reduce(comm, d_AB, nAB, GRX_F64, GRX_SUM, stream);
+                if (rc != GRX_OK) return rc;
+            }
             if (it) h_in = h_out;
         }
         {
@@ -1770,15 +1777,40 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
         GRX_LAUNCH_CHECK();
     } else {
         for (int it = 0; it < iters; ++it) {
-            int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, d_workspace, workspace_bytes, stream);
+            int rc = grx_nmf_w_pass(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H, d_AB, d_workspace,
+                                    workspace_bytes, stream);
             if (rc != GRX_OK) return rc;
+            if (comm) {
+                rc = grx_comm_all_reduce(comm, d_AB, nAB, GRX_F64, GRX_SUM, stream);
+                if (rc != GRX_OK) return rc;
+            }
             rc = grx_nmf_h_update(F, r, d_H, d_AB, stream);
             if (rc != GRX_OK) return rc;
         }
     }
+    return GRX_OK;
+}
+
+int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                    double *d_H, double *d_AB, double *d_err, int iters, void *d_workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(iters >= 0, "grx_nmf_iterate: iters < 0");
+    int rc = nmf_iterate_impl(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_AB, iters, nullptr, d_workspace, workspace_bytes,
+                              stream);
+    if (rc != GRX_OK) return rc;
     if (d_err)
         return grx_nmf_residual(n, F, r, d_X, ldx, d_W, ldw, 0, n, d_H, d_err, d_workspace, workspace_bytes, stream);
     return GRX_OK;
+}
+
+int grx_nmf_iterate_rows(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                         int64_t row_begin, int64_t row_end, double *d_H, double *d_AB, int iters, grx_comm *comm,
+                         void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GRX_REQUIRE(iters >= 0, "grx_nmf_iterate_rows: iters < 0");
+    return nmf_iterate_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H, d_AB, iters, comm, d_workspace,
+                            workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -114,7 +114,8 @@ extern "C" {
 
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
-                  int n_aggs, const int *h_aggs, void *d_arena, size_t arena_bytes, int max_columns,
+                  int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
+                  size_t arena_bytes, int max_columns,
                   grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
                   int *generation_count, size_t *arena_needed, void *stream)
 {
@@ -128,6 +129,13 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         has[h_aggs[a]] = true;
     }
     hipStream_t st = grx_stream(stream);
+    // node-range sharding (include/grx.h): this rank computes rows [rb, re) of every per-node kernel; a candidate
+    // block holds only those rows until the exchanges below complete what the next step reads
+    const int P = comm ? grx_comm_world(comm) : 1, me = comm ? grx_comm_rank(comm) : 0;
+    GRX_REQUIRE(!comm || h_bounds, "grx_refex_run: a communicator needs the row partition h_bounds");
+    if (comm)
+        GRX_REQUIRE(h_bounds[0] == 0 && h_bounds[P] == n, "grx_refex_run: h_bounds must run from 0 to n");
+    const int64_t rb = comm ? h_bounds[me] : 0, re = comm ? h_bounds[me + 1] : n;
     Arena arena{reinterpret_cast<char *>(d_arena), d_arena ? arena_bytes : 0};
     std::vector<Column> cols;
     std::vector<int> work;                                   // working set, insertion order (extract.py:128-133)
@@ -137,7 +145,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
 
     // add the new columns to the working set, bin them, prune across the set, record what survives
     // (extract.py:121-142); `block` = the new columns as one contiguous [count, n] block
-    auto update = [&](int first_new, int count, const double *block, int generation) -> int {
+    auto update = [&](int first_new, int count, const double *block, int generation, bool partial) -> int {
         const size_t scratch_mark = arena.top;
         uint8_t *bins = nullptr;
         if (count) {
@@ -146,27 +154,47 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             bins = reinterpret_cast<uint8_t *>(arena.take((size_t)count * n));
         }
         const size_t persistent_top = arena.top;
-        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, count);
-        void *ws = count ? arena.take(ws_bytes) : nullptr;
+        // sharded: rank q bins columns q, q + P, ... of the new block as WHOLE columns (the threshold walk needs every
+        // row), every rank gets back the bins of its own rows of every column -- the only rows its Chebyshev pass reads
+        const int n_owned = comm ? (count > me ? (count - me + P - 1) / P : 0) : count;
+        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, n_owned);
+        void *ws = n_owned ? arena.take(ws_bytes) : nullptr;
+        double *owned = (comm && partial && n_owned) ? reinterpret_cast<double *>(arena.take((size_t)n_owned * n * 8)) : nullptr;
+        uint8_t *owned_bins = (comm && n_owned) ? reinterpret_cast<uint8_t *>(arena.take((size_t)n_owned * n)) : nullptr;
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
         const int F = (int)work.size();
         int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take((size_t)F * F * 4));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
-            if (count) {
+            if (count && !comm) {
                 GRX_TRY(grx_vertical_log_bin(n, count, block, n, 0.5, bins, n, nullptr, ws, ws_bytes, stream));
-                for (int j = 0; j < count; ++j) cols[first_new + j].bins = bins + (size_t)j * n;
+            } else if (count) {
+                const double *src = block + (size_t)me * n;       // complete columns: the owned ones are a strided view
+                int64_t ld_src = (int64_t)P * n;
+                if (partial) {
+                    // step 1: every rank's row slice of a column travels to the column's owner
+                    GRX_TRY(grx_comm_columns_to_owners(comm, h_bounds, count, block, n, 8, owned, n, stream));
+                    src = owned;
+                    ld_src = n;
+                }
+                if (n_owned)
+                    GRX_TRY(grx_vertical_log_bin(n, n_owned, src, ld_src, 0.5, owned_bins, n, nullptr, ws, ws_bytes, stream));
+                // step 2: the owners' bins of this rank's rows come back
+                GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));
             }
+            for (int j = 0; j < count; ++j) cols[first_new + j].bins = bins + (size_t)j * n;
             if (F >= 2) {
                 std::vector<const uint8_t *> ptrs(F);
                 for (int j = 0; j < F; ++j) ptrs[j] = cols[work[j]].bins;
                 GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, (size_t)F * F * 4, st));
                 // the pruner only asks "distance <= generation number?" (prune.py:110-113)
-                GRX_TRY(grx_chebyshev(0, n, F, 0, ptrs.data(), d_dist, generation, stream));
+                if (re > rb) GRX_TRY(grx_chebyshev(rb, re, F, 0, ptrs.data(), d_dist, generation, stream));
+                if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F, GRX_I32, GRX_MAX, stream));
                 void *host = nullptr;
                 GRX_TRY(pinned((size_t)F * F * 4, &host));
                 GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, (size_t)F * F * 4, hipMemcpyDeviceToHost, st));
                 GRX_CHECK_HIP(hipStreamSynchronize(st));
+                // identical distances on every rank -> identical decisions, no further agreement needed
                 drop_idx = prune(cols, work, reinterpret_cast<const int32_t *>(host), generation, recorded);
             }
         }
@@ -178,6 +206,13 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         std::vector<int> kept;
         for (int j = 0; j < count; ++j)
             if (!dropped[first_new + j]) kept.push_back(first_new + j);
+        if (comm && partial && !kept.empty() && !arena.overflow) {
+            // step 3: the retained new columns -- the next generation's gather source and part of the result -- and
+            // only those become complete on every rank (typically 1/3 to 1/6 of the candidates)
+            std::vector<void *> ptrs;
+            for (int c : kept) ptrs.push_back(const_cast<double *>(cols[c].data));
+            GRX_TRY(grx_comm_all_gather_rows(comm, h_bounds, (int)ptrs.size(), ptrs.data(), 8, stream));
+        }
         // extract.py:140 Index.difference: name-sorted iff the drop list is non-empty (pandas 2)
         if (!drop_idx.empty())
             std::stable_sort(kept.begin(), kept.end(), [&](int a, int b) { return cols[a].name < cols[b].name; });
@@ -215,7 +250,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         if (!arena.overflow) GRX_TRY(grx_gather_columns(n, f0, h_gen0_cols, copy, n, stream));
         (void)mark;
         // (the copy stays below the bins in the arena: a few columns, once per run)
-        GRX_TRY(update(0, f0, copy, 0));
+        GRX_TRY(update(0, f0, copy, 0, false));
     }
     int generation = 0;
     for (int g = 1; g < max_generations && !arena.overflow && !table_full; ++g) {
@@ -250,17 +285,17 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 GRX_TRY(grx_pack_rows(n, f, ptrs.data(), rows, ldr, stream));
                 double *d_mean = has[GRX_AGG_MEAN] ? out_of(GRX_AGG_MEAN) : mean_scratch;
                 if (has[GRX_AGG_SUM] || d_mean)
-                    GRX_TRY(grx_aggregate(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, out_of(GRX_AGG_SUM), d_mean, n, stream));
+                    GRX_TRY(grx_aggregate(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_SUM), d_mean, n, stream));
                 if (need_var)
-                    GRX_TRY(grx_aggregate_var(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, d_mean, out_of(GRX_AGG_VAR),
+                    GRX_TRY(grx_aggregate_var(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, d_mean, out_of(GRX_AGG_VAR),
                                               out_of(GRX_AGG_STD), n, stream));
                 if (has[GRX_AGG_MIN] || has[GRX_AGG_MAX])
-                    GRX_TRY(grx_aggregate_minmax(plan, d_row_ptr, d_agg_col, f, rows, ldr, 0, n, out_of(GRX_AGG_MIN),
+                    GRX_TRY(grx_aggregate_minmax(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_MIN),
                                                  out_of(GRX_AGG_MAX), n, stream));
             }
             arena.top = mark;                                 // the gather source is scratch
         }
-        GRX_TRY(update(first_new, count, block, g));
+        GRX_TRY(update(first_new, count, block, g, comm != nullptr));
         if (recorded[g].empty()) break;                       // extract.py:86-87
     }
     if (arena_needed) *arena_needed = arena.peak;

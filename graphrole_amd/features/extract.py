@@ -154,9 +154,11 @@ class RecursiveFeatureExtractor:
 
         # generation 0: neighbourhood (local + ego-net) features
         names, cols, dtypes = self.graph.neighborhood_feature_columns()
-        if self._plan is None and self._native_loop and 'prod' not in aggs and len(set(aggs)) == len(aggs) \
-                and hasattr(self._K(), 'refex_run'):
-            # one GPU: the whole generation loop runs below the ABI (grx_refex_run)
+        K = self._K()
+        native = hasattr(K, 'refex_run') and (self._plan is None or getattr(K, 'NATIVE_SHARDING', False))
+        if native and self._native_loop and 'prod' not in aggs and len(set(aggs)) == len(aggs):
+            # the whole generation loop runs below the ABI (grx_refex_run); with a ShardPlan it aggregates this rank's
+            # rows and issues the exchanges itself
             self._run_native(names, cols, dtypes, aggs)
             return
         self._update_columns(names, cols, dtypes)
@@ -178,8 +180,12 @@ class RecursiveFeatureExtractor:
         dtypes, the final working set, per-generation statistics."""
         K = self._K()
         _, dev_graph, _ = self.graph._device_graph()
-        columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
-                                                                   aggs, self._arena)
+        if self._plan is None:
+            columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
+                                                                       aggs, self._arena)
+        else:
+            columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
+                                                                       aggs, self._arena, shard=self._plan)
         host = self.graph._device_graph()[0]
         no_empty_rows = self._no_empty_rows(host)
         names: List[str] = []
@@ -294,8 +300,7 @@ class RecursiveFeatureExtractor:
         if list(aggs) == ['sum', 'mean']:
             sub = block
         else:
-            import torch
-            sub = torch.cat([pieces[a] for a in aggs], dim=0).contiguous()
+            sub = self._as_block([pieces[a][j] for a in aggs for j in range(f)], n)
         picked = range(len(aggs) * f)
         # sharded: only this rank's rows of the candidate block are valid from here on; the
         # exchanges happen in _update_columns (owners bin whole columns, only retained ones are
@@ -365,11 +370,9 @@ class RecursiveFeatureExtractor:
         kept = list(dict.fromkeys(nm for nm in names if nm not in dropped))
         if partial and kept:
             # step 3: the retained new columns, and only those, become complete on every rank
-            import torch
-            blk = torch.stack([self._work[nm] for nm in kept])
-            plan.all_gather_block(blk)
-            for j, nm in enumerate(kept):
-                self._work[nm] = blk[j]
+            # (columns are completed where they lie: no copy, no packing)
+            for nm, col in zip(kept, plan.all_gather_columns([self._work[nm] for nm in kept])):
+                self._work[nm] = col
         self._partial_block = None
         retained = sorted(kept) if dropped else kept
         self._final_names[self.generation_count] = retained

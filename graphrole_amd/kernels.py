@@ -88,7 +88,25 @@ def empty(shape, dtype=torch.float64) -> torch.Tensor:
 
 
 def zeros(shape, dtype=torch.float64) -> torch.Tensor:
-    return torch.zeros(shape, dtype=dtype, device=device())
+    """Zero-filled device tensor without a torch kernel: allocation + hipMemsetAsync on the current stream (torch
+    is plumbing here -- no torch compute op runs on the product path, tests/test_gpu_no_torch_ops.py)."""
+    t = torch.empty(shape, dtype=dtype, device=device())
+    if t.numel():
+        _lib.call('grx_memset', _ptr(t), 0, t.numel() * t.element_size(), _stream())
+    return t
+
+
+NATIVE_SHARDING = True      # grx_refex_run / grx_nmf_fit take a communicator: a ShardPlan runs below the ABI
+
+
+def _shard_args(shard):
+    """(grx_comm handle, host bounds pointer) of a ShardPlan, (None, None) on one GPU."""
+    if shard is None:
+        return None, None
+    comm = shard.comm()
+    if comm is None:
+        return None, None
+    return comm, shard.bounds_ptr()
 
 
 def _ld(t: torch.Tensor) -> int:
@@ -285,7 +303,7 @@ def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: O
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     row_end = csr.n if row_end is None else row_end
     if out is None:
-        out = torch.zeros(csr.n, dtype=torch.float64, device=device())
+        out = zeros(csr.n, dtype=torch.float64)
     _lib.call('grx_row_sums', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), int(add_self_loop),
               row_begin, row_end, _ptr(out), _stream())
     return out
@@ -313,8 +331,8 @@ def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tenso
             T = triangle_counts(csr, *csr.triangle_split(shard.rank, shard.world))
             shard.all_reduce_sum_(T)
         return egonet_from_triangles(csr, T, row_begin, row_end)
-    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
-    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    internal = zeros(csr.n, dtype=torch.float64)
+    external = zeros(csr.n, dtype=torch.float64)
     if csr.w is not None and rowsum is None:
         rowsum = row_sums(csr, False)
     _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
@@ -327,7 +345,7 @@ def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] =
     [row_begin,row_end) (all-reduce SUM across ranks when the rows are split)."""
     row_end = csr.n if row_end is None else row_end
     o = csr.oriented()
-    T = torch.zeros(max(csr.n, 1), dtype=torch.int64, device=device())
+    T = zeros(max(csr.n, 1), dtype=torch.int64)
     _lib.call('grx_triangle_counts', csr.n, _ptr(o.row_ptr), _ptr(o.col), _ptr(o.arc), row_begin, row_end, _ptr(T),
               _stream())
     return T
@@ -336,9 +354,8 @@ def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] =
 def egonet_from_triangles(csr: DeviceCSR, T: torch.Tensor, row_begin: int = 0,
                           row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     row_end = csr.n if row_end is None else row_end
-    alloc = torch.empty if (row_begin == 0 and row_end == csr.n) else torch.zeros
-    internal = alloc(csr.n, dtype=torch.float64, device=device())
-    external = alloc(csr.n, dtype=torch.float64, device=device())
+    internal = torch.empty(csr.n, dtype=torch.float64, device=device())
+    external = torch.empty(csr.n, dtype=torch.float64, device=device())
     scratch = torch.empty(max(csr.n, 1), dtype=torch.int32, device=device())
     _lib.call('grx_egonet_unweighted', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(T), row_begin, row_end,
               _ptr(internal), _ptr(external), _ptr(scratch), _ptr(csr.hub_rows), csr.n_hubs,
@@ -350,8 +367,8 @@ def egonet_features_general(csr: DeviceCSR, directed: bool, rowsum: Optional[tor
                             row_begin: int = 0, row_end: Optional[int] = None):
     """The gather kernel for any graph (weighted / directed); also valid for unweighted undirected."""
     row_end = csr.n if row_end is None else row_end
-    internal = torch.zeros(csr.n, dtype=torch.float64, device=device())
-    external = torch.zeros(csr.n, dtype=torch.float64, device=device())
+    internal = zeros(csr.n, dtype=torch.float64)
+    external = zeros(csr.n, dtype=torch.float64)
     if csr.w is not None and rowsum is None:
         rowsum = row_sums(csr, False)
     _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
@@ -383,7 +400,7 @@ def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: i
     row_end = n if row_end is None else row_end
     if out is None:
         full = row_begin == 0 and row_end == n and want_sum and want_mean
-        out = (torch.empty if full else torch.zeros)((2 * f, n), dtype=torch.float64, device=device())
+        out = torch.empty((2 * f, n), dtype=torch.float64, device=device()) if full else zeros((2 * f, n))
     if f == 0:
         return out
     s_ptr = c_void_p(out.data_ptr()) if want_sum else None
@@ -399,7 +416,7 @@ def aggregate_var(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, mean: to
     its square root; `mean` = the [f, n] neighbour means of the same rows (aggregate()[f:])."""
     n = csr.n
     row_end = n if row_end is None else row_end
-    out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+    out = zeros((2 * f, n), dtype=torch.float64)
     if f == 0:
         return out
     assert mean.shape == (f, n) and mean.is_contiguous()
@@ -412,11 +429,11 @@ def aggregate_var(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, mean: to
 
 def aggregate_prod(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
                    row_end: Optional[int] = None) -> torch.Tensor:
-    """[f, n] block: left-to-right product of the neighbours' values (agg 'prod'); rows outside
-    [row_begin, row_end) hold 1 like rows without neighbours."""
+    """[f, n] block: left-to-right product of the neighbours' values (agg 'prod'); only rows
+    [row_begin, row_end) are written."""
     n = csr.n
     row_end = n if row_end is None else row_end
-    out = torch.ones((f, n), dtype=torch.float64, device=device())
+    out = torch.empty((f, n), dtype=torch.float64, device=device())
     if f:
         _lib.call('grx_aggregate_prod', _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr, row_begin, row_end,
                   _ptr(out), n, _stream())
@@ -428,7 +445,7 @@ def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_b
     """[2f, n] block: rows 0..f-1 = neighbour minima, rows f..2f-1 = neighbour maxima."""
     n = csr.n
     row_end = n if row_end is None else row_end
-    out = torch.zeros((2 * f, n), dtype=torch.float64, device=device())
+    out = zeros((2 * f, n), dtype=torch.float64)
     if f == 0:
         return out
     lo = c_void_p(out.data_ptr()) if want_min else None
@@ -457,8 +474,8 @@ def vertical_log_bin(block: torch.Tensor, frac: float = 0.5,
     `block` (and `out`) may be row-strided views (e.g. every P-th column of a candidate block)."""
     ncols, n = block.shape
     assert n <= 1 or block.stride(1) == 1
-    bins = out if out is not None else torch.zeros((ncols, max(n, 1)), dtype=torch.uint8, device=device())[:, :n]
-    nbins = torch.zeros(max(ncols, 1), dtype=torch.int32, device=device())
+    bins = out if out is not None else zeros((ncols, max(n, 1)), dtype=torch.uint8)[:, :n]
+    nbins = zeros(max(ncols, 1), dtype=torch.int32)
     lib = _lib.load()
     ws_bytes = lib.grx_log_bin_workspace_bytes(n, ncols)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
@@ -473,7 +490,7 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
     exact, larger ones are some value > cap (cap = 255: all exact)."""
     F = len(bin_cols)
     row_end = n if row_end is None else row_end
-    dist = torch.zeros((F, F), dtype=torch.int32, device=device())
+    dist = zeros((F, F), dtype=torch.int32)
     if F >= 2 and row_end > row_begin:
         ptrs = ptr_array(bin_cols)
         _lib.call('grx_chebyshev', row_begin, row_end, F, first_new, ptrs, _ptr(dist), int(cap), _stream())
@@ -482,14 +499,17 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
 
 # ------------------------------------------------------------------------------- whole ReFeX loop
 def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
-              aggs: Sequence[str], arena: Optional[torch.Tensor] = None):
+              aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None):
     """
     grx_refex_run: the generation loop of RecursiveFeatureExtractor below the ABI (one call, one GPU).
     Returns (columns, generations, generation_count, arena): `columns` = one dict per RECORDED feature in
     record order {generation, parent, agg (name or None), gen0_index, work_position, col (fp64[n] tensor --
     a view into `arena`, or the caller's generation-0 column)}; `generations` = per-generation counts.
     The arena (uint8 tensor) is grown until the run fits; pass it back in to reuse it.
+    shard: a ShardPlan -- the loop aggregates this rank's rows only and issues its own exchanges (RCCL or the
+    plan's callback transport) between the kernels; every rank gets the complete columns.
     """
+    comm, bounds = _shard_args(shard)
     n = csr.n
     f0 = len(gen0_cols)
     agg_ids = (ctypes.c_int * len(aggs))(*[_lib.AGG_IDS[a] for a in aggs])
@@ -505,13 +525,16 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         lib = _lib.load()
         rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names,
-                               int(max_generations), len(aggs), agg_ids, _ptr(arena), arena.numel(), max_columns, table,
+                               int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), arena.numel(),
+                               max_columns, table,
                                ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),
                                _stream())
         if rc == -3:                                    # GRX_ERR_WORKSPACE: arena or column table too small
             if needed.value > arena.numel():
+                # `needed` is what the run used up to the generation that failed -- a lower bound: grow geometrically
+                want = max(int(needed.value * 1.5), 2 * arena.numel()) + (32 << 20)
                 del arena
-                arena = torch.empty(int(needed.value * 1.5) + (32 << 20), dtype=torch.uint8, device=device())
+                arena = torch.empty(want, dtype=torch.uint8, device=device())
             else:
                 max_columns *= 4
             continue
@@ -571,7 +594,7 @@ def project(X: torch.Tensor, n: int, Z: np.ndarray, row_begin: int = 0,
     Z = np.ascontiguousarray(Z, dtype=np.float64)
     r = Z.shape[1]
     if out is None:
-        out = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+        out = zeros((r, X.shape[1]), dtype=torch.float64)
     lib = _lib.load()
     ws_bytes = lib.grx_project_workspace_bytes(n, r)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
@@ -634,7 +657,7 @@ def lloyd_max(values: torch.Tensor, n_bins: int, max_iter: int = 300):
     m = values.numel()
     out = torch.empty_like(values)
     centers = torch.empty(max(n_bins, 1), dtype=torch.float64, device=device())
-    info = torch.zeros(3, dtype=torch.int32, device=device())
+    info = zeros(3, dtype=torch.int32)
     ws_bytes = _lib.load().grx_lloyd_max_workspace_bytes(m)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     _lib.call('grx_lloyd_max', m, _ptr(values), int(n_bins), int(max_iter), _ptr(out), _ptr(centers), _ptr(info),
@@ -677,7 +700,7 @@ def kmeans1d(values: torch.Tensor, n_bins: int, max_iter: int = 300, rel_tol: fl
     first, uniform, trials = kmeans_draws(m, int(n_bins))
     out = torch.empty_like(values)
     centers = torch.empty(max(int(n_bins), 1), dtype=torch.float64, device=device())
-    info = torch.zeros(3, dtype=torch.int32, device=device())
+    info = zeros(3, dtype=torch.int32)
     ws_bytes = _lib.load().grx_kmeans1d_workspace_bytes(m, int(n_bins))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     _lib.call('grx_kmeans1d', m, _ptr(values), int(n_bins), first, _hptr(uniform), trials, int(max_iter), float(rel_tol),
@@ -716,8 +739,8 @@ class NmfState:
             self.H = H.to(dev).contiguous()
         else:
             self.H = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)
-        self.AB = torch.zeros(self.r * self.F + self.r * self.r, dtype=torch.float64, device=dev)
-        self.err = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.AB = zeros(self.r * self.F + self.r * self.r)
+        self.err = zeros(1)
         self.ws_bytes = _lib.load().grx_nmf_workspace_bytes(n, self.F, self.r)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
 
@@ -752,7 +775,7 @@ class NmfState:
     def kl_cost(self, W: torch.Tensor, H: torch.Tensor, row_begin: int = 0, row_end: Optional[int] = None) -> float:
         """Generalised-KL error cost of X against the (encoded) factors W [r, ld], H [r, F]."""
         row_end = self.n if row_end is None else row_end
-        out = torch.zeros(1, dtype=torch.float64, device=device())
+        out = zeros(1, dtype=torch.float64)
         _lib.call('grx_nmf_kl_cost', self.n, self.F, self.r, _ptr(self.X), _ld(self.X), _ptr(W), _ld(W),
                   row_begin, row_end, _ptr(H), _ptr(out), _ptr(self.ws), self.ws_bytes, _stream())
         return float(to_host(out)[0])
@@ -776,12 +799,12 @@ def _omega_arg(omega: np.ndarray, F: int) -> np.ndarray:
     return omega
 
 
-def nmf_init(X: torch.Tensor, n: int, r: int, omega: np.ndarray):
+def nmf_init(X: torch.Tensor, n: int, r: int, omega: np.ndarray, shard=None):
     """NNDSVDa start of the feature-major device matrix X [F, ld] (n valid rows, n >= F) in one call:
     (W0 [r, ld] device, H0 [r, F] device, ||X||_F^2)."""
     F = X.shape[0]
     omega = _omega_arg(omega, F)
-    W = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+    W = zeros((r, X.shape[1]), dtype=torch.float64)
     H = torch.empty((r, F), dtype=torch.float64, device=device())
     ws, ws_bytes = _fit_workspace(n, F, r)
     xx = ctypes.c_double(0.0)
@@ -790,22 +813,27 @@ def nmf_init(X: torch.Tensor, n: int, r: int, omega: np.ndarray):
     return W, H, float(xx.value)
 
 
-def nmf_mu(state: NmfState, tol: float, max_iter: int) -> int:
-    """Multiplicative updates with sklearn's stopping rule on the state's W, H in place; returns n_iter."""
+def nmf_mu(state: NmfState, tol: float, max_iter: int, shard=None) -> int:
+    """Multiplicative updates with sklearn's stopping rule on the state's W, H in place; returns n_iter.
+    shard: a ShardPlan -- W rows of this rank only, one all-reduce per iteration below the ABI, W completed at the end."""
+    comm, bounds = _shard_args(shard)
     ws, ws_bytes = _fit_workspace(state.n, state.F, state.r)
     info = _lib.NmfInfo()
     xx = state.x_sq_norm if state.x_sq_norm is not None else -1.0
     _lib.call('grx_nmf_mu', state.n, state.F, state.r, _ptr(state.X), _ld(state.X), _ptr(state.W), _ld(state.W),
-              _ptr(state.H), float(xx), float(tol), int(max_iter), ctypes.byref(info), _ptr(ws), ws_bytes, _stream())
+              _ptr(state.H), float(xx), float(tol), int(max_iter), ctypes.byref(info), comm, bounds, _ptr(ws), ws_bytes,
+              _stream())
     state.info = info
     return int(info.n_iter)
 
 
-def nmf_fit(X: torch.Tensor, n: int, r: int, omega: np.ndarray, tol: float, max_iter: int):
-    """grx_nmf_fit: NNDSVDa + multiplicative updates in ONE call; returns (NmfState, n_iter)."""
+def nmf_fit(X: torch.Tensor, n: int, r: int, omega: np.ndarray, tol: float, max_iter: int, shard=None):
+    """grx_nmf_fit: NNDSVDa + multiplicative updates in ONE call; returns (NmfState, n_iter).  shard: a ShardPlan --
+    the row passes cover this rank's rows, the exchanges run below the ABI, W and H end complete on every rank."""
+    comm, bounds = _shard_args(shard)
     F = X.shape[0]
     omega = _omega_arg(omega, F)
-    W = torch.zeros((r, X.shape[1]), dtype=torch.float64, device=device())
+    W = zeros((r, X.shape[1]), dtype=torch.float64)
     H = torch.empty((r, F), dtype=torch.float64, device=device())
     ws, ws_bytes = _fit_workspace(n, F, r)
     info = _lib.NmfInfo()

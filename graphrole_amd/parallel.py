@@ -19,14 +19,26 @@ Scheme:
     bins with all-reduce(MAX).
   * NMF: W rows sharded, H replicated; one all-reduce(SUM) of [W^T X | W^T W] per iteration and
     of the residual at convergence checks.
+
+Where the exchanges run: on the product path (HIP kernels) a ShardPlan is a row partition plus a ``grx_comm``
+(include/grx.h, csrc/grx_comm.hip) -- RCCL bound directly from libgrx.so when torch.distributed's backend is
+"nccl", a callback transport staged through gloo otherwise (the two-ranks-on-one-GPU test) -- and the whole-loop
+drivers grx_refex_run / grx_nmf_fit issue every exchange themselves, below the ABI, between their kernels.  The
+methods of this class are thin wrappers over the same C entry points for device tensors (the per-kernel driver,
+RoleExtractor's model selection): nothing is packed, no torch compute op runs.  For host tensors (the CPU test double
+of tests/, gloo) the same protocol is spelled with torch.distributed calls.
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+_NP_DTYPES = {0: np.float64, 1: np.int32, 2: np.int64, 3: np.uint8}            # grx_dtype
 
 
 class ShardPlan:
@@ -53,10 +65,40 @@ class ShardPlan:
         # real RCCL calls, dtypes and split sizes on a one-GPU box, tests/test_gpu_sharded.py)
         self._solo = self.world == 1 and not _force_collectives()
         self._perm_cache: dict = {}
+        self._bounds_c = (ctypes.c_int64 * (self.world + 1))(*[int(b) for b in self.bounds])
+        self._comm = None               # grx_comm handle (device exchanges), looked up on first use
         #: exchange timing (bench.py --gpus N): name -> [calls, device ms]; off by default
-        self.timing = False
+        self._timing = False
         self._timed_events: list = []
         self.exchange_stats: dict = {}
+
+    # ------------------------------------------------------------------ the transport below the ABI
+    def bounds_ptr(self):
+        """Host int64[world + 1] row partition, as the h_bounds argument of the C entry points."""
+        return ctypes.cast(self._bounds_c, ctypes.c_void_p)
+
+    def comm(self):
+        """grx_comm handle of this plan (None for a one-rank group without forced exchanges); one communicator per
+        process group, shared by every plan of the group (the row partition is an argument of the calls, not a
+        property of the transport)."""
+        if self._comm is not None or self._solo:
+            return self._comm
+        self._comm = _communicator(self.group)
+        if self._timing:
+            from graphrole_amd import _lib
+            _lib.call('grx_comm_timing', self._comm, 1)
+        return self._comm
+
+    @property
+    def timing(self) -> bool:
+        return self._timing
+
+    @timing.setter
+    def timing(self, on: bool) -> None:
+        self._timing = bool(on)
+        if self._comm is not None:
+            from graphrole_amd import _lib
+            _lib.call('grx_comm_timing', self._comm, int(self._timing))
 
     # ------------------------------------------------------------------ exchange timing
     def _time(self, name: str):
@@ -66,7 +108,7 @@ class ShardPlan:
 
         class _Scope:
             def __enter__(self_inner):
-                self_inner.on = plan.timing and torch.cuda.is_available()
+                self_inner.on = plan.timing and torch.cuda.is_available() and plan._comm is None
                 if self_inner.on:
                     self_inner.start = torch.cuda.Event(enable_timing=True)
                     self_inner.stop = torch.cuda.Event(enable_timing=True)
@@ -90,18 +132,33 @@ class ShardPlan:
                 cell[0] += 1
                 cell[1] += start.elapsed_time(stop)
             self._timed_events = []
+        if self._comm is not None:
+            from graphrole_amd import _lib
+            for kind, name in enumerate(_lib.COMM_KINDS):
+                calls, ms = ctypes.c_longlong(0), ctypes.c_double(0.0)
+                _lib.call('grx_comm_timing_read', self._comm, kind, ctypes.byref(calls), ctypes.byref(ms))
+                if calls.value:
+                    cell = self.exchange_stats.setdefault(name, [0, 0.0])
+                    cell[0] += calls.value
+                    cell[1] += ms.value
+            _lib.call('grx_comm_timing_reset', self._comm)
         return self.exchange_stats
 
     def reset_timing(self) -> None:
         self._timed_events = []
         self.exchange_stats = {}
+        if self._comm is not None:
+            from graphrole_amd import _lib
+            _lib.call('grx_comm_timing_reset', self._comm)
 
     # ------------------------------------------------------------------ collectives
-    def _staged(self, t: torch.Tensor) -> bool:
-        """gloo has no device collectives for every op/dtype used here: with that backend (the
-        two-ranks-on-one-GPU test, tests/test_gpu_sharded.py) device tensors travel through the
-        host.  With nccl (= RCCL, the product path) tensors are exchanged in HBM."""
-        return t.is_cuda and dist.get_backend(self.group) == 'gloo'
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _col_ptrs(tensors):
+        return (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
 
     def all_gather_block(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> every slice valid, in place."""
@@ -110,20 +167,19 @@ class ShardPlan:
         ncols = block.shape[0]
         if ncols == 0 or self.n == 0:
             return block
+        if block.is_cuda:
+            assert block.stride(1) == 1
+            self.all_gather_columns([block[j] for j in range(ncols)])
+            return block
         with self._time('all_gather_block'):
             return self._all_gather_block(block, ncols)
 
     def _all_gather_block(self, block: torch.Tensor, ncols: int) -> torch.Tensor:
-        send = torch.zeros((ncols, self.max_rows), dtype=block.dtype, device=block.device)
+        # host tensors (CPU test double)
+        send = torch.zeros((ncols, self.max_rows), dtype=block.dtype)
         send[:, :self.row_end - self.row_begin] = block[:, self.row_begin:self.row_end]
-        if self._staged(block):
-            send_h = send.cpu()
-            flat_h = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype)
-            dist.all_gather_into_tensor(flat_h, send_h, group=self.group)
-            flat = flat_h.to(block.device)
-        else:
-            flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype, device=block.device)
-            dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
+        flat = torch.empty((self.world * ncols, self.max_rows), dtype=block.dtype)
+        dist.all_gather_into_tensor(flat, send, group=self.group)      # concatenates along dim 0
         recv = flat.view(self.world, ncols, self.max_rows)
         # one concatenation + one copy instead of a slice copy per rank (every small launch is host time
         # on the critical path of a sharded generation)
@@ -133,18 +189,21 @@ class ShardPlan:
         return block
 
     def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, out_split, in_split) -> None:
-        if self._staged(send):
-            recv_h = torch.empty(recv.shape, dtype=recv.dtype)
-            dist.all_to_all_single(recv_h, send.cpu(), output_split_sizes=out_split, input_split_sizes=in_split,
-                                   group=self.group)
-            recv.copy_(recv_h)
-        else:
-            dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split,
-                                   group=self.group)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
 
     def columns_to_owners(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> the WHOLE columns this rank owns
         (columns rank, rank + world, ...) as a [n_owned, n] tensor."""
+        if block.is_cuda:
+            from graphrole_amd import _lib
+            ncols = block.shape[0]
+            n_owned = len(range(self.rank, ncols, self.world))
+            owned = torch.empty((n_owned, max(self.n, 1)), dtype=block.dtype, device=block.device)
+            assert ncols <= 1 or block.stride(1) == 1
+            _lib.call('grx_comm_columns_to_owners', self.comm(), self.bounds_ptr(), ncols, ctypes.c_void_p(block.data_ptr()),
+                      block.stride(0) if ncols > 1 else max(self.n, 1), block.element_size(),
+                      ctypes.c_void_p(owned.data_ptr()), owned.stride(0) if n_owned else max(self.n, 1), self._stream())
+            return owned[:, :self.n]
         with self._time('columns_to_owners'):
             return self._columns_to_owners(block)
 
@@ -171,7 +230,16 @@ class ShardPlan:
 
     def owned_to_rows(self, owned: torch.Tensor, ncols: int) -> torch.Tensor:
         """Inverse direction for per-column results (uint8 bins): owned [n_owned, n] whole columns ->
-        [ncols, n] with this rank's row slice of EVERY column valid (other rows zero)."""
+        [ncols, n] with this rank's row slice of EVERY column valid (other rows: unspecified on the device path,
+        zero on the host path -- each rank only ever scans its own rows)."""
+        if owned.is_cuda:
+            from graphrole_amd import _lib
+            out = torch.empty((ncols, max(self.n, 1)), dtype=owned.dtype, device=owned.device)
+            assert owned.shape[0] <= 1 or owned.stride(1) == 1
+            _lib.call('grx_comm_owned_to_rows', self.comm(), self.bounds_ptr(), ncols, ctypes.c_void_p(owned.data_ptr()),
+                      owned.stride(0) if owned.shape[0] > 1 else max(self.n, 1), owned.element_size(),
+                      ctypes.c_void_p(out.data_ptr()), out.stride(0), self._stream())
+            return out[:, :self.n]
         with self._time('owned_to_rows'):
             return self._owned_to_rows(owned, ncols)
 
@@ -209,19 +277,28 @@ class ShardPlan:
         return hit
 
     def all_gather_columns(self, cols: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """Same for a list of separate [n] columns."""
+        """Same for a list of separate [n] columns (device columns: completed in place, where they lie)."""
         if self._solo or not cols:
             return list(cols)
+        if cols[0].is_cuda:
+            from graphrole_amd import _lib
+            cols = list(cols)
+            assert all(c.is_contiguous() and c.dtype == cols[0].dtype for c in cols)
+            _lib.call('grx_comm_all_gather_rows', self.comm(), self.bounds_ptr(), len(cols), self._col_ptrs(cols),
+                      cols[0].element_size(), self._stream())
+            return cols
         block = torch.stack(list(cols))
         self.all_gather_block(block)
         return [block[j] for j in range(len(cols))]
 
     def _all_reduce_(self, t: torch.Tensor, op) -> torch.Tensor:
         if not self._solo and t.numel():
-            if self._staged(t):
-                h = t.cpu()
-                dist.all_reduce(h, op=op, group=self.group)
-                t.copy_(h)
+            if t.is_cuda:
+                from graphrole_amd import _lib
+                assert t.is_contiguous()
+                dtype = _lib.DTYPE_IDS[str(t.dtype).replace('torch.', '')]
+                _lib.call('grx_comm_all_reduce', self.comm(), ctypes.c_void_p(t.data_ptr()), t.numel(), dtype,
+                          0 if op == dist.ReduceOp.SUM else 1, self._stream())
             elif t.is_contiguous():
                 dist.all_reduce(t, op=op, group=self.group)
             else:
@@ -261,6 +338,105 @@ class ShardPlan:
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         with self._time('all_reduce_sum'):
             return self._all_reduce_(t, dist.ReduceOp.SUM)
+
+
+class _StagedTransport:
+    """Callback transport for torch.distributed backends without device collectives (gloo): device buffers are
+    staged through host memory with the library's own copies.  Used by the two-ranks-on-one-GPU tests; the
+    product transport is RCCL (grx_comm_create_rccl)."""
+
+    def __init__(self, group) -> None:
+        from graphrole_amd import _lib
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.callbacks = (_lib.ALL_REDUCE_FN(self.all_reduce), _lib.EXCHANGE_FN(self.exchange))   # kept alive here
+
+    def all_reduce(self, user, d_buf, count, dtype, op, stream) -> int:
+        try:
+            from graphrole_amd import _lib
+            host = np.empty(count, dtype=_NP_DTYPES[dtype])
+            _lib.call('grx_memcpy_d2h', host.ctypes.data_as(ctypes.c_void_p), d_buf, host.nbytes, stream)
+            _lib.call('grx_stream_sync', stream)
+            dist.all_reduce(torch.from_numpy(host), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX,
+                            group=self.group)
+            _lib.call('grx_memcpy_h2d', d_buf, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, stream)
+            _lib.call('grx_stream_sync', stream)
+            return 0
+        except Exception:                                    # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return -2
+
+    def exchange(self, user, n_ops, ops, stream) -> int:
+        try:
+            from graphrole_amd import _lib
+            sends = [[] for _ in range(self.world)]
+            recvs = [[] for _ in range(self.world)]
+            for i in range(n_ops):
+                op = ops[i]
+                if op.is_recv:
+                    recvs[op.peer].append((op.d_ptr, int(op.bytes)))
+                else:
+                    buf = np.empty(int(op.bytes), dtype=np.uint8)
+                    _lib.call('grx_memcpy_d2h', buf.ctypes.data_as(ctypes.c_void_p), op.d_ptr, buf.nbytes, stream)
+                    sends[op.peer].append(buf)
+            _lib.call('grx_stream_sync', stream)
+            in_split = [sum(b.nbytes for b in sends[q]) for q in range(self.world)]
+            out_split = [sum(nb for _, nb in recvs[q]) for q in range(self.world)]
+            flat = [b for q in range(self.world) for b in sends[q]]
+            send_t = torch.from_numpy(np.concatenate(flat) if flat else np.empty(0, dtype=np.uint8))
+            recv_t = torch.empty(sum(out_split), dtype=torch.uint8)
+            # between one pair of ranks, transfers are matched in op order: concatenation keeps that order
+            dist.all_to_all_single(recv_t, send_t, output_split_sizes=out_split, input_split_sizes=in_split,
+                                   group=self.group)
+            host = recv_t.numpy()
+            off = 0
+            for q in range(self.world):
+                for d_ptr, nb in recvs[q]:
+                    _lib.call('grx_memcpy_h2d', d_ptr, host[off:off + nb].ctypes.data_as(ctypes.c_void_p), nb, stream)
+                    off += nb
+            _lib.call('grx_stream_sync', stream)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -2
+
+
+_COMMUNICATORS: dict = {}
+
+
+def _communicator(group):
+    """The grx_comm of a torch.distributed process group, created once per process.  Backend "nccl": RCCL bound inside
+    libgrx.so -- rank 0 draws the unique id, torch.distributed carries it to the others (the NCCL bootstrap pattern).
+    Any other backend: the staged callback transport."""
+    from graphrole_amd import _lib
+    backend = dist.get_backend(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    forced = _force_collectives()
+    key = (id(group) if group is not None else 0, backend, rank, world, forced)
+    hit = _COMMUNICATORS.get(key)
+    if hit is not None:
+        return hit[0]
+    handle = ctypes.c_void_p()
+    keep = None
+    if backend == 'nccl':
+        box = [None]
+        if rank == 0:
+            buf = (ctypes.c_char * _lib.COMM_ID_BYTES)()
+            _lib.call('grx_comm_rccl_unique_id', ctypes.cast(buf, ctypes.c_void_p))
+            box = [bytes(buf)]
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(box, src=src, group=group)
+        ident = ctypes.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+        _lib.call('grx_comm_create_rccl', ctypes.cast(ident, ctypes.c_void_p), rank, world,
+                  _lib.COMM_SELF_VIA_TRANSPORT if forced else 0, ctypes.byref(handle))
+    else:
+        keep = _StagedTransport(group)
+        _lib.call('grx_comm_create_callbacks', rank, world, keep.callbacks[0], keep.callbacks[1], None,
+                  ctypes.byref(handle))
+    _COMMUNICATORS[key] = (handle, keep)
+    return handle
 
 
 def _force_collectives() -> bool:

@@ -242,6 +242,10 @@ def nmf_device(Xd, n: int, n_roles: int, omega: np.ndarray,
     K = _kernels()
     if plan is None:
         return K.nmf_fit(Xd, n, n_roles, omega, tol, max_iter)
+    if getattr(K, 'NATIVE_SHARDING', False):
+        # the sharded fit below the ABI: row passes on the rank's rows, exchanges issued by the C++ driver, W
+        # completed on every rank at the end
+        return K.nmf_fit(Xd, n, n_roles, omega, tol, max_iter, shard=plan)
     W0, H0, xx = _init_orchestrated(Xd, n, n_roles, omega, plan)
     state = K.NmfState(Xd, n, W0, H0, x_sq_norm=xx)
     return run_mu_loop(state, tol, max_iter, plan)
@@ -281,7 +285,8 @@ def nmf_state(Xd, X: np.ndarray, n_roles: int, plan=None):
     omega = draw_omega(X.shape, n_roles)
     if plan is not None and n >= F:
         state, n_iter = nmf_device(Xd, n, n_roles, omega, plan=plan)
-        plan.all_gather_block(state.W[:, :n])
+        if not getattr(K, 'NATIVE_SHARDING', False):
+            plan.all_gather_block(state.W[:, :n])
         return state, n_iter
     if n < F:
         # fewer nodes than features: every matrix of the initialisation is small (k x F algebra)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 200          /* 0.2.0: whole-loop entry points (grx_refex_run, grx_nmf_fit) */
+#define GRX_VERSION 300          /* 0.3.0: grx_comm -- the sharded loops and their exchanges below the ABI */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 16         /* NMF rank limit of the device kernels */
 #define GRX_MAX_NMF_FEATURES 480 /* NMF feature-count limit of the device kernels (fast paths: 120) */
@@ -64,6 +64,10 @@ int grx_event_destroy(void *event);
 int grx_event_record(void *event, void *stream);
 int grx_event_elapsed_ms(void *start, void *stop, float *ms_out);   /* synchronises on stop */
 
+/* Launches the one-thread `grx_marker_kernel` on `stream`: a named fence in a rocprofv3 kernel trace (tests
+ * delimit the product path with it, tools/step_timeline.py a step). */
+int grx_trace_marker(int tag, void *stream);
+
 /*
  * Per-kernel timing with HIP events recorded on the launch stream around every kernel launch
  * of this library (bench.py's roofline numbers).  Off by default.  Kernel ids are dense in
@@ -78,6 +82,67 @@ int grx_profile_reset(void);
 int grx_profile_kernel_count(void);
 const char *grx_profile_kernel_name(int id);
 int grx_profile_read(int id, double *total_ms, long long *launches);
+
+/* ------------------------------------------------------------------ node-range sharding -- */
+/*
+ * NEW (the reference is single-process): one process per GPU, the graph and the
+ * feature columns replicated, rank p computes node rows [h_bounds[p], h_bounds[p+1]) of every per-node
+ * kernel.  A grx_comm is the transport between the ranks; the whole-loop drivers (grx_refex_run,
+ * grx_nmf_fit) take one and issue their exchanges themselves, stream-ordered between the kernels.
+ *
+ *   grx_comm_create_rccl       RCCL over xGMI.  librccl.so.1 is resolved at run time (the copy the process
+ *                              already loaded -- e.g. PyTorch's -- else the system one; GRX_RCCL_PATH overrides),
+ *                              so single-GPU users carry no RCCL dependency.  Bootstrap as with NCCL: rank 0
+ *                              calls grx_comm_rccl_unique_id, hands the GRX_COMM_ID_BYTES to every rank through
+ *                              any channel it has (torch.distributed, MPI, a file), every rank calls create.
+ *                              flags & GRX_COMM_SELF_VIA_TRANSPORT: transfers of a rank to itself go through
+ *                              ncclSend / ncclRecv as well (functional test of the RCCL calls on a one-GPU box).
+ *   grx_comm_create_callbacks  any other transport (the gloo-staged test transport of tests/, MPI ...): the two
+ *                              primitives below as function pointers.
+ * Primitives (stream-ordered; d_* are device pointers):
+ *   grx_comm_all_reduce        in place over `count` elements of grx_dtype with GRX_SUM / GRX_MAX
+ *   grx_comm_exchange          a group of point-to-point transfers.  Between one pair of ranks, sends and
+ *                              receives are matched in the order they appear in `ops`.
+ * Composites over a row partition h_bounds (host int64[world + 1]); column j of a block = base + j * ld
+ * elements; rank q OWNS columns q, q + world, ... of a block.  None of them packs: every transfer reads /
+ * writes the row slice of a column where it lies.
+ *   grx_comm_all_gather_rows     every column (host table of device pointers) holds this rank's rows ->
+ *                                complete on every rank (the next generation's gather source, W of the NMF)
+ *   grx_comm_columns_to_owners   d_block [ncols x ld] with this rank's rows valid -> d_owned [n_owned x ld_owned]:
+ *                                the owned columns with ALL rows (the owner bins whole columns)
+ *   grx_comm_owned_to_rows       the inverse for per-column results (uint8 bins): d_owned whole owned columns
+ *                                -> d_block [ncols x ld] with this rank's rows of EVERY column
+ * Timing (bench.py --gpus N): grx_comm_timing(comm, 1) records HIP events around every primitive;
+ * grx_comm_timing_read folds them into calls / milliseconds per kind (grx_comm_kind) and synchronises.
+ */
+typedef struct grx_comm grx_comm;
+typedef enum { GRX_F64 = 0, GRX_I32 = 1, GRX_I64 = 2, GRX_U8 = 3 } grx_dtype;
+typedef enum { GRX_SUM = 0, GRX_MAX = 1 } grx_reduce_op;
+typedef enum { GRX_COMM_ALL_REDUCE = 0, GRX_COMM_EXCHANGE = 1, GRX_COMM_ALL_GATHER_ROWS = 2,
+               GRX_COMM_COLUMNS_TO_OWNERS = 3, GRX_COMM_OWNED_TO_ROWS = 4, GRX_COMM_KINDS = 5 } grx_comm_kind;
+typedef struct { int is_recv; int peer; void *d_ptr; size_t bytes; } grx_p2p_op;
+typedef int (*grx_all_reduce_fn)(void *user, void *d_buf, size_t count, int dtype, int op, void *stream);
+typedef int (*grx_exchange_fn)(void *user, int n_ops, const grx_p2p_op *ops, void *stream);
+#define GRX_COMM_ID_BYTES 128
+#define GRX_COMM_SELF_VIA_TRANSPORT 1
+int grx_comm_rccl_unique_id(void *h_id);
+int grx_comm_create_rccl(const void *h_id, int rank, int world, int flags, grx_comm **out);
+int grx_comm_create_callbacks(int rank, int world, grx_all_reduce_fn all_reduce, grx_exchange_fn exchange, void *user,
+                              grx_comm **out);
+int grx_comm_destroy(grx_comm *comm);
+int grx_comm_rank(const grx_comm *comm);
+int grx_comm_world(const grx_comm *comm);
+int grx_comm_all_reduce(grx_comm *comm, void *d_buf, size_t count, int dtype, int op, void *stream);
+int grx_comm_exchange(grx_comm *comm, int n_ops, const grx_p2p_op *ops, void *stream);
+int grx_comm_all_gather_rows(grx_comm *comm, const int64_t *h_bounds, int ncols, void *const *h_col_ptrs,
+                             int elem_bytes, void *stream);
+int grx_comm_columns_to_owners(grx_comm *comm, const int64_t *h_bounds, int ncols, const void *d_block, int64_t ld,
+                               int elem_bytes, void *d_owned, int64_t ld_owned, void *stream);
+int grx_comm_owned_to_rows(grx_comm *comm, const int64_t *h_bounds, int ncols, const void *d_owned, int64_t ld_owned,
+                           int elem_bytes, void *d_block, int64_t ld, void *stream);
+int grx_comm_timing(grx_comm *comm, int on);
+int grx_comm_timing_read(grx_comm *comm, int kind, long long *calls, double *ms);
+int grx_comm_timing_reset(grx_comm *comm);
 
 /* ------------------------------------------------------------------ graph ingest -------- */
 /*
@@ -244,6 +309,14 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * `parent` indexes this table, names are rebuilt by the caller as name[parent] + '(' + agg + ')'.
  * h_gens (capacity max_gens >= max_generations): per-generation counts.  *generation_count = the last
  * executed generation (the reference's generation_count).  Synchronises `stream` before returning.
+ *
+ * comm / h_bounds (NULL / NULL = one GPU): node-range sharding.  Every rank calls with the same arguments and the
+ * COMPLETE generation-0 columns; it aggregates rows [h_bounds[rank], h_bounds[rank + 1]) only and the loop issues
+ * its own exchanges on `stream`: candidate row slices to the column owners (grx_comm_columns_to_owners), the owners'
+ * bins of the rank's rows back (grx_comm_owned_to_rows), all-reduce(MAX) of the F x F distance matrix (identical
+ * pruning decisions everywhere), then the RETAINED new columns -- and only those -- completed on every rank
+ * (grx_comm_all_gather_rows).  Every recorded column is complete on every rank on return; the neighbour sums
+ * follow a tree that depends on the row length only, so the bits equal those of a one-GPU run.
  */
 typedef enum { GRX_AGG_SUM = 0, GRX_AGG_MEAN = 1, GRX_AGG_MIN = 2, GRX_AGG_MAX = 3, GRX_AGG_VAR = 4, GRX_AGG_STD = 5 } grx_agg;
 typedef struct {
@@ -257,9 +330,9 @@ typedef struct {
 typedef struct { int candidates, working, dropped, retained; } grx_refex_generation;
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
-                  int n_aggs, const int *h_aggs, void *d_arena, size_t arena_bytes, int max_columns,
-                  grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
-                  int *generation_count, size_t *arena_needed, void *stream);
+                  int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
+                  size_t arena_bytes, int max_columns, grx_refex_column *h_columns, int *n_columns, int max_gens,
+                  grx_refex_generation *h_gens, int *generation_count, size_t *arena_needed, void *stream);
 
 /* ------------------------------------------------------------------ pruning ------------- */
 /*
@@ -407,6 +480,12 @@ int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, con
 int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W,
                     int64_t ldw, double *d_H, double *d_AB, double *d_err, int iters,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same block of iterations on a row shard: W rows [row_begin,row_end) are updated, the partial sums of every
+ * pass are summed over the ranks of `comm` (NULL: no exchange) before the H update that consumes them -- one
+ * small all-reduce per iteration, enqueued between the launches.  H ends identical on every rank. */
+int grx_nmf_iterate_rows(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                         int64_t row_begin, int64_t row_end, double *d_H, double *d_AB, int iters, grx_comm *comm,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The whole factorisation below the ABI.  Replaces get_nmf_decomposition (graphrole/roles/factor.py:10-26),
@@ -426,6 +505,12 @@ int grx_nmf_iterate(int64_t n, int F, int r, const double *d_X, int64_t ldx, dou
  *   grx_nmf_fit   both.
  * Kernels are enqueued on `stream`; the calls synchronise it at every small read-back (three in the
  * initialisation, one per ten iterations) and return with the results complete in d_W / d_H.
+ * comm / h_bounds (NULL / NULL = one GPU): row-sharded fit.  Every rank holds the same X and passes the same
+ * omega; the O(n) passes cover rows [h_bounds[rank], h_bounds[rank + 1]) and the drivers issue the exchanges:
+ * all-reduce(SUM) of the two Gram matrices, the projection statistics of every rank merged on the host, one
+ * all-reduce of [W^T X | W^T W] per iteration (grx_nmf_iterate_rows), of the residual at direct convergence
+ * checks; grx_nmf_mu / grx_nmf_fit finish by completing W on every rank (grx_comm_all_gather_rows).  H and n_iter
+ * are identical on every rank.
  */
 typedef struct {
     int n_iter;               /* executed iterations: sklearn's n_iter_ */
@@ -436,14 +521,14 @@ typedef struct {
 } grx_nmf_info;
 size_t grx_nmf_fit_workspace_bytes(int64_t n, int F, int r);
 int grx_nmf_init(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
-                 double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, void *d_workspace,
-                 size_t workspace_bytes, void *stream);
+                 double *d_W, int64_t ldw, double *d_H, double *x_sq_norm, grx_comm *comm, const int64_t *h_bounds,
+                 void *d_workspace, size_t workspace_bytes, void *stream);
 int grx_nmf_mu(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw, double *d_H,
-               double x_sq_norm, double tol, int max_iter, grx_nmf_info *info, void *d_workspace,
-               size_t workspace_bytes, void *stream);
+               double x_sq_norm, double tol, int max_iter, grx_nmf_info *info, grx_comm *comm, const int64_t *h_bounds,
+               void *d_workspace, size_t workspace_bytes, void *stream);
 int grx_nmf_fit(int64_t n, int F, int r, const double *d_X, int64_t ldx, const double *h_omega, int n_over,
-                double tol, int max_iter, double *d_W, int64_t ldw, double *d_H, grx_nmf_info *info,
-                void *d_workspace, size_t workspace_bytes, void *stream);
+                double tol, int max_iter, double *d_W, int64_t ldw, double *d_H, grx_nmf_info *info, grx_comm *comm,
+                const int64_t *h_bounds, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ RolX encode --------- */
 /*

@@ -94,7 +94,7 @@ class Info(C.Structure):
 info = Info()
 fit_bytes = _lib.grx_nmf_fit_workspace_bytes(_i64(n), _i32(F), _i32(r)); fit_ws = DeviceArray(nbytes=fit_bytes)
 _check(_lib.grx_nmf_fit(_i64(n), _i32(F), _i32(r), dX.ptr, _i64(n), omega.ctypes.data_as(_vp), _i32(r + 10),
-                        _f64(1e-4), _i32(200), dW.ptr, _i64(n), dH.ptr, C.byref(info), fit_ws.ptr,
+                        _f64(1e-4), _i32(200), dW.ptr, _i64(n), dH.ptr, C.byref(info), None, None, fit_ws.ptr,
                         C.c_size_t(fit_bytes), None))
 We, He, it = rolx.nmf(Xn, r, omega)
 W = dW.to_host(np.float64, (r, n)).T

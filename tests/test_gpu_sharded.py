@@ -36,7 +36,7 @@ def _graph(kind):
     return synth.directed_weighted_graph(40_000, 400_000, seed=4)
 
 
-def _worker(rank, port, kind, out_dir):
+def _worker(rank, port, kind, driver, out_dir):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -48,10 +48,14 @@ def _worker(rank, port, kind, out_dir):
         from graphrole_amd import RecursiveFeatureExtractor, kernels as K
         from graphrole_amd.roles import factor
         G = _graph(kind)
-        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True)
+        # 'native': grx_refex_run / grx_nmf_fit with the plan's communicator (the staged callback transport under
+        # gloo) -- the exchanges are issued by the C++ drivers; 'per_kernel': the Python driver over the same C
+        # exchange entry points
+        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, native_loop=driver == 'native')
         X = fe.extract_features()
         plan = fe._shard()
         assert plan is not None and plan.world == WORLD and 0 < plan.row_end - plan.row_begin < G.n
+        assert plan.comm() is not None
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
@@ -72,9 +76,10 @@ def _worker(rank, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['ba', 'directed_weighted', 'ba1m'])
-def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
-    mp.spawn(_worker, args=(_free_port(), kind, str(tmp_path)), nprocs=WORLD, join=True)
+@pytest.mark.parametrize('kind,driver', [('ba', 'native'), ('ba', 'per_kernel'), ('directed_weighted', 'native'),
+                                         ('directed_weighted', 'per_kernel'), ('ba1m', 'native')])
+def test_two_ranks_one_gpu_equal_single_process(kind, driver, tmp_path):
+    mp.spawn(_worker, args=(_free_port(), kind, driver, str(tmp_path)), nprocs=WORLD, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     assert list(r0['cols']) == list(r1['cols']) == list(r0['cols1'])
     assert np.array_equal(r0['X'], r1['X'])
@@ -88,7 +93,7 @@ def test_two_ranks_one_gpu_equal_single_process(kind, tmp_path):
         np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-12 * np.abs(r0['W1']).max())
 
 
-def _worker_rccl(rank, port, kind, out_dir):
+def _worker_rccl(rank, port, kind, driver, out_dir):
     """One rank, backend 'nccl' (= RCCL), GRX_FORCE_COLLECTIVES=1: every exchange of the N > 1 path
     runs as a real RCCL call on HBM tensors (all_to_all_single on fp64 / uint8, all_gather_into_tensor,
     all_reduce SUM / MAX on fp64 / int32) -- what a gloo test cannot cover."""
@@ -104,10 +109,18 @@ def _worker_rccl(rank, port, kind, out_dir):
         from graphrole_amd import RecursiveFeatureExtractor, kernels as K
         from graphrole_amd.roles import factor
         G = _graph(kind)
-        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, aggs=['sum', 'mean', 'max'])
+        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, aggs=['sum', 'mean', 'max'],
+                                      native_loop=driver == 'native')
         X = fe.extract_features()
         plan = fe._shard()
         assert plan is not None and plan.world == 1 and not plan._solo
+        plan.timing = True                                    # every exchange of one more pass, by kind
+        fe.reset()
+        fe.run_on_device()
+        kinds = plan.collect_timing()
+        plan.timing = False
+        assert kinds.get('columns_to_owners', [0])[0] >= 1 and kinds.get('owned_to_rows', [0])[0] >= 1, kinds
+        assert kinds.get('all_gather_rows', [0])[0] >= 1 and kinds.get('all_reduce', [0])[0] >= 1, kinds
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
         omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
@@ -124,9 +137,10 @@ def _worker_rccl(rank, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['ba', 'directed_weighted', 'ba1m'])
-def test_rccl_collectives_one_rank(kind, tmp_path):
-    mp.spawn(_worker_rccl, args=(_free_port(), kind, str(tmp_path)), nprocs=1, join=True)
+@pytest.mark.parametrize('kind,driver', [('ba', 'native'), ('ba', 'per_kernel'), ('directed_weighted', 'native'),
+                                         ('ba1m', 'native')])
+def test_rccl_collectives_one_rank(kind, driver, tmp_path):
+    mp.spawn(_worker_rccl, args=(_free_port(), kind, driver, str(tmp_path)), nprocs=1, join=True)
     r = np.load(tmp_path / 'rccl.npz')
     assert list(r['cols']) == list(r['cols1'])
     assert np.array_equal(r['X'], r['X1'])
