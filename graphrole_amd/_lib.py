@@ -74,6 +74,12 @@ _SIGNATURES = {
     'grx_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_memset': (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     'grx_stream_sync': (c_int, [c_void_p]),
+    'grx_download': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_upload': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_upload_i64_as_i32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_host_checksums': (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
+    'grx_min_value_workspace_bytes': (c_size_t, []),
+    'grx_min_value': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_event_create': (c_int, [POINTER(c_void_p)]),
     'grx_event_destroy': (c_int, [c_void_p]),
     'grx_event_record': (c_int, [c_void_p, c_void_p]),

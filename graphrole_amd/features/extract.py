@@ -393,30 +393,46 @@ class RecursiveFeatureExtractor:
     def _finalize_features(self) -> DataFrameLike:
         """DataFrame of every recorded feature, latest generation first (extract.py:91-96): the columns are put
         back into label order on the device (one permutation kernel for the whole table), copied out as one
-        block, and wrapped without another copy."""
+        block at link rate, and wrapped without another copy.  The device block is remembered next to the frame
+        (features/handoff.py): RoleExtractor.extract_role_factors(X) on the unmodified table skips the upload."""
         columns = self.final_columns()
-        frame = self._frame_of(columns, [self._final_cols[nm] for nm in columns])
+        frame = self._frame_of(columns, [self._final_cols[nm] for nm in columns], handoff=True)
         return frame
 
-    def _frame_of(self, names: Sequence[str], cols: Sequence) -> pd.DataFrame:
+    def _frame_of(self, names: Sequence[str], cols: Sequence, handoff: bool = False) -> pd.DataFrame:
         K = self._K()
         n = self._n()
         csr = self.graph.to_csr()
         labels = csr.label_index() if hasattr(csr, 'label_index') else pd.Index(self._labels())
         if not names:
             return pd.DataFrame(index=labels)
-        block = K.to_host(K.permute_columns(list(cols), self._inv_device(), n))           # [F, n], label order
-        frame = pd.DataFrame(block.T, index=labels, columns=list(names), copy=False)
-        for nm in names:                                   # the few integer columns (generation 0 of unweighted graphs)
-            dt = np.dtype(self._dtypes.get(nm, 'float64'))
-            if dt.kind in 'iu':
-                frame[nm] = frame[nm].to_numpy().astype(dt)
+        names = list(names)
+        dev_block = K.permute_columns(list(cols), self._inv_device(), n)                  # [F, n], label order
+        block = K.to_host(dev_block)
+        # one frame per run of equally typed columns, each wrapping its rows of the block (integer runs -- generation 0
+        # of unweighted graphs -- as int64 copies), joined without copying: assigning the integer columns one by one
+        # into a single float frame cost a block split per column
+        kinds = [np.dtype(self._dtypes.get(nm, 'float64')) for nm in names]
+        parts, a = [], 0
+        while a < len(names):
+            b = a + 1
+            while b < len(names) and kinds[b] == kinds[a]:
+                b += 1
+            values = block[a:b] if kinds[a] == np.dtype('float64') else block[a:b].astype(kinds[a])
+            parts.append(pd.DataFrame(values.T, index=labels, columns=names[a:b], copy=False))
+            a = b
+        frame = parts[0] if len(parts) == 1 else pd.concat(parts, axis=1, copy=False)
+        if handoff and hasattr(K, 'host_checksums'):
+            from graphrole_amd.features import handoff as _handoff
+            _handoff.register(K, frame, dev_block)
         return frame
 
     def _inv_device(self):
-        """inv (label row -> internal row) as an int32 device tensor, uploaded once."""
+        """inv (label row -> internal row) as an int32 device tensor (already there after a device ingest)."""
         if getattr(self, '_inv_dev', None) is None:
-            self._inv_dev = self._K().to_device(self._order().inv.astype(np.int32))
+            order = self._order()
+            dev = getattr(order, 'inv_dev', None)
+            self._inv_dev = dev if dev is not None else self._K().to_device(order.inv.astype(np.int32))
         return self._inv_dev
 
     # ------------------------------------------------------------------ reference-compatible internals

@@ -287,10 +287,29 @@ class DeviceBuiltGraph:
     column arrays, which exist on the device only.
     """
 
-    def __init__(self, g: CSRGraph, perm: np.ndarray, inv: np.ndarray, row_ptr: np.ndarray) -> None:
-        self.perm, self.inv, self.row_ptr = perm, inv, row_ptr
+    def __init__(self, g: CSRGraph, perm, inv, row_ptr: np.ndarray) -> None:
+        # perm / inv: int32 DEVICE tensors (the internal order never has to leave HBM on the hot path: the result table
+        # is permuted on the device); host copies are fetched on first use (attribute columns, adapter views)
+        self.perm_dev, self.inv_dev, self.row_ptr = perm, inv, row_ptr
+        self._perm = self._inv = None
         self.n, self.directed, self.weighted, self.integral = g.n, g.directed, g.weighted, g.integral
         self.labels, self.num_edges = g.labels, g.num_edges
+
+    @staticmethod
+    def _fetch(t) -> np.ndarray:
+        return np.ascontiguousarray(t.cpu().numpy() if hasattr(t, 'cpu') else t).astype(np.int64)
+
+    @property
+    def perm(self) -> np.ndarray:
+        if self._perm is None:
+            self._perm = self._fetch(self.perm_dev)
+        return self._perm
+
+    @property
+    def inv(self) -> np.ndarray:
+        if self._inv is None:
+            self._inv = self._fetch(self.inv_dev)
+        return self._inv
 
     @property
     def nnz(self) -> int:

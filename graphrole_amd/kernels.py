@@ -50,8 +50,49 @@ def num_cus() -> int:
     return _NUM_CUS
 
 
+_BULK_BYTES = 1 << 20          # above this, host <-> device copies go through the pipelined staging ring
+
+
 def to_device(a: np.ndarray) -> torch.Tensor:
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device())
+    a = np.ascontiguousarray(a)
+    if a.nbytes < _BULK_BYTES or a.dtype.kind not in 'fiu':
+        return torch.from_numpy(a).to(device())
+    t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, device=device())
+    _lib.call('grx_upload', _ptr(t), _hptr(a), a.nbytes, _stream())
+    return t
+
+
+def upload_into(dst: torch.Tensor, a: np.ndarray) -> None:
+    """Host array -> an existing contiguous device tensor of the same byte size (pipelined pinned staging)."""
+    a = np.ascontiguousarray(a)
+    assert dst.is_contiguous() and dst.numel() * dst.element_size() == a.nbytes
+    _lib.call('grx_upload', _ptr(dst), _hptr(a), a.nbytes, _stream())
+
+
+def edges_to_device(a: np.ndarray) -> torch.Tensor:
+    """Edge endpoint array -> int32 device tensor; int64 input (numpy's default) is narrowed while staging."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.int64 and a.nbytes >= _BULK_BYTES:
+        t = torch.empty(a.shape, dtype=torch.int32, device=device())
+        _lib.call('grx_upload_i64_as_i32', _ptr(t), _hptr(a), a.size, _stream())
+        return t
+    return to_device(np.ascontiguousarray(a, dtype=np.int32))
+
+
+def host_checksums(base_ptr: int, ncols: int, col_bytes: int, stride_bytes: int) -> np.ndarray:
+    """64-bit content hash of ncols host columns (grx_host_checksums)."""
+    out = np.empty(ncols, dtype=np.uint64)
+    _lib.call('grx_host_checksums', c_void_p(base_ptr), int(ncols), int(col_bytes), int(stride_bytes), _hptr(out))
+    return out
+
+
+def min_value(X: torch.Tensor, n: int) -> float:
+    """min over the n valid rows of a feature-major device matrix [F, ld]; NaN if any entry is NaN."""
+    ws_bytes = _lib.load().grx_min_value_workspace_bytes()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    out = torch.empty(1, dtype=torch.float64, device=device())
+    _lib.call('grx_min_value', n, X.shape[0], _ptr(X), _ld(X), _ptr(out), _ptr(ws), ws_bytes, _stream())
+    return float(to_host(out)[0])
 
 
 import threading
@@ -68,6 +109,12 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     of queued work at every read-back, the step time did not change measurably."""
     t = t.detach()
     nbytes = t.numel() * t.element_size()
+    if t.is_cuda and nbytes > _PINNED_MAX_BYTES and t.is_contiguous():
+        # bulk results (the feature table, the node-role factor): chunks through the pinned staging ring, host memcpy
+        # threaded (grx_download) -- a plain Tensor.cpu() into pageable memory runs at a fraction of the link rate
+        out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+        _lib.call('grx_download', _hptr(out), _ptr(t), nbytes, _stream())
+        return out
     if not t.is_cuda or nbytes == 0 or nbytes > _PINNED_MAX_BYTES:
         return t.cpu().numpy()
     bufs = getattr(_PINNED, 'bufs', None)
@@ -269,9 +316,9 @@ def device_ingest(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarr
     """
     dev = device()
     m = int(len(src))
-    d_src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)).to(dev)
-    d_dst = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int32)).to(dev)
-    d_w = None if w is None else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64)).to(dev)
+    d_src = edges_to_device(src)
+    d_dst = edges_to_device(dst)
+    d_w = None if w is None else to_device(np.ascontiguousarray(w, dtype=np.float64))
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     inv = torch.empty(n, dtype=torch.int32, device=dev)
     row_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
@@ -289,14 +336,13 @@ def device_ingest(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarr
               _ptr(row_ptr), _ptr(col), _ptr(wcol), _ptr(agg_col), _ptr(t_row_ptr), _ptr(t_col), _ptr(t_w), _ptr(ws),
               ws_bytes, _stream())
     del ws
-    h_perm = perm.cpu().numpy().astype(np.int64)
-    h_inv = inv.cpu().numpy().astype(np.int64)
-    h_row_ptr = row_ptr.cpu().numpy()
+    h_row_ptr = to_host(row_ptr)
     out = DeviceCSR.from_device(row_ptr, col, wcol, agg_col, h_row_ptr)
     tr = None
     if directed:
-        tr = DeviceCSR.from_device(t_row_ptr, t_col, t_w, None, t_row_ptr.cpu().numpy())
-    return h_perm, h_inv, h_row_ptr, out, tr
+        tr = DeviceCSR.from_device(t_row_ptr, t_col, t_w, None, to_host(t_row_ptr))
+    # the internal order stays on the device (int32); the host copies are fetched only if something asks
+    return perm, inv, h_row_ptr, out, tr
 
 
 def row_sums(csr: DeviceCSR, add_self_loop: bool, row_begin: int = 0, row_end: Optional[int] = None,
@@ -808,8 +854,9 @@ def nmf_init(X: torch.Tensor, n: int, r: int, omega: np.ndarray, shard=None):
     H = torch.empty((r, F), dtype=torch.float64, device=device())
     ws, ws_bytes = _fit_workspace(n, F, r)
     xx = ctypes.c_double(0.0)
+    comm, bounds = _shard_args(shard)
     _lib.call('grx_nmf_init', n, F, r, _ptr(X), _ld(X), _hptr(omega), omega.shape[1], _ptr(W), _ld(W), _ptr(H),
-              ctypes.byref(xx), _ptr(ws), ws_bytes, _stream())
+              ctypes.byref(xx), comm, bounds, _ptr(ws), ws_bytes, _stream())
     return W, H, float(xx.value)
 
 
@@ -838,7 +885,7 @@ def nmf_fit(X: torch.Tensor, n: int, r: int, omega: np.ndarray, tol: float, max_
     ws, ws_bytes = _fit_workspace(n, F, r)
     info = _lib.NmfInfo()
     _lib.call('grx_nmf_fit', n, F, r, _ptr(X), _ld(X), _hptr(omega), omega.shape[1], float(tol), int(max_iter),
-              _ptr(W), _ld(W), _ptr(H), ctypes.byref(info), _ptr(ws), ws_bytes, _stream())
+              _ptr(W), _ld(W), _ptr(H), ctypes.byref(info), comm, bounds, _ptr(ws), ws_bytes, _stream())
     del ws
     state = NmfState(X, n, W, H, x_sq_norm=float(info.x_sq_norm))
     state.info = info

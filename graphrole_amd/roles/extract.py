@@ -106,10 +106,9 @@ class RoleExtractor:
         """
         from graphrole_amd import backend
         K = backend.get()
-        V = factor._checked_matrix(features.values)
-        Vd = factor.feature_major(V)
-        plan = self._plan(V.shape[0])
-        rb, re = (0, V.shape[0]) if plan is None else (plan.row_begin, plan.row_end)
+        Vd, V = factor.device_matrix(features)             # V = (n, F): the table itself stays in HBM
+        plan = self._plan(V[0])
+        rb, re = (0, V[0]) if plan is None else (plan.row_begin, plan.row_end)
         bit_stop = self.max_bits + 1
         role_stop = min(min(features.shape), self.max_roles) + 1
         encoding_costs = np.full((role_stop, bit_stop), np.nan)
@@ -139,7 +138,9 @@ class RoleExtractor:
         self.model_selection_ = {'encoding_costs': encoding_costs, 'error_costs': error_costs,
                                  'selected': (int(best_roles), int(best_bits))}
         Wq, Hq = factors[best_roles][best_bits]
-        return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
+        # transposed to the n x r layout of the result in HBM: a strided host transpose of the factor costs more
+        # than the copy itself
+        return K.to_host(K.transpose(Wq, int(best_roles), V[0])), K.to_host(Hq).copy()
 
     @staticmethod
     def _get_encoded_role_factors(features: pd.DataFrame, n_roles: int, n_bits: int,
@@ -147,11 +148,11 @@ class RoleExtractor:
         """NMF of the feature matrix with both factors quantised to 2**n_bits levels (:144-161)"""
         from graphrole_amd import backend
         K = backend.get()
-        V = factor._checked_matrix(features.values)
-        Vd = factor.feature_major(V)
-        _, Wq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer,
-                                                        plan)
-        return K.to_host(Wq).T.copy(), K.to_host(Hq).copy()
+        Vd, V = factor.device_matrix(features)
+        _, Gq, Hq, _, _ = factor.encoded_factors_device(Vd, V, n_roles, n_bits, quantizer or RoleExtractor.quantizer,
+                                                        plan, want_node_major=True)
+        # Gq is already the n x r row-major matrix the reference returns: one copy out, no host transpose
+        return K.to_host(Gq.contiguous() if hasattr(Gq, 'contiguous') else Gq).reshape(V[0], n_roles), K.to_host(Hq).copy()
 
     @staticmethod
     def _rescale_costs(costs: np.ndarray) -> np.ndarray:

@@ -270,19 +270,24 @@ def _checked_matrix(X) -> np.ndarray:
     return X
 
 
-def nmf_state(Xd, X: np.ndarray, n_roles: int, plan=None):
+def _shape_of(X) -> Tuple[int, int]:
+    return (int(X[0]), int(X[1])) if isinstance(X, tuple) else tuple(X.shape)
+
+
+def nmf_state(Xd, X, n_roles: int, plan=None):
     """
-    Run the factorisation of the host matrix X whose feature-major copy Xd [F, n] is already in
-    HBM; returns (NmfState with W [r, n] and H [r, F] on the device, n_iter).  Consumes numpy's
+    Run the factorisation of the matrix whose feature-major copy Xd [F, n] is already in HBM; X is the host matrix
+    (n x F) or just its shape (n, F) when the table never left the device (features/handoff.py).
+    Returns (NmfState with W [r, n] and H [r, F] on the device, n_iter).  Consumes numpy's
     global RNG exactly like sklearn (one Gaussian test matrix).  With a ShardPlan the row passes cover the
     rank's rows only (every rank must hold the same X and draw the same test matrix: seed numpy alike) and the
     rows of W are gathered at the end, so that every rank returns the complete factor.
     """
     K = _kernels()
-    n, F = X.shape
+    n, F = _shape_of(X)
     if n_roles > min(n, F):
         raise ValueError("init = 'nndsvda' can only be used when n_components <= min(n_samples, n_features)")
-    omega = draw_omega(X.shape, n_roles)
+    omega = draw_omega((n, F), n_roles)
     if plan is not None and n >= F:
         state, n_iter = nmf_device(Xd, n, n_roles, omega, plan=plan)
         if not getattr(K, 'NATIVE_SHARDING', False):
@@ -290,6 +295,8 @@ def nmf_state(Xd, X: np.ndarray, n_roles: int, plan=None):
         return state, n_iter
     if n < F:
         # fewer nodes than features: every matrix of the initialisation is small (k x F algebra)
+        if isinstance(X, tuple):
+            X = np.ascontiguousarray(K.to_host(Xd)[:, :n].T)
         W0h, H0 = _host_init(X, n_roles, omega)
         H0 = H0.copy()
         W0h[W0h < NNDSVD_EPS] = 0
@@ -306,6 +313,41 @@ def feature_major(X: np.ndarray):
     K = _kernels()
     n, F = X.shape
     return K.transpose(K.to_device(X), n, F)
+
+
+def device_matrix(features):
+    """
+    (Xd [F, n] feature-major on the device, (n, F)) of the table handed to RoleExtractor -- a DataFrame or an array.
+      * a DataFrame that RecursiveFeatureExtractor.extract_features() returned and nobody modified: the device block
+        it was copied from (features/handoff.py) -- no upload, no transpose;
+      * any other DataFrame: column by column (pandas stores columns contiguously) through the pipelined upload,
+        straight into the feature-major layout;
+      * arrays: upload + transpose in HBM.
+    Negative or NaN entries raise ValueError like sklearn's NMF (_nmf.py:283, check_array); the check is one pass in
+    HBM instead of a host pass.
+    """
+    import pandas as pd
+    K = _kernels()
+    if isinstance(features, pd.DataFrame) and hasattr(K, 'upload_into'):
+        n, F = features.shape
+        from graphrole_amd.features import handoff
+        Xd = handoff.lookup(K, features)
+        if Xd is None:
+            Xd = K.empty((F, max(n, 1)))
+            for j in range(F):
+                col = features.iloc[:, j].to_numpy()
+                if col.dtype != np.float64 or not col.flags.c_contiguous:
+                    col = np.ascontiguousarray(col, dtype=np.float64)
+                K.upload_into(Xd[j, :n], col) if n else None
+        if n and F:
+            lo = K.min_value(Xd, n)
+            if lo != lo:
+                raise ValueError('Input X contains NaN.')
+            if lo < 0:
+                raise ValueError('Negative values in data passed to NMF (input X)')        # _nmf.py:283
+        return Xd, (n, F)
+    X = _checked_matrix(features.values if isinstance(features, pd.DataFrame) else features)
+    return feature_major(X), tuple(X.shape)
 
 
 def nmf_with_info(X: np.ndarray, n_roles: int):
@@ -333,17 +375,19 @@ def _quantize_flat(flat, n_bins: int, quantizer: str):
     return q, info
 
 
-def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantizer: str = 'kmeans', plan=None):
+def encoded_factors_device(Xd, X, n_roles: int, n_bits: int, quantizer: str = 'kmeans', plan=None,
+                           want_node_major: bool = False):
     """
-    NMF of X followed by the quantisation of both factors with 2**n_bits levels, without leaving
-    HBM (roles/extract.py:144-161).  Returns (state, Wq [r, n], Hq [r, F], distinct values of Wq,
-    distinct values of Hq); raises TooFewSamples (a ValueError, like the reference) when there are fewer
-    factor entries than levels.
+    NMF of X (host matrix, or its shape (n, F) when only the device copy Xd exists) followed by the quantisation
+    of both factors with 2**n_bits levels, without leaving HBM (roles/extract.py:144-161).  Returns (state,
+    Wq [r, n], Hq [r, F], distinct values of Wq, distinct values of Hq); raises TooFewSamples (a ValueError, like the
+    reference) when there are fewer factor entries than levels.  want_node_major: Wq is returned as the n x r
+    row-major matrix the caller copies out (the layout the quantiser worked in) instead of [r, n].
     quantizer='kmeans' reproduces the reference's sklearn KMeans(random_state=1) (grx_kmeans1d);
     'lloyd_max' is the deterministic optimum-seeking quantiser (grx_lloyd_max): lower error, other numbers.
     """
     K = _kernels()
-    n, F = X.shape
+    n, F = _shape_of(X)
     state, _ = nmf_state(Xd, X, n_roles, plan)
     n_bins = int(2 ** n_bits)
     for size in (n_roles * n, n_roles * F):               # encode(G) first, then encode(F)
@@ -353,7 +397,7 @@ def encoded_factors_device(Xd, X: np.ndarray, n_roles: int, n_bits: int, quantiz
     # order of its cumulative sums, so the feature-major device factor is transposed first
     G_flat = K.transpose(state.W, n_roles, n).reshape(-1)
     Gq_flat, info_w = _quantize_flat(G_flat, n_bins, quantizer)
-    Wq = K.transpose(Gq_flat.view(n, n_roles), n, n_roles)
+    Wq = Gq_flat.view(n, n_roles) if want_node_major else K.transpose(Gq_flat.view(n, n_roles), n, n_roles)
     Hq, info_h = _quantize_flat(state.H.reshape(-1), n_bins, quantizer)
     info_w, info_h = K.to_host(info_w), K.to_host(info_h)
     return state, Wq, Hq.view(n_roles, F), int(info_w[2]), int(info_h[2])

@@ -58,6 +58,25 @@ int grx_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int grx_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int grx_memset(void *d_dst, int value, size_t bytes, void *stream);
 int grx_stream_sync(void *stream);
+/*
+ * Bulk host <-> device copies for PAGEABLE host memory (numpy arrays) at close to link rate: chunks through a ring
+ * of pinned staging buffers, the host-side memcpy on a small thread pool while the next chunk is on the link.  The
+ * only bulk data of the two public calls that crosses PCIe is the result table extract_features() hands to
+ * extract_role_factors() (graphrole/roles/extract.py:59-93) and the edge arrays.  Synchronous on return.
+ * grx_upload_i64_as_i32 narrows int64 edge arrays (numpy's default) while staging; GRX_ERR_INVALID if a value
+ * does not fit.  grx_host_checksums: 64-bit content hash of each of ncols host columns (col_bytes each, a multiple
+ * of 8; column c at h_base + c * stride_bytes) -- how a result table is recognised as unmodified when it comes back.
+ * grx_min_value: min over the n x F entries of a feature-major device matrix (NaN if any entry is NaN): sklearn's
+ * "Negative values in data passed to NMF" check (_nmf.py:283) without a host pass.
+ */
+int grx_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int grx_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int grx_upload_i64_as_i32(int32_t *d_dst, const int64_t *h_src, size_t count, void *stream);
+int grx_host_checksums(const void *h_base, int ncols, size_t col_bytes, size_t stride_bytes, uint64_t *h_out);
+size_t grx_min_value_workspace_bytes(void);
+int grx_min_value(int64_t n, int F, const double *d_X, int64_t ld, double *d_out, void *d_workspace,
+                  size_t workspace_bytes, void *stream);
+
 /* Stream-ordered event timing helpers (bench.py measures kernels on the launch stream). */
 int grx_event_create(void **event_out);
 int grx_event_destroy(void *event);

@@ -104,3 +104,32 @@ def test_product_code_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f'{fn} imports oracle'
                 assert 'liboracle' not in text, f'{fn} references liboracle'
+
+
+def test_every_binding_call_passes_the_declared_number_of_arguments():
+    """Static guard (no GPU needed): each `_lib.call('grx_x', ...)` / `lib.grx_x(...)` in the host package passes as
+    many arguments as the ctypes signature -- and therefore include/grx.h -- declares."""
+    import ast
+    from graphrole_amd import _lib
+    root = os.path.join(ROOT, 'graphrole_amd')
+    checked = 0
+    for dirpath, _, files in os.walk(root):
+        for fn in files:
+            if not fn.endswith('.py'):
+                continue
+            path = os.path.join(dirpath, fn)
+            for node in ast.walk(ast.parse(open(path).read())):
+                if not isinstance(node, ast.Call) or any(isinstance(a, ast.Starred) for a in node.args):
+                    continue
+                f = node.func
+                if isinstance(f, ast.Attribute) and f.attr == 'call' and node.args and isinstance(node.args[0], ast.Constant) \
+                        and str(node.args[0].value).startswith('grx_'):
+                    name, got = node.args[0].value, len(node.args) - 1
+                elif isinstance(f, ast.Attribute) and f.attr.startswith('grx_') and f.attr in _lib._SIGNATURES:
+                    name, got = f.attr, len(node.args)
+                else:
+                    continue
+                want = len(_lib._SIGNATURES[name][1])
+                assert got == want, f'{path}:{node.lineno}: {name} takes {want} arguments, {got} given'
+                checked += 1
+    assert checked > 60

@@ -1,0 +1,43 @@
+"""-m "not gpu": the host half of csrc/grx_hostio.hip -- the content hashes behind the device-resident hand-off."""
+import ctypes
+
+import numpy as np
+
+
+def _sums(a):
+    from graphrole_amd import _lib
+    a = np.ascontiguousarray(a)
+    out = np.zeros(a.shape[0], dtype=np.uint64)
+    _lib.call('grx_host_checksums', a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1] * 8, a.strides[0],
+              out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def test_checksums_see_bit_flips_swaps_and_shifts():
+    rng = np.random.default_rng(0)
+    a = rng.random((7, 200_003))
+    base = _sums(a)
+    assert len(set(base.tolist())) == 7
+    assert np.array_equal(base, _sums(a.copy()))
+    b = a.copy()
+    b[3, 77] = np.nextafter(b[3, 77], 2)                         # one bit
+    assert (base != _sums(b)).tolist() == [False, False, False, True, False, False, False]
+    b = a.copy()
+    b[5, [10, 11]] = b[5, [11, 10]]                               # two neighbours swapped
+    assert (base != _sums(b)).nonzero()[0].tolist() == [5]
+    b = a.copy()
+    b[1, 64:128], b[1, 128:192] = a[1, 128:192], a[1, 64:128]     # two whole cache-line groups swapped
+    assert (base != _sums(b)).nonzero()[0].tolist() == [1]
+    b = a.copy()
+    b[6] = np.roll(a[6], 8)                                       # shifted by one step of the hash
+    assert (base != _sums(b)).nonzero()[0].tolist() == [6]
+
+
+def test_checksum_of_a_column_does_not_depend_on_the_batch():
+    rng = np.random.default_rng(1)
+    a = rng.random((5, 131_072 + 9))
+    together = _sums(a)
+    for j in range(5):
+        assert _sums(a[j:j + 1])[0] == together[j]
+    ints = rng.integers(0, 1 << 40, size=(3, 70_000), dtype=np.int64)
+    assert np.array_equal(_sums(ints.view(np.float64)), _sums(ints.view(np.float64).copy()))
