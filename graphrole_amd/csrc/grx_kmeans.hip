@@ -23,6 +23,8 @@
 // with a 1e-12 tolerance (see km_choose_kernel).  Centres agree with sklearn to ~1e-12 otherwise.
 #include "grx_common.h"
 
+#include <cstdlib>
+
 int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
                               void *workspace, hipStream_t st);
 extern "C" size_t grx_sort_workspace_bytes(int64_t n, int ncols);
@@ -48,6 +50,7 @@ struct KmState {                 // device scalars shared by the kernels of one 
     int64_t cand_id[KM_MAX_TRIALS];
     double best_x;
     int64_t best_id;
+    unsigned bar_count, bar_gen;   // grid barrier of the persistent seeding kernel
 };
 
 // fixed-shape workgroup sum (256 threads): wave butterflies, then the four wave totals in order
@@ -56,6 +59,18 @@ __device__ __forceinline__ double km_block_sum(double v, double *red)
     v = grx_group_sum<64>(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// the same sum for one of several 256-thread sub-blocks of a larger workgroup (lt = thread id inside the sub-block,
+// red = the sub-block's four slots): identical tree, so a sub-block of the persistent kernel produces the bits a
+// 256-thread workgroup of the per-seed kernels does
+__device__ __forceinline__ double km_subblock_sum(double v, double *red, int lt)
+{
+    v = grx_group_sum<64>(v);
+    __syncthreads();
+    if ((lt & 63) == 0) red[lt >> 6] = v;
     __syncthreads();
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
@@ -117,13 +132,12 @@ __global__ __launch_bounds__(256) void km_init_kernel(const double *__restrict__
 // ---- k-means++ : one further seed = pick -> potentials -> choose -> update ---------------------------
 // pick: inclusive scan of the tile sums (potential = last), then per trial r = uniform * potential and the first
 // index whose cumulative sum reaches r: binary search over the tile prefixes, sequential additions inside the tile
-__global__ __launch_bounds__(1024) void km_pick_kernel(const double *__restrict__ x, const double *__restrict__ d,
-                                                       int64_t m, double *__restrict__ tsum, int64_t ntiles,
-                                                       const double *__restrict__ uniform, int n_trials, int first_call,
-                                                       KmState *st)
+__device__ __forceinline__ void km_pick_body(const double *__restrict__ x, const double *__restrict__ d,
+                                             int64_t m, double *__restrict__ tsum, int64_t ntiles,
+                                             const double *__restrict__ uniform, int n_trials, int first_call,
+                                             KmState *st, double *s_scan, double *s_pot_p)
 {
-    __shared__ double s_scan[1024];
-    __shared__ double s_pot;
+    double &s_pot = *s_pot_p;
     {
         // inclusive prefixes of the tile sums in place: a contiguous chunk of tiles per thread, the chunk totals
         // scanned across the workgroup
@@ -184,12 +198,22 @@ __global__ __launch_bounds__(1024) void km_pick_kernel(const double *__restrict_
     }
 }
 
-// potentials of the candidates: sum over all values of min(d, squared distance to the candidate)
-__global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__ x, const double *__restrict__ d, int64_t m,
-                                                      int n_trials, const KmState *__restrict__ st,
-                                                      double *__restrict__ ppart)
+__global__ __launch_bounds__(1024) void km_pick_kernel(const double *__restrict__ x, const double *__restrict__ d,
+                                                       int64_t m, double *__restrict__ tsum, int64_t ntiles,
+                                                       const double *__restrict__ uniform, int n_trials, int first_call,
+                                                       KmState *st)
 {
-    __shared__ double red[4];
+    __shared__ double s_scan[1024];
+    __shared__ double s_pot;
+    km_pick_body(x, d, m, tsum, ntiles, uniform, n_trials, first_call, st, s_scan, &s_pot);
+}
+
+// potentials of the candidates: sum over all values of min(d, squared distance to the candidate).  One 256-thread
+// (sub-)block vb of nb: thread lt adds the values vb * 256 + lt, + nb * 256, ... in order, then the block tree.
+__device__ __forceinline__ void km_pots_block(const double *__restrict__ x, const double *__restrict__ d, int64_t m,
+                                              int n_trials, const KmState *__restrict__ st, double *__restrict__ ppart,
+                                              int vb, int nb, int lt, double *red, bool valid)
+{
     double c[KM_MAX_TRIALS], csq[KM_MAX_TRIALS], s[KM_MAX_TRIALS];
 #pragma unroll
     for (int j = 0; j < KM_MAX_TRIALS; ++j) {
@@ -197,8 +221,8 @@ __global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__
         csq[j] = __dmul_rn(c[j], c[j]);
         s[j] = 0.0;
     }
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+    const int64_t stride = (int64_t)nb * 256;
+    for (int64_t i = valid ? (int64_t)vb * 256 + lt : m; i < m; i += stride) {
         const double xi = x[i], di = d[i];
 #pragma unroll
         for (int j = 0; j < KM_MAX_TRIALS; ++j) {
@@ -209,19 +233,25 @@ __global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__
         }
     }
     for (int j = 0; j < n_trials; ++j) {
-        const double tot = km_block_sum(s[j], red);
-        if (threadIdx.x == 0) ppart[(size_t)j * gridDim.x + blockIdx.x] = tot;
+        const double tot = km_subblock_sum(s[j], red, lt);
+        if (lt == 0 && valid) ppart[(size_t)j * nb + vb] = tot;
     }
+}
+
+__global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__ x, const double *__restrict__ d, int64_t m,
+                                                      int n_trials, const KmState *__restrict__ st,
+                                                      double *__restrict__ ppart)
+{
+    __shared__ double red[4];
+    km_pots_block(x, d, m, n_trials, st, ppart, blockIdx.x, gridDim.x, threadIdx.x, red, true);
 }
 
 // one wavefront per candidate: lane-strided partial sums (eight loads in flight), fixed butterfly -- a single
 // thread walking the thousands of block partials of its candidate was a 0.1 ms latency chain per seed
-__global__ __launch_bounds__(64 * KM_MAX_TRIALS) void km_choose_kernel(const double *__restrict__ ppart, int nb,
-                                                                       int n_trials, int seed_no, KmState *st,
-                                                                       double *__restrict__ seeds_x,
-                                                                       int64_t *__restrict__ seeds_id)
+__device__ __forceinline__ void km_choose_body(const double *__restrict__ ppart, int nb, int n_trials, int seed_no,
+                                               KmState *st, double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
+                                               double *pots)
 {
-    __shared__ double pots[KM_MAX_TRIALS];
     const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (j < n_trials) {
         const double *src = ppart + (size_t)j * nb;
@@ -255,18 +285,28 @@ __global__ __launch_bounds__(64 * KM_MAX_TRIALS) void km_choose_kernel(const dou
     }
 }
 
-// d = min(d, squared distance to the chosen seed); tile sums for the next cumulative sum
-__global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ x, double *__restrict__ d, int64_t m,
-                                                        const KmState *__restrict__ st, double *__restrict__ tsum)
+__global__ __launch_bounds__(64 * KM_MAX_TRIALS) void km_choose_kernel(const double *__restrict__ ppart, int nb,
+                                                                       int n_trials, int seed_no, KmState *st,
+                                                                       double *__restrict__ seeds_x,
+                                                                       int64_t *__restrict__ seeds_id)
 {
-    __shared__ double red[4];
+    __shared__ double pots[KM_MAX_TRIALS];
+    km_choose_body(ppart, nb, n_trials, seed_no, st, seeds_x, seeds_id, pots);
+}
+
+// d = min(d, squared distance to the chosen seed); tile sums for the next cumulative sum.  One 256-thread
+// (sub-)block per tile of KM_TILE values.
+__device__ __forceinline__ void km_update_tile(const double *__restrict__ x, double *__restrict__ d, int64_t m,
+                                               const KmState *__restrict__ st, double *__restrict__ tsum, int64_t tile,
+                                               int lt, double *red, bool valid)
+{
     const double c = st->best_x, csq = __dmul_rn(c, c);
-    const int64_t base = (int64_t)blockIdx.x * KM_TILE;
+    const int64_t base = tile * KM_TILE;
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        if (i < m) {
+        const int64_t i = base + j * 256 + lt;
+        if (valid && i < m) {
             const double dj = km_sqdist(c, csq, x[i]);
             const double di = d[i];
             const double nd = dj < di ? dj : di;
@@ -274,8 +314,106 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
             s += nd;
         }
     }
-    s = km_block_sum(s, red);
-    if (threadIdx.x == 0) tsum[blockIdx.x] = s;
+    s = km_subblock_sum(s, red, lt);
+    if (lt == 0 && valid) tsum[tile] = s;
+}
+
+__global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ x, double *__restrict__ d, int64_t m,
+                                                        const KmState *__restrict__ st, double *__restrict__ tsum)
+{
+    __shared__ double red[4];
+    km_update_tile(x, d, m, st, tsum, blockIdx.x, threadIdx.x, red, true);
+}
+
+// ---- the whole k-means++ seeding in ONE cooperative launch --------------------------------------------------------
+// Per further seed the four steps above depend on each other through grid-wide results (the cumulative sum of every
+// tile, the potentials over all values): as separate launches that is 4 (k - 1) launches per encode -- 2 044 for the
+// 512 levels of a wide table.  Here every workgroup stays resident (hipLaunchCooperativeKernel) and the steps are
+// separated by grid barriers; the serial steps (pick, choose) are run by the LAST workgroup to arrive, before it
+// releases the others: two barriers per seed.  A workgroup is four 256-thread sub-blocks that take the role of the
+// 256-thread workgroups of the per-seed kernels (same index sets, same trees), so the seeds are bit-identical.
+__device__ __forceinline__ bool km_grid_arrive(KmState *st, unsigned nwg, unsigned *s_flag, unsigned *gen_out)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&st->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                      // this workgroup's results first
+        const unsigned prev = __hip_atomic_fetch_add(&st->bar_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag[0] = prev == nwg - 1;
+        s_flag[1] = gen;
+        if (prev == nwg - 1) __threadfence();                 // ... and everybody else's before the serial step reads them
+    }
+    __syncthreads();
+    *gen_out = s_flag[1];
+    return s_flag[0] != 0;
+}
+
+__device__ __forceinline__ void km_grid_release(KmState *st)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&st->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_fetch_add(&st->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ void km_grid_wait(KmState *st, unsigned gen)
+{
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&st->bar_gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen)
+            __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void km_seed_kernel(const double *__restrict__ x, double *__restrict__ d, int64_t m,
+                                                       double *__restrict__ tsum, int64_t ntiles,
+                                                       const double *__restrict__ uniform, int n_trials, int k, int nb,
+                                                       KmState *st, double *__restrict__ ppart,
+                                                       double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id)
+{
+    __shared__ double s_scan[1024];
+    __shared__ double s_pot;
+    __shared__ double s_red[4][4];
+    __shared__ double s_pots[KM_MAX_TRIALS];
+    __shared__ unsigned s_flag[2];
+    const unsigned nwg = gridDim.x;
+    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
+    const int64_t vstride = (int64_t)nwg * 4;
+    unsigned gen;
+    // the first pick needs the tile sums of km_init_kernel (an earlier launch): workgroup 0 runs it, the others wait
+    if (km_grid_arrive(st, nwg, s_flag, &gen)) {
+        km_pick_body(x, d, m, tsum, ntiles, uniform, n_trials, 1, st, s_scan, &s_pot);
+        km_grid_release(st);
+    } else {
+        km_grid_wait(st, gen);
+    }
+    for (int c = 1; c < k; ++c) {
+        // potentials of this seed's candidates
+        for (int64_t v0 = (int64_t)blockIdx.x * 4; v0 < nb; v0 += vstride) {
+            const int64_t vb = v0 + sub;
+            km_pots_block(x, d, m, n_trials, st, ppart, (int)vb, nb, lt, s_red[sub], vb < nb);
+        }
+        if (km_grid_arrive(st, nwg, s_flag, &gen)) {
+            km_choose_body(ppart, nb, n_trials, c, st, seeds_x, seeds_id, s_pots);
+            km_grid_release(st);
+        } else {
+            km_grid_wait(st, gen);
+        }
+        if (c == k - 1) break;                                 // the distances to the last seed are never needed
+        for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < ntiles; t0 += vstride) {
+            const int64_t tile = t0 + sub;
+            km_update_tile(x, d, m, st, tsum, tile, lt, s_red[sub], tile < ntiles);
+        }
+        if (km_grid_arrive(st, nwg, s_flag, &gen)) {
+            km_pick_body(x, d, m, tsum, ntiles, uniform + (size_t)c * n_trials, n_trials, 0, st, s_scan, &s_pot);
+            km_grid_release(st);
+        } else {
+            km_grid_wait(st, gen);
+        }
+    }
 }
 
 // ---- prefix sums of the sorted values: P[i] = sum_{j < i} xs[j] ------------------------------------
@@ -640,13 +778,39 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     km_moment_final_kernel<<<1, 64, 0, st>>>(part, p.nb, m, 1, rel_tol, state);
     km_init_kernel<<<(int)p.ntiles, 256, 0, st>>>(d_values, m, first_seed, state, x, d, tsum, seeds_x, seeds_id);
     GRX_LAUNCH_CHECK();
-    for (int c = 1; c < k; ++c) {
-        km_pick_kernel<<<1, 1024, 0, st>>>(x, d, m, tsum, p.ntiles,
-                                                                        d_uniform + (size_t)(c - 1) * n_trials, n_trials,
-                                                                        c == 1, state);
-        km_pots_kernel<<<p.nb, 256, 0, st>>>(x, d, m, n_trials, state, ppart);
-        km_choose_kernel<<<1, 64 * n_trials, 0, st>>>(ppart, p.nb, n_trials, c, state, seeds_x, seeds_id);
-        km_update_kernel<<<(int)p.ntiles, 256, 0, st>>>(x, d, m, state, tsum);
+    if (k > 1) {
+        // one cooperative launch for all k - 1 further seeds (GRX_KMEANS_PER_SEED=1: the four launches per seed the
+        // kernel replaces -- same bits, kept for the A/B test)
+        static const bool per_seed = [] { const char *e = std::getenv("GRX_KMEANS_PER_SEED"); return e && *e == '1'; }();
+        int resident = 0;
+        if (!per_seed) {
+            int per_cu = 0, dev = 0, cus = 0;
+            GRX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_seed_kernel, 1024, 0));
+            GRX_CHECK_HIP(hipGetDevice(&dev));
+            GRX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            resident = per_cu * cus;
+        }
+        if (resident >= 1) {
+            const int64_t useful = grx_ceil_div(p.ntiles > p.nb ? p.ntiles : (int64_t)p.nb, 4);
+            int grid = (int)(useful < resident ? useful : resident);
+            if (grid < 1) grid = 1;
+            GRX_CHECK_HIP(hipMemsetAsync(&state->bar_count, 0, 2 * sizeof(unsigned), st));
+            int64_t m_arg = m, ntiles_arg = p.ntiles;
+            int trials_arg = n_trials, k_arg = k, nb_arg = p.nb;
+            const double *x_arg = x, *u_arg = d_uniform;
+            void *args[] = {&x_arg, &d, &m_arg, &tsum, &ntiles_arg, &u_arg, &trials_arg, &k_arg, &nb_arg, &state, &ppart,
+                            &seeds_x, &seeds_id};
+            GRX_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(km_seed_kernel), dim3(grid), dim3(1024),
+                                                     args, 0, st));
+        } else {
+            for (int c = 1; c < k; ++c) {
+                km_pick_kernel<<<1, 1024, 0, st>>>(x, d, m, tsum, p.ntiles, d_uniform + (size_t)(c - 1) * n_trials, n_trials,
+                                                   c == 1, state);
+                km_pots_kernel<<<p.nb, 256, 0, st>>>(x, d, m, n_trials, state, ppart);
+                km_choose_kernel<<<1, 64 * n_trials, 0, st>>>(ppart, p.nb, n_trials, c, state, seeds_x, seeds_id);
+                km_update_kernel<<<(int)p.ntiles, 256, 0, st>>>(x, d, m, state, tsum);
+            }
+        }
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values
