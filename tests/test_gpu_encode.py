@@ -211,3 +211,39 @@ def test_kmeans_quantizer_equals_the_oracle_restatement():
         enc = factor.encode(X, n_bins)                           # default quantizer = 'kmeans'
         ref, _, _ = kmeans1d.kmeans_quantize(X, n_bins)
         assert np.abs(enc - ref).max() <= 1e-9 * np.abs(X).max()
+
+
+_AB_DRIVER = '''
+import sys
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from graphrole_amd import kernels as K
+out = {}
+for tag, m, k, seed in (('a', 50_000, 64, 0), ('b', 300_007, 256, 1), ('c', 4_099, 17, 2), ('d', 1_200_000, 512, 3)):
+    rng = np.random.default_rng(seed)
+    v = np.abs(rng.standard_normal(m)) * rng.choice([1e-3, 1.0, 40.0], size=m)
+    q, centers, info = K.kmeans1d(K.to_device(v), k)
+    out[tag + '_q'] = K.to_host(q); out[tag + '_c'] = K.to_host(centers); out[tag + '_i'] = K.to_host(info)
+np.savez(OUT, **out)
+'''
+
+
+def test_cooperative_seeding_equals_the_per_seed_launches(tmp_path):
+    """The one-launch k-means++ seeding (km_seed_kernel: resident workgroups, grid barriers) against the four
+    launches per seed it replaces (GRX_KMEANS_PER_SEED=1): same index sets and summation trees -> identical bits."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = []
+    for mode in ('0', '1'):
+        out = tmp_path / f'km{mode}.npz'
+        code = 'ROOT = %r\nOUT = %r\n' % (root, str(out)) + textwrap.dedent(_AB_DRIVER)
+        env = dict(os.environ, GRX_KMEANS_PER_SEED=mode)
+        res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+        results.append(np.load(out))
+    a, b = results
+    for key in a.files:
+        assert np.array_equal(a[key], b[key]), key
