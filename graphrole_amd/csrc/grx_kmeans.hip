@@ -310,7 +310,7 @@ __device__ __forceinline__ void km_update_tile(const double *__restrict__ x, dou
             const double dj = km_sqdist(c, csq, x[i]);
             const double di = d[i];
             const double nd = dj < di ? dj : di;
-            d[i] = nd;
+            if (dj < di) d[i] = nd;                           // late seeds move few points: most lines stay clean
             s += nd;
         }
     }
@@ -779,9 +779,13 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     km_init_kernel<<<(int)p.ntiles, 256, 0, st>>>(d_values, m, first_seed, state, x, d, tsum, seeds_x, seeds_id);
     GRX_LAUNCH_CHECK();
     if (k > 1) {
-        // one cooperative launch for all k - 1 further seeds (GRX_KMEANS_PER_SEED=1: the four launches per seed the
-        // kernel replaces -- same bits, kept for the A/B test)
-        static const bool per_seed = [] { const char *e = std::getenv("GRX_KMEANS_PER_SEED"); return e && *e == '1'; }();
+        // GRX_KMEANS_COOPERATIVE=1: one cooperative launch for all k - 1 further seeds instead of four launches per
+        // seed -- same bits (tests/test_gpu_encode.py), but MEASURED SLOWER on MI355X (1 M x 6 factor, 64 levels: 16.1
+        // against 6.3 ms): every grid barrier needs an agent-scope release / acquire so that the distances written
+        // on one XCD are seen on another, i.e. an L2 write-back + invalidate per workgroup per barrier, which costs
+        // more than the launch boundary it replaces (the same finding as the fused reduce + H update of the NMF,
+        // DESIGN.md section 3).  Kept as an option; the default is the per-seed sequence.
+        static const bool per_seed = [] { const char *e = std::getenv("GRX_KMEANS_COOPERATIVE"); return !(e && *e == '1'); }();
         int resident = 0;
         if (!per_seed) {
             int per_cu = 0, dev = 0, cus = 0;

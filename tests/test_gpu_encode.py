@@ -229,8 +229,9 @@ np.savez(OUT, **out)
 
 
 def test_cooperative_seeding_equals_the_per_seed_launches(tmp_path):
-    """The one-launch k-means++ seeding (km_seed_kernel: resident workgroups, grid barriers) against the four
-    launches per seed it replaces (GRX_KMEANS_PER_SEED=1): same index sets and summation trees -> identical bits."""
+    """The one-launch k-means++ seeding (km_seed_kernel: resident workgroups, grid barriers; GRX_KMEANS_COOPERATIVE=1,
+    measured slower and therefore not the default) against the four launches per seed: same index sets and summation
+    trees -> identical bits."""
     import os
     import subprocess
     import sys
@@ -240,7 +241,7 @@ def test_cooperative_seeding_equals_the_per_seed_launches(tmp_path):
     for mode in ('0', '1'):
         out = tmp_path / f'km{mode}.npz'
         code = 'ROOT = %r\nOUT = %r\n' % (root, str(out)) + textwrap.dedent(_AB_DRIVER)
-        env = dict(os.environ, GRX_KMEANS_PER_SEED=mode)
+        env = dict(os.environ, GRX_KMEANS_COOPERATIVE=mode)
         res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
         results.append(np.load(out))
