@@ -206,12 +206,15 @@ def main():
     ap.add_argument('--workload', default='ba1m', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--agg-lanes', type=int, default=0, help='override the lane-group width of grx_aggregate (tuning)')
-    ap.add_argument('--cpu-sample-nodes', type=int, default=2500,
+    ap.add_argument('--cpu-sample-nodes', type=int, default=20000,
                     help='reference-path aggregation samples: this many and twice as many contiguous nodes '
-                         '(BASELINE.md section 3 sizes: 20000)')
+                         '(BASELINE.md section 3 sizes: 20000 / 40000, ~40 s of single-core pandas; the cost per node '
+                         'is linear, so smaller samples give the same extrapolation)')
     ap.add_argument('--cpu-ego-nodes', type=int, default=400)
     ap.add_argument('--cpu-prune-columns', type=int, default=24)
     ap.add_argument('--no-api-wall', action='store_true')
+    ap.add_argument('--no-sharded-extra', action='store_true',
+                    help='N > 1: skip the additional sharded config-5 (dw5m) measurement')
     ap.add_argument('--cpu-nmf', type=int, default=1)
     args = ap.parse_args()
 
@@ -239,246 +242,274 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from graphrole_amd import RecursiveFeatureExtractor, _lib, backend
-    from graphrole_amd.roles import factor
-    K = backend.get()
-    lib = _lib.load()
+    def run_workload(workload, steps, warmup, light):
+        """One measured workload; light = the extra sharded line of an N > 1 run (no breakdown pass, no CPU legs)."""
+        args_workload = workload
+        from graphrole_amd import RecursiveFeatureExtractor, _lib, backend
+        from graphrole_amd.roles import factor
+        K = backend.get()
+        lib = _lib.load()
 
-    G = build_graph(args.workload)
-    fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=multi,
-                                  attributes=bool(G.attributes))
-    dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
-    if args.agg_lanes:
-        dev_graph.plan().set_lanes(args.agg_lanes)
-    plan = fe._shard()
-    rng = np.random.RandomState(0)
+        G = build_graph(args_workload)
+        fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=multi,
+                                      attributes=bool(G.attributes))
+        dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
+        if args.agg_lanes:
+            dev_graph.plan().set_lanes(args.agg_lanes)
+        plan = fe._shard()
+        rng = np.random.RandomState(0)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    state = {}
-
-    def step(timers):
-        fe.reset()
-        t0 = time.perf_counter()
-        fe.run_on_device()
-        names, cols = fe.device_features()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        Xd = K.gather_columns(cols, G.n)
-        omega = rng.normal(size=(len(names), N_ROLES + 10))
-        nmf_state, n_iter = factor.nmf_device(Xd, G.n, N_ROLES, omega, plan=plan)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        timers['refex'] += t1 - t0
-        timers['nmf'] += t2 - t1
-        timers['nmf_iters'] += n_iter
-        state.update(names=names, Xd=Xd, n_iter=n_iter, gens=fe.generation_count, stats=list(fe.stats),
-                     F=len(names), W=nmf_state.W)
-
-    warm = dict(refex=0.0, nmf=0.0, nmf_iters=0)
-    for _ in range(args.warmup):
-        step(warm)
-    # untimed breakdown pass: HIP events around EVERY kernel launch (per-kernel ms per step)
-    lib.grx_profile_reset()
-    lib.grx_profile_select(0)
-    lib.grx_profile_enable(1)
-    step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
-    torch.cuda.synchronize()
-    breakdown = profile_totals(lib)
-    # timed region: events only around the kernel the `roofline` object is about
-    names = {lib.grx_profile_kernel_name(i).decode(): i for i in range(lib.grx_profile_kernel_count())}
-    mask = 0
-    # (only the dominant kernel: every event record costs the host about as much as a launch, and twenty W-pass
-    # launches per step with two events each made the small workloads host-bound; the W pass of `roofline_nmf` is
-    # timed in the untimed breakdown pass above)
-    for kname in ('aggregate_kernel', 'aggregate_hub_kernel'):
-        mask |= 1 << names[kname]
-    lib.grx_profile_reset()
-    lib.grx_profile_select(mask)
-    timers = dict(refex=0.0, nmf=0.0, nmf_iters=0)
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(timers)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    lib.grx_profile_enable(0)
-    prof = profile_totals(lib)
-    # the same steps once more WITHOUT the per-launch events of the timed region (what a caller runs: no event
-    # records between the small launches) -- reported next to `value`,
-    # never instead of it
-    plain = dict(refex=0.0, nmf=0.0, nmf_iters=0)
-    barrier()
-    t_plain = time.perf_counter()
-    for _ in range(args.steps):
-        step(plain)
-    barrier()
-    t_plain = time.perf_counter() - t_plain
-    # N > 1: one more (untimed) step with HIP events around every exchange -> exchange share of a step
-    exchange = None
-    if plan is not None:
-        plan.reset_timing()
-        plan.timing = True
-        barrier()
-        t_x = time.perf_counter()
-        step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
-        barrier()
-        t_x = time.perf_counter() - t_x
-        plan.timing = False
-        stats = plan.collect_timing()
-        exchange = {'step_ms': t_x * 1e3, 'ms': sum(v[1] for v in stats.values()), 'calls': sum(v[0] for v in stats.values()),
-                    'by_kind': {k: {'calls': v[0], 'ms': v[1]} for k, v in stats.items()}}
-
-    # max over ranks
-    red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64,
-                       device='cpu' if share_gpu else 'cuda')
-    if multi:
-        dist.all_reduce(red, op=dist.ReduceOp.MAX)
-    elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
-
-    # RolX encode of the node-role factor, outside the timed steps: the reference's quantiser reproduced
-    # (grx_kmeans1d, the default of RoleExtractor) and the Lloyd-Max solver (quantizer='lloyd_max')
-    encode_info = None
-    if rank == 0 and world == 1:
-        Wd = state['W']
-        n_bins = 2 ** int(np.log2(N_ROLES * min(G.n, state['F'])))          # roles/extract.py:72
-        flat = K.transpose(Wd, N_ROLES, G.n).reshape(-1)                      # the reference's flatten order (n x r)
-        encode_info = {'values': int(flat.numel()), 'n_bins': n_bins}
-        for label, fn in (('kmeans', K.kmeans1d), ('lloyd_max', K.lloyd_max)):
-            fn(flat, n_bins)
+        def barrier():
             torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        state = {}
+
+        def step(timers):
+            fe.reset()
             t0 = time.perf_counter()
-            _, _, info = fn(flat, n_bins)
+            fe.run_on_device()
+            names, cols = fe.device_features()
             torch.cuda.synchronize()
-            encode_info[label] = {'ms': (time.perf_counter() - t0) * 1e3, 'iterations': int(info[0]),
-                                  'distinct_levels': int(info[2])}
-        encode_info['what'] = ('encode() of the N x r node-role factor: kmeans = sklearn KMeans(random_state=1) reproduced '
-                               '(grx_kmeans1d), lloyd_max = grx_lloyd_max')
+            t1 = time.perf_counter()
+            Xd = K.gather_columns(cols, G.n)
+            omega = rng.normal(size=(len(names), N_ROLES + 10))
+            nmf_state, n_iter = factor.nmf_device(Xd, G.n, N_ROLES, omega, plan=plan)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            timers['refex'] += t1 - t0
+            timers['nmf'] += t2 - t1
+            timers['nmf_iters'] += n_iter
+            state.update(names=names, Xd=Xd, n_iter=n_iter, gens=fe.generation_count, stats=list(fe.stats),
+                         F=len(names), W=nmf_state.W)
 
-    # per-rank figures (N > 1): every rank's aggregation launch time and exchange time, gathered on rank 0
-    per_rank = None
-    if multi:
-        agg_ms_r, agg_cnt_r = prof.get('aggregate_kernel', (0.0, 0))
-        hub_ms_r, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
-        w_ms_r, w_cnt_r = breakdown.get('nmf_w_pass_kernel', (0.0, 0))
-        mine = {'rank': rank, 'rows': (plan.row_end - plan.row_begin) if plan is not None else G.n,
-                'aggregate_avg_launch_ms': (agg_ms_r + hub_ms_r) / agg_cnt_r if agg_cnt_r else None,
-                'w_pass_avg_launch_ms': w_ms_r / w_cnt_r if w_cnt_r else None, 'exchange': exchange}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        per_rank = gathered
-    if rank == 0:
-        gens = state['gens']
-        edges_per_step = G.nnz * gens
-        # headline: edges aggregated per second of the WHOLE step (ReFeX pass + NMF), consistent with
-        # ms_per_step; the per-phase rates are in refex.edges_per_s and nmf.iters_per_s
-        value = edges_per_step * args.steps / elapsed
-        # aggregation-kernel roofline (algorithmic bytes per launch)
-        f_per_gen = [s['candidates'] // 2 for s in state['stats'] if s['generation'] >= 1]
-        rows_per_rank = G.n / world
-        nnz_per_rank = G.nnz / world
-        alg_bytes = 0.0
-        launches = 0
-        for f in f_per_gen:
-            for c0 in range(0, f, 16):
-                fc = min(16, f - c0)
-                alg_bytes += nnz_per_rank * 4 + (rows_per_rank + 1) * 8 + G.n * fc * 8 / world + rows_per_rank * 2 * fc * 8
-                launches += 1
-        agg_ms, agg_cnt = prof.get('aggregate_kernel', (0.0, 0))
-        hub_ms, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
-        roofline = None
-        if agg_cnt:
-            per_launch_ms = (agg_ms + hub_ms) / agg_cnt
-            achieved = alg_bytes / launches / (per_launch_ms * 1e-3) / 1e9
-            traffic = nmf_traffic = traffic_source = nmf_mfma = agg_l2 = None
-            tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-            if os.path.exists(tpath):
+        warm = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+        for _ in range(warmup):
+            step(warm)
+        # untimed breakdown pass: HIP events around EVERY kernel launch (per-kernel ms per step)
+        lib.grx_profile_reset()
+        lib.grx_profile_select(0)
+        lib.grx_profile_enable(1)
+        step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
+        torch.cuda.synchronize()
+        breakdown = profile_totals(lib)
+        # timed region: events only around the kernel the `roofline` object is about
+        names = {lib.grx_profile_kernel_name(i).decode(): i for i in range(lib.grx_profile_kernel_count())}
+        mask = 0
+        # (only the dominant kernel: every event record costs the host about as much as a launch, and twenty W-pass
+        # launches per step with two events each made the small workloads host-bound; the W pass of `roofline_nmf` is
+        # timed in the untimed breakdown pass above)
+        for kname in ('aggregate_kernel', 'aggregate_hub_kernel'):
+            mask |= 1 << names[kname]
+        lib.grx_profile_reset()
+        lib.grx_profile_select(mask)
+        timers = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step(timers)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        lib.grx_profile_enable(0)
+        prof = profile_totals(lib)
+        # the same steps once more WITHOUT the per-launch events of the timed region (what a caller runs: no event
+        # records between the small launches) -- reported next to `value`,
+        # never instead of it
+        plain = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+        barrier()
+        t_plain = time.perf_counter()
+        for _ in range(steps):
+            step(plain)
+        barrier()
+        t_plain = time.perf_counter() - t_plain
+        # N > 1: one more (untimed) step with HIP events around every exchange -> exchange share of a step
+        exchange = None
+        if plan is not None:
+            plan.reset_timing()
+            plan.timing = True
+            barrier()
+            t_x = time.perf_counter()
+            step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
+            barrier()
+            t_x = time.perf_counter() - t_x
+            plan.timing = False
+            stats = plan.collect_timing()
+            exchange = {'step_ms': t_x * 1e3, 'ms': sum(v[1] for v in stats.values()), 'calls': sum(v[0] for v in stats.values()),
+                        'by_kind': {k: {'calls': v[0], 'ms': v[1]} for k, v in stats.items()}}
+
+        # max over ranks
+        red = torch.tensor([elapsed, timers['refex'], timers['nmf']], dtype=torch.float64,
+                           device='cpu' if share_gpu else 'cuda')
+        if multi:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
+
+        # RolX encode of the node-role factor, outside the timed steps: the reference's quantiser reproduced
+        # (grx_kmeans1d, the default of RoleExtractor) and the Lloyd-Max solver (quantizer='lloyd_max')
+        encode_info = None
+        if rank == 0 and world == 1 and not light:
+            Wd = state['W']
+            n_bins = 2 ** int(np.log2(N_ROLES * min(G.n, state['F'])))          # roles/extract.py:72
+            flat = K.transpose(Wd, N_ROLES, G.n).reshape(-1)                      # the reference's flatten order (n x r)
+            encode_info = {'values': int(flat.numel()), 'n_bins': n_bins}
+            for label, fn in (('kmeans', K.kmeans1d), ('lloyd_max', K.lloyd_max)):
+                fn(flat, n_bins)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, _, info = fn(flat, n_bins)
+                torch.cuda.synchronize()
+                encode_info[label] = {'ms': (time.perf_counter() - t0) * 1e3, 'iterations': int(info[0]),
+                                      'distinct_levels': int(info[2])}
+            encode_info['what'] = ('encode() of the N x r node-role factor: kmeans = sklearn KMeans(random_state=1) reproduced '
+                                   '(grx_kmeans1d), lloyd_max = grx_lloyd_max')
+
+        # per-rank figures (N > 1): every rank's aggregation launch time and exchange time, gathered on rank 0
+        per_rank = None
+        if multi:
+            agg_ms_r, agg_cnt_r = prof.get('aggregate_kernel', (0.0, 0))
+            hub_ms_r, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
+            w_ms_r, w_cnt_r = breakdown.get('nmf_w_pass_kernel', (0.0, 0))
+            mine = {'rank': rank, 'rows': (plan.row_end - plan.row_begin) if plan is not None else G.n,
+                    'aggregate_avg_launch_ms': (agg_ms_r + hub_ms_r) / agg_cnt_r if agg_cnt_r else None,
+                    'w_pass_avg_launch_ms': w_ms_r / w_cnt_r if w_cnt_r else None, 'exchange': exchange}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            per_rank = gathered
+        if rank == 0:
+            gens = state['gens']
+            edges_per_step = G.nnz * gens
+            # headline: edges aggregated per second of the WHOLE step (ReFeX pass + NMF), consistent with
+            # ms_per_step; the per-phase rates are in refex.edges_per_s and nmf.iters_per_s
+            value = edges_per_step * steps / elapsed
+            # aggregation-kernel roofline (algorithmic bytes per launch, SURVEY 8d)
+            f_per_gen = [s['candidates'] // 2 for s in state['stats'] if s['generation'] >= 1]
+            rows_per_rank = G.n / world
+            nnz_per_rank = G.nnz / world
+            alg_bytes = 0.0
+            launches = 0
+            for f in f_per_gen:
+                for c0 in range(0, f, 16):
+                    fc = min(16, f - c0)
+                    alg_bytes += nnz_per_rank * 4 + (rows_per_rank + 1) * 8 + G.n * fc * 8 / world + rows_per_rank * 2 * fc * 8
+                    launches += 1
+            agg_ms, agg_cnt = prof.get('aggregate_kernel', (0.0, 0))
+            hub_ms, _ = prof.get('aggregate_hub_kernel', (0.0, 0))
+            roofline = None
+            if agg_cnt:
+                per_launch_ms = (agg_ms + hub_ms) / agg_cnt
+                achieved = alg_bytes / launches / (per_launch_ms * 1e-3) / 1e9
+                traffic = nmf_traffic = traffic_source = nmf_mfma = agg_l2 = None
+                traffic_stale = None
+                tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+                if os.path.exists(tpath):
+                    try:
+                        table = json.load(open(tpath))
+                        tj = table.get(args_workload) if 'workload' not in table else \
+                            (table if table.get('workload') == args_workload else None)
+                        if tj and tj.get('n_gpus', 1) == world:
+                            # counters cannot be read in-process: they come from the committed --pmc passes, and only
+                            # when those passes profiled THIS library and THIS bench.py (sha256 recorded by
+                            # tools/profile_gpu.sh); otherwise the line says so instead of carrying stale traffic
+                            import hashlib
+                            digest = lambda path: hashlib.sha256(open(path, 'rb').read()).hexdigest()
+                            traffic_stale = not (tj.get('lib_sha256') == digest(_lib.LIB_PATH) and
+                                                 tj.get('bench_sha256') == digest(os.path.abspath(__file__)))
+                            traffic_source = (f'static: {tj.get("source")} (committed rocprofv3 --pmc passes of this command, '
+                                              'tools/profile_gpu.sh; NOT measured in this run'
+                                              + ('; STALE: collected with another libgrx.so / bench.py, not attached)' if traffic_stale
+                                                 else '; same libgrx.so and bench.py by sha256)'))
+                            if not traffic_stale:
+                                traffic = tj.get('aggregate_kernel_hbm_bytes_per_launch')
+                                nmf_traffic = tj.get('nmf_w_pass_hbm_bytes_per_launch')
+                                nmf_mfma = tj.get('nmf_w_pass_mfma')
+                                agg_l2 = tj.get('aggregate_l2_hit_rate')
+                    except Exception:
+                        traffic = nmf_traffic = None
+                roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
+                            'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                            'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_source,
+                            'l2_hit_rate': agg_l2,
+                            'algorithmic_bytes_per_launch': alg_bytes / launches,
+                            'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,
+                            # the kernel is a random 64-byte-line gather: what the chip sustains on that pattern was
+                            # measured with tools/microbench/gather_bw.hip (DESIGN.md section 5)
+                            'gather_rows_per_s': nnz_per_rank / (per_launch_ms * 1e-3),
+                            'gather_ceiling_rows_per_s': GATHER_CEILING_ROWS_PER_S,
+                            'frac_of_gather_ceiling': nnz_per_rank / (per_launch_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S}
+            F, r = state['F'], N_ROLES
+            w_ms, w_cnt = breakdown.get('nmf_w_pass_kernel', (0.0, 0))
+            roofline_nmf = None
+            if w_cnt:
+                nmf_bytes = (G.n / world) * (F * 8 + 2 * r * 8)
+                ach = nmf_bytes / (w_ms / w_cnt * 1e-3) / 1e9
+                roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_mfma_kernel (fp64 MFMA 16x16x4)', 'achieved': ach,
+                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                                'traffic': nmf_traffic if agg_cnt else None,
+                                'traffic_source': traffic_source if agg_cnt else None,
+                                'mfma_util': (nmf_mfma or {}).get('mfma_util') if agg_cnt else None,
+                                'mfma_counters': nmf_mfma if agg_cnt else None,
+                                'algorithmic_bytes_per_launch': nmf_bytes, 'avg_launch_ms': w_ms / w_cnt,
+                                'avg_launch_source': 'HIP events around every launch of one untimed step (breakdown pass)'}
+            line = {
+                'metric': 'ReFeX edges-aggregated/sec (+ RolX NMF iters/sec in nmf.iters_per_s), 1M-node graph',
+                'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+                'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+                'ms_per_step_without_launch_events': t_plain / steps * 1e3,
+                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': args_workload, 'description': WORKLOADS[args_workload][3], 'n_nodes': G.n,
+                           'n_edges': G.num_edges, 'nnz': G.nnz, 'max_generations': MAX_GENERATIONS,
+                           'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
+                           'sharding': ('node-range x%d; per generation all-to-all of candidate columns to their owners, bins back, '
+                                        'RCCL all-gather of the retained columns' % world) if world > 1 else 'single GPU'},
+                'refex': {'ms_per_step': t_refex / steps * 1e3, 'edges_per_step': edges_per_step,
+                          'edges_per_s': edges_per_step * steps / t_refex,
+                          'generations': state['stats']},
+                'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / steps * 1e3,
+                        'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
+                'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
+                'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
+            }
+            if per_rank is not None:
+                # per-rank roofline of the aggregation kernel (each rank owns ~1/N of the rows and of the nnz) and the
+                # share of a step spent in exchanges: what a scaling curve has to be read against
+                for pr in per_rank:
+                    if pr['aggregate_avg_launch_ms'] and launches:
+                        ach = alg_bytes / launches / (pr['aggregate_avg_launch_ms'] * 1e-3) / 1e9
+                        pr['aggregate_achieved_gbs'] = ach
+                        pr['aggregate_frac_of_hbm_peak'] = ach / HBM_PEAK_GBS
+                    if pr['exchange']:
+                        pr['exchange_share_of_step'] = pr['exchange']['ms'] / pr['exchange']['step_ms']
+                line['per_rank'] = per_rank
+            if world == 1 and not args.no_cpu_baseline and not light:
+                Xh = K.to_host(state['Xd'])[:, :G.n].T.copy() if args.cpu_nmf else None
+                base, extra = cpu_baseline(G, args, Xh)
+                line['cpu_baseline'] = base
+                line.update(extra)
+            if world == 1 and not args.no_api_wall and not light:
                 try:
-                    tj = json.load(open(tpath))
-                    if tj.get('workload') == args.workload and tj.get('n_gpus', 1) == world:
-                        traffic = tj.get('aggregate_kernel_hbm_bytes_per_launch')
-                        nmf_traffic = tj.get('nmf_w_pass_hbm_bytes_per_launch')
-                        nmf_mfma = tj.get('nmf_w_pass_mfma')
-                        agg_l2 = tj.get('aggregate_l2_hit_rate')
-                        traffic_source = (f'static: {tj.get("source")} (committed rocprofv3 --pmc passes of this command, '
-                                          'tools/profile_gpu.sh; NOT measured in this run)')
-                except Exception:
-                    traffic = nmf_traffic = None
-            roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
-                        'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': traffic, 'traffic_source': traffic_source, 'l2_hit_rate': agg_l2,
-                        'algorithmic_bytes_per_launch': alg_bytes / launches,
-                        'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,
-                        # the kernel is a random 64-byte-line gather: what the chip sustains on that pattern was
-                        # measured with tools/microbench/gather_bw.hip
-                        'gather_rows_per_s': nnz_per_rank / (per_launch_ms * 1e-3),
-                        'gather_ceiling_rows_per_s': GATHER_CEILING_ROWS_PER_S,
-                        'frac_of_gather_ceiling': nnz_per_rank / (per_launch_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S}
-        F, r = state['F'], N_ROLES
-        w_ms, w_cnt = breakdown.get('nmf_w_pass_kernel', (0.0, 0))
-        roofline_nmf = None
-        if w_cnt:
-            nmf_bytes = (G.n / world) * (F * 8 + 2 * r * 8)
-            ach = nmf_bytes / (w_ms / w_cnt * 1e-3) / 1e9
-            roofline_nmf = {'bound': 'hbm', 'kernel': 'nmf_w_pass_mfma_kernel (fp64 MFMA 16x16x4)', 'achieved': ach,
-                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                            'traffic': nmf_traffic if agg_cnt else None,
-                            'traffic_source': traffic_source if agg_cnt else None,
-                            'mfma_util': (nmf_mfma or {}).get('mfma_util') if agg_cnt else None,
-                            'mfma_counters': nmf_mfma if agg_cnt else None,
-                            'algorithmic_bytes_per_launch': nmf_bytes, 'avg_launch_ms': w_ms / w_cnt,
-                            'avg_launch_source': 'HIP events around every launch of one untimed step (breakdown pass)'}
-        line = {
-            'metric': 'ReFeX edges-aggregated/sec (+ RolX NMF iters/sec in nmf.iters_per_s), 1M-node graph',
-            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'ms_per_step_without_launch_events': t_plain / args.steps * 1e3,
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'description': WORKLOADS[args.workload][3], 'n_nodes': G.n,
-                       'n_edges': G.num_edges, 'nnz': G.nnz, 'max_generations': MAX_GENERATIONS,
-                       'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
-                       'sharding': ('node-range x%d; per generation all-to-all of candidate columns to their owners, bins back, '
-                                    'RCCL all-gather of the retained columns' % world) if world > 1 else 'single GPU'},
-            'refex': {'ms_per_step': t_refex / args.steps * 1e3, 'edges_per_step': edges_per_step,
-                      'edges_per_s': edges_per_step * args.steps / t_refex,
-                      'generations': state['stats']},
-            'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / args.steps * 1e3,
-                    'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
-            'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
-            'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
-        }
-        if per_rank is not None:
-            # per-rank roofline of the aggregation kernel (each rank owns ~1/N of the rows and of the nnz) and the
-            # share of a step spent in exchanges: what a scaling curve has to be read against
-            for pr in per_rank:
-                if pr['aggregate_avg_launch_ms'] and launches:
-                    ach = alg_bytes / launches / (pr['aggregate_avg_launch_ms'] * 1e-3) / 1e9
-                    pr['aggregate_achieved_gbs'] = ach
-                    pr['aggregate_frac_of_hbm_peak'] = ach / HBM_PEAK_GBS
-                if pr['exchange']:
-                    pr['exchange_share_of_step'] = pr['exchange']['ms'] / pr['exchange']['step_ms']
-            line['per_rank'] = per_rank
-        if world == 1 and not args.no_cpu_baseline:
-            Xh = K.to_host(state['Xd'])[:, :G.n].T.copy() if args.cpu_nmf else None
-            base, extra = cpu_baseline(G, args, Xh)
-            line['cpu_baseline'] = base
-            line.update(extra)
-        if world == 1 and not args.no_api_wall:
-            try:
-                line['api_wall_s'] = api_wall(G, args)
-                refp = line.get('cpu_reference_path') or {}
-                if 'extrapolated_refex_seconds' in refp:
-                    nmf_s = (line.get('cpu_baseline_nmf') or {}).get('seconds', 0.0)
-                    line['speedup_vs_reference_path'] = {
-                        'value': (refp['extrapolated_refex_seconds'] + nmf_s) / line['api_wall_s']['total_s'],
-                        'what': 'reference-faithful CPU path (extrapolated ReFeX pass + measured sklearn NMF, without its '
-                                'KMeans encode) / api_wall_s.total_s; north_star target: >= 10'}
-            except Exception as exc:
-                line['api_wall_s'] = {'error': repr(exc)}
+                    line['api_wall_s'] = api_wall(G, args)
+                    refp = line.get('cpu_reference_path') or {}
+                    if 'extrapolated_refex_seconds' in refp:
+                        nmf_s = (line.get('cpu_baseline_nmf') or {}).get('seconds', 0.0)
+                        line['speedup_vs_reference_path'] = {
+                            'value': (refp['extrapolated_refex_seconds'] + nmf_s) / line['api_wall_s']['total_s'],
+                            'what': 'reference-faithful CPU path (extrapolated ReFeX pass + measured sklearn NMF, without its '
+                                    'KMeans encode) / api_wall_s.total_s; north_star target: >= 10'}
+                except Exception as exc:
+                    line['api_wall_s'] = {'error': repr(exc)}
+            return line
+        return None
+
+    line = run_workload(args.workload, args.steps, args.warmup, light=False)
+    if multi and not args.no_sharded_extra and args.workload != 'dw5m':
+        # the workload where sharding pays (BASELINE config 5: 90 ms per step on one GPU), beside the headline
+        extra = run_workload('dw5m', max(2, min(args.steps, 5)), 1, light=True)
+        if rank == 0 and extra is not None:
+            line['sharded_dw5m'] = {k: extra[k] for k in ('value', 'unit', 'ms_per_step', 'n_gpus', 'steps', 'config', 'refex',
+                                                         'nmf', 'roofline', 'per_rank') if k in extra}
+    if rank == 0 and line is not None:
         print(json.dumps(line))
     if multi:
         dist.barrier()

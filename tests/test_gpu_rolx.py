@@ -340,6 +340,12 @@ def test_model_selection_on_a_larger_matrix_runs_in_hbm():
 
 
 # ---------------------------------------------------------------- model selection vs the reference (fixtures)
+# (n_roles, n_bits) cells of the MDL grid whose k-means++ seeding meets candidates of mathematically EQUAL potential:
+# sklearn's pick there is decided by the last-bit rounding of its BLAS dot product, not by the algorithm
+TIED_CELLS = {
+    'karate': [], 'er300': [], 'ba300': [],
+    'karate_weighted': 'FILL', 'dw200_attrs': 'FILL', 'directed120': 'FILL', 'loops_dangling150': 'FILL',
+}
 def _selection_record(name, quantizer):
     """(reference grid + selection, ours) for one golden feature table."""
     from graphrole_amd import RoleExtractor
@@ -382,30 +388,33 @@ def test_model_selection_vs_reference(name):
     assert np.array_equal(np.isnan(enc_o), np.isnan(enc_r)) and np.array_equal(np.isnan(err_o), np.isnan(err_r))
     live = ~np.isnan(enc_r)
     assert np.array_equal(enc_o[live], enc_r[live])
-    rel = np.abs(err_o[live] - err_r[live]) / np.abs(err_r[live])
+    rel_grid = np.abs(err_o - err_r) / np.abs(err_r)
+    rel = rel_grid[live]
     same = rel <= 1e-6
+    tied = sorted([int(r), int(b)] for r, b in np.argwhere(live & ~(rel_grid <= 1e-6)))
     record = {'table': name, 'cells': int(live.sum()), 'cells_equal_1e-6': int(same.sum()),
               'max_rel_diff_of_the_others': float(rel[~same].max()) if (~same).any() else 0.0,
+              'cells_that_differ': tied,
               'reference_selected': [int(v) for v in ref['selected']], 'ours_selected': list(ours['selected'])}
     _record('model_selection.json', name, record)
-    assert same.mean() >= 0.85, record
-    assert rel.max() < 0.10, record
-    if same.all():
-        # no tied seeding anywhere in the grid: the reference's cell, and its factors
-        assert list(ours['selected']) == [int(v) for v in ref['selected']]
+    # the cells whose seeding meets mathematically tied candidates are KNOWN (an explicit allow-list, observed on
+    # MI355X and stable: the draws do not depend on the data); every other cell must agree to 1e-6, the tied ones to
+    # 10 x the largest deviation ever observed (0.26 %), and the reference's cell is selected on every table
+    allowed = [list(c) for c in TIED_CELLS[name]]
+    assert all(c in allowed for c in tied), record
+    assert rel.max() < 0.03, record
+    assert list(ours['selected']) == [int(v) for v in ref['selected']], record
+    if list(ours['selected']) not in tied:
         scale = np.abs(ref['node_role_factor']).max()
         assert np.abs(rx.node_role_factor.values - ref['node_role_factor']).max() <= 1e-7 * scale
         assert np.abs(rx.role_feature_factor.values - ref['role_feature_factor']).max() <= \
             1e-7 * np.abs(ref['role_feature_factor']).max()
-    else:
-        assert abs(ours['selected'][0] - int(ref['selected'][0])) <= 1 and ours['selected'][1] == int(ref['selected'][1]), record
 
 
 @pytest.mark.parametrize('name', util.ROLES_CASES)
 def test_fixed_rank_role_factors_equal_reference(name):
     """RoleExtractor(n_roles=3) (roles/extract.py:69-77) against the reference's encoded factors for the same
-    table: NMF + KMeans quantisation of both factors, numerically (1e-7), unless the seeding met a tie (see
-    test_model_selection_vs_reference), in which case the level counts still agree."""
+    table: NMF + KMeans quantisation of both factors, to rounding (2e-13 of the factor's scale)."""
     from graphrole_amd import RoleExtractor
     ref = util.load_roles(name)
     g = util.load_refex(name)
@@ -419,7 +428,7 @@ def test_fixed_rank_role_factors_equal_reference(name):
     dG = np.abs(G - ref['fixed3_node_role_factor']).max() / np.abs(ref['fixed3_node_role_factor']).max()
     dF = np.abs(F - ref['fixed3_role_feature_factor']).max() / np.abs(ref['fixed3_role_feature_factor']).max()
     _record('fixed_rank_factors.json', name, {'node_role_max_rel_diff': float(dG), 'role_feature_max_rel_diff': float(dF)})
-    assert dG < 0.05 and dF < 0.05
+    assert dG < 2e-13 and dF < 2e-13            # observed <= 2e-14 on all seven tables (profiles/r02_fixed_rank_factors.json)
 
 
 @pytest.mark.parametrize('name', util.ROLES_CASES)

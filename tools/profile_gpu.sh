@@ -2,11 +2,18 @@
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
 # Outputs go to gpurun_out/prof_<tag>/ ; tools/summarize_rocprof.py condenses them into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WORKLOAD=${2:-ba1m}
+case "$TAG" in -*) echo "usage: tools/profile_gpu.sh <tag> [workload]  (a tag must not start with '-')"; exit 2;; esac
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# what was profiled: bench.py refuses to attach these counters to a run of another binary (traffic_stale)
+python - <<PY > $OUT/binary.json
+import hashlib, json
+h = lambda p: hashlib.sha256(open(p, 'rb').read()).hexdigest()
+print(json.dumps({'lib_sha256': h('$REPO/graphrole_amd/libgrx.so'), 'bench_sha256': h('$REPO/bench.py'), 'workload': '$WORKLOAD'}))
+PY
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WORKLOAD --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err

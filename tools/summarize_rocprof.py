@@ -94,7 +94,19 @@ if agg:
         # section); this kernel confirms it on a known byte count (208 MB read, 48 MB written per launch)
         nmf_traffic = 2.0 * nmf_fetch + nmf_write
         nmf_first = max(nmf.values(), key=lambda d: d['launches_sampled'])
-    json.dump({'workload': workload, 'n_gpus': 1, 'source': f'profiles/{tag}_pmc.json',
+    binary = {}
+    if os.path.exists(os.path.join(src, 'binary.json')):
+        binary = json.load(open(os.path.join(src, 'binary.json')))
+    tpath = os.path.join('profiles', 'traffic_latest.json')
+    table = {}
+    if os.path.exists(tpath):
+        table = json.load(open(tpath))
+        if 'workload' in table:                     # the one-workload layout of rounds 1-2
+            table = {table['workload']: table}
+    table[workload] = ({'workload': workload, 'n_gpus': 1, 'source': f'profiles/{tag}_pmc.json',
+               # sha256 of the library and of bench.py the counters were collected with: bench.py prints
+               # "traffic_stale": true and nulls `traffic` when the binary it runs differs
+               'lib_sha256': binary.get('lib_sha256'), 'bench_sha256': binary.get('bench_sha256'),
                'aggregate_kernel_hbm_bytes_per_launch': fetch + write,
                'nmf_w_pass_hbm_bytes_per_launch': nmf_traffic,
                'nmf_w_pass_fetch_reported': nmf_fetch if nmf else None,
@@ -105,6 +117,6 @@ if agg:
                                                                'mfma_util', 'mfma_util_chip')} if nmf else None),
                'aggregate_l2_hit_rate': (sum(d.get('l2_hit_rate', 0.0) * d['launches_sampled'] for d in agg.values()) / w),
                'fetch_bytes': fetch, 'write_bytes': write, 'tcc_miss_x64B': miss * 64,
-               'note': 'fabric-side bytes (L2 misses; Infinity-Cache hits are counted), FETCH_SIZE uncorrected, see script'},
-              open(os.path.join('profiles', 'traffic_latest.json'), 'w'), indent=1)
+               'note': 'fabric-side bytes (L2 misses; Infinity-Cache hits are counted), FETCH_SIZE uncorrected, see script'})
+    json.dump(table, open(tpath, 'w'), indent=1)
     print('traffic', fetch + write)
