@@ -112,6 +112,29 @@ std::vector<int> prune(const std::vector<Column> &cols, const std::vector<int> &
 
 extern "C" {
 
+// The pruning decision of grx_refex_run as a host-only entry point (no device work): tests drive it without a GPU
+// against the Python FeaturePruner and the reference's known-answer tables (tests/test_host_logic_cpu.py).
+int grx_host_prune(int F, const char *const *h_names, const int *h_recorded_generation, int n_generations,
+                   const int32_t *h_dist, int thresh, int *h_drop)
+{
+    GRX_REQUIRE(F >= 0 && n_generations >= 0 && (F == 0 || (h_names && h_recorded_generation && h_dist && h_drop)),
+                "grx_host_prune: bad arguments");
+    std::vector<Column> cols;
+    std::vector<int> work;
+    std::vector<std::vector<int>> recorded(n_generations);
+    for (int j = 0; j < F; ++j) {
+        GRX_REQUIRE(h_names[j] != nullptr, "grx_host_prune: name %d is NULL", j);
+        cols.push_back({h_names[j], 0, -1, -1, nullptr, nullptr, -1});
+        work.push_back(j);
+        const int g = h_recorded_generation[j];
+        GRX_REQUIRE(g < n_generations, "grx_host_prune: column %d recorded in generation %d of %d", j, g, n_generations);
+        if (g >= 0) recorded[g].push_back(j);
+        h_drop[j] = 0;
+    }
+    for (int m : prune(cols, work, h_dist, thresh, recorded)) h_drop[m] = 1;
+    return GRX_OK;
+}
+
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
                   int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,

@@ -85,7 +85,9 @@ class DeviceGraphInterface(BaseGraphInterface):
             K = self._K()
             g = self.to_csr()
             edges = g.edge_arrays() if hasattr(K, 'device_ingest') else None
-            if edges is not None and g.num_edges > 0 and self._device_ingest:
+            # grx_ingest packs (row, slot) into 64-bit sort keys: fewer than 2^30 edges; larger graphs (and explicit
+            # neighbour orders) take the host construction + upload
+            if edges is not None and 0 < g.num_edges < (1 << 30) and self._device_ingest:
                 # the whole construction -- degree-descending relabelling, CSR in adjacency and in ascending
                 # column order, weights, transposed CSR -- in HBM (grx_ingest); no host CSR is ever built
                 src, dst, w = edges

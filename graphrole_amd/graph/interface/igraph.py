@@ -75,9 +75,13 @@ class IgraphInterface(DeviceGraphInterface):
         return self._edge_cache
 
     def _is_simple(self) -> bool:
-        src, dst, _ = self._edges()
-        n = int(self.G.vcount())
-        return not np.any(src == dst) and len(np.unique(src * n + dst)) == len(src)
+        """No loops, no parallel edges -- a property of the wrapped graph, computed once (the O(m log m) np.unique ran
+        on every _device_graph() call of a generation before)."""
+        if getattr(self, '_simple', None) is None:
+            src, dst, _ = self._edges()
+            n = int(self.G.vcount())
+            self._simple = bool(not np.any(src == dst) and len(np.unique(src * n + dst)) == len(src))
+        return self._simple
 
     def _dict_edges(self):
         """The reference's ``edge_weights`` dict (igraph.py:36-39): one entry per distinct tuple, the weight of its

@@ -323,13 +323,14 @@ def device_ingest(n: int, src: np.ndarray, dst: np.ndarray, w: Optional[np.ndarr
     inv = torch.empty(n, dtype=torch.int32, device=dev)
     row_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
     col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-    wcol = None if w is None else torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    # zero-filled: with validate=False a duplicate edge writes one slot only -- the others must not be garbage
+    wcol = None if w is None else zeros(max(nnz, 1))
     agg_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
     t_row_ptr = t_col = t_w = None
     if directed:
         t_row_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
         t_col = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
-        t_w = None if w is None else torch.empty(max(m, 1), dtype=torch.float64, device=dev)
+        t_w = None if w is None else zeros(max(m, 1))
     ws_bytes = _lib.load().grx_ingest_workspace_bytes(n, m, int(directed))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.call('grx_ingest', n, m, _ptr(d_src), _ptr(d_dst), _ptr(d_w), int(directed), int(nnz), _ptr(perm), _ptr(inv),

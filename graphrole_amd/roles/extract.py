@@ -21,6 +21,7 @@ class RoleExtractor:
     """RolX: factor the node-feature table into node-role and role-feature parts (GPU-resident NMF)."""
 
     N_ROLE_RANGE = (2, 8)
+    MAX_ROLES = 16          # GRX_MAX_ROLES of include/grx.h
     N_BIT_RANGE = (1, 8)
     #: 'kmeans' = the reference's quantiser reproduced (sklearn KMeans(random_state=1), grx_kmeans1d);
     #: 'lloyd_max' = the deterministic Lloyd-Max solver (lower error, other numbers).  Class attribute: set it
@@ -48,6 +49,12 @@ class RoleExtractor:
 
         self.min_roles, self.max_roles = n_role_range if n_role_range else self.N_ROLE_RANGE
         self.min_bits, self.max_bits = n_bit_range if n_bit_range else self.N_BIT_RANGE
+        # the device kernels factor with at most MAX_ROLES roles (GRX_MAX_ROLES, include/grx.h; the reference accepts
+        # any rank, its default grid is 2..8): say so here, not in the middle of a grid search
+        too_many = [r for r in (n_roles, self.max_roles if not n_roles else None) if r is not None and r > self.MAX_ROLES]
+        if too_many:
+            raise ValueError(f'graphrole_amd factors with at most {self.MAX_ROLES} roles (GRX_MAX_ROLES); '
+                             f'got {too_many[0]} -- there is no CPU fallback')
 
         self.node_role_factor: Optional[pd.DataFrame] = None
         self.role_feature_factor: Optional[pd.DataFrame] = None

@@ -337,6 +337,11 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * (grx_comm_all_gather_rows).  Every recorded column is complete on every rank on return; the neighbour sums
  * follow a tree that depends on the row length only, so the bits equal those of a one-GPU run.
  */
+/* The pruning decision of the loop alone, on the host (no device work): FeaturePruner.prune_features given the
+ * Chebyshev matrix (prune.py:76-130).  h_recorded_generation[j]: generation that recorded column j, -1 if none (a
+ * new candidate); h_dist F x F; h_drop[j] = 1 for every member of a feature group but its oldest. */
+int grx_host_prune(int F, const char *const *h_names, const int *h_recorded_generation, int n_generations,
+                   const int32_t *h_dist, int thresh, int *h_drop);
 typedef enum { GRX_AGG_SUM = 0, GRX_AGG_MEAN = 1, GRX_AGG_MIN = 2, GRX_AGG_MAX = 3, GRX_AGG_VAR = 4, GRX_AGG_STD = 5 } grx_agg;
 typedef struct {
     int generation;            /* generation that recorded the column */
