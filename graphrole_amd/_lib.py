@@ -13,7 +13,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgrx.so')
+# GRX_LIB_PATH: load another build of the same ABI (tuning A/B runs of tools/; never set in production)
+LIB_PATH = os.environ.get('GRX_LIB_PATH') or os.path.join(_HERE, 'libgrx.so')
 
 
 class GrxError(RuntimeError):
@@ -124,6 +125,11 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_aggregate_minmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_ldi': (c_int, [c_int]),
+    'grx_aggregate_i32_ok': (c_int, [c_void_p, c_int]),
+    'grx_pack_rows_i32': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'grx_aggregate_i32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_int64, c_void_p]),
     'grx_aggregate_prod': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64,
                                    c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
@@ -162,8 +168,8 @@ _SIGNATURES = {
     'grx_nmf_kl_cost': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_host_prune': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
-    'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                              c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p,
+    'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p,
                               POINTER(c_int), POINTER(c_size_t), c_void_p]),
     'grx_kmeans1d_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_kmeans1d': (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,

@@ -13,6 +13,23 @@
 // geometry; the other reductions are "per-lane sequential, then a fixed butterfly".
 #include "grx_common.h"
 
+// Streams that are read exactly once per launch (the neighbour index list, the oriented arc tables, the output
+// columns) can carry the non-temporal hint so that they do not evict the hot rows / hub lists the random gathers of
+// the same kernel hit in L2.  MEASURED WITHOUT GAIN on MI355X (round 3, -DGRX_NT_STREAMS=1 against 0: aggregation
+// 1.011 vs 0.995 ms per step at BA 1 M, 12.95 vs 12.33 ms at config 5, triangle counting 0.588 vs 0.585): the L2 hit
+// rate of these kernels is set by how many gather rows fit (sqrt(C / N) on a power-law graph), not by what the
+// streams displace.  Off by default; the macro stays for the next experiment.
+#ifndef GRX_NT_STREAMS
+#define GRX_NT_STREAMS 0
+#endif
+#if GRX_NT_STREAMS
+#define GRX_STREAM_LD(p) __builtin_nontemporal_load(&(p))
+#define GRX_STREAM_ST(p, v) __builtin_nontemporal_store((v), &(p))
+#else
+#define GRX_STREAM_LD(p) (p)
+#define GRX_STREAM_ST(p, v) ((p) = (v))
+#endif
+
 #include <vector>
 
 namespace {
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int64_t idx = base + lane + (int64_t)G * i;
-                uu[i] = (idx < ue) ? o_col[idx] : -2;
+                uu[i] = (idx < ue) ? GRX_STREAM_LD(o_col[idx]) : -2;
             }
             // 256-bit membership filter of the (up to 24) ids of N+(u) held by the group, one bit per
             // id & 255: an element of N+(v) is compared against the list only when its bit is set --
@@ -414,8 +431,8 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
             const int32_t uu0 = uu[0], uu1 = uu[1], uu2 = uu[2];
             for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
                 const bool have = k0 + lane < ue;
-                const int32_t v_mine = have ? o_col[k0 + lane] : -1;
-                const unsigned long long d_mine = have ? o_arc[k0 + lane] : 0ull;
+                const int32_t v_mine = have ? GRX_STREAM_LD(o_col[k0 + lane]) : -1;
+                const unsigned long long d_mine = have ? GRX_STREAM_LD(o_arc[k0 + lane]) : 0ull;
                 const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
                 // four target lists at a time: their first two chunks are eight independent loads in
                 // flight per lane (scalars, not arrays: arrays end up in scratch memory here)
@@ -656,7 +673,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
 #pragma unroll
         for (int t = 0; t < A; ++t) {
             const int idx = c8 + slot + t * S;
-            ut[t] = col[b + (idx < cnt ? idx : cnt - 1)];
+            ut[t] = GRX_STREAM_LD(col[b + (idx < cnt ? idx : cnt - 1)]);
         }
 #pragma unroll
         for (int t = 0; t < A; ++t) xt[t] = *reinterpret_cast<const double2 *>(base + ut[t] * row_stride);
@@ -665,7 +682,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
         double r0[A], r1[A];
 #pragma unroll
         for (int t = 0; t < A; ++t) {
-            const int64_t u = col[b + slot + t * S];
+            const int64_t u = GRX_STREAM_LD(col[b + slot + t * S]);
             const double2 x = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
             r0[t] = x.x; r1[t] = x.y;
         }
@@ -675,7 +692,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
                 double2 x[2 * A];
 #pragma unroll
                 for (int t = 0; t < A; ++t) {
-                    const int64_t u0 = col[b + i + slot + t * S], u1 = col[b + i + 8 + slot + t * S];
+                    const int64_t u0 = GRX_STREAM_LD(col[b + i + slot + t * S]), u1 = GRX_STREAM_LD(col[b + i + 8 + slot + t * S]);
                     x[t] = tr(*reinterpret_cast<const double2 *>(base + u0 * row_stride));
                     x[A + t] = tr(*reinterpret_cast<const double2 *>(base + u1 * row_stride));
                 }
@@ -688,7 +705,7 @@ __device__ __forceinline__ void pairwise_segment(const int32_t *__restrict__ col
         for (; i < c8; i += 8) {
 #pragma unroll
             for (int t = 0; t < A; ++t) {
-                const int64_t u = col[b + i + slot + t * S];
+                const int64_t u = GRX_STREAM_LD(col[b + i + slot + t * S]);
                 const double2 x = tr(*reinterpret_cast<const double2 *>(base + u * row_stride));
                 r0[t] += x.x; r1[t] += x.y;
             }
@@ -802,12 +819,12 @@ __global__ __launch_bounds__(256) void aggregate_kernel(
                 }
             } else {
                 if (c0 < f) {
-                    if (out_sum) out_sum[(int64_t)c0 * ld + v] = a0;
-                    if (out_mean) out_mean[(int64_t)c0 * ld + v] = (d > 0) ? a0 / cnt : 0.0;
+                    if (out_sum) GRX_STREAM_ST(out_sum[(int64_t)c0 * ld + v], a0);
+                    if (out_mean) GRX_STREAM_ST(out_mean[(int64_t)c0 * ld + v], (d > 0) ? a0 / cnt : 0.0);
                 }
                 if (c1 < f) {
-                    if (out_sum) out_sum[(int64_t)c1 * ld + v] = a1;
-                    if (out_mean) out_mean[(int64_t)c1 * ld + v] = (d > 0) ? a1 / cnt : 0.0;
+                    if (out_sum) GRX_STREAM_ST(out_sum[(int64_t)c1 * ld + v], a1);
+                    if (out_mean) GRX_STREAM_ST(out_mean[(int64_t)c1 * ld + v], (d > 0) ? a1 / cnt : 0.0);
                 }
             }
         }
@@ -873,6 +890,126 @@ __global__ __launch_bounds__(256) void aggregate_combine_kernel(
                 if (out_sum) out_sum[(int64_t)c * ld + v] = total;
                 if (out_mean) out_mean[(int64_t)c * ld + v] = total / (double)n;
             }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// neighbour aggregation of INTEGER rows (generation 1 of unweighted graphs)
+// ---------------------------------------------------------------------------------------
+// When every source column holds exact non-negative integers below 2^31 (degrees, ego-net edge counts: the whole
+// generation-0 block of an unweighted graph) the sums are integers below 2^53, so ANY order of additions gives the
+// bits numpy's pairwise tree gives -- and the gather source shrinks from 8 to 4 bytes per column: three columns
+// are a 16-byte row, four rows per 64-byte request line, a quarter of the table a 4 MiB L2 has to hold (the hit
+// rate of the gather follows sqrt(rows that fit / N) on a power-law graph).  Lane = (slot,
+// part): CL = LDI / 4 adjacent lanes fetch one neighbour row (int4 each), slot s takes neighbours s, s + S, ...;
+// int64 accumulators, xor-butterfly over the slots, mean = double(sum) / count like the fp64 kernel.
+// Rows with more than 128 neighbours reuse the block list of the plan: one lane group per block -> int64 partial
+// sums (the blk_sums scratch), added per row by aggregate_i32_combine_kernel.
+__global__ __launch_bounds__(256) void pack_rows_i32_kernel(int64_t n, int f, int ldi, GrxPtrTable cols_tab,
+                                                            int32_t *__restrict__ rows)
+{
+    const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int32_t *dst = rows + i * ldi;
+        for (int c = 0; c < f; ++c) dst[c] = (int32_t)cols[c][i];
+        for (int c = f; c < ldi; ++c) dst[c] = 0;
+    }
+}
+
+template <int LDI, int G>
+__device__ __forceinline__ void i32_segment(const int32_t *__restrict__ col, const int32_t *__restrict__ rows, int64_t b,
+                                            int cnt, int part, int slot, long long (&acc)[4])
+{
+    constexpr int CL = LDI / 4, S = G / CL;
+    const int32_t *base = rows + 4 * part;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    // four neighbours of this slot per trip: indices first (clamped), then the four row loads, all independent
+    for (int k0 = slot; k0 < cnt; k0 += 4 * S) {
+        int64_t u[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + t * S;
+            u[t] = GRX_STREAM_LD(col[b + (k < cnt ? k : cnt - 1)]);
+        }
+        int4 x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = *reinterpret_cast<const int4 *>(base + u[t] * LDI);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (k0 + t * S < cnt) { acc[0] += x[t].x; acc[1] += x[t].y; acc[2] += x[t].z; acc[3] += x[t].w; }
+        }
+    }
+#pragma unroll
+    for (int off = CL; off < G; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], off, G);
+    }
+}
+
+template <int LDI, int G>
+__global__ __launch_bounds__(256) void aggregate_i32_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows, int f,
+    int64_t row_begin, int64_t row_end, double *__restrict__ out_sum, double *__restrict__ out_mean, int64_t ld,
+    BlockWork bw)
+{
+    constexpr int CL = LDI / 4;
+    const int lane = threadIdx.x % G;
+    const int part = lane % CL, slot = lane / CL;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    long long acc[4];
+    long long *blk = reinterpret_cast<long long *>(bw.blk_sums);
+    for (int64_t k = group; k < bw.n_blocks; k += ngroups) {
+        const int64_t v = bw.long_rows[bw.blk_row[k]];
+        if (v < row_begin || v >= row_end) continue;
+        i32_segment<LDI, G>(col, rows, bw.blk_begin[k], bw.blk_len[k], part, slot, acc);
+        if (slot == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[k * 16 + 4 * part + j] = acc[j];
+        }
+    }
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        const int64_t d = e - b;
+        if (d > PW_BLOCK) continue;
+        i32_segment<LDI, G>(col, rows, b, (int)d, part, slot, acc);
+        if (slot == 0) {
+            const double cnt = (double)d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * part + j;
+                if (c < f) {
+                    const double sum = (double)acc[j];
+                    if (out_sum) GRX_STREAM_ST(out_sum[(int64_t)c * ld + v], sum);
+                    if (out_mean) GRX_STREAM_ST(out_mean[(int64_t)c * ld + v], (d > 0) ? sum / cnt : 0.0);
+                }
+            }
+        }
+    }
+}
+
+// sixteen lanes per long row (lane c = column c): integer partial sums of its blocks, any order
+__global__ __launch_bounds__(256) void aggregate_i32_combine_kernel(
+    const int64_t *__restrict__ row_ptr, int f, int64_t row_begin, int64_t row_end, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ blk_ptr, int64_t n_long, const double *__restrict__ blk_sums, double *__restrict__ out_sum,
+    double *__restrict__ out_mean, int64_t ld)
+{
+    const long long *blk = reinterpret_cast<const long long *>(blk_sums);
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t gstride = (int64_t)gridDim.x * 16;
+    for (int64_t h = (int64_t)blockIdx.x * 16 + grp; h < n_long; h += gstride) {
+        const int64_t v = long_rows[h];
+        if (v < row_begin || v >= row_end) continue;
+        const int64_t n = row_ptr[v + 1] - row_ptr[v];
+        long long total = 0;
+        for (int64_t k = blk_ptr[h]; k < blk_ptr[h + 1]; ++k) total += blk[k * 16 + c];
+        if (c < f) {
+            const double sum = (double)total;
+            if (out_sum) out_sum[(int64_t)c * ld + v] = sum;
+            if (out_mean) out_mean[(int64_t)c * ld + v] = sum / (double)n;
         }
     }
 }
@@ -945,6 +1082,7 @@ struct grx_aggregate_plan {
     int64_t n = 0;
     int lanes_per_row = 8;
     int64_t n_long = 0, n_blocks = 0;
+    int64_t max_degree = 0;             // longest row (bounds the integer sums of grx_aggregate_i32)
     int32_t *d_long_rows = nullptr;     // [n_long] ascending
     int64_t *d_blk_ptr = nullptr;       // [n_long + 1]
     int64_t *d_blk_begin = nullptr;     // [n_blocks] position in d_col
@@ -1242,6 +1380,7 @@ int grx_aggregate_plan_create(int64_t n, const int64_t *h_row_ptr, grx_aggregate
     std::vector<uint8_t> blk_ops;
     for (int64_t v = 0; v < n; ++v) {
         const int64_t d = h_row_ptr[v + 1] - h_row_ptr[v];
+        if (d > p->max_degree) p->max_degree = d;
         if (d <= PW_BLOCK) continue;
         blk_ptr.push_back((int64_t)blk_begin.size());
         const size_t before = blk_begin.size();
@@ -1340,6 +1479,78 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
     const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
     aggregate_prod_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_rows, ldr, f, row_begin, row_end,
                                                                d_prod, ld);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+/* row stride in int32 of the integer gather source: 16- or 32-byte rows; 0 = no integer kernel for that many columns */
+int grx_aggregate_ldi(int f) { return f <= 0 ? 0 : f <= 4 ? 4 : f <= 8 ? 8 : 0; }
+
+int grx_pack_rows_i32(int64_t n, int f, const double *const *h_col_ptrs, int32_t *d_rows, int ldi, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && f >= 1 && ldi == grx_aggregate_ldi(f), "grx_pack_rows_i32: ldi must be grx_aggregate_ldi(f)");
+    if (n == 0) return GRX_OK;
+    GRX_REQUIRE(h_col_ptrs && d_rows, "grx_pack_rows_i32: NULL pointer");
+    GrxPtrTable tab;
+    for (int c = 0; c < f; ++c) {
+        GRX_REQUIRE(h_col_ptrs[c] != nullptr, "grx_pack_rows_i32: column %d is NULL", c);
+        tab.p[c] = h_col_ptrs[c];
+    }
+    const int64_t want = grx_ceil_div(n, 256);
+    { GRX_PROF(GRX_K_PACK_ROWS, grx_stream(stream));
+    pack_rows_i32_kernel<<<(int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want), 256, 0, grx_stream(stream)>>>(
+        n, f, ldi, tab, d_rows);
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_aggregate_i32_ok(const grx_aggregate_plan *plan, int f)
+{
+    // integer sums stay exact in fp64 while max_degree * 2^31 <= 2^53
+    return plan != nullptr && grx_aggregate_ldi(f) != 0 && plan->max_degree < ((int64_t)1 << 22);
+}
+
+int grx_aggregate_i32(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                      const int32_t *d_rows, int ldi, int64_t row_begin, int64_t row_end, double *d_sum, double *d_mean,
+                      int64_t ld, void *stream)
+{
+    GRX_REQUIRE(plan != nullptr, "grx_aggregate_i32: NULL plan");
+    GRX_REQUIRE(grx_aggregate_i32_ok(plan, f) && ldi == grx_aggregate_ldi(f),
+                "grx_aggregate_i32: f=%d / ldi=%d / max degree %lld outside the integer kernel's range", f, ldi,
+                (long long)plan->max_degree);
+    const int64_t n = plan->n;
+    GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= n && ld >= n, "grx_aggregate_i32: bad row range");
+    if (row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate_i32: NULL pointer");
+    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 63) == 0, "grx_aggregate_i32: d_rows must be 64-byte aligned");
+    hipStream_t st = grx_stream(stream);
+    const int CL = ldi / 4;
+    int G = plan->lanes_per_row;
+    if (G < 4) G = 4;
+    if (G > 16) G = 16;
+    if (G < CL) G = CL;
+    const int64_t want = grx_ceil_div((row_end - row_begin) * G, 256);
+    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    const BlockWork bw{plan->d_long_rows, plan->d_blk_begin, plan->d_blk_len, plan->d_blk_row,
+                       plan->n_long > 0 ? plan->n_blocks : 0, plan->d_blk_sums};
+    {
+        GRX_PROF(GRX_K_AGGREGATE, st);
+#define GRX_I32_CASE(LL, GG)                                                                                          \
+        if (ldi == LL && G == GG)                                                                                     \
+            aggregate_i32_kernel<LL, GG><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_rows, f, row_begin, row_end, d_sum, \
+                                                               d_mean, ld, bw);
+        GRX_I32_CASE(4, 4) GRX_I32_CASE(4, 8) GRX_I32_CASE(4, 16) GRX_I32_CASE(8, 4) GRX_I32_CASE(8, 8) GRX_I32_CASE(8, 16)
+#undef GRX_I32_CASE
+    }
+    GRX_LAUNCH_CHECK();
+    if (plan->n_long > 0) {
+        GRX_PROF(GRX_K_AGGREGATE_HUB, st);
+        const int64_t cwant = grx_ceil_div(plan->n_long, 16);
+        aggregate_i32_combine_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
+            d_row_ptr, f, row_begin, row_end, plan->d_long_rows, plan->d_blk_ptr, plan->n_long, plan->d_blk_sums, d_sum,
+            d_mean, ld);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

@@ -31,6 +31,7 @@ struct Column {
     const double *data;
     const uint8_t *bins;
     int record_index;         // position in the output table, -1 while not recorded
+    bool int32_exact = false; // every value an exact integer in [0, 2^31): may travel as an int32 gather source
 };
 
 // bump allocator over the caller's arena; keeps counting past the end so that the caller learns how
@@ -136,8 +137,8 @@ int grx_host_prune(int F, const char *const *h_names, const int *h_recorded_gene
 }
 
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
-                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
-                  int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
+                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
+                  int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
                   size_t arena_bytes, int max_columns,
                   grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
                   int *generation_count, size_t *arena_needed, void *stream)
@@ -265,6 +266,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
     for (int j = 0; j < f0; ++j) {
         GRX_REQUIRE(h_gen0_cols[j] && h_gen0_names[j], "grx_refex_run: generation-0 column %d is NULL", j);
         cols.push_back({h_gen0_names[j], 0, -1, -1, h_gen0_cols[j], nullptr, -1});
+        cols.back().int32_exact = h_gen0_int32 && h_gen0_int32[j] != 0;
     }
     {
         // binning wants one contiguous block: a scratch copy of the (separately allocated) input columns
@@ -293,8 +295,13 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 }
             const size_t mark = arena.top;
             const int ldr = grx_aggregate_ldr(f);
-            double *rows = reinterpret_cast<double *>(arena.take((size_t)n * ldr * 8));
             const bool need_var = has[GRX_AGG_VAR] || has[GRX_AGG_STD];
+            // integer gather source (16- / 32-byte rows) when every parent is an exact int32 column and only sums /
+            // means are wanted: any summation order gives the reference's bits there (grx.h, grx_aggregate_i32)
+            bool int_rows = !need_var && !has[GRX_AGG_MIN] && !has[GRX_AGG_MAX] && grx_aggregate_i32_ok(plan, f);
+            for (int j = 0; j < f && int_rows; ++j) int_rows = cols[prev[j]].int32_exact;
+            const int ldi = int_rows ? grx_aggregate_ldi(f) : 0;
+            double *rows = reinterpret_cast<double *>(arena.take(int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
             double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
                                                                     : nullptr;
             if (!arena.overflow) {
@@ -305,10 +312,17 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 };
                 std::vector<const double *> ptrs(f);
                 for (int j = 0; j < f; ++j) ptrs[j] = cols[prev[j]].data;
-                GRX_TRY(grx_pack_rows(n, f, ptrs.data(), rows, ldr, stream));
                 double *d_mean = has[GRX_AGG_MEAN] ? out_of(GRX_AGG_MEAN) : mean_scratch;
-                if (has[GRX_AGG_SUM] || d_mean)
-                    GRX_TRY(grx_aggregate(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_SUM), d_mean, n, stream));
+                if (int_rows) {
+                    int32_t *irows = reinterpret_cast<int32_t *>(rows);
+                    GRX_TRY(grx_pack_rows_i32(n, f, ptrs.data(), irows, ldi, stream));
+                    GRX_TRY(grx_aggregate_i32(plan, d_row_ptr, d_agg_col, f, irows, ldi, rb, re, out_of(GRX_AGG_SUM), d_mean, n,
+                                              stream));
+                } else {
+                    GRX_TRY(grx_pack_rows(n, f, ptrs.data(), rows, ldr, stream));
+                    if (has[GRX_AGG_SUM] || d_mean)
+                        GRX_TRY(grx_aggregate(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_SUM), d_mean, n, stream));
+                }
                 if (need_var)
                     GRX_TRY(grx_aggregate_var(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, d_mean, out_of(GRX_AGG_VAR),
                                               out_of(GRX_AGG_STD), n, stream));

@@ -92,6 +92,7 @@ class RecursiveFeatureExtractor:
         self._dtypes: Dict[str, np.dtype] = {}                     # pandas dtype of each column
         self._final_names: Dict[int, List[str]] = {}               # generation -> recorded names
         self._final_cols: Dict[str, object] = {}                   # recorded name -> fp64 column
+        self._int32_exact: set = set()                             # generation-0 names that may travel as int32 rows
         self._plan = None
         self._plan_ready = False
         self._arena = None            # device memory of grx_refex_run, reused by later runs of this instance
@@ -161,6 +162,8 @@ class RecursiveFeatureExtractor:
             # rows and issues the exchanges itself
             self._run_native(names, cols, dtypes, aggs)
             return
+        flags = self._int32_flags(names, dtypes)
+        self._int32_exact = {nm for nm, ok in zip(names, flags or []) if ok}
         self._update_columns(names, cols, dtypes)
 
         for generation in range(1, self.max_generations):
@@ -180,12 +183,9 @@ class RecursiveFeatureExtractor:
         dtypes, the final working set, per-generation statistics."""
         K = self._K()
         _, dev_graph, _ = self.graph._device_graph()
-        if self._plan is None:
-            columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
-                                                                       aggs, self._arena)
-        else:
-            columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
-                                                                       aggs, self._arena, shard=self._plan)
+        flags = self._int32_flags(names0, dtypes0)
+        columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
+                                                                   aggs, self._arena, shard=self._plan, gen0_int32=flags)
         host = self.graph._device_graph()[0]
         no_empty_rows = self._no_empty_rows(host)
         names: List[str] = []
@@ -208,6 +208,11 @@ class RecursiveFeatureExtractor:
         self.generation_count = gen_count
         self._feature_group_thresh = gen_count
         self.stats = generations
+
+    def _int32_flags(self, names, dtypes):
+        """Which generation-0 columns hold exact integers in [0, 2^31) (adapter knowledge; None = unknown)."""
+        probe = getattr(self.graph, 'int32_exact_flags', None)
+        return None if probe is None else probe(names, dtypes)
 
     @staticmethod
     def _no_empty_rows(host) -> bool:
@@ -263,11 +268,21 @@ class RecursiveFeatureExtractor:
         if f == 0:
             return [], [], [], None
         _, dev_graph, _ = self.graph._device_graph()
-        rows, ldr = K.pack_rows([self._work[c] for c in prev], n)
         rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
         pieces = {}
         need_var = 'var' in aggs or 'std' in aggs
-        if 'sum' in aggs or 'mean' in aggs or need_var:
+        # generation 1 of an unweighted graph: every parent an exact int32 column and only sums / means wanted -> the
+        # integer gather source (the same choice grx_refex_run makes)
+        int_rows = (set(aggs) <= {'sum', 'mean'} and hasattr(K, 'aggregate_i32') and
+                    all(c in self._int32_exact for c in prev) and K.aggregate_i32_ok(dev_graph, f))
+        if int_rows:
+            irows, ldi = K.pack_rows_i32([self._work[c] for c in prev], n)
+            block = K.aggregate_i32(dev_graph, irows, f, ldi, rb, re, want_sum='sum' in aggs, want_mean='mean' in aggs)
+            pieces['sum'], pieces['mean'] = block[:f], block[f:]
+            rows = ldr = None
+        else:
+            rows, ldr = K.pack_rows([self._work[c] for c in prev], n)
+        if not int_rows and ('sum' in aggs or 'mean' in aggs or need_var):
             block = K.aggregate(dev_graph, rows, f, ldr, rb, re,
                                 want_sum='sum' in aggs, want_mean='mean' in aggs or need_var)
             pieces['sum'], pieces['mean'] = block[:f], block[f:]

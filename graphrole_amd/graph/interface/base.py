@@ -178,6 +178,25 @@ class DeviceGraphInterface(BaseGraphInterface):
         n2, c2, d2 = self.egonet_feature_columns()
         return n1 + n2, c1 + c2, d1 + d2
 
+    def int32_exact_flags(self, names, dtypes) -> List[bool]:
+        """Per generation-0 column: every value an exact integer in [0, 2^31)?  True for the degree / ego-net columns
+        of an unweighted graph with fewer than 2^31 adjacency entries (each is bounded by nnz: a degree, a number of
+        edges, a sum of degrees over distinct nodes) and for integer attributes inside that range -- the condition
+        under which a generation may gather int32 rows (grx_aggregate_i32)."""
+        host = self._device_graph()[0]
+        structural = bool(host.integral and not host.weighted and host.nnz < 2 ** 31)
+        attr_ok = {}
+        cached = getattr(self, '_attr_cols', None)
+        if cached is not None:
+            arrays = self._attribute_arrays() or {}
+            for name, dt in zip(cached[0], cached[2]):
+                values = arrays.get(name)
+                attr_ok[name] = bool(np.dtype(dt).kind in 'iu' and values is not None and len(values) and
+                                     int(np.min(values)) >= 0 and int(np.max(values)) < 2 ** 31)
+        prefix = self.attribute_feature_prefix + '_'
+        return [attr_ok.get(nm, False) if nm.startswith(prefix) else (structural and np.dtype(dt).kind in 'iu')
+                for nm, dt in zip(names, dtypes)]
+
     def _frame(self, names, cols, dtypes) -> pd.DataFrame:
         K = self._K()
         host = self._device_graph()[0]

@@ -435,6 +435,34 @@ def pack_rows(cols: Sequence[torch.Tensor], n: int) -> Tuple[torch.Tensor, int]:
     return rows, ldr
 
 
+def aggregate_i32_ok(csr: DeviceCSR, f: int) -> bool:
+    """Can f exact-int32 columns be aggregated through the integer kernel on this graph (grx_aggregate_i32_ok)?"""
+    return bool(_lib.load().grx_aggregate_i32_ok(csr.plan().handle, int(f)))
+
+
+def pack_rows_i32(cols: Sequence[torch.Tensor], n: int) -> Tuple[torch.Tensor, int]:
+    """fp64 columns holding exact integers in [0, 2^31) -> row-major int32 [n, ldi] gather source (16- / 32-byte rows)."""
+    f = len(cols)
+    ldi = _lib.load().grx_aggregate_ldi(f)
+    rows = torch.empty((max(n, 1), ldi), dtype=torch.int32, device=device())
+    if n:
+        _lib.call('grx_pack_rows_i32', n, f, ptr_array(cols), _ptr(rows), ldi, _stream())
+    return rows, ldi
+
+
+def aggregate_i32(csr: DeviceCSR, rows: torch.Tensor, f: int, ldi: int, row_begin: int = 0, row_end: Optional[int] = None,
+                  want_sum: bool = True, want_mean: bool = True) -> torch.Tensor:
+    """grx_aggregate_i32: the [2f, n] sums / means block of aggregate() from an int32 gather source."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.empty((2 * f, n), dtype=torch.float64, device=device())
+    s_ptr = c_void_p(out.data_ptr()) if want_sum else None
+    m_ptr = c_void_p(out.data_ptr() + f * n * 8) if want_mean else None
+    _lib.call('grx_aggregate_i32', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldi,
+              row_begin, row_end, s_ptr, m_ptr, n, _stream())
+    return out
+
+
 def aggregate(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
               row_end: Optional[int] = None, want_sum: bool = True, want_mean: bool = True,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -546,7 +574,8 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
 
 # ------------------------------------------------------------------------------- whole ReFeX loop
 def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
-              aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None):
+              aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None,
+              gen0_int32: Optional[Sequence[bool]] = None):
     """
     grx_refex_run: the generation loop of RecursiveFeatureExtractor below the ABI (one call, one GPU).
     Returns (columns, generations, generation_count, arena): `columns` = one dict per RECORDED feature in
@@ -559,6 +588,7 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
     comm, bounds = _shard_args(shard)
     n = csr.n
     f0 = len(gen0_cols)
+    int_flags = None if gen0_int32 is None else (ctypes.c_int * max(f0, 1))(*[int(bool(b)) for b in gen0_int32])
     agg_ids = (ctypes.c_int * len(aggs))(*[_lib.AGG_IDS[a] for a in aggs])
     names = (ctypes.c_char_p * f0)(*[nm.encode('utf-8') for nm in gen0_names])
     col_ptrs = ptr_array(list(gen0_cols))
@@ -571,7 +601,7 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         gens = (_lib.RefexGeneration * max_gens)()
         n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         lib = _lib.load()
-        rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names,
+        rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names, int_flags,
                                int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), arena.numel(),
                                max_columns, table,
                                ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),

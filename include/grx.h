@@ -303,6 +303,20 @@ int grx_aggregate_var(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, 
 int grx_aggregate_minmax(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                          const double *d_rows, int ldr, int64_t row_begin, int64_t row_end,
                          double *d_min, double *d_max, int64_t ld, void *stream);
+/*
+ * The same sums / means for an INTEGER gather source: when every source column holds exact non-negative integers
+ * below 2^31 (the generation-0 block of an unweighted graph: degrees and ego-net edge counts are bounded by nnz), the
+ * neighbour sums are integers below 2^53 and ANY order of additions gives the bits of the reference's pairwise tree.
+ * The gather source is then n x ldi int32 (ldi = grx_aggregate_ldi(f): 4 or 8, i.e. 16- / 32-byte rows instead of 32 /
+ * 64): four times as many rows per cache line and per MiB of L2.  grx_aggregate_i32_ok: the plan's longest row keeps
+ * max_degree * 2^31 <= 2^53 and f <= 8.  Outputs as grx_aggregate.
+ */
+int grx_aggregate_ldi(int f);
+int grx_aggregate_i32_ok(const grx_aggregate_plan *plan, int f);
+int grx_pack_rows_i32(int64_t n, int f, const double *const *h_col_ptrs, int32_t *d_rows, int ldi, void *stream);
+int grx_aggregate_i32(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
+                      const int32_t *d_rows, int ldi, int64_t row_begin, int64_t row_end, double *d_sum, double *d_mean,
+                      int64_t ld, void *stream);
 /* agg 'prod' (extract.py:36-47 with Series.prod): left-to-right product over the neighbours in the order
  * of d_col, 1 for a row without neighbours.  fp64 arithmetic: exact for integer columns below 2^53 (the
  * reference multiplies int64 columns in int64 and wraps silently beyond 2^63; the caller checks). */
@@ -329,6 +343,10 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * h_gens (capacity max_gens >= max_generations): per-generation counts.  *generation_count = the last
  * executed generation (the reference's generation_count).  Synchronises `stream` before returning.
  *
+ * h_gen0_int32 (may be NULL): per generation-0 column, non-zero if every value is an exact integer in [0, 2^31) --
+ * a generation whose parents all are (generation 1 of an unweighted graph) then gathers 16- / 32-byte integer rows
+ * (grx_aggregate_i32) when only sums and means are asked for.
+ *
  * comm / h_bounds (NULL / NULL = one GPU): node-range sharding.  Every rank calls with the same arguments and the
  * COMPLETE generation-0 columns; it aggregates rows [h_bounds[rank], h_bounds[rank + 1]) only and the loop issues
  * its own exchanges on `stream`: candidate row slices to the column owners (grx_comm_columns_to_owners), the owners'
@@ -353,8 +371,8 @@ typedef struct {
 } grx_refex_column;
 typedef struct { int candidates, working, dropped, retained; } grx_refex_generation;
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
-                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, int max_generations,
-                  int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
+                  int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
+                  int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
                   size_t arena_bytes, int max_columns, grx_refex_column *h_columns, int *n_columns, int max_gens,
                   grx_refex_generation *h_gens, int *generation_count, size_t *arena_needed, void *stream);
 

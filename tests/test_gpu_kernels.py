@@ -161,6 +161,61 @@ def test_aggregate_bit_exact_vs_oracle(K, f, lanes):
     assert torch.equal(only_mean[f:], blk[f:]) and float(only_mean[:f].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('lanes', [None, 4, 16, 32])
+@pytest.mark.parametrize('f', [1, 2, 3, 4, 5, 8])
+def test_aggregate_i32_bit_exact_vs_oracle(K, f, lanes):
+    """The integer gather source (grx_aggregate_i32: 16- / 32-byte int32 rows, any summation order, int64
+    accumulators) gives the oracle's pairwise-order fp64 sums and means bit for bit whenever the columns hold exact
+    integers below 2^31 -- rows of every length class, blocks of long rows, row ranges, dangling rows."""
+    import torch
+    from oracle import ckernels
+    if lanes is not None and f not in (3, 5):
+        pytest.skip('lane-group sweep on two widths')
+    n, m = 20000, 6
+    src, dst, _ = util.powerlaw_graph(n, m, seed=40 + f)
+    og = _oracle_graph(n, src, dst, None, False)
+    deg = np.diff(og.row_ptr)
+    assert deg.max() > 300 and (deg < 8).any()
+    og.row_ptr = np.concatenate([og.row_ptr, np.full(5, og.row_ptr[-1])])
+    n2 = og.n
+    rng = np.random.default_rng(f)
+    X = rng.integers(0, 2 ** 31, size=(n2, f)).astype(np.float64)
+    X[:, 0] = rng.integers(0, 50, size=n2)                       # a degree-like column next to full-range ones
+    S, M = ckernels.aggregate(og.row_ptr, og.adj_col, X)
+    csr = _dev_csr(K, og)
+    if lanes is not None:
+        csr.plan().set_lanes(lanes)
+    assert K.aggregate_i32_ok(csr, f)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    rows, ldi = K.pack_rows_i32([Xd[c] for c in range(f)], n2)
+    assert ldi == (4 if f <= 4 else 8) and np.array_equal(rows.cpu().numpy()[:, :f], X.astype(np.int32))
+    got = K.aggregate_i32(csr, rows, f, ldi).cpu().numpy()
+    assert np.array_equal(got[:f].T, S), f'{int((got[:f].T != S).sum())} sums differ'
+    assert np.array_equal(got[f:].T, M), f'{int((got[f:].T != M).sum())} means differ'
+    part = K.aggregate_i32(csr, rows, f, ldi, row_begin=77, row_end=12345).cpu().numpy()
+    assert np.array_equal(part[:, 77:12345], got[:, 77:12345])
+    # and it is what the fp64 kernel computes
+    rows64, ldr = K.pack_rows([Xd[c] for c in range(f)], n2)
+    assert torch.equal(K.aggregate(csr, rows64, f, ldr), torch.from_numpy(got).cuda())
+    assert not K.aggregate_i32_ok(csr, 9)
+
+
+def test_aggregate_i32_on_huge_row(K):
+    """70 001 neighbours of full-range int32 values: 1 024 integer block sums, the total near 2^47."""
+    import torch
+    n = 70002
+    src = np.zeros(n - 1, dtype=np.int64)
+    dst = np.arange(1, n, dtype=np.int64)
+    og = _oracle_graph(n, src, dst, None, False)
+    csr = _dev_csr(K, og)
+    x = np.random.default_rng(9).integers(2 ** 30, 2 ** 31, size=n).astype(np.float64)
+    rows, ldi = K.pack_rows_i32([torch.from_numpy(x).cuda()], n)
+    got = K.aggregate_i32(csr, rows, 1, ldi).cpu().numpy()
+    total = int(x[1:].astype(np.int64).sum())
+    assert got[0, 0] == float(total) and got[1, 0] == float(total) / (n - 1)
+    assert np.array_equal(got[0, 1:], np.full(n - 1, x[0]))
+
+
 def test_aggregate_equals_numpy_sum_on_huge_row(K):
     """A star: the centre has 70 001 neighbours -> 1 024 blocks, 10 tree levels; the device sum
     must equal ndarray.sum() of the neighbour values in adjacency order."""

@@ -344,7 +344,8 @@ def test_model_selection_on_a_larger_matrix_runs_in_hbm():
 # sklearn's pick there is decided by the last-bit rounding of its BLAS dot product, not by the algorithm
 TIED_CELLS = {
     'karate': [], 'er300': [], 'ba300': [],
-    'karate_weighted': 'FILL', 'dw200_attrs': 'FILL', 'directed120': 'FILL', 'loops_dangling150': 'FILL',
+    'karate_weighted': [(6, 4)], 'dw200_attrs': [(4, 8), (7, 8), (8, 7), (8, 8)], 'directed120': [(8, 6)],
+    'loops_dangling150': [(8, 6)],
 }
 def _selection_record(name, quantizer):
     """(reference grid + selection, ours) for one golden feature table."""
