@@ -401,8 +401,9 @@ def triangle_counts(csr: DeviceCSR, row_begin: int = 0, row_end: Optional[int] =
 def egonet_from_triangles(csr: DeviceCSR, T: torch.Tensor, row_begin: int = 0,
                           row_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     row_end = csr.n if row_end is None else row_end
-    internal = torch.empty(csr.n, dtype=torch.float64, device=device())
-    external = torch.empty(csr.n, dtype=torch.float64, device=device())
+    # a partial row range leaves the other rows zero (callers complete them by an exchange, tests read them)
+    alloc = (lambda k: torch.empty(k, dtype=torch.float64, device=device())) if (row_begin == 0 and row_end == csr.n) else zeros
+    internal, external = alloc(csr.n), alloc(csr.n)
     scratch = torch.empty(max(csr.n, 1), dtype=torch.int32, device=device())
     _lib.call('grx_egonet_unweighted', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(T), row_begin, row_end,
               _ptr(internal), _ptr(external), _ptr(scratch), _ptr(csr.hub_rows), csr.n_hubs,
