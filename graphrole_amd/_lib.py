@@ -46,7 +46,8 @@ class RefexGeneration(ctypes.Structure):
     _fields_ = [('candidates', c_int), ('working', c_int), ('dropped', c_int), ('retained', c_int)]
 
 
-AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5}       # grx_agg
+AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5, 'prod': 6, 'median': 7, 'count': 8,
+           'size': 9}                                                           # grx_agg
 
 
 class P2pOp(ctypes.Structure):
@@ -130,6 +131,14 @@ _SIGNATURES = {
     'grx_pack_rows_i32': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_aggregate_i32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p,
                                   c_void_p, c_int64, c_void_p]),
+    'grx_convert_i64_to_f64': (c_int, [c_int64, c_void_p, c_void_p, c_void_p]),
+    'grx_convert_f64_to_i64': (c_int, [c_int64, c_void_p, c_void_p, c_void_p]),
+    'grx_aggregate_i64': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_count': (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    'grx_aggregate_median_workspace_bytes': (c_size_t, [c_int64]),
+    'grx_aggregate_median': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64,
+                                     c_void_p, c_size_t, c_void_p]),
     'grx_aggregate_prod': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64,
                                    c_void_p]),
     'grx_triangle_counts': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
@@ -138,6 +147,8 @@ _SIGNATURES = {
     'grx_log_bin_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_vertical_log_bin': (c_int, [c_int64, c_int, c_void_p, c_int64, c_double, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    'grx_vertical_log_bin_typed': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_double, c_void_p, c_int64, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
     'grx_sort_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_sort_columns': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     'grx_chebyshev': (c_int, [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

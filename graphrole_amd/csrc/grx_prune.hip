@@ -384,6 +384,16 @@ struct BinPlanCol {
     uint8_t dshift[4];        // per round: shift of the stored key that exposes the round's digit
 };
 
+// Columns that hold int64 BITS instead of doubles (the reference's integer columns once 'prod' made them overflow
+// 2^53, csrc/grx_aggx.hip): their order key is the two's-complement value with the sign bit flipped.  One bit per
+// column of the call, passed by value.
+struct ColFlags { uint64_t w[8]; };
+constexpr int MAX_TYPED_COLS = 512;
+__device__ __forceinline__ bool col_is_i64(const ColFlags &f, int col) { return col < MAX_TYPED_COLS && ((f.w[col >> 6] >> (col & 63)) & 1ull); }
+__device__ __forceinline__ uint64_t i64_bits_to_key(double raw) { return (uint64_t)__double_as_longlong(raw) ^ 0x8000000000000000ull; }
+// order key of a stored value of either kind (-0.0 and 0.0 are one value for doubles, like np.unique)
+__device__ __forceinline__ uint64_t value_key(double raw, bool is_i64) { return is_i64 ? i64_bits_to_key(raw) : f64_to_key(raw + 0.0); }
+
 constexpr int BITS_TILE = 256 * 32;
 // INTEGER columns (every value a non-negative integer below 2^32: degrees, ego-net counts, their neighbour sums) may
 // be sorted by the integer itself instead of the fp64 bit pattern: a degree-like column below 2^16 varies in two
@@ -391,9 +401,10 @@ constexpr int BITS_TILE = 256 * 32;
 constexpr int LO_SHIFT_INT = 255;
 
 __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                       int ntiles, uint64_t *__restrict__ bits)
+                                                       int ntiles, uint64_t *__restrict__ bits, ColFlags flags)
 {
     const int col = blockIdx.y, tile = blockIdx.x;
+    const bool i64 = col_is_i64(flags, col);
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)tile * BITS_TILE;
     uint64_t o = 0, z = 0;
@@ -412,10 +423,10 @@ __global__ __launch_bounds__(256) void key_bits_kernel(const double *__restrict_
         for (int j = 0; j < 8; ++j) {
             const int64_t idx = base + (int64_t)(i0 + j) * 256 + threadIdx.x;
             const double v = raw[j] + 0.0;                    // + 0.0: -0.0 and 0.0 are one value (np.unique)
-            const uint64_t k = f64_to_key(v);
+            const uint64_t k = i64 ? i64_bits_to_key(raw[j]) : f64_to_key(v);
             o |= idx < n ? k : 0;
             z |= idx < n ? ~k : 0;
-            const bool in_range = v >= 0.0 && v < 4294967296.0;  // false for NaN
+            const bool in_range = !i64 && v >= 0.0 && v < 4294967296.0;  // false for NaN; int64 columns keep their own key
             const uint32_t iv = in_range ? (uint32_t)v : 0u;
             const bool isint = in_range && (double)iv == v;
             oi |= idx < n ? iv : 0u;
@@ -503,10 +514,12 @@ __global__ __launch_bounds__(64) void bin_plan_kernel(const uint64_t *__restrict
 }
 
 // keys of one thread (wave-contiguous slices like load_keys); round 0 converts the fp64 input
+// src_kind: 0 = stored keys of an earlier round, 1 = the fp64 input column, 2 = an int64 input column
 template <typename KeyT>
-__device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool from_f64, int lo_shift, int64_t n,
+__device__ __forceinline__ void load_keys2(const void *__restrict__ src, int src_kind, int lo_shift, int64_t n,
                                            int64_t tile_base, KeyT (&keys)[SORT_ITEMS], uint32_t &valid_mask)
 {
+    const bool from_f64 = src_kind != 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = tile_base + (int64_t)wave * 64 * SORT_ITEMS + lane;
     const int64_t last = n > 0 ? n - 1 : 0;
@@ -525,7 +538,7 @@ __device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool fr
             const bool ok = base + (int64_t)i * 64 < n;
             valid_mask |= ok ? 1u << i : 0u;
             const KeyT k = lo_shift == LO_SHIFT_INT ? (KeyT)(uint32_t)(raw[i] + 0.0)
-                                                    : (KeyT)(f64_to_key(raw[i] + 0.0) >> lo_shift);
+                                                    : (KeyT)(value_key(raw[i], src_kind == 2) >> lo_shift);
             keys[i] = ok ? k : (KeyT)~(KeyT)0;
         }
     } else {
@@ -546,13 +559,13 @@ __device__ __forceinline__ void load_keys2(const void *__restrict__ src, bool fr
 }
 
 template <typename KeyT>
-__device__ __forceinline__ void count_body(const void *src, bool from_f64, int lo_shift, int dshift, int64_t n,
+__device__ __forceinline__ void count_body(const void *src, int src_kind, int lo_shift, int dshift, int64_t n,
                                            int tile, uint32_t *cnt)
 {
     KeyT keys[SORT_ITEMS];
     uint32_t vm;
-    if (from_f64) load_keys2<KeyT>(src, true, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
-    else load_keys2<KeyT>(src, false, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
+    if (src_kind) load_keys2<KeyT>(src, src_kind, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys2<KeyT>(src, 0, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
@@ -583,17 +596,18 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count2_kernel(const double 
                                                                    int64_t n, int round, int ntiles,
                                                                    const BinPlanCol *__restrict__ plan,
                                                                    const uint64_t *buf_a, const uint64_t *buf_b,
-                                                                   uint32_t *__restrict__ hist)
+                                                                   uint32_t *__restrict__ hist, ColFlags flags)
 {
     __shared__ uint32_t cnt[RADIX];
     const int col = blockIdx.y, tile = blockIdx.x;
     if (round >= plan[col].npass) return;
+    const int src_kind = round == 0 ? (col_is_i64(flags, col) ? 2 : 1) : 0;
     const int narrow = plan[col].narrow, lo_shift = plan[col].lo_shift, dshift = plan[col].dshift[round];
     cnt[threadIdx.x] = 0;
     __syncthreads();
     const void *src = round_src(round, col, cols, ld, n, buf_a, buf_b);
-    if (narrow) count_body<uint32_t>(src, round == 0, lo_shift, dshift, n, tile, cnt);
-    else count_body<uint64_t>(src, round == 0, 0, dshift, n, tile, cnt);
+    if (narrow) count_body<uint32_t>(src, src_kind, lo_shift, dshift, n, tile, cnt);
+    else count_body<uint64_t>(src, src_kind, 0, dshift, n, tile, cnt);
     __syncthreads();
     hist[((size_t)col * RADIX + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(64) void scan_rows2_kernel(uint32_t *__restrict__ h
 }
 
 template <typename KeyT>
-__device__ __forceinline__ void scatter_body(const void *src, bool from_f64, int lo_shift, int dshift, void *dst,
+__device__ __forceinline__ void scatter_body(const void *src, int src_kind, int lo_shift, int dshift, void *dst,
                                              int64_t n, int tile, int ntiles, const uint32_t *offsets_col,
                                              const uint32_t *digit_tot_col, uint32_t (*cnt)[RADIX], uint32_t *gdelta,
                                              uint32_t *wsum, KeyT *stage)
@@ -638,8 +652,8 @@ __device__ __forceinline__ void scatter_body(const void *src, bool from_f64, int
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     KeyT keys[SORT_ITEMS];
     uint32_t vm;
-    if (from_f64) load_keys2<KeyT>(src, true, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
-    else load_keys2<KeyT>(src, false, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
+    if (src_kind) load_keys2<KeyT>(src, src_kind, lo_shift, n, (int64_t)tile * SORT_TILE, keys, vm);
+    else load_keys2<KeyT>(src, 0, 0, n, (int64_t)tile * SORT_TILE, keys, vm);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rank[SORT_ITEMS];
 #pragma unroll
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter2_kernel(const double *__
                                                                 int64_t n, int round, int ntiles,
                                                                 const BinPlanCol *__restrict__ plan, uint64_t *buf_a,
                                                                 uint64_t *buf_b, const uint32_t *__restrict__ offsets,
-                                                                const uint32_t *__restrict__ digit_tot)
+                                                                const uint32_t *__restrict__ digit_tot, ColFlags flags)
 {
     __shared__ uint32_t cnt[4][RADIX];
     __shared__ uint32_t gdelta[RADIX];
@@ -721,6 +735,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter2_kernel(const double *__
     const int col = blockIdx.y, tile = blockIdx.x;
     if (round >= plan[col].npass) return;
     const int narrow = plan[col].narrow, lo_shift = plan[col].lo_shift, dshift = plan[col].dshift[round];
+    const int src_kind = round == 0 ? (col_is_i64(flags, col) ? 2 : 1) : 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -729,10 +744,10 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter2_kernel(const double *__
     const uint32_t *off_col = offsets + (size_t)col * RADIX * ntiles;
     const uint32_t *tot_col = digit_tot + (size_t)col * RADIX;
     if (narrow)
-        scatter_body<uint32_t>(src, round == 0, lo_shift, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum,
+        scatter_body<uint32_t>(src, src_kind, lo_shift, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum,
                                reinterpret_cast<uint32_t *>(stage));
     else
-        scatter_body<uint64_t>(src, round == 0, 0, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum, stage);
+        scatter_body<uint64_t>(src, src_kind, 0, dshift, dst, n, tile, ntiles, off_col, tot_col, cnt, gdelta, wsum, stage);
 }
 
 // ---- threshold walk on a window-sorted column --------------------------------------------------
@@ -814,14 +829,16 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
                                                              double frac, const BinPlanCol *__restrict__ plan,
                                                              const uint64_t *__restrict__ buf_a,
                                                              const uint64_t *__restrict__ buf_b,
-                                                             double *__restrict__ thr, int32_t *__restrict__ nbins)
+                                                             uint64_t *__restrict__ thr, int32_t *__restrict__ nbins,
+                                                             ColFlags flags)
 {
+    // thresholds are stored as ORDER KEYS (value_key): one comparison rule for fp64 and int64 columns
     const int col = blockIdx.x;
     const BinPlanCol p = plan[col];
-    double *t = thr + (size_t)col * GRX_MAX_BINS;
+    uint64_t *t = thr + (size_t)col * GRX_MAX_BINS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (p.npass == 0) {                                       // every value equal: one bin
-        if (threadIdx.x == 0) { t[0] = cols[(size_t)col * ld]; nbins[col] = 1; }
+        if (threadIdx.x == 0) { t[0] = value_key(cols[(size_t)col * ld], col_is_i64(flags, col)); nbins[col] = 1; }
         return;
     }
     const uint64_t *buf = ((p.npass & 1) ? buf_a : buf_b) + (size_t)col * n;
@@ -839,7 +856,7 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
             const uint32_t k = s[pos];
             const int64_t end = run_end<uint32_t>(s, 0, (uint64_t)k, pos + 1, n);
             if (threadIdx.x == 0)
-                t[nb] = p.lo_shift == LO_SHIFT_INT ? (double)k : key_to_f64(((uint64_t)k << p.lo_shift) | p.const_bits);
+                t[nb] = p.lo_shift == LO_SHIFT_INT ? f64_to_key((double)k) : (((uint64_t)k << p.lo_shift) | p.const_bits);
             ++nb;
             done = end;
         }
@@ -936,7 +953,7 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
                     end = a + below + equal;
                 }
             }
-            if (threadIdx.x == 0) t[nb] = key_to_f64(tk);
+            if (threadIdx.x == 0) t[nb] = tk;
             ++nb;
             done = end;
         }
@@ -946,23 +963,24 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
 }
 
 __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restrict__ cols, int64_t ld,
-                                                         int64_t n, const double *__restrict__ thr,
+                                                         int64_t n, const uint64_t *__restrict__ thr,
                                                          const int32_t *__restrict__ nbins,
-                                                         uint8_t *__restrict__ bins, int64_t ld_bins)
+                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags)
 {
-    __shared__ double t[GRX_MAX_BINS];
+    __shared__ uint64_t t[GRX_MAX_BINS];
     const int col = blockIdx.y;
+    const bool i64 = col_is_i64(flags, col);
     int nb = nbins[col];
     if (nb < 0) nb = GRX_MAX_BINS;                    // more than GRX_MAX_BINS bins: labels saturate, the caller is told
     if (threadIdx.x < GRX_MAX_BINS)
-        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0.0;
+        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     uint8_t *o = bins + (size_t)col * ld_bins;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double v = x[i];
-        int lo = 0, hi = nb;                 // first threshold >= v
+        const uint64_t v = value_key(x[i], i64);
+        int lo = 0, hi = nb;                 // first threshold >= v (order keys compare like the values)
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (t[mid] < v) lo = mid + 1; else hi = mid;
@@ -1230,6 +1248,22 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
                          uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
                          size_t workspace_bytes, void *stream)
 {
+    return grx_vertical_log_bin_typed(n, ncols, d_cols, ld, nullptr, frac, d_bins, ld_bins, d_nbins, d_workspace,
+                                      workspace_bytes, stream);
+}
+
+int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64_t ld, const uint8_t *h_is_i64, double frac,
+                               uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    ColFlags flags;
+    for (int j = 0; j < 8; ++j) flags.w[j] = 0;
+    if (h_is_i64)
+        for (int c = 0; c < ncols; ++c)
+            if (h_is_i64[c]) {
+                GRX_REQUIRE(c < MAX_TYPED_COLS, "grx_vertical_log_bin_typed: int64 columns beyond the first %d of a call", MAX_TYPED_COLS);
+                flags.w[c >> 6] |= 1ull << (c & 63);
+            }
     GRX_REQUIRE(frac > 0.0 && frac < 1.0, "must specify frac in interval (0, 1)");
     GRX_REQUIRE(n >= 0 && ncols >= 0 && ld >= n && ld_bins >= n, "grx_vertical_log_bin: bad shape");
     GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_vertical_log_bin: n must be < 2^31");
@@ -1246,7 +1280,7 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
     uint64_t *buf_b = reinterpret_cast<uint64_t *>(ws + p.keys_bytes);
     uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 2 * p.keys_bytes);
     uint32_t *tot = hist + grx_align_up((size_t)ncols * RADIX * (size_t)p.ntiles * 4, 256) / 4;
-    double *thr = reinterpret_cast<double *>(ws + 2 * p.keys_bytes + p.hist_bytes);
+    uint64_t *thr = reinterpret_cast<uint64_t *>(ws + 2 * p.keys_bytes + p.hist_bytes);
     int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
     char *plan_ws = reinterpret_cast<char *>(nb_ws) + grx_align_up((size_t)ncols * 4, 256);
@@ -1256,7 +1290,7 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
     const int nbt = (int)grx_ceil_div(n, BITS_TILE);
     {
         GRX_PROF(GRX_K_KEY_BITS, st);
-        key_bits_kernel<<<dim3(nbt, ncols), 256, 0, st>>>(d_cols, ld, n, nbt, bits);
+        key_bits_kernel<<<dim3(nbt, ncols), 256, 0, st>>>(d_cols, ld, n, nbt, bits, flags);
         bin_plan_kernel<<<ncols, 64, 0, st>>>(bits, nbt, plan);
     }
     GRX_LAUNCH_CHECK();
@@ -1264,7 +1298,7 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
     for (int round = 0; round < 4; ++round) {
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            tile_count2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist);
+            tile_count2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
@@ -1272,18 +1306,18 @@ int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld,
         }
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            scatter2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist, tot);
+            scatter2_kernel<<<sgrid, SORT_THREADS, 0, st>>>(d_cols, ld, n, round, p.ntiles, plan, buf_a, buf_b, hist, tot, flags);
         }
         GRX_LAUNCH_CHECK();
     }
     { GRX_PROF(GRX_K_BIN_THRESHOLD, st);
-    bin_threshold2_kernel<<<ncols, 256, 0, st>>>(d_cols, ld, n, frac, plan, buf_a, buf_b, thr, nb_ws);
+    bin_threshold2_kernel<<<ncols, 256, 0, st>>>(d_cols, ld, n, frac, plan, buf_a, buf_b, thr, nb_ws, flags);
     }
     GRX_LAUNCH_CHECK();
     const int64_t want = grx_ceil_div(n, 256 * 4);
     const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
     { GRX_PROF(GRX_K_BIN_ASSIGN, st);
-    bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins);
+    bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags);
     }
     GRX_LAUNCH_CHECK();
     if (d_nbins)

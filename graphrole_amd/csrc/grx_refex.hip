@@ -20,8 +20,8 @@
 
 namespace {
 
-const char *const AGG_NAMES[] = {"sum", "mean", "min", "max", "var", "std"};
-constexpr int N_AGG_KINDS = 6;
+const char *const AGG_NAMES[] = {"sum", "mean", "min", "max", "var", "std", "prod", "median", "count", "size"};
+constexpr int N_AGG_KINDS = 10;
 
 struct Column {
     std::string name;
@@ -147,7 +147,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 "grx_refex_run: bad graph / generation-0 arguments");
     GRX_REQUIRE(n_aggs >= 1 && h_aggs && h_columns && n_columns && h_gens && generation_count && max_columns >= f0 &&
                 max_gens >= 1, "grx_refex_run: bad output arguments");
-    bool has[N_AGG_KINDS] = {false, false, false, false, false, false};
+    bool has[N_AGG_KINDS] = {};
     for (int a = 0; a < n_aggs; ++a) {
         GRX_REQUIRE(h_aggs[a] >= 0 && h_aggs[a] < N_AGG_KINDS, "grx_refex_run: unknown aggregation id %d", h_aggs[a]);
         has[h_aggs[a]] = true;
@@ -161,6 +161,14 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         GRX_REQUIRE(h_bounds[0] == 0 && h_bounds[P] == n, "grx_refex_run: h_bounds must run from 0 to n");
     const int64_t rb = comm ? h_bounds[me] : 0, re = comm ? h_bounds[me + 1] : n;
     Arena arena{reinterpret_cast<char *>(d_arena), d_arena ? arena_bytes : 0};
+    int64_t nnz_rows = 0;                                    // adjacency entries of this rank's rows (median workspace)
+    if (has[GRX_AGG_MEDIAN]) {
+        int64_t ends[2] = {0, 0};
+        GRX_CHECK_HIP(hipMemcpyAsync(&ends[0], d_row_ptr + rb, 8, hipMemcpyDeviceToHost, st));
+        GRX_CHECK_HIP(hipMemcpyAsync(&ends[1], d_row_ptr + re, 8, hipMemcpyDeviceToHost, st));
+        GRX_CHECK_HIP(hipStreamSynchronize(st));
+        nnz_rows = ends[1] - ends[0];
+    }
     std::vector<Column> cols;
     std::vector<int> work;                                   // working set, insertion order (extract.py:128-133)
     std::vector<std::vector<int>> recorded;                  // generation -> recorded columns (_final_features)
@@ -298,12 +306,16 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             const bool need_var = has[GRX_AGG_VAR] || has[GRX_AGG_STD];
             // integer gather source (16- / 32-byte rows) when every parent is an exact int32 column and only sums /
             // means are wanted: any summation order gives the reference's bits there (grx.h, grx_aggregate_i32)
-            bool int_rows = !need_var && !has[GRX_AGG_MIN] && !has[GRX_AGG_MAX] && grx_aggregate_i32_ok(plan, f);
+            bool only_sum_mean = true;
+            for (int a = 0; a < n_aggs; ++a) only_sum_mean = only_sum_mean && (h_aggs[a] == GRX_AGG_SUM || h_aggs[a] == GRX_AGG_MEAN);
+            bool int_rows = only_sum_mean && grx_aggregate_i32_ok(plan, f);
             for (int j = 0; j < f && int_rows; ++j) int_rows = cols[prev[j]].int32_exact;
             const int ldi = int_rows ? grx_aggregate_ldi(f) : 0;
             double *rows = reinterpret_cast<double *>(arena.take(int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
             double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
                                                                     : nullptr;
+            const size_t med_bytes = has[GRX_AGG_MEDIAN] ? grx_aggregate_median_workspace_bytes(nnz_rows) : 0;
+            void *med_ws = has[GRX_AGG_MEDIAN] ? arena.take(med_bytes) : nullptr;
             if (!arena.overflow) {
                 auto out_of = [&](int agg) -> double * {
                     for (int a = 0; a < n_aggs; ++a)
@@ -329,6 +341,17 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 if (has[GRX_AGG_MIN] || has[GRX_AGG_MAX])
                     GRX_TRY(grx_aggregate_minmax(plan, d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_MIN),
                                                  out_of(GRX_AGG_MAX), n, stream));
+                // the aggregations beyond the tuned six (csrc/grx_aggx.hip, fp64 columns; integer columns with 'prod' need
+                // int64 arithmetic and are driven per kernel by the host, features/extract.py)
+                if (has[GRX_AGG_PROD])
+                    GRX_TRY(grx_aggregate_prod(d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_PROD), n, stream));
+                if (has[GRX_AGG_MEDIAN])
+                    GRX_TRY(grx_aggregate_median(d_row_ptr, d_agg_col, f, rows, ldr, rb, re, out_of(GRX_AGG_MEDIAN), n, med_ws,
+                                                 med_bytes, stream));
+                if (has[GRX_AGG_COUNT])
+                    GRX_TRY(grx_aggregate_count(d_row_ptr, f, rb, re, 0, out_of(GRX_AGG_COUNT), n, stream));
+                if (has[GRX_AGG_SIZE])
+                    GRX_TRY(grx_aggregate_count(d_row_ptr, f, rb, re, 0, out_of(GRX_AGG_SIZE), n, stream));
             }
             arena.top = mark;                                 // the gather source is scratch
         }

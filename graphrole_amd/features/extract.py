@@ -23,8 +23,10 @@ from graphrole_amd.features.prune import FeaturePruner
 from graphrole_amd.graph import interface
 from graphrole_amd.types import DataFrameDict, DataFrameLike
 
-_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std', 'prod')
-_EXACT_INT_LIMIT = 2.0 ** 53          # fp64 holds every integer below it
+_SUPPORTED_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std', 'prod', 'median', 'count', 'size')
+_FAST_AGGS = ('sum', 'mean', 'min', 'max', 'var', 'std')             # the tuned pairwise-order kernels
+_FLOAT_AGGS = ('mean', 'std', 'var', 'median')                       # their result makes the whole agg frame float64
+_INT_SAFE_ON_EMPTY = ('sum', 'prod', 'count', 'size')                # integers even for a node without neighbours
 
 
 def _agg_name(agg) -> str:
@@ -59,8 +61,10 @@ class RecursiveFeatureExtractor:
         :param G: graph object from a supported graph package (networkx, graphrole_amd.CSRGraph)
         :param max_generations: maximum levels of recursion
         :param aggs: optional list of aggregations for each recursive generation
-          ('sum', 'mean', 'min', 'max', 'std', 'var', 'prod' in any spelling pandas accepts; others raise
-          NotImplementedError)
+          ('sum', 'mean', 'min', 'max', 'std', 'var', 'prod', 'median', 'count', 'size' in any spelling pandas
+          accepts; arbitrary callables and the remaining pandas names raise NotImplementedError: there is no CPU
+          fallback).  With 'prod' the integer columns of an unweighted graph follow the reference's wrapping int64
+          arithmetic (csrc/grx_aggx.hip)
         :kwargs: attributes / attributes_include / attributes_exclude for the graph interface;
           distributed=True|ProcessGroup shards node ranges over the ranks of torch.distributed;
           native_loop=False drives the generations from Python even on one GPU (tests)
@@ -93,6 +97,7 @@ class RecursiveFeatureExtractor:
         self._final_names: Dict[int, List[str]] = {}               # generation -> recorded names
         self._final_cols: Dict[str, object] = {}                   # recorded name -> fp64 column
         self._int32_exact: set = set()                             # generation-0 names that may travel as int32 rows
+        self._i64: set = set()        # columns stored as int64 BITS (integer columns of a run with 'prod': they wrap)
         self._plan = None
         self._plan_ready = False
         self._arena = None            # device memory of grx_refex_run, reused by later runs of this instance
@@ -157,7 +162,15 @@ class RecursiveFeatureExtractor:
         names, cols, dtypes = self.graph.neighborhood_feature_columns()
         K = self._K()
         native = hasattr(K, 'refex_run') and (self._plan is None or getattr(K, 'NATIVE_SHARDING', False))
-        if native and self._native_loop and 'prod' not in aggs and len(set(aggs)) == len(aggs):
+        # 'prod' over INTEGER columns follows the reference's wrapping int64 arithmetic: those columns are carried as
+        # int64 bits from generation 0 on, and the generations are driven from here (the per-kernel driver)
+        wrapping = 'prod' in aggs and any(np.dtype(dt).kind in 'iu' for dt in dtypes)
+        if wrapping:
+            if not hasattr(K, 'convert_f64_to_i64'):
+                raise NotImplementedError("'prod' over integer features needs the int64 kernels of libgrx.so")
+            cols = [K.convert_f64_to_i64(c) if np.dtype(dt).kind in 'iu' else c for c, dt in zip(cols, dtypes)]
+            self._i64 = {nm for nm, dt in zip(names, dtypes) if np.dtype(dt).kind in 'iu'}
+        if native and self._native_loop and not wrapping and len(set(aggs)) == len(aggs):
             # the whole generation loop runs below the ABI (grx_refex_run); with a ShardPlan it aggregates this rank's
             # rows and issues the exchanges itself
             self._run_native(names, cols, dtypes, aggs)
@@ -226,10 +239,10 @@ class RecursiveFeatureExtractor:
     @staticmethod
     def _candidate_dtype(parent_dtype, aggs, no_empty_rows: bool):
         """pandas dtype of a candidate column in the reference's frame (extract.py:104-119): the per-node
-        agg frame of an integer column stays integer unless 'mean' / 'std' / 'var' is among the aggs or a
-        node without neighbours turns min / max into NaN -> 0.0 (sum and prod of nothing are the integers 0
-        and 1); one float value makes the column float64."""
-        keeps_int = not ({'mean', 'std', 'var'} & set(aggs)) and (no_empty_rows or set(aggs) <= {'sum', 'prod'})
+        agg frame of an integer column stays integer unless 'mean' / 'std' / 'var' / 'median' is among the aggs or
+        a node without neighbours turns min / max into NaN -> 0.0 (sum, prod, count and size of nothing are the
+        integers 0, 1, 0, 0); one float value makes the column float64."""
+        keeps_int = not (set(_FLOAT_AGGS) & set(aggs)) and (no_empty_rows or set(aggs) <= set(_INT_SAFE_ON_EMPTY))
         f64 = np.dtype('float64')
         return np.dtype('int64') if keeps_int and np.dtype(parent_dtype).kind in 'iu' else f64
 
@@ -241,6 +254,7 @@ class RecursiveFeatureExtractor:
         self._work_bins.clear()
         self._final_names = {}
         self._final_cols = {}
+        self._i64 = set()
         self.stats = []
 
     def final_columns(self) -> List[str]:
@@ -269,12 +283,35 @@ class RecursiveFeatureExtractor:
             return [], [], [], None
         _, dev_graph, _ = self.graph._device_graph()
         rb, re = (0, n) if plan is None else (plan.row_begin, plan.row_end)
+        host = self.graph._device_graph()[0]
+        no_empty_rows = self._no_empty_rows(host)
+        f64 = np.dtype('float64')
+        names = [f'{c}({a})' for a in aggs for c in prev]
+        dtypes = [self._candidate_dtype(self._dtypes.get(c, f64), aggs, no_empty_rows) for a in aggs for c in prev]
+        if set(aggs) <= set(_FAST_AGGS) and not (self._i64 & set(prev)):
+            sub = self._aggregate_fast(K, dev_graph, prev, aggs, n, rb, re)
+        else:
+            sub = self._aggregate_general(K, dev_graph, prev, aggs, names, dtypes, n, rb, re)
+        # sharded: only this rank's rows of the candidate block are valid from here on; the
+        # exchanges happen in _update_columns (owners bin whole columns, only retained ones are
+        # gathered everywhere) -- or right here when a caller wants complete columns
+        if plan is not None and complete:
+            plan.all_gather_block(sub)
+        self._partial_block = sub if (plan is not None and not complete) else None
+        cols = [sub[j] for j in range(len(names))]
+        return names, cols, dtypes, sub
+
+    def _aggregate_fast(self, K, dev_graph, prev, aggs, n, rb, re):
+        """sum / mean / min / max / var / std of fp64 columns: the tuned kernels (numpy's pairwise order); the
+        [len(aggs) * f, n] candidate block in aggregation-major order."""
+        f = len(prev)
         pieces = {}
         need_var = 'var' in aggs or 'std' in aggs
         # generation 1 of an unweighted graph: every parent an exact int32 column and only sums / means wanted -> the
         # integer gather source (the same choice grx_refex_run makes)
         int_rows = (set(aggs) <= {'sum', 'mean'} and hasattr(K, 'aggregate_i32') and
                     all(c in self._int32_exact for c in prev) and K.aggregate_i32_ok(dev_graph, f))
+        block = None
         if int_rows:
             irows, ldi = K.pack_rows_i32([self._work[c] for c in prev], n)
             block = K.aggregate_i32(dev_graph, irows, f, ldi, rb, re, want_sum='sum' in aggs, want_mean='mean' in aggs)
@@ -295,41 +332,72 @@ class RecursiveFeatureExtractor:
             mm = K.aggregate_minmax(dev_graph, rows, f, ldr, rb, re,
                                     want_min='min' in aggs, want_max='max' in aggs)
             pieces['min'], pieces['max'] = mm[:f], mm[f:]
-        if 'prod' in aggs:
-            pieces['prod'] = K.aggregate_prod(dev_graph, rows, f, ldr, rb, re)
-            # the reference multiplies integer columns in int64 (and wraps silently past 2^63); the
-            # columns here are fp64, exact below 2^53: refuse anything beyond instead of drifting
-            int_parents = [j for j, c in enumerate(prev) if self._dtypes.get(c, np.dtype('float64')).kind in 'iu']
-            if int_parents:
-                # every rank takes part in the all-reduce, also one that owns no rows
-                peak = (pieces['prod'][int_parents][:, rb:re].abs().max().reshape(1) if re > rb
-                        else pieces['prod'].new_zeros(1))
-                if plan is not None:
-                    plan.all_reduce_max_(peak)
-                if float(K.to_host(peak)[0]) >= _EXACT_INT_LIMIT:
-                    raise OverflowError(
-                        "'prod' of an integer feature exceeds 2**53 in generation "
-                        f'{self.generation_count}: not representable in the fp64 feature columns (the reference '
-                        'would continue in wrapping int64 arithmetic); lower max_generations or drop prod')
         # candidate order: every column under the first aggregation, then the second, ... (:158-162)
         if list(aggs) == ['sum', 'mean']:
-            sub = block
-        else:
-            sub = self._as_block([pieces[a][j] for a in aggs for j in range(f)], n)
-        picked = range(len(aggs) * f)
-        # sharded: only this rank's rows of the candidate block are valid from here on; the
-        # exchanges happen in _update_columns (owners bin whole columns, only retained ones are
-        # gathered everywhere) -- or right here when a caller wants complete columns
-        if plan is not None and complete:
-            plan.all_gather_block(sub)
-        self._partial_block = sub if (plan is not None and not complete) else None
-        cols = [sub[j] for j in range(len(picked))]
-        names = [f'{c}({a})' for a in aggs for c in prev]
-        host = self.graph._device_graph()[0]
-        no_empty_rows = self._no_empty_rows(host)
-        f64 = np.dtype('float64')
-        dtypes = [self._candidate_dtype(self._dtypes.get(c, f64), aggs, no_empty_rows) for a in aggs for c in prev]
-        return names, cols, dtypes, sub
+            return block
+        return self._as_block([pieces[a][j] for a in aggs for j in range(f)], n)
+
+    def _aggregate_general(self, K, dev_graph, prev, aggs, names, dtypes, n, rb, re):
+        """Any supported aggregation list, including 'prod', 'median', 'count' / 'size' and parents that are carried as
+        int64 bits (the reference's integer columns in a run with 'prod': numpy multiplies and adds them in wrapping
+        int64 arithmetic, extract.py:111).  Per parent column:
+          * integer aggregations (sum, prod, min, max) of an int64 parent: wrapping integer kernels (grx_aggregate_i64);
+          * everything else on the fp64 VALUES of the parent (an int64 parent converted like astype(float64), which is
+            what pandas does before mean / var / median): the pairwise-order kernels, grx_aggregate_prod,
+            grx_aggregate_median, grx_aggregate_count.
+        A candidate whose reference dtype is int64 stays in int64 bits, any other is fp64 (an integer result cast)."""
+        f = len(prev)
+        cols = [self._work[c] for c in prev]
+        is_i64 = [c in self._i64 for c in prev]
+        fp_cols = [K.convert_i64_to_f64(col) if i64 else col for col, i64 in zip(cols, is_i64)]
+        rows, ldr = K.pack_rows(fp_cols, n)
+        pieces = {}
+        need_var = 'var' in aggs or 'std' in aggs
+        if 'sum' in aggs or 'mean' in aggs or need_var:
+            block = K.aggregate(dev_graph, rows, f, ldr, rb, re, want_sum=True, want_mean=True)
+            pieces['sum'], pieces['mean'] = block[:f], block[f:]
+        if need_var:
+            vs = K.aggregate_var(dev_graph, rows, f, ldr, pieces['mean'], rb, re, want_var=True, want_std=True)
+            pieces['var'], pieces['std'] = vs[:f], vs[f:]
+        if 'min' in aggs or 'max' in aggs:
+            mm = K.aggregate_minmax(dev_graph, rows, f, ldr, rb, re, want_min=True, want_max=True)
+            pieces['min'], pieces['max'] = mm[:f], mm[f:]
+        if 'prod' in aggs:
+            pieces['prod'] = K.aggregate_prod(dev_graph, rows, f, ldr, rb, re)
+        if 'median' in aggs:
+            pieces['median'] = K.aggregate_median(dev_graph, rows, f, ldr, rb, re)
+        if 'count' in aggs or 'size' in aggs:
+            pieces['count'] = pieces['size'] = K.aggregate_count(dev_graph, f, rb, re, as_i64=False)
+        ints = {}
+        if any(is_i64):
+            # the integer parents once more, as integers: their sums and products wrap modulo 2^64 like numpy's
+            idx = [j for j in range(f) if is_i64[j]]
+            irows, ildr = K.pack_rows([cols[j] for j in idx], n)
+            want = [a for a in ('sum', 'prod', 'min', 'max') if a in aggs]
+            if want:
+                got = K.aggregate_i64(dev_graph, irows, len(idx), ildr, rb, re, want=want)
+                for a in want:
+                    ints[a] = {j: got[a][k] for k, j in enumerate(idx)}
+            if 'count' in aggs or 'size' in aggs:
+                cnt = K.aggregate_count(dev_graph, 1, rb, re, as_i64=True)[0]
+                ints['count'] = ints['size'] = {j: cnt for j in idx}
+        picked, flags = [], []
+        for k, a in enumerate(aggs):
+            for j in range(f):
+                keep_int = np.dtype(dtypes[k * f + j]).kind in 'iu' and is_i64[j]
+                if is_i64[j] and a in ints:
+                    col = ints[a][j]                              # int64 bits
+                    if not keep_int:
+                        col = K.convert_i64_to_f64(col)          # the agg frame became float64: cast like pandas
+                else:
+                    col = pieces[a][j]
+                    assert not keep_int, (a, prev[j])
+                picked.append(col)
+                flags.append(keep_int)
+        for nm, flag in zip(names, flags):
+            if flag:
+                self._i64.add(nm)
+        return self._as_block(picked, n)
 
     def _update_columns(self, names: Sequence[str], cols: Sequence, dtypes: Sequence[np.dtype],
                         block=None) -> None:
@@ -349,21 +417,25 @@ class RecursiveFeatureExtractor:
         if fresh:
             if block is None or fresh != names:
                 block = self._as_block([self._work[nm] for nm in fresh], n)
+            typed = [nm in self._i64 for nm in fresh] if self._i64 else None
+            kw = {'is_i64': typed} if typed and any(typed) else {}
             if plan is None:
-                bins, _ = K.vertical_log_bin(block)
+                bins, _ = K.vertical_log_bin(block, **kw)
             elif partial:
                 # candidate block with only this rank's rows: whole columns to their owners, the
                 # owners' bins of this rank's rows back (parallel.py, steps 1 and 2)
                 owned = plan.columns_to_owners(block)
                 owned_bins = K.zeros((owned.shape[0], max(n, 1)), dtype=self._uint8())[:, :n]
                 if owned.shape[0]:
-                    K.vertical_log_bin(owned, out=owned_bins)
+                    own_kw = {'is_i64': typed[plan.rank::plan.world]} if kw else {}
+                    K.vertical_log_bin(owned, out=owned_bins, **own_kw)
                 bins = plan.owned_to_rows(owned_bins, len(fresh))
             else:
                 bins = K.zeros((len(fresh), max(n, 1)), dtype=self._uint8())[:, :n]
                 mine = slice(plan.rank, len(fresh), plan.world)
                 if len(range(len(fresh))[mine]):
-                    K.vertical_log_bin(block[mine], out=bins[mine])
+                    own_kw = {'is_i64': typed[mine]} if kw else {}
+                    K.vertical_log_bin(block[mine], out=bins[mine], **own_kw)
                 plan.all_reduce_max_(bins)
             for j, nm in enumerate(fresh):
                 self._work_bins[nm] = bins[j]
@@ -433,11 +505,16 @@ class RecursiveFeatureExtractor:
             b = a + 1
             while b < len(names) and kinds[b] == kinds[a]:
                 b += 1
-            values = block[a:b] if kinds[a] == np.dtype('float64') else block[a:b].astype(kinds[a])
+            if kinds[a] == np.dtype('float64'):
+                values = block[a:b]
+            else:
+                # integer columns: fp64 values of exact integers -> astype; int64 BITS (runs with 'prod') -> a view
+                values = np.stack([block[j].view(np.int64) if names[j] in self._i64 else block[j].astype(kinds[a])
+                                   for j in range(a, b)])
             parts.append(pd.DataFrame(values.T, index=labels, columns=names[a:b], copy=False))
             a = b
         frame = parts[0] if len(parts) == 1 else pd.concat(parts, axis=1, copy=False)
-        if handoff and hasattr(K, 'host_checksums'):
+        if handoff and hasattr(K, 'host_checksums') and not (self._i64 & set(names)):
             from graphrole_amd.features import handoff as _handoff
             _handoff.register(K, frame, dev_block)
         return frame

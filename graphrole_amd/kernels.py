@@ -531,6 +531,59 @@ def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_b
     return out
 
 
+# ---- integer (int64-bits) columns, median, count: csrc/grx_aggx.hip -------------------------------------------------
+def convert_i64_to_f64(col: torch.Tensor) -> torch.Tensor:
+    """A column of int64 BITS (stored in an fp64 tensor) -> the fp64 values (numpy astype(float64))."""
+    out = torch.empty_like(col)
+    _lib.call('grx_convert_i64_to_f64', col.numel(), _ptr(col), _ptr(out), _stream())
+    return out
+
+
+def convert_f64_to_i64(col: torch.Tensor) -> torch.Tensor:
+    """fp64 values (exact integers) -> int64 bits in an fp64 tensor."""
+    out = torch.empty_like(col)
+    _lib.call('grx_convert_f64_to_i64', col.numel(), _ptr(col), _ptr(out), _stream())
+    return out
+
+
+def aggregate_i64(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0, row_end: Optional[int] = None,
+                  want: Sequence[str] = ('sum', 'prod', 'min', 'max')) -> dict:
+    """Wrapping int64 sum / prod and min / max over the neighbours; `rows` = pack_rows() of int64-bits columns.
+    Returns {agg: [f, n] tensor of int64 bits}."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    outs = {a: torch.empty((f, n), dtype=torch.float64, device=device()) for a in want}
+    if f:
+        _lib.call('grx_aggregate_i64', _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr, row_begin, row_end,
+                  _ptr(outs.get('sum')), _ptr(outs.get('prod')), _ptr(outs.get('min')), _ptr(outs.get('max')), n, _stream())
+    return outs
+
+
+def aggregate_count(csr: DeviceCSR, f: int, row_begin: int = 0, row_end: Optional[int] = None,
+                    as_i64: bool = False) -> torch.Tensor:
+    """[f, n] block: the number of neighbours of every row, as fp64 values or int64 bits (aggs 'count' / 'size')."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.empty((f, n), dtype=torch.float64, device=device())
+    if f:
+        _lib.call('grx_aggregate_count', _ptr(csr.row_ptr), f, row_begin, row_end, int(as_i64), _ptr(out), n, _stream())
+    return out
+
+
+def aggregate_median(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_begin: int = 0,
+                     row_end: Optional[int] = None) -> torch.Tensor:
+    """[f, n] block: numpy's median of the neighbours' values (agg 'median'); 0 for rows without neighbours."""
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    out = torch.empty((f, n), dtype=torch.float64, device=device())
+    if f and row_end > row_begin:
+        ws_bytes = _lib.load().grx_aggregate_median_workspace_bytes(csr.nnz)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+        _lib.call('grx_aggregate_median', _ptr(csr.row_ptr), _ptr(csr.agg_col), f, _ptr(rows), ldr, row_begin, row_end,
+                  _ptr(out), n, _ptr(ws), ws_bytes, _stream())
+    return out
+
+
 def sort_columns(block: torch.Tensor) -> torch.Tensor:
     """Ascending sort of every row of a [ncols, n] fp64 block (each row is one feature column)."""
     ncols, n = block.shape
@@ -544,10 +597,11 @@ def sort_columns(block: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vertical_log_bin(block: torch.Tensor, frac: float = 0.5,
-                     out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+def vertical_log_bin(block: torch.Tensor, frac: float = 0.5, out: Optional[torch.Tensor] = None,
+                     is_i64: Optional[Sequence[bool]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Bin every row of a [ncols, n] fp64 block -> (uint8 [ncols, n], int32 [ncols] bin counts).
-    `block` (and `out`) may be row-strided views (e.g. every P-th column of a candidate block)."""
+    `block` (and `out`) may be row-strided views (e.g. every P-th column of a candidate block).
+    is_i64[j]: row j holds int64 bits and is ordered as integers (grx_vertical_log_bin_typed)."""
     ncols, n = block.shape
     assert n <= 1 or block.stride(1) == 1
     bins = out if out is not None else zeros((ncols, max(n, 1)), dtype=torch.uint8)[:, :n]
@@ -555,8 +609,11 @@ def vertical_log_bin(block: torch.Tensor, frac: float = 0.5,
     lib = _lib.load()
     ws_bytes = lib.grx_log_bin_workspace_bytes(n, ncols)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
-    _lib.call('grx_vertical_log_bin', n, ncols, _ptr(block), block.stride(0) if ncols else n, float(frac),
-              _ptr(bins), bins.stride(0) if ncols else max(n, 1), _ptr(nbins), _ptr(ws), ws_bytes, _stream())
+    flags = None
+    if is_i64 is not None and any(is_i64):
+        flags = np.ascontiguousarray(np.asarray(list(is_i64), dtype=np.uint8))
+    _lib.call('grx_vertical_log_bin_typed', n, ncols, _ptr(block), block.stride(0) if ncols else n, _hptr(flags),
+              float(frac), _ptr(bins), bins.stride(0) if ncols else max(n, 1), _ptr(nbins), _ptr(ws), ws_bytes, _stream())
     return bins, nbins[:ncols]
 
 

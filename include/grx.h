@@ -317,6 +317,27 @@ int grx_pack_rows_i32(int64_t n, int f, const double *const *h_col_ptrs, int32_t
 int grx_aggregate_i32(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int f,
                       const int32_t *d_rows, int ldi, int64_t row_begin, int64_t row_end, double *d_sum, double *d_mean,
                       int64_t ld, void *stream);
+/*
+ * INTEGER feature columns with the reference's int64 semantics, 'median', 'count' / 'size' (csrc/grx_aggx.hip;
+ * extract.py:26,47,111 passes any pandas-aggregatable to DataFrame.agg).
+ *   grx_convert_*          switch a column between fp64 values and int64 bits (numpy astype semantics)
+ *   grx_aggregate_i64      d_rows: n x ldr row-major int64 (grx_pack_rows moves bits); wrapping sum / product, min, max
+ *                          over the neighbours -> int64 columns (any output may be NULL); min / max of no neighbours: 0
+ *   grx_aggregate_count    number of neighbours into f columns, as fp64 values or int64 bits
+ *   grx_aggregate_median   numpy's median of the neighbours' values (middle element, or (a + b) / 2 of the two middle
+ *                          ones; 0 for no neighbours); workspace grx_aggregate_median_workspace_bytes(nnz of the rows)
+ */
+int grx_convert_i64_to_f64(int64_t n, const int64_t *d_in, double *d_out, void *stream);
+int grx_convert_f64_to_i64(int64_t n, const double *d_in, int64_t *d_out, void *stream);
+int grx_aggregate_i64(const int64_t *d_row_ptr, const int32_t *d_col, int f, const int64_t *d_rows, int ldr,
+                      int64_t row_begin, int64_t row_end, int64_t *d_sum, int64_t *d_prod, int64_t *d_min, int64_t *d_max,
+                      int64_t ld, void *stream);
+int grx_aggregate_count(const int64_t *d_row_ptr, int f, int64_t row_begin, int64_t row_end, int as_i64, double *d_out,
+                        int64_t ld, void *stream);
+size_t grx_aggregate_median_workspace_bytes(int64_t nnz);
+int grx_aggregate_median(const int64_t *d_row_ptr, const int32_t *d_col, int f, const double *d_rows, int ldr,
+                         int64_t row_begin, int64_t row_end, double *d_median, int64_t ld, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
 /* agg 'prod' (extract.py:36-47 with Series.prod): left-to-right product over the neighbours in the order
  * of d_col, 1 for a row without neighbours.  fp64 arithmetic: exact for integer columns below 2^53 (the
  * reference multiplies int64 columns in int64 and wraps silently beyond 2^63; the caller checks). */
@@ -360,7 +381,8 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * new candidate); h_dist F x F; h_drop[j] = 1 for every member of a feature group but its oldest. */
 int grx_host_prune(int F, const char *const *h_names, const int *h_recorded_generation, int n_generations,
                    const int32_t *h_dist, int thresh, int *h_drop);
-typedef enum { GRX_AGG_SUM = 0, GRX_AGG_MEAN = 1, GRX_AGG_MIN = 2, GRX_AGG_MAX = 3, GRX_AGG_VAR = 4, GRX_AGG_STD = 5 } grx_agg;
+typedef enum { GRX_AGG_SUM = 0, GRX_AGG_MEAN = 1, GRX_AGG_MIN = 2, GRX_AGG_MAX = 3, GRX_AGG_VAR = 4, GRX_AGG_STD = 5,
+               GRX_AGG_PROD = 6, GRX_AGG_MEDIAN = 7, GRX_AGG_COUNT = 8, GRX_AGG_SIZE = 9 } grx_agg;
 typedef struct {
     int generation;            /* generation that recorded the column */
     int parent;                /* index of the parent column in this table, -1 for generation 0 */
@@ -389,6 +411,13 @@ size_t grx_log_bin_workspace_bytes(int64_t n, int ncols);
 int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, double frac,
                          uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins,
                          void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The same with a per-column representation flag (host array, may be NULL): h_is_i64[j] != 0 -- column j holds int64
+ * BITS (the reference's integer columns under aggs with 'prod', see grx_aggregate_i64) and is ordered as integers:
+ * np.unique on an int64 array, prune.py:27.  At most the first 512 columns of a call may be flagged. */
+int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64_t ld, const uint8_t *h_is_i64, double frac,
+                               uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* Batched ascending sort of fp64 columns (the first stage of the binning; exposed for tests).
  * Workspace: grx_sort_workspace_bytes(n, ncols). */

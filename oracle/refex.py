@@ -574,3 +574,110 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         columns.extend(final_names[gen])
     values = np.column_stack([final_vals[c] for c in columns]) if columns else np.zeros((g.n, 0))
     return RefexResult(g.labels, columns, values, generation_count, trace, g.w is None)
+
+
+# --------------------------------------------------------------------------------------
+# any aggregation list, with the reference's dtypes (test infrastructure like the rest of this file)
+# --------------------------------------------------------------------------------------
+FLOAT_AGGS = ('mean', 'std', 'var', 'median')
+INT_SAFE_ON_EMPTY = ('sum', 'prod', 'count', 'size')
+
+
+def _agg_one(vals: np.ndarray, agg: str):
+    """One pandas aggregation of one node's neighbour values (features/extract.py:108-113 ->
+    DataFrame.agg -> Series.<agg>), restated with the numpy calls pandas' nanops make (pandas 2.x without
+    bottleneck): integer columns add and multiply in wrapping int64; mean / var / std / median work on the fp64
+    conversion; NaN where pandas gives NaN (no neighbours)."""
+    n = len(vals)
+    is_int = vals.dtype.kind in 'iu'
+    if agg == 'sum':
+        return vals.sum() if n else (0 if is_int else 0.0)
+    if agg == 'prod':
+        return np.multiply.reduce(vals) if n else (1 if is_int else 1.0)
+    if agg in ('count', 'size'):
+        return n
+    if n == 0:
+        return np.nan
+    if agg == 'min':
+        return vals.min()
+    if agg == 'max':
+        return vals.max()
+    x = np.ascontiguousarray(vals, dtype=np.float64)
+    if agg == 'mean':
+        return x.sum() / n
+    if agg == 'median':
+        return float(np.median(x))
+    if agg in ('var', 'std'):
+        if n < 2:
+            return np.nan
+        avg = x.sum() / n
+        var = np.ascontiguousarray((avg - x) ** 2).sum() / (n - 1)
+        return var if agg == 'var' else float(np.sqrt(var))
+    raise ValueError(agg)
+
+
+@dataclass
+class TypedResult:
+    columns: List[str]
+    arrays: Dict[str, np.ndarray]      # final columns, int64 or float64 like the reference's frame
+    generation_count: int
+    retained: Dict[int, List[str]]
+
+
+def extract_features_typed(g: OracleGraph, names0: Sequence[str], cols0: Sequence[np.ndarray],
+                           max_generations: int = 10, aggs: Sequence[str] = ('sum', 'mean')) -> TypedResult:
+    """
+    features/extract.py:65-142 for ANY list of pandas aggregation names, keeping the dtypes the reference's frames
+    have: cols0 are the generation-0 columns with their reference dtypes (int64 for the degree / ego-net columns of an
+    unweighted graph).  A candidate column is int64 iff its parent is and every entry of every node's agg frame for
+    it is an integer (no mean / std / var / median among the aggs, and no node without neighbours unless all aggs are
+    integer-valued on nothing); integer sums and products WRAP modulo 2^64 (numpy int64).  Pure-Python loop over the
+    nodes: small cases only.
+    """
+    n = g.n
+    deg = np.diff(g.row_ptr)
+    no_empty = bool(n == 0 or deg.min() > 0)
+    work: Dict[str, np.ndarray] = {}
+    final_names: Dict[int, List[str]] = {}
+    final_vals: Dict[str, np.ndarray] = {}
+
+    def update(gen, cand_names, cand_cols, thresh):
+        for nm, col in zip(cand_names, cand_cols):
+            work[nm] = col
+        cols = list(work)
+        B = np.column_stack([vertical_log_binning(work[c]) for c in cols]) if cols else np.zeros((n, 0))
+        D = chebyshev_matrix(B)
+        drop = prune_features(cols, D, thresh, final_names)
+        for nm in drop:
+            del work[nm]
+        kept = [c for c in cand_names if c not in drop]
+        final_names[gen] = sorted(kept) if drop else kept
+        for nm in final_names[gen]:
+            final_vals[nm] = work[nm].copy()
+
+    update(0, list(names0), [np.asarray(c) for c in cols0], 0)
+    generation_count = 0
+    for gen in range(1, max_generations):
+        generation_count = gen
+        prev = final_names[gen - 1]
+        cand_names = [f'{c}({a})' for a in aggs for c in prev]
+        cand_cols = []
+        for a in aggs:
+            for c in prev:
+                parent = work[c]
+                keeps_int = (parent.dtype.kind in 'iu' and not (set(FLOAT_AGGS) & set(aggs))
+                             and (no_empty or set(aggs) <= set(INT_SAFE_ON_EMPTY)))
+                out = np.empty(n, dtype=np.int64 if keeps_int else np.float64)
+                for v in range(n):
+                    val = _agg_one(parent[g.adj_row(v)], a)
+                    if isinstance(val, float) and val != val:
+                        val = 0                                   # fillna(0), extract.py:113
+                    out[v] = val                                  # an int64 result in a float frame: cast like pandas
+                cand_cols.append(out)
+        update(gen, cand_names, cand_cols, gen)
+        if not final_names[gen]:
+            break
+    columns: List[str] = []
+    for gen in sorted(final_names, reverse=True):
+        columns.extend(final_names[gen])
+    return TypedResult(columns, {c: final_vals[c] for c in columns}, generation_count, final_names)

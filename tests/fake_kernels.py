@@ -133,18 +133,74 @@ def aggregate_minmax(csr, rows, f, ldr, row_begin=0, row_end=None, want_min=True
     return res
 
 
+# ---- int64-bits columns, median, count (csrc/grx_aggx.hip) on numpy -------------------------------------------------
+def convert_i64_to_f64(col):
+    return torch.from_numpy(col.numpy().view(np.int64).astype(np.float64))
+
+
+def convert_f64_to_i64(col):
+    return torch.from_numpy(col.numpy().astype(np.int64).view(np.float64).copy())
+
+
+def _rows_of(csr, row_begin, row_end):
+    return [(v, csr.agg_col[csr.row_ptr[v]:csr.row_ptr[v + 1]]) for v in range(row_begin, row_end)]
+
+
+def aggregate_i64(csr, rows, f, ldr, row_begin=0, row_end=None, want=('sum', 'prod', 'min', 'max')):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    X = rows.numpy()[:n, :f].view(np.int64)
+    outs = {a: np.zeros((f, n), dtype=np.int64) for a in want}
+    with np.errstate(over='ignore'):
+        for v, nb in _rows_of(csr, row_begin, row_end):
+            vals = X[nb]
+            if 'sum' in outs:
+                outs['sum'][:, v] = vals.sum(axis=0) if len(nb) else 0
+            if 'prod' in outs:
+                outs['prod'][:, v] = np.multiply.reduce(vals, axis=0) if len(nb) else 1
+            if 'min' in outs:
+                outs['min'][:, v] = vals.min(axis=0) if len(nb) else 0
+            if 'max' in outs:
+                outs['max'][:, v] = vals.max(axis=0) if len(nb) else 0
+    return {a: torch.from_numpy(o.view(np.float64).copy()) for a, o in outs.items()}
+
+
+def aggregate_count(csr, f, row_begin=0, row_end=None, as_i64=False):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    deg = np.diff(csr.row_ptr).astype(np.int64)
+    out = np.zeros((f, n), dtype=np.int64 if as_i64 else np.float64)
+    out[:, row_begin:row_end] = deg[row_begin:row_end]
+    return torch.from_numpy(out.view(np.float64).copy() if as_i64 else out)
+
+
+def aggregate_median(csr, rows, f, ldr, row_begin=0, row_end=None):
+    n = csr.n
+    row_end = n if row_end is None else row_end
+    X = rows.numpy()[:n, :f]
+    out = np.zeros((f, n))
+    for v, nb in _rows_of(csr, row_begin, row_end):
+        if len(nb):
+            out[:, v] = np.median(X[nb], axis=0)
+    return torch.from_numpy(out)
+
+
 def sort_columns(block):
     return torch.from_numpy(np.sort(block.numpy(), axis=1))
 
 
-def vertical_log_bin(block, frac=0.5, out=None):
+def vertical_log_bin(block, frac=0.5, out=None, is_i64=None):
     ncols, n = block.shape
     bins = out if out is not None else torch.zeros((ncols, n), dtype=torch.uint8)
     nb = torch.zeros(ncols, dtype=torch.int32)
     if not 0 < frac < 1:
         raise ValueError('must specify frac in interval (0, 1)')
     for j in range(ncols):
-        b = ckernels.vertical_log_binning(np.ascontiguousarray(block[j].numpy()), frac)
+        if is_i64 is not None and is_i64[j]:
+            from oracle import refex
+            b = refex.vertical_log_binning(block[j].numpy().view(np.int64), frac)
+        else:
+            b = ckernels.vertical_log_binning(np.ascontiguousarray(block[j].numpy()), frac)
         bins[j] = torch.from_numpy(b.astype(np.uint8))
         nb[j] = int(b.max()) + 1 if n else 0
     return bins, nb

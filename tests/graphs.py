@@ -90,6 +90,18 @@ CASE_AGGS = {
     'iface7_prod': ('iface7', ['sum', 'prod'], 4),
     'dw200_prod': ('dw200_attrs', ['prod', 'mean'], 2),
     'path4_prod': ('path4', ['prod', 'max'], 3),
+    # round 3: the reference's wrapping int64 products, median, count / size (pandas names; any aggregatable is legal)
+    'karate_prodwrap': ('karate', ['prod'], 4),
+    'karate_sumprodwrap': ('karate', ['sum', 'prod'], 4),
+    'ba300_prodmean': ('ba300', ['prod', 'mean'], 3),
+    'karate_summedian': ('karate', ['sum', 'median']),
+    'ba300_medianmean': ('ba300', ['median', 'mean'], 4),
+    'dw200_medianmax': ('dw200_attrs', ['median', 'max'], 3),
+    'loops_dangling150_median': ('loops_dangling150', ['median'], 4),
+    'karate_sumcount': ('karate', ['sum', 'count']),
+    'er300_meansize': ('er300', ['mean', 'size'], 4),
+    'loops_dangling150_countmax': ('loops_dangling150', ['count', 'max'], 4),
+    'directed120_prodcount': ('directed120', ['prod', 'count'], 3),
 }
 
 BUILDERS = {

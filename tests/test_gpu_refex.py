@@ -244,7 +244,9 @@ class TestExtractorLikeReference:
     def test_unsupported_aggregation_fails_loudly(self):
         from graphrole_amd import RecursiveFeatureExtractor
         with pytest.raises(NotImplementedError, match='no device kernel'):
-            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['median']).extract_features()
+            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['sum', 'nunique']).extract_features()
+        with pytest.raises(NotImplementedError, match='no device kernel'):
+            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=[lambda s: s.sum()]).extract_features()
 
     def test_agg_order_follows_aggs(self):
         from graphrole_amd import RecursiveFeatureExtractor
@@ -436,13 +438,78 @@ def test_random_graphs_match_oracle(spec, aggs):
         assert np.array_equal(got, ref.values), f'{int((got != ref.values).sum())} entries differ'
 
 
-def test_prod_on_integer_features_refuses_beyond_2_53():
-    """The reference multiplies int64 columns in int64 (wrapping past 2^63); the fp64 columns here are
-    exact below 2^53 only, so a larger integer product is an error, not a silently different number."""
+@pytest.mark.parametrize('native', [True, False], ids=['grx_refex_run', 'per_kernel'])
+@pytest.mark.parametrize('name', util.TYPED_CASES)
+def test_any_aggregation_list_matches_reference(name, native):
+    """aggs with 'prod' over integer columns (the reference's WRAPPING int64 arithmetic, values far beyond 2^53 and
+    negative), 'median', 'count' / 'size', mixed with the others -- against tables the reference produced with those
+    aggs: columns, dtypes, generation count, integer columns bit for bit (int64), float columns exactly on unweighted
+    graphs.  native: the loop below the ABI takes these aggregations too, except where int64 semantics are needed
+    (then both parametrisations run the per-kernel driver)."""
     from graphrole_amd import RecursiveFeatureExtractor
+    g = util.load_refex(name)
+    G, kwargs = _graph_for(name, g)
+    fe = RecursiveFeatureExtractor(G, aggs=util.golden_aggs(g), max_generations=int(g['max_generations']),
+                                  native_loop=native, **kwargs)
+    X = fe.extract_features()
+    assert list(X.index) == g.js('labels')
+    assert fe.generation_count == int(g['generation_count'])
+    weighted = bool(len(g['w']))
+    util.assert_typed_final_equal(g, list(X.columns), {c: X[c].to_numpy() for c in X.columns}, rtol=RTOL if weighted else 0.0)
+    for gen in range(int(g['n_generations_recorded'])):
+        assert fe._final_names[gen] == g.js(f'g{gen}_retained'), f'generation {gen}'
+    pd.testing.assert_frame_equal(X, fe.extract_features())
+
+
+def test_prod_on_integer_features_wraps_like_the_reference():
+    """The reference multiplies int64 columns in int64 and wraps silently past 2^63 (numpy): so do the int64-bits
+    columns here (csrc/grx_aggx.hip) -- on a graph where products overflow in the first generation."""
+    from graphrole_amd import RecursiveFeatureExtractor
+    from oracle import refex
     G, _ = graphs.BUILDERS['ba300']()
-    with pytest.raises(OverflowError, match='2\\*\\*53'):
-        RecursiveFeatureExtractor(G, aggs=['sum', 'prod'], max_generations=3).extract_features()
+    fe = RecursiveFeatureExtractor(G, aggs=['sum', 'prod'], max_generations=3)
+    X = fe.extract_features()
+    assert all(dt == np.int64 for dt in X.dtypes)
+    assert np.abs(X.to_numpy().astype(np.float64)).max() > 2.0 ** 60          # wrapped territory
+    og = refex.graph_from_networkx(G)
+    names0, block0 = refex.neighborhood_features(og)
+    ref = refex.extract_features_typed(og, names0, [block0[:, j].astype(np.int64) for j in range(len(names0))], 3,
+                                       ['sum', 'prod'])
+    assert list(X.columns) == ref.columns and fe.generation_count == ref.generation_count
+    for c in X.columns:
+        assert np.array_equal(X[c].to_numpy(), ref.arrays[c]), c
+
+
+@pytest.mark.parametrize('aggs', [['median', 'sum'], ['count', 'mean', 'max'], ['prod', 'median', 'size']],
+                         ids=['mediansum', 'countmeanmax', 'prodmediansize'])
+@pytest.mark.parametrize('spec', [dict(n=700, m=9000, seed=1, directed=False, weighted=False, self_loops=4),
+                                  dict(n=500, m=3000, seed=2, directed=True, weighted=True, self_loops=3),
+                                  dict(n=129, m=128 * 64, seed=3, directed=False, weighted=False, self_loops=0)],
+                         ids=['u700', 'dw500', 'dense129'])
+def test_any_aggregation_list_on_random_graphs_matches_typed_oracle(spec, aggs):
+    """Random graphs (rows of 100+ neighbours: the radix-selection branch of the median; isolated nodes) against
+    oracle.refex.extract_features_typed, itself pinned on the reference's tables for such aggs."""
+    from graphrole_amd import RecursiveFeatureExtractor
+    from graphrole_amd.graph import CSRGraph
+    from oracle import refex
+    src, dst, w = util.random_graph(**spec)
+    n = spec['n'] + 2
+    G = CSRGraph(n, src, dst, weights=w, directed=spec['directed'])
+    fe = RecursiveFeatureExtractor(G, max_generations=3, aggs=aggs)
+    X = fe.extract_features()
+    og = refex.graph_from_arrays(n, src, dst, w, spec['directed'])
+    names0, block0 = refex.neighborhood_features(og, fast=True)
+    int0 = w is None
+    cols0 = [block0[:, j].astype(np.int64) if int0 else block0[:, j] for j in range(len(names0))]
+    ref = refex.extract_features_typed(og, names0, cols0, 3, aggs)
+    assert list(X.columns) == ref.columns and fe.generation_count == ref.generation_count
+    for c in X.columns:
+        got, want = X[c].to_numpy(), ref.arrays[c]
+        assert got.dtype == want.dtype, c
+        if spec['weighted']:
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=0, err_msg=c)
+        else:
+            assert np.array_equal(got, want), c
 
 
 def test_prod_on_float_features_matches_oracle():

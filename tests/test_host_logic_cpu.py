@@ -24,7 +24,8 @@ def _cpu_double():
 test_extract_features_matches_reference = R.test_extract_features_matches_reference
 test_generation_trace_matches_reference = R.test_generation_trace_matches_reference
 test_csr_graph_input_equals_networkx_input = R.test_csr_graph_input_equals_networkx_input
-test_prod_on_integer_features_refuses_beyond_2_53 = R.test_prod_on_integer_features_refuses_beyond_2_53
+test_prod_on_integer_features_wraps_like_the_reference = R.test_prod_on_integer_features_wraps_like_the_reference
+test_any_aggregation_list_matches_reference = R.test_any_aggregation_list_matches_reference
 test_prod_on_float_features_matches_oracle = R.test_prod_on_float_features_matches_oracle
 
 

@@ -274,3 +274,18 @@ def test_oracle_kmeans1d_equals_sklearn():
         assert len(np.unique(q)) == len(np.unique(ref))
     with pytest.raises(ValueError, match='n_clusters'):
         kmeans1d.kmeans_quantize(np.arange(3.0), 8)
+
+
+@pytest.mark.parametrize('name', util.TYPED_CASES)
+def test_typed_oracle_equals_reference_on_any_aggregation_list(name):
+    """oracle.refex.extract_features_typed ('prod' with wrapping int64, 'median', 'count' / 'size', mixed with the
+    others) against fixtures generated by running the reference with those aggs (tools/make_golden.py): columns,
+    generation count, dtypes, integer columns bit for bit beyond 2^53, float columns exactly on unweighted graphs."""
+    from oracle import refex
+    g = util.load_refex(name)
+    og = util.oracle_graph_from_golden(g)
+    names0, cols0 = util.typed_gen0(g)
+    res = refex.extract_features_typed(og, names0, cols0, int(g['max_generations']), util.golden_aggs(g))
+    assert res.generation_count == int(g['generation_count'])
+    weighted = len(g['w']) > 0
+    util.assert_typed_final_equal(g, res.columns, res.arrays, rtol=1e-12 if weighted else 0.0)

@@ -11,6 +11,10 @@ REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'lo
                'directed120', 'path4', 'iface7', 'iface7_dw', 'er2000', 'ba2000',
                'karate_minmax', 'ba300_maxsum', 'dw200_minmax', 'loops_dangling150_minmax', 'ba300_stdvar',
                'karate_sumstd', 'iface7_prod', 'dw200_prod', 'path4_prod']
+# round 3: aggregation lists with 'prod' over integer columns (wrapping int64), 'median', 'count' / 'size'
+TYPED_CASES = ['karate_prodwrap', 'karate_sumprodwrap', 'ba300_prodmean', 'karate_summedian', 'ba300_medianmean',
+               'dw200_medianmax', 'loops_dangling150_median', 'karate_sumcount', 'er300_meansize',
+               'loops_dangling150_countmax', 'directed120_prodcount']
 ROLES_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'directed120', 'loops_dangling150']
 NMF_CASES = ['rand20x30_r3', 'rand500x12_r6', 'rand800x40_r6', 'rand3000x9_r2', 'karate_r4', 'er2000_r6',
              'ba2000_r6', 'dw200_r5']
@@ -57,6 +61,30 @@ def oracle_graph_from_golden(g):
         assert np.array_equal(g['adj_ptr'], og.row_ptr)
         og.adj_col = g['adj_idx'].astype(np.int32)
     return og
+
+
+def typed_gen0(g):
+    """Generation-0 columns of a fixture with the reference's dtypes (int64 where its frame had integers)."""
+    names = g.js('gen0_names')
+    kinds = g.js('gen0_dtypes') if 'gen0_dtypes_json' in g else ['int64' if bool(g['gen0_is_int']) else 'float64'] * len(names)
+    vals = g['gen0_values']
+    return names, [vals[:, j].astype(np.int64) if 'int' in kinds[j] else vals[:, j].copy() for j in range(len(names))]
+
+
+def assert_typed_final_equal(g, columns, arrays, rtol=0.0):
+    """Final table of a typed run against the fixture: column order, dtypes, integer columns bit for bit (int64, also
+    beyond 2^53), float columns exactly (unweighted) or to rtol."""
+    assert list(columns) == g.js('final_columns')
+    kinds = g.js('final_dtypes')
+    for j, nm in enumerate(columns):
+        got = np.asarray(arrays[nm])
+        assert str(got.dtype) == kinds[j], f'{nm}: dtype {got.dtype}, reference {kinds[j]}'
+        if 'int' in kinds[j]:
+            assert np.array_equal(got, g['final_values_i64'][:, j]), nm
+        elif rtol:
+            np.testing.assert_allclose(got, g['final_values'][:, j], rtol=rtol, atol=0, err_msg=nm)
+        else:
+            assert np.array_equal(got, g['final_values'][:, j]), nm
 
 
 def random_graph(n, m, seed, directed=False, weighted=False, self_loops=0):

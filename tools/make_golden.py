@@ -145,6 +145,13 @@ def capture_refex(name, G, kwargs, max_generations=10):
     out['final_columns_json'] = json.dumps(list(final.columns))
     out['final_values'] = final.loc[labels].values.astype(np.float64)
     out['final_dtypes_json'] = json.dumps([str(t) for t in final.dtypes])
+    # integer columns exactly (fp64 loses the low bits of wrapped int64 products): int64 per column, 0 where float
+    ordered = final.loc[labels]
+    out['final_values_i64'] = np.column_stack([ordered[c].to_numpy().astype(np.int64) if ordered[c].dtype.kind in 'iu'
+                                               else np.zeros(len(labels), dtype=np.int64) for c in ordered.columns]) \
+        if ordered.shape[1] else np.zeros((len(labels), 0), dtype=np.int64)
+    gen0 = fe.graph.get_neighborhood_features().loc[labels]
+    out['gen0_dtypes_json'] = json.dumps([str(t) for t in gen0.dtypes])
 
     # cross-check: an untouched instance run through the public entry point agrees exactly
     fe2 = RecursiveFeatureExtractor(G, max_generations=max_generations, aggs=aggs, **kwargs)
