@@ -80,6 +80,7 @@ _SIGNATURES = {
     'grx_upload': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_upload_i64_as_i32': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_host_checksums': (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
+    'grx_host_uniform_choice': (c_int, [c_int64, c_double, POINTER(c_int64)]),
     'grx_min_value_workspace_bytes': (c_size_t, []),
     'grx_min_value': (c_int, [c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_event_create': (c_int, [POINTER(c_void_p)]),

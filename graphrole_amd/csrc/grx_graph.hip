@@ -13,6 +13,8 @@
 // geometry; the other reductions are "per-lane sequential, then a fixed butterfly".
 #include "grx_common.h"
 
+#include <cstdlib>
+
 // Streams that are read exactly once per launch (the neighbour index list, the oriented arc tables, the output
 // columns) can carry the non-temporal hint so that they do not evict the hot rows / hub lists the random gathers of
 // the same kernel hit in L2.  MEASURED WITHOUT GAIN on MI355X (round 3, -DGRX_NT_STREAMS=1 against 0: aggregation
@@ -368,6 +370,11 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 constexpr int TRI_ARC_SHIFT = 40;
 constexpr int TRI_G = 8;                     // lanes per source row
 
+// MEASURED AND REJECTED (round 3): an XCD-partitioned variant -- targets split into eight classes of 32-row runs,
+// workgroup b following only the arcs into class b % 8 so that each XCD's private L2 has to hold one eighth of the
+// target lists, the target list located through o_row_ptr[v] instead of the per-arc table.  Counts equal, but
+// 1.74 ms against 0.58 ms at BA 1 M (0.178 against 0.053 ms at ER 100 k): every source list is then read and
+// filtered by all eight XCDs, and that fixed cost (8 M group visits instead of 1 M) outweighs the better hit rate.
 __global__ __launch_bounds__(256) void triangle_count_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
     const uint64_t *__restrict__ o_arc, int64_t row_begin, int64_t row_end,

@@ -152,7 +152,14 @@ class DeviceGraphInterface(BaseGraphInterface):
                     values = np.asarray(values)
                     a_names.append(name)
                     a_dtypes.append(values.dtype if values.dtype.kind in 'iu' else np.dtype('float64'))
-                    a_cols.append(K.to_device(host.to_internal(values.astype(np.float64))))
+                    perm_dev = getattr(host, 'perm_dev', None)
+                    if perm_dev is not None and hasattr(K, 'permute_columns'):
+                        # label order up, internal order by one gather in HBM (a host fancy-index of a few million
+                        # doubles per attribute cost more than the whole generation loop)
+                        up = K.to_device(np.ascontiguousarray(values, dtype=np.float64))
+                        a_cols.append(K.permute_columns([up], perm_dev, host.n)[0])
+                    else:
+                        a_cols.append(K.to_device(host.to_internal(values.astype(np.float64))))
                 self._attr_cols = (a_names, a_cols, a_dtypes)
             names += self._attr_cols[0]
             cols += self._attr_cols[1]

@@ -815,9 +815,10 @@ def kmeans_draws(m: int, n_bins: int):
     if hit is None:
         rs = np.random.RandomState(1)
         u = rs.random_sample()
-        cdf = np.cumsum(np.full(m, 1.0 / m))
-        cdf /= cdf[-1]
-        first = int(np.searchsorted(cdf, u, side='right'))
+        # searchsorted(cumsum(full(m, 1 / m)) / total, u, 'right') without the m-element arrays (grx_host_uniform_choice)
+        idx = ctypes.c_int64(0)
+        _lib.call('grx_host_uniform_choice', int(m), float(u), ctypes.byref(idx))
+        first = int(idx.value)
         trials = 2 + int(np.log(n_bins))
         uniform = rs.uniform(size=(max(n_bins - 1, 0), trials))
         hit = (first, np.ascontiguousarray(uniform), trials)

@@ -73,6 +73,10 @@ int grx_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int grx_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int grx_upload_i64_as_i32(int32_t *d_dst, const int64_t *h_src, size_t count, void *stream);
 int grx_host_checksums(const void *h_base, int ncols, size_t col_bytes, size_t stride_bytes, uint64_t *h_out);
+/* The index numpy's RandomState.choice(m, p = uniform) returns for its one uniform draw u -- searchsorted(cumsum(full(m,
+ * 1 / m)) / total, u, 'right') -- without the three m-element arrays: the first k-means++ seed of sklearn's KMeans
+ * (_kmeans.py:221) as grx_kmeans1d needs it. */
+int grx_host_uniform_choice(int64_t m, double u, int64_t *index);
 size_t grx_min_value_workspace_bytes(void);
 int grx_min_value(int64_t n, int F, const double *d_X, int64_t ld, double *d_out, void *d_workspace,
                   size_t workspace_bytes, void *stream);

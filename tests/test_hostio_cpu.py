@@ -41,3 +41,27 @@ def test_checksum_of_a_column_does_not_depend_on_the_batch():
         assert _sums(a[j:j + 1])[0] == together[j]
     ints = rng.integers(0, 1 << 40, size=(3, 70_000), dtype=np.int64)
     assert np.array_equal(_sums(ints.view(np.float64)), _sums(ints.view(np.float64).copy()))
+
+
+def test_uniform_choice_equals_numpy_searchsorted_of_the_cumulative_sum():
+    """grx_host_uniform_choice: the index RandomState.choice(m, p=uniform) derives from its one draw (sklearn's first
+    k-means++ seed) -- numpy's searchsorted(cumsum(full(m, 1/m)) / total, u, 'right') -- incl. draws that sit on or
+    next to a boundary of the cumulative sum (the exact-loop branch)."""
+    from graphrole_amd import _lib
+
+    def ours(m, u):
+        idx = ctypes.c_int64(0)
+        _lib.call('grx_host_uniform_choice', int(m), float(u), ctypes.byref(idx))
+        return idx.value
+
+    def numpy_way(m, u):
+        cdf = np.cumsum(np.full(m, 1.0 / m))
+        cdf /= cdf[-1]
+        return int(np.searchsorted(cdf, u, side='right'))
+
+    u1 = np.random.RandomState(1).random_sample()
+    for m in list(range(1, 120)) + [1000, 4099, 65536, 100003, 1234567]:
+        draws = [u1, 0.0, 0.5, 0.999999, 1.0 / 3]
+        draws += [(k + eps) / m for k in (0, 1, m // 2, m - 1) for eps in (0.0, 1e-12, -1e-12, 0.5) if 0 <= (k + eps) / m < 1]
+        for u in draws:
+            assert ours(m, u) == numpy_way(m, u), (m, u)
