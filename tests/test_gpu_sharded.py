@@ -33,6 +33,9 @@ def _graph(kind):
     if kind == 'ba1m':
         # BASELINE config 4's graph (the 1 M / 10 M power-law graph of config 3, node-range sharded)
         return synth.ba_graph(1_000_000, 10, seed=0)
+    if kind == 'dw1m':
+        # BASELINE config 5's shape (weighted directed power-law + 8 attributes) at 1 M nodes / 10 M arcs
+        return synth.directed_weighted_graph(1_000_000, 10_000_000, seed=0)
     return synth.directed_weighted_graph(40_000, 400_000, seed=4)
 
 
@@ -51,7 +54,8 @@ def _worker(rank, port, kind, driver, out_dir):
         # 'native': grx_refex_run / grx_nmf_fit with the plan's communicator (the staged callback transport under
         # gloo) -- the exchanges are issued by the C++ drivers; 'per_kernel': the Python driver over the same C
         # exchange entry points
-        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, native_loop=driver == 'native')
+        fe = RecursiveFeatureExtractor(G, max_generations=4, distributed=True, native_loop=driver == 'native',
+                                      attributes=bool(G.attributes))
         X = fe.extract_features()
         plan = fe._shard()
         assert plan is not None and plan.world == WORLD and 0 < plan.row_end - plan.row_begin < G.n
@@ -65,7 +69,7 @@ def _worker(rank, port, kind, driver, out_dir):
                    rb=plan.row_begin, re=plan.row_end)
         if rank == 0:
             # the single-GPU answer, same process, same kernels
-            fe1 = RecursiveFeatureExtractor(G, max_generations=4)
+            fe1 = RecursiveFeatureExtractor(G, max_generations=4, attributes=bool(G.attributes))
             X1 = fe1.extract_features()
             Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
             s1, it1 = factor.nmf_device(Xd1, G.n, 4, omega)
@@ -77,7 +81,7 @@ def _worker(rank, port, kind, driver, out_dir):
 
 
 @pytest.mark.parametrize('kind,driver', [('ba', 'native'), ('ba', 'per_kernel'), ('directed_weighted', 'native'),
-                                         ('directed_weighted', 'per_kernel'), ('ba1m', 'native')])
+                                         ('directed_weighted', 'per_kernel'), ('ba1m', 'native'), ('dw1m', 'native')])
 def test_two_ranks_one_gpu_equal_single_process(kind, driver, tmp_path):
     mp.spawn(_worker, args=(_free_port(), kind, driver, str(tmp_path)), nprocs=WORLD, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
