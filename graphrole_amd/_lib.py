@@ -157,6 +157,7 @@ _SIGNATURES = {
     'grx_host_whiten': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_host_range_finder': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_host_small_svd': (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'grx_host_nndsvd_plan': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_gram_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_gram': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p,

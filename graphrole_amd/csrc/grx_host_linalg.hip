@@ -493,6 +493,71 @@ int grx_host_range_finder(int F, int k, const double *T1, const double *lam_keep
     return GRX_OK;
 }
 
+// Fewer nodes than features (n < F): sklearn's randomized_svd takes its transposed branch (extmath.py:565-569,
+// 587-604: the range finder runs on M = X^T, the factors are swapped back) and every matrix is small -- X itself is
+// at most GRX_MAX_NMF_FEATURES squared.  The whole SVD part of the initialisation on the host, from the library's own
+// routines: U (n x r, before svd_flip), S [r], V (r x F).  omega: n x n_over Gaussian test matrix.
+int grx_host_small_svd(int n, int F, const double *X, const double *omega, int n_over, int r, int n_iter, double *U_out,
+                       double *S, double *V_out)
+{
+    GRX_REQUIRE(n >= 1 && F >= 1 && n_over >= 1 && r >= 1 && n_iter >= 0, "grx_host_small_svd: bad shape");
+    GRX_REQUIRE(X && omega && U_out && S && V_out, "grx_host_small_svd: NULL pointer");
+    // M = X^T: F x n
+    Mat M((size_t)F * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < F; ++j) M[(size_t)j * n + i] = X[(size_t)i * F + j];
+    int w = n_over;
+    Mat Qs(omega, omega + (size_t)n * n_over), tmp, PL;
+    for (int it = 0; it < n_iter; ++it) {
+        tmp.assign((size_t)F * w, 0.0);
+        matmul(F, n, w, M.data(), Qs.data(), tmp.data());          // M Qs: F x w
+        const int w1 = std::min(F, w);
+        PL.assign((size_t)F * w1, 0.0);
+        lu_permuted_l(F, w, tmp.data(), PL.data());                // F x w1
+        tmp.assign((size_t)n * w1, 0.0);
+        matmul_tn(n, F, w1, M.data(), PL.data(), tmp.data());      // M^T PL: n x w1
+        const int w2 = std::min(n, w1);
+        Qs.assign((size_t)n * w2, 0.0);
+        lu_permuted_l(n, w1, tmp.data(), Qs.data());               // n x w2
+        w = w2;
+    }
+    tmp.assign((size_t)F * w, 0.0);
+    matmul(F, n, w, M.data(), Qs.data(), tmp.data());              // F x w
+    const int m = std::min(F, w);
+    Mat Q((size_t)F * m);
+    qr_q(F, w, tmp.data(), Q.data());                              // F x m
+    Mat B((size_t)m * n);
+    matmul_tn(m, F, n, Q.data(), M.data(), B.data());              // Q^T M: m x n
+    // thin SVD of B; jacobi_svd wants no more rows than columns
+    const int mm = std::min(m, n);
+    Mat Uh((size_t)m * mm), Vt((size_t)mm * n);
+    std::vector<double> s(mm);
+    if (m <= n) {
+        jacobi_svd(m, n, B.data(), Uh.data(), s.data(), Vt.data());
+    } else {
+        Mat Bt((size_t)n * m), U2((size_t)n * n), Vt2((size_t)n * m);
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < n; ++j) Bt[(size_t)j * m + i] = B[(size_t)i * n + j];
+        jacobi_svd(n, m, Bt.data(), U2.data(), s.data(), Vt2.data());   // B^T = U2 s Vt2  =>  B = Vt2^T s U2^T
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < n; ++j) Uh[(size_t)i * n + j] = Vt2[(size_t)j * m + i];
+        for (int j = 0; j < n; ++j)
+            for (int c = 0; c < n; ++c) Vt[(size_t)j * n + c] = U2[(size_t)c * n + j];
+    }
+    // M = X^T ~ (Q Uh) s Vt  =>  X ~ Vt^T s (Q Uh)^T:  U = Vt^T (n x r),  V = (Q Uh)^T (r x F)
+    for (int j = 0; j < r; ++j) {
+        S[j] = j < mm ? s[j] : 0.0;
+        for (int i = 0; i < n; ++i) U_out[(size_t)i * r + j] = j < mm ? Vt[(size_t)j * n + i] : 0.0;
+        for (int c = 0; c < F; ++c) {
+            double v = 0.0;
+            if (j < mm)
+                for (int l = 0; l < m; ++l) v += Q[(size_t)c * m + l] * Uh[(size_t)l * mm + j];
+            V_out[(size_t)j * F + c] = v;
+        }
+    }
+    return GRX_OK;
+}
+
 // NNDSVD column choices (_nmf.py:324-352) from the statistics of the raw U = X Z columns:
 // stats[j] = {signed max-|.| entry, its row, sum sq of the positive part, of the negative part}.
 // Outputs sign[r], scale[r] for grx_nndsvd_apply and H (r x F) before thresholding.

@@ -631,6 +631,22 @@ def chebyshev(bin_cols: Sequence[torch.Tensor], n: int, first_new: int = 0, row_
 
 
 # ------------------------------------------------------------------------------- whole ReFeX loop
+def _refex_arena_guess(n: int, f0: int, n_aggs: int, max_gens: int) -> int:
+    """First size of the grx_refex_run arena: a wrong guess costs a whole second run (the call reports what it needed
+    and is repeated), an oversized one a larger hipMalloc.  Model: a generation keeps ~90 % of n_aggs x its parents
+    (what the benchmark graphs do), every candidate block, its bins and the binning workspace of the widest generation
+    live at once."""
+    lib = _lib.load()
+    growth = min(0.9 * n_aggs, 4.0)
+    per_gen = [f0 * growth ** g for g in range(max(1, min(max_gens, 6)))]
+    cols = sum(min(c, 400.0) for c in per_gen)
+    widest = int(min(max(per_gen) + 1, 400))
+    blocks = int(cols * max(n, 1) * 9.2)                               # fp64 columns + uint8 bins, 256-byte slack
+    scratch = max(lib.grx_log_bin_workspace_bytes(n, widest), max(n, 1) * 8 * lib.grx_aggregate_ldr(widest))
+    return blocks + int(scratch) + (64 << 20)
+
+
+
 def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
               aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None,
               gen0_int32: Optional[Sequence[bool]] = None):
@@ -652,7 +668,7 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
     col_ptrs = ptr_array(list(gen0_cols))
     max_gens = max(int(max_generations), 1)
     if arena is None:
-        arena = torch.empty(max(n, 1) * 8 * 96 + (32 << 20), dtype=torch.uint8, device=device())
+        arena = torch.empty(_refex_arena_guess(n, f0, len(aggs), max_gens), dtype=torch.uint8, device=device())
     max_columns = 256
     while True:
         table = (_lib.RefexColumn * max_columns)()
@@ -776,6 +792,18 @@ def host_range_finder(T1: np.ndarray, lam: np.ndarray, V: np.ndarray, G2: np.nda
               _hp(np.ascontiguousarray(V)), _hp(np.ascontiguousarray(G2, dtype=np.float64)), _hp(omega),
               omega.shape[1], int(r), int(n_iter), _hp(Z), _hp(S), _hp(Vt))
     return Z, S, Vt
+
+
+def host_small_svd(X: np.ndarray, omega: np.ndarray, r: int, n_iter: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """n < F: sklearn's transposed randomized_svd on the small host matrix (grx_host_small_svd): (U [n, r], S [r],
+    V [r, F]) before svd_flip."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    omega = np.ascontiguousarray(omega, dtype=np.float64)
+    n, F = X.shape
+    assert omega.shape[0] == n
+    U, S, V = np.empty((n, r)), np.empty(r), np.empty((r, F))
+    _lib.call('grx_host_small_svd', n, F, _hp(X), _hp(omega), omega.shape[1], int(r), int(n_iter), _hp(U), _hp(S), _hp(V))
+    return U, S, V
 
 
 def host_nndsvd_plan(S: np.ndarray, Vt: np.ndarray, stats: np.ndarray):

@@ -54,26 +54,13 @@ def _host():
 
 
 def _host_init(X: np.ndarray, r: int, omega: np.ndarray):
-    """N < F (fewer nodes than features): every matrix of the initialisation is small -- numpy / scipy
-    on the host, sklearn's transposed branch (extmath.py:565-569, 587-604)."""
-    from scipy import linalg
-
-    def lu_norm(a):
-        return linalg.lu(a, permute_l=True, check_finite=False)[0]
-
+    """N < F (fewer nodes than features): every matrix of the initialisation is small -- sklearn's transposed
+    randomized_svd branch (extmath.py:565-569, 587-604) runs in the library's host routines (grx_host_small_svd:
+    LU-normalised power iterations, Householder QR, one-sided Jacobi SVD), then the NNDSVD column choices."""
     n, F = X.shape
-    M = X.T                                                          # F x n, more rows than columns
     n_iter = 7 if r < 0.1 * min(X.shape) else 4                      # extmath.py:557-560
-    Qs = omega
-    for _ in range(n_iter):                                          # extmath.py:349-351
-        Qs = lu_norm(M @ Qs)
-        Qs = lu_norm(M.T @ Qs)
-    Qs, _ = linalg.qr(M @ Qs, mode='economic', check_finite=False)
-    Uhat, S, Vt = linalg.svd(Qs.T @ M, full_matrices=False, lapack_driver='gesdd')
-    Us = (Qs @ Uhat)[:, :r]
-    S, Vt = S[:r], Vt[:r]
-    # X^T ~= Us S Vt  ->  X ~= Vt^T S Us^T ; sklearn flips on the rows of its "Vt" = our Us^T
-    U, V = Vt.T, Us.T
+    U, S, V = _host().host_small_svd(X, omega, r, n_iter)
+    # sklearn flips on the rows of its "Vt" = the columns of U here
     idx = np.argmax(np.abs(U), axis=0)
     stats = np.stack([U[idx, np.arange(r)], idx.astype(float), (np.maximum(U, 0) ** 2).sum(0),
                       (np.minimum(U, 0) ** 2).sum(0)], axis=1)

@@ -469,6 +469,10 @@ int grx_host_range_finder(int F, int k, const double *h_T1, const double *h_lam_
                           double *h_Z, double *h_S, double *h_Vt);
 int grx_host_nndsvd_plan(int r, int F, const double *h_S, const double *h_Vt, const double *h_stats,
                          double *h_sign, double *h_scale, double *h_H);
+/* n < F (fewer nodes than features): sklearn's transposed randomized_svd branch (extmath.py:565-569) on the small
+ * host matrix itself -- h_X n x F row-major, h_omega n x n_over; h_U n x r (before svd_flip), h_S [r], h_V r x F. */
+int grx_host_small_svd(int n, int F, const double *h_X, const double *h_omega, int n_over, int r, int n_iter,
+                       double *h_U, double *h_S, double *h_V);
 
 /*
  * All NMF matrices are "feature-major": X is F x ldx (row c = feature column c, n valid

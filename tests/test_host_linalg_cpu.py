@@ -149,3 +149,21 @@ def test_host_eigh_matches_numpy(n):
     np.testing.assert_allclose(w, we, atol=1e-13 * scale * n)
     np.testing.assert_allclose(A @ V, V * w, atol=1e-13 * scale * n)
     np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12)
+
+
+@pytest.mark.parametrize('n,F,r', [(20, 30, 3), (5, 8, 3), (3, 40, 2), (12, 13, 6), (40, 100, 8), (7, 9, 7)])
+def test_small_svd_of_tables_with_fewer_nodes_than_features(n, F, r):
+    """grx_host_small_svd (n < F: sklearn's transposed randomized_svd branch on the library's own LU / QR / Jacobi
+    routines) against numpy's SVD: when r + 10 >= n the range finder spans the whole row space, so the leading r
+    singular triplets are exact (up to the sign of a pair)."""
+    from graphrole_amd import kernels as K
+    rng = np.random.default_rng(n * 100 + F)
+    X = np.abs(rng.standard_normal((n, F))) * np.linspace(1, 5, F)
+    omega = rng.standard_normal((n, r + 10))
+    U, S, V = K.host_small_svd(X, omega, r, 4)
+    Ue, Se, Vte = np.linalg.svd(X, full_matrices=False)
+    np.testing.assert_allclose(S, Se[:r], rtol=1e-10)
+    for j in range(r):
+        sgn = np.sign(U[:, j] @ Ue[:, j])
+        np.testing.assert_allclose(sgn * U[:, j], Ue[:, j], atol=1e-8)
+        np.testing.assert_allclose(sgn * V[j], Vte[j], atol=1e-8)
