@@ -35,9 +35,13 @@ barrier + synchronize pairs; the time is the max over ranks.
                      RecursiveFeatureExtractor(G).extract_features() -> DataFrame and
                      RoleExtractor(6).extract_role_factors(X) (NMF + encode), ingest share broken out
 
-With --gpus N > 1 the same graph is node-range sharded over the ranks (strong scaling); per
-generation the candidate columns go to their owners (all-to-all), bins come back, and only the
-retained columns are all-gathered (graphrole_amd/parallel.py).
+With --gpus N > 1 the same graph is node-range sharded over the ranks (strong scaling): grx_refex_run and
+grx_nmf_fit take the run's communicator (csrc/grx_comm.hip: RCCL bound inside libgrx.so) and issue the exchanges
+themselves -- per generation the candidate row slices go to the column owners, bins come back, and only the
+retained columns are completed on every rank; one all-reduce per NMF iteration.  The line then also carries
+`sharded_dw5m`: the same measurement on BASELINE config 5 (5 M nodes / 100 M weighted arcs), the workload where
+sharding pays (90 ms per step on one GPU).  `per_rank` lists every rank's aggregation launch time and the device
+time of its exchanges by kind.
 """
 import argparse
 import ctypes
@@ -461,8 +465,10 @@ def main():
                 'config': {'workload': args_workload, 'description': WORKLOADS[args_workload][3], 'n_nodes': G.n,
                            'n_edges': G.num_edges, 'nnz': G.nnz, 'max_generations': MAX_GENERATIONS,
                            'recursive_generations_executed': gens, 'n_roles': N_ROLES, 'n_features': F,
-                           'sharding': ('node-range x%d; per generation all-to-all of candidate columns to their owners, bins back, '
-                                        'RCCL all-gather of the retained columns' % world) if world > 1 else 'single GPU'},
+                           'sharding': ('node-range x%d, loops and exchanges below the C ABI (grx_comm: RCCL grouped send / recv + '
+                                        'all-reduce over xGMI): per generation candidate row slices to the column owners, '
+                                        'bins back, all-gather of the retained columns only; one all-reduce per NMF '
+                                        'iteration' % world) if world > 1 else 'single GPU'},
                 'refex': {'ms_per_step': t_refex / steps * 1e3, 'edges_per_step': edges_per_step,
                           'edges_per_s': edges_per_step * steps / t_refex,
                           'generations': state['stats']},
