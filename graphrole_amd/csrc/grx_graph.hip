@@ -1012,7 +1012,15 @@ __global__ __launch_bounds__(256) void aggregate_i32_combine_kernel(
         if (v < row_begin || v >= row_end) continue;
         const int64_t n = row_ptr[v + 1] - row_ptr[v];
         long long total = 0;
-        for (int64_t k = blk_ptr[h]; k < blk_ptr[h + 1]; ++k) total += blk[k * 16 + c];
+        // sixteen block sums in flight at a time (hubs have ~100 blocks: one load at a time is a 100-deep latency chain)
+        const int64_t kb = blk_ptr[h], ke = blk_ptr[h + 1];
+        for (int64_t k0 = kb; k0 < ke; k0 += 16) {
+            long long part[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) part[j] = blk[(k0 + j < ke ? k0 + j : ke - 1) * 16 + c];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) total += k0 + j < ke ? part[j] : 0;
+        }
         if (c < f) {
             const double sum = (double)total;
             if (out_sum) out_sum[(int64_t)c * ld + v] = sum;
