@@ -12,6 +12,8 @@
 // All integer work: results are bit-exact functions of the input columns.
 #include "grx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int SORT_THREADS = 256;
@@ -1126,6 +1128,354 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
     }
 }
 
+// =======================================================================================
+// Binning WITHOUT sorting (round 3).  prune.py:13-56 needs ~20 order statistics of a column and the ends of their
+// tie runs -- not a sorted column.  Per column:
+//   sel_range_kernel    1024 strided samples -> [kmin, kmax] of the order keys -> a linear map of the key space onto
+//                       <= 4096 buckets (keys outside the sampled range fall into the end buckets: monotone, exact)
+//   sel_hist_kernel     ONE pass: bucket histogram (LDS, wave-aggregated atomics)
+//   sel_walk1_kernel    prefix sums; the threshold walk in INTERVAL arithmetic over the bucket boundaries (the exact
+//                       end of a tie run is unknown yet, so `done` is an interval [lo, hi]): every bucket a threshold
+//                       rank can fall into is marked -- typically one or two per threshold
+//   sel_collect_kernel  ONE pass: the keys of the marked buckets, appended to per-bucket segments (unordered)
+//   sel_walk2_kernel    the exact walk: the threshold is the q-th smallest key of its bucket's segment, the bin ends
+//                       after the keys <= it (shuffle ranking up to 64 keys, min/max test for tie blocks, workgroup
+//                       radix selection otherwise) -> thresholds as order keys
+//   bin_assign_kernel   as before.
+// Three streaming passes of 8 bytes per key and 6 launches per call instead of key_bits + 4 x (count, scan, scatter) +
+// walk + assign (~70 bytes per key, 15 launches): the binning of a BA 1 M step went from 1.22 to X ms.  The bins
+// are identical (both are exact); the sort path stays behind GRX_BIN_SORT=1 and in the A/B test.
+// =======================================================================================
+constexpr int SEL_NB = 4096;
+constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
+constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
+struct SelRange { uint64_t kmin; int shift; int nb; };
+
+__device__ __forceinline__ int sel_bucket(uint64_t key, uint64_t kmin, int shift, int nb)
+{
+    if (key <= kmin) return 0;
+    const uint64_t b = (key - kmin) >> shift;
+    return b >= (uint64_t)nb ? nb - 1 : (int)b;
+}
+
+__global__ __launch_bounds__(256) void sel_range_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                        SelRange *__restrict__ range, ColFlags flags)
+{
+    const int col = blockIdx.x;
+    const bool i64 = col_is_i64(flags, col);
+    const double *x = cols + (size_t)col * ld;
+    uint64_t mn = ~0ull, mx = 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t s = (int64_t)threadIdx.x * 4 + j;
+        int64_t idx;
+        if (n <= 1024) { if (s >= n) continue; idx = s; }
+        else idx = (s * (n - 1)) / 1023;
+        const uint64_t k = value_key(x[idx], i64);
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ uint64_t red[8];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mn; red[4 + (threadIdx.x >> 6)] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        const uint64_t span = mx - mn;
+        const int bits = span ? 64 - __clzll((long long)span) : 0;
+        SelRange r;
+        r.kmin = mn;
+        r.shift = bits > 12 ? bits - 12 : 0;
+        r.nb = (int)(span >> r.shift) + 1;
+        range[col] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                       const SelRange *__restrict__ range, uint32_t *__restrict__ hist,
+                                                       ColFlags flags)
+{
+    __shared__ uint32_t h[SEL_NB];
+    const int col = blockIdx.y;
+    const bool i64 = col_is_i64(flags, col);
+    const SelRange r = range[col];
+    for (int b = threadIdx.x; b < r.nb; b += 256) h[b] = 0;
+    __syncthreads();
+    const double *x = cols + (size_t)col * ld;
+    const int64_t base = (int64_t)blockIdx.x * SEL_HIST_TILE;
+    const int64_t last = n - 1;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < SEL_HIST_ITEMS; i0 += 8) {
+        double raw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t idx = base + (int64_t)(i0 + j) * 256 + threadIdx.x;
+            raw[j] = x[idx < n ? idx : last];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
+            const int b = sel_bucket(value_key(raw[j], i64), r.kmin, r.shift, r.nb);
+            // heavy ties put a whole wavefront into one bucket: one atomic for all of it
+            const uint64_t active = __ballot(valid);
+            if (active == 0) continue;
+            const int b0 = __shfl(b, __ffsll((long long)active) - 1, 64);
+            if (__ballot(valid && b != b0) == 0) {
+                if (lane == __ffsll((long long)active) - 1) atomicAdd(&h[b0], (uint32_t)__popcll(active));
+            } else if (valid) {
+                atomicAdd(&h[b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *out = hist + (size_t)col * SEL_NB;
+    for (int b = threadIdx.x; b < r.nb; b += 256)
+        if (h[b]) atomicAdd(&out[b], h[b]);
+}
+
+// prefix sums of the bucket counts, the interval walk that marks the buckets a threshold can fall into, and the
+// segment offsets of the marked buckets.  One workgroup of 1024 threads per column (four buckets per thread).
+__global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
+                                                         const uint32_t *__restrict__ hist, uint32_t *__restrict__ cum,
+                                                         uint8_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
+{
+    __shared__ uint32_t C[SEL_NB];
+    __shared__ uint32_t S[SEL_NB];
+    __shared__ uint8_t M[SEL_NB];
+    __shared__ uint32_t wsum[16];
+    const int col = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = range[col].nb;
+    const uint32_t *h = hist + (size_t)col * SEL_NB;
+    auto scan4 = [&](uint32_t (&v)[4], uint32_t *dst) {            // inclusive scan of 4096 values, 4 per thread, into dst
+        const uint32_t local = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - local;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        uint32_t run = before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { run += v[j]; dst[4 * t + j] = run; }
+        __syncthreads();
+    };
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; v[j] = b < nb ? h[b] : 0u; M[b] = 0; }
+    scan4(v, C);
+    if (t == 0) {
+        // first bucket whose inclusive prefix exceeds the rank
+        auto bucket_of = [&](int64_t pos) {
+            int lo = 0, hi = nb - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)C[mid] > pos) hi = mid; else lo = mid + 1; }
+            return lo;
+        };
+        int64_t dlo = 0, dhi = 0;
+        for (int step = 0; step < GRX_MAX_BINS && dlo < n; ++step) {
+            int64_t slo = (int64_t)(frac * (double)(n - dlo));
+            if (slo < 1) slo = 1;
+            const int64_t plo = dlo + slo - 1;
+            const int64_t dh = dhi < n ? dhi : n - 1;           // states that are already done need no threshold
+            int64_t shi = (int64_t)(frac * (double)(n - dh));
+            if (shi < 1) shi = 1;
+            int64_t phi = dh + shi - 1;
+            if (phi < plo) phi = plo;
+            const int jlo = bucket_of(plo), jhi = bucket_of(phi);
+            for (int j = jlo; j <= jhi; ++j) M[j] = 1;
+            dlo = plo + 1;                                      // the bin ends at or after its threshold's rank
+            dhi = (int64_t)C[jhi];                              // ... and inside the threshold's bucket
+            if (dhi < dlo) dhi = dlo;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * t + j;
+        const uint32_t cnt = b < nb ? (C[b] - (b ? C[b - 1] : 0u)) : 0u;
+        v[j] = M[b] ? cnt : 0u;
+    }
+    scan4(v, S);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * t + j;
+        if (b < nb) {
+            cum[(size_t)col * SEL_NB + b] = C[b];
+            mark[(size_t)col * SEL_NB + b] = M[b];
+            seg_off[(size_t)col * SEL_NB + b] = S[b] - v[j];    // exclusive
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                          const SelRange *__restrict__ range, const uint8_t *__restrict__ mark,
+                                                          const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
+                                                          uint64_t *__restrict__ coll, ColFlags flags)
+{
+    __shared__ uint32_t cnt[SEL_NB];
+    __shared__ uint32_t basev[SEL_NB];
+    __shared__ uint8_t M[SEL_NB];
+    const int col = blockIdx.y;
+    const bool i64 = col_is_i64(flags, col);
+    const SelRange r = range[col];
+    for (int b = threadIdx.x; b < r.nb; b += 256) { cnt[b] = 0; M[b] = mark[(size_t)col * SEL_NB + b]; }
+    __syncthreads();
+    const double *x = cols + (size_t)col * ld;
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t last = n - 1;
+    double raw[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
+        raw[i] = x[idx < n ? idx : last];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint64_t keys[SORT_ITEMS];
+    int rank[SORT_ITEMS], bucket[SORT_ITEMS];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
+        keys[i] = value_key(raw[i], i64);
+        bucket[i] = sel_bucket(keys[i], r.kmin, r.shift, r.nb);
+        rank[i] = -1;
+        if (valid && M[bucket[i]]) { rank[i] = (int)atomicAdd(&cnt[bucket[i]], 1u); any = true; }
+    }
+    if (__syncthreads_or(any) == 0) return;                     // nothing of this tile is wanted
+    uint32_t *cur = cursor + (size_t)col * SEL_NB;
+    const uint32_t *off = seg_off + (size_t)col * SEL_NB;
+    for (int b = threadIdx.x; b < r.nb; b += 256)
+        if (cnt[b]) basev[b] = off[b] + atomicAdd(&cur[b], cnt[b]);
+    __syncthreads();
+    uint64_t *dst = coll + (size_t)col * n;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i)
+        if (rank[i] >= 0) dst[basev[bucket[i]] + (uint32_t)rank[i]] = keys[i];
+}
+
+// the q-th smallest (0-based) key of an unordered segment and the number of its keys <= that key; whole workgroup
+// (256 threads), every thread returns the same values
+__device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t *tk_out,
+                                   int64_t *le_out, uint64_t *s_red, uint32_t *s_hist, uint64_t *s_pick)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (len == 1) { *tk_out = seg[0]; *le_out = 1; return; }
+    if (len <= 64) {
+        const uint64_t mine = (lane < len) ? seg[lane] : ~0ull;
+        int lt = 0, le = 0;
+        for (int j = 0; j < (int)len; ++j) {
+            const uint64_t other = __shfl(mine, j, 64);
+            lt += other < mine;
+            le += other <= mine;
+        }
+        const uint64_t hit = __ballot(lane < len && lt <= q && q < le);
+        const int src = __ffsll((long long)hit) - 1;
+        *tk_out = __shfl(mine, src, 64);
+        *le_out = __shfl(le, src, 64);
+        return;
+    }
+    uint64_t mn = ~0ull, mx = 0;
+    for (int64_t i = threadIdx.x; i < len; i += 256) {
+        const uint64_t v = seg[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o1 = __shfl_xor(mn, off, 64), o2 = __shfl_xor(mx, off, 64);
+        mn = o1 < mn ? o1 : mn;
+        mx = o2 > mx ? o2 : mx;
+    }
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+    __syncthreads();
+    mn = s_red[0]; mx = s_red[4];
+    for (int w = 1; w < 4; ++w) { mn = s_red[w] < mn ? s_red[w] : mn; mx = s_red[4 + w] > mx ? s_red[4 + w] : mx; }
+    if (mn == mx) { *tk_out = mn; *le_out = len; return; }     // a block of ties
+    // radix selection over the bytes in which the segment's keys can differ, most significant first
+    const int top = (63 - __clzll((long long)(mn ^ mx))) >> 3;
+    uint64_t prefix = top < 7 ? (mn >> (8 * (top + 1))) << (8 * (top + 1)) : 0ull;
+    int64_t below = 0, qrem = q, equal = len;
+    for (int byte = top; byte >= 0; --byte) {
+        __syncthreads();
+        s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int hs = 8 * (byte + 1);
+        for (int64_t i = threadIdx.x; i < len; i += 256) {
+            const uint64_t v = seg[i];
+            if (byte == 7 || (v >> hs) == (prefix >> hs)) atomicAdd(&s_hist[(uint32_t)(v >> (8 * byte)) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t cumv = 0;
+            int d = 0;
+            for (; d < 255; ++d) {
+                if (cumv + (int64_t)s_hist[d] > qrem) break;
+                cumv += s_hist[d];
+            }
+            s_pick[0] = (uint64_t)d;
+            s_pick[1] = (uint64_t)cumv;
+        }
+        __syncthreads();
+        const int d = (int)s_pick[0];
+        prefix |= (uint64_t)d << (8 * byte);
+        below += (int64_t)s_pick[1];
+        qrem -= (int64_t)s_pick[1];
+        equal = (int64_t)s_hist[d];
+    }
+    *tk_out = prefix;
+    *le_out = below + equal;
+}
+
+__global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
+                                                        const uint32_t *__restrict__ cum, const uint8_t *__restrict__ mark,
+                                                        const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
+                                                        uint64_t *__restrict__ thr, int32_t *__restrict__ nbins,
+                                                        int32_t *__restrict__ fault)
+{
+    __shared__ uint64_t s_red[8];
+    __shared__ uint32_t s_hist[RADIX];
+    __shared__ uint64_t s_pick[2];
+    const int col = blockIdx.x;
+    const int nb_buckets = range[col].nb;
+    const uint32_t *C = cum + (size_t)col * SEL_NB;
+    const uint64_t *segs = coll + (size_t)col * n;
+    uint64_t *t = thr + (size_t)col * GRX_MAX_BINS;
+    int64_t done = 0;
+    int nb = 0;
+    while (done < n && nb < GRX_MAX_BINS) {
+        int64_t size = (int64_t)(frac * (double)(n - done));
+        if (size < 1) size = 1;
+        const int64_t pos = done + size - 1;
+        int lo = 0, hi = nb_buckets - 1;                         // first bucket whose inclusive prefix exceeds pos
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)C[mid] > pos) hi = mid; else lo = mid + 1; }
+        const int j = lo;
+        const int64_t before = j ? (int64_t)C[j - 1] : 0;
+        const int64_t len = (int64_t)C[j] - before;
+        if (!mark[(size_t)col * SEL_NB + j]) {                   // cannot happen: the interval walk covers every exact walk
+            if (threadIdx.x == 0) atomicAdd(fault, 1);
+            break;
+        }
+        uint64_t tk;
+        int64_t le;
+        sel_segment_select(segs + seg_off[(size_t)col * SEL_NB + j], len, pos - before, &tk, &le, s_red, s_hist, s_pick);
+        if (threadIdx.x == 0) t[nb] = tk;
+        ++nb;
+        done = before + le;
+    }
+    if (threadIdx.x == 0) nbins[col] = (done < n) ? -nb : nb;
+}
+
 struct SortPlan {
     int ntiles;
     size_t keys_bytes;      // one key buffer: ncols * n * 8
@@ -1217,14 +1567,38 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
     return p.keys_bytes + p.hist_bytes;
 }
 
+namespace {
+struct SelLayout { size_t range, hist, cum, seg_off, cursor, mark, coll, thr, nbins, fault, total; };
+SelLayout sel_layout(int64_t n, int ncols)
+{
+    SelLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
+    L.range = take((size_t)ncols * sizeof(SelRange));
+    L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist and cursor are zeroed together
+    L.cursor = take((size_t)ncols * SEL_NB * 4);
+    L.cum = take((size_t)ncols * SEL_NB * 4);
+    L.seg_off = take((size_t)ncols * SEL_NB * 4);
+    L.mark = take((size_t)ncols * SEL_NB);
+    L.coll = take((size_t)ncols * (size_t)n * 8);
+    L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
+    L.nbins = take((size_t)ncols * 4);
+    L.fault = take(4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
 size_t grx_log_bin_workspace_bytes(int64_t n, int ncols)
 {
     if (n <= 0 || ncols <= 0) return 256;
     const SortPlan p = make_plan(n, ncols);
     // keysA + sorted + hist + thresholds + nbins + pass-skipping state (key bits, flags)
-    return 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
-           grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 32, 256) +
-           grx_align_up((size_t)ncols * sizeof(BinPlanCol), 256);
+    const size_t sort_path = 2 * p.keys_bytes + p.hist_bytes + grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256) +
+                             grx_align_up((size_t)ncols * 4, 256) + grx_align_up((size_t)ncols * p.ntiles * 32, 256) +
+                             grx_align_up((size_t)ncols * sizeof(BinPlanCol), 256);
+    const size_t select_path = sel_layout(n, ncols).total;
+    return sort_path > select_path ? sort_path : select_path;
 }
 
 int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, double *d_sorted,
@@ -1276,6 +1650,54 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
     hipStream_t st = grx_stream(stream);
     const SortPlan p = make_plan(n, ncols);
     char *ws = reinterpret_cast<char *>(d_workspace);
+    static const bool use_sort = [] { const char *e = std::getenv("GRX_BIN_SORT"); return e && *e == '1'; }();
+    if (!use_sort) {
+        // binning without sorting: sample range -> bucket histogram -> interval walk -> collect -> exact walk -> assign
+        const SelLayout L = sel_layout(n, ncols);
+        SelRange *range = reinterpret_cast<SelRange *>(ws + L.range);
+        uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
+        uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.cursor);
+        uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
+        uint32_t *seg_off = reinterpret_cast<uint32_t *>(ws + L.seg_off);
+        uint8_t *mark = reinterpret_cast<uint8_t *>(ws + L.mark);
+        uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
+        uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
+        int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
+        int32_t *fault = reinterpret_cast<int32_t *>(ws + L.fault);
+        GRX_CHECK_HIP(hipMemsetAsync(hist, 0, L.cum - L.hist, st));                     // hist + cursor
+        GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
+        {
+            GRX_PROF(GRX_K_KEY_BITS, st);
+            sel_range_kernel<<<ncols, 256, 0, st>>>(d_cols, ld, n, range, flags);
+        }
+        {
+            GRX_PROF(GRX_K_SORT_COUNT, st);
+            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, range, hist, flags);
+        }
+        {
+            GRX_PROF(GRX_K_SORT_SCAN, st);
+            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, range, hist, cum, mark, seg_off);
+        }
+        {
+            GRX_PROF(GRX_K_SORT_SCATTER, st);
+            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, range, mark, seg_off, cursor, coll, flags);
+        }
+        {
+            GRX_PROF(GRX_K_BIN_THRESHOLD, st);
+            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, range, cum, mark, seg_off, coll, thr, nb_ws, fault);
+        }
+        GRX_LAUNCH_CHECK();
+        const int64_t want = grx_ceil_div(n, 256 * 4);
+        const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
+        {
+            GRX_PROF(GRX_K_BIN_ASSIGN, st);
+            bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags);
+        }
+        GRX_LAUNCH_CHECK();
+        if (d_nbins)
+            GRX_CHECK_HIP(hipMemcpyAsync(d_nbins, nb_ws, (size_t)ncols * 4, hipMemcpyDeviceToDevice, st));
+        return GRX_OK;
+    }
     uint64_t *buf_a = reinterpret_cast<uint64_t *>(ws);
     uint64_t *buf_b = reinterpret_cast<uint64_t *>(ws + p.keys_bytes);
     uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 2 * p.keys_bytes);

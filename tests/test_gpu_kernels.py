@@ -534,6 +534,56 @@ def test_log_bin_window_sort_adversarial(K, n):
             assert int(nb[j]) == exp.max() + 1
 
 
+@pytest.mark.parametrize('n', [3, 64, 65, 1023, 1025, 50_000, 700_001])
+def test_log_bin_bucket_select_adversarial(K, n):
+    """The default binning does not sort: 1024 strided samples fix a linear map of the key range onto <= 4096 buckets,
+    one pass counts, an interval walk marks the buckets a threshold can fall into, one pass collects their keys, the
+    exact walk selects inside the segments.  Patterns aimed at every step: values outside the sampled range (at
+    positions the samples skip), sorted and reverse-sorted input (samples = quantiles), one dense non-uniform cluster
+    (long segments: radix selection), a column whose every bucket is a candidate, two-valued and constant columns,
+    subnormals / huge magnitudes / negatives, and int64-bits columns over the whole int64 range."""
+    import torch
+    from oracle import ckernels, refex
+    rng = np.random.default_rng(n + 99)
+    base = rng.random(n)
+    out_hi = base.copy(); out_hi[1 % n::max(n // 7, 1)] = 1e300                      # huge outliers off the sample grid
+    out_lo = base + 10.0; out_lo[2 % n::max(n // 5, 1)] = -1e-300
+    cluster = 1.0 + rng.integers(0, 1 << 30, n) * 2.0 ** -52                         # one bucket, 2^30 distinct keys
+    cluster[::max(n // 3, 1)] = 1e6
+    cols = [
+        out_hi, out_lo,
+        np.sort(rng.pareto(1.3, n)), np.sort(rng.pareto(1.3, n))[::-1].copy(),
+        cluster,
+        np.arange(n, dtype=np.float64),                                               # every rank its own key
+        np.where(rng.random(n) < 0.5, 1.0, 2.0), np.full(n, -3.5),
+        rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n),                  # the whole exponent range
+        np.where(rng.random(n) < 0.2, 5e-324, 0.0) * rng.integers(0, 50, n),          # subnormals and zeros
+        -np.round(rng.pareto(1.1, n) * 20),                                           # negative integers, heavy ties
+    ]
+    wrapped = (rng.integers(-2 ** 63, 2 ** 63 - 1, n, dtype=np.int64, endpoint=True))
+    small_int = rng.integers(-5, 5, n).astype(np.int64)
+    near = (2 ** 53 + rng.integers(0, 3, n)).astype(np.int64)                         # distinct as int64, equal as fp64
+    icols = [wrapped, small_int, near]
+    for frac in (0.5, 0.25):
+        block = np.stack(cols + [c.view(np.float64) for c in icols])
+        flags = [False] * len(cols) + [True] * len(icols)
+        bins, nb = K.vertical_log_bin(torch.from_numpy(block).cuda(), frac, is_i64=flags)
+        got = bins.cpu().numpy()
+        for j, c in enumerate(cols):
+            exp = ckernels.vertical_log_binning(c, frac)
+            if exp.max() >= 128:
+                assert int(nb[j]) < 0
+                continue
+            assert np.array_equal(got[j], exp), f'col {j} frac {frac}'
+            assert int(nb[j]) == exp.max() + 1
+        for j, c in enumerate(icols):
+            exp = refex.vertical_log_binning(c, frac)                                 # numpy on the int64 array
+            if exp.max() >= 128:
+                assert int(nb[len(cols) + j]) < 0
+                continue
+            assert np.array_equal(got[len(cols) + j], exp), f'int64 col {j} frac {frac}'
+
+
 def test_log_bin_too_many_bins_is_reported(K):
     """frac so small that more than 128 bins are needed: the reference returns them, the device labels are
     7-bit -- the standalone API raises instead of returning saturated labels."""
