@@ -1274,12 +1274,15 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; v[j] = b < nb ? h[b] : 0u; M[b] = 0; }
     scan4(v, C);
-    if (t == 0) {
-        // first bucket whose inclusive prefix exceeds the rank
+    if (wave == 0) {
+        // first bucket whose inclusive prefix exceeds the rank: two 64-ary ballot steps (the whole wavefront walks)
         auto bucket_of = [&](int64_t pos) {
-            int lo = 0, hi = nb - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)C[mid] > pos) hi = mid; else lo = mid + 1; }
-            return lo;
+            const int coarse = lane * 64 + 63;
+            const bool gt = coarse < nb ? (int64_t)C[coarse] > pos : true;
+            const int blk = __ffsll((long long)__ballot(gt)) - 1;
+            const int fine = blk * 64 + lane;
+            const bool gt2 = fine < nb ? (int64_t)C[fine] > pos : true;
+            return blk * 64 + __ffsll((long long)__ballot(gt2)) - 1;
         };
         int64_t dlo = 0, dhi = 0;
         for (int step = 0; step < GRX_MAX_BINS && dlo < n; ++step) {
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
             int64_t phi = dh + shi - 1;
             if (phi < plo) phi = plo;
             const int jlo = bucket_of(plo), jhi = bucket_of(phi);
-            for (int j = jlo; j <= jhi; ++j) M[j] = 1;
+            for (int j = jlo + lane; j <= jhi; j += 64) M[j] = 1;
             dlo = plo + 1;                                      // the bin ends at or after its threshold's rank
             dhi = (int64_t)C[jhi];                              // ... and inside the threshold's bucket
             if (dhi < dlo) dhi = dlo;
@@ -1320,7 +1323,8 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
                                                           const SelRange *__restrict__ range, const uint8_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
-                                                          uint64_t *__restrict__ coll, ColFlags flags)
+                                                          uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
+                                                          unsigned long long *__restrict__ bmax, ColFlags flags)
 {
     __shared__ uint32_t cnt[SEL_NB];
     __shared__ uint32_t basev[SEL_NB];
@@ -1349,7 +1353,32 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
         keys[i] = value_key(raw[i], i64);
         bucket[i] = sel_bucket(keys[i], r.kmin, r.shift, r.nb);
         rank[i] = -1;
-        if (valid && M[bucket[i]]) { rank[i] = (int)atomicAdd(&cnt[bucket[i]], 1u); any = true; }
+        const bool want = valid && M[bucket[i]];
+        if (want) { rank[i] = (int)atomicAdd(&cnt[bucket[i]], 1u); any = true; }
+        // smallest / largest key of every marked bucket (the exact walk recognises a block of ties without reading it):
+        // one pair of atomics per wavefront when its wanted keys share a bucket -- the tie-heavy case -- else per key
+        const uint64_t active = __ballot(want);
+        if (active) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)active) - 1;
+            const int b0 = __shfl(bucket[i], leader, 64);
+            if (__ballot(want && bucket[i] != b0) == 0) {
+                uint64_t lo = want ? keys[i] : ~0ull, hi = want ? keys[i] : 0ull;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint64_t a = __shfl_xor(lo, off, 64), c = __shfl_xor(hi, off, 64);
+                    lo = a < lo ? a : lo;
+                    hi = c > hi ? c : hi;
+                }
+                if (lane == leader) {
+                    atomicMin(&bmin[(size_t)col * SEL_NB + b0], (unsigned long long)lo);
+                    atomicMax(&bmax[(size_t)col * SEL_NB + b0], (unsigned long long)hi);
+                }
+            } else if (want) {
+                atomicMin(&bmin[(size_t)col * SEL_NB + bucket[i]], (unsigned long long)keys[i]);
+                atomicMax(&bmax[(size_t)col * SEL_NB + bucket[i]], (unsigned long long)keys[i]);
+            }
+        }
     }
     if (__syncthreads_or(any) == 0) return;                     // nothing of this tile is wanted
     uint32_t *cur = cursor + (size_t)col * SEL_NB;
@@ -1363,13 +1392,13 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
         if (rank[i] >= 0) dst[basev[bucket[i]] + (uint32_t)rank[i]] = keys[i];
 }
 
-// the q-th smallest (0-based) key of an unordered segment and the number of its keys <= that key; whole workgroup
-// (256 threads), every thread returns the same values
-__device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t *tk_out,
-                                   int64_t *le_out, uint64_t *s_red, uint32_t *s_hist, uint64_t *s_pick)
+// the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
+// its keys <= that key; whole workgroup (256 threads), every thread returns the same values
+__device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
+                                   uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (len == 1) { *tk_out = seg[0]; *le_out = 1; return; }
+    if (mn == mx) { *tk_out = mn; *le_out = len; return; }      // a block of ties: nothing to read
     if (len <= 64) {
         const uint64_t mine = (lane < len) ? seg[lane] : ~0ull;
         int lt = 0, le = 0;
@@ -1384,54 +1413,59 @@ __device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len
         *le_out = __shfl(le, src, 64);
         return;
     }
-    uint64_t mn = ~0ull, mx = 0;
-    for (int64_t i = threadIdx.x; i < len; i += 256) {
-        const uint64_t v = seg[i];
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o1 = __shfl_xor(mn, off, 64), o2 = __shfl_xor(mx, off, 64);
-        mn = o1 < mn ? o1 : mn;
-        mx = o2 > mx ? o2 : mx;
-    }
-    __syncthreads();
-    if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
-    __syncthreads();
-    mn = s_red[0]; mx = s_red[4];
-    for (int w = 1; w < 4; ++w) { mn = s_red[w] < mn ? s_red[w] : mn; mx = s_red[4 + w] > mx ? s_red[4 + w] : mx; }
-    if (mn == mx) { *tk_out = mn; *le_out = len; return; }     // a block of ties
     // radix selection over the bytes in which the segment's keys can differ, most significant first
     const int top = (63 - __clzll((long long)(mn ^ mx))) >> 3;
     uint64_t prefix = top < 7 ? (mn >> (8 * (top + 1))) << (8 * (top + 1)) : 0ull;
     int64_t below = 0, qrem = q, equal = len;
-    for (int byte = top; byte >= 0; --byte) {
+    for (int byte = top; byte >= 0 && equal > 1; --byte) {
         __syncthreads();
         s_hist[threadIdx.x] = 0;
         __syncthreads();
         const int hs = 8 * (byte + 1);
-        for (int64_t i = threadIdx.x; i < len; i += 256) {
-            const uint64_t v = seg[i];
-            if (byte == 7 || (v >> hs) == (prefix >> hs)) atomicAdd(&s_hist[(uint32_t)(v >> (8 * byte)) & 0xFF], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t cumv = 0;
-            int d = 0;
-            for (; d < 255; ++d) {
-                if (cumv + (int64_t)s_hist[d] > qrem) break;
-                cumv += s_hist[d];
+        for (int64_t i0 = threadIdx.x; i0 < len; i0 += 256 * 8) {        // eight loads in flight
+            uint64_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int64_t i = i0 + (int64_t)j * 256; v[j] = seg[i < len ? i : len - 1]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = i0 + (int64_t)j * 256 < len && (byte == 7 || (v[j] >> hs) == (prefix >> hs));
+                if (in) atomicAdd(&s_hist[(uint32_t)(v[j] >> (8 * byte)) & 0xFF], 1u);
             }
-            s_pick[0] = (uint64_t)d;
-            s_pick[1] = (uint64_t)cumv;
         }
         __syncthreads();
-        const int d = (int)s_pick[0];
-        prefix |= (uint64_t)d << (8 * byte);
+        // digit d with cum(d - 1) <= qrem < cum(d): inclusive scan of the 256 counts, one per thread
+        const uint32_t cntd = s_hist[threadIdx.x];
+        uint32_t inc = cntd;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - cntd;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        if ((int64_t)before <= qrem && qrem < (int64_t)before + (int64_t)cntd) {   // exactly one thread
+            s_pick[0] = (uint64_t)threadIdx.x;
+            s_pick[1] = (uint64_t)before;
+            s_pick[2] = (uint64_t)cntd;
+        }
+        __syncthreads();
+        prefix |= s_pick[0] << (8 * byte);
         below += (int64_t)s_pick[1];
         qrem -= (int64_t)s_pick[1];
-        equal = (int64_t)s_hist[d];
+        equal = (int64_t)s_pick[2];
+        if (equal == 1 && byte > 0) {
+            // a single key carries the prefix: fetch it instead of resolving its remaining bytes one by one
+            __syncthreads();
+            const int hs2 = 8 * byte;
+            for (int64_t i = threadIdx.x; i < len; i += 256) {
+                const uint64_t v = seg[i];
+                if ((v >> hs2) == (prefix >> hs2)) s_pick[3] = v;
+            }
+            __syncthreads();
+            prefix = s_pick[3];
+        }
     }
     *tk_out = prefix;
     *le_out = below + equal;
@@ -1440,35 +1474,48 @@ __device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len
 __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
                                                         const uint32_t *__restrict__ cum, const uint8_t *__restrict__ mark,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
+                                                        const unsigned long long *__restrict__ bmin,
+                                                        const unsigned long long *__restrict__ bmax,
                                                         uint64_t *__restrict__ thr, int32_t *__restrict__ nbins,
                                                         int32_t *__restrict__ fault)
 {
-    __shared__ uint64_t s_red[8];
+    __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t s_hist[RADIX];
-    __shared__ uint64_t s_pick[2];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint64_t s_pick[4];
     const int col = blockIdx.x;
     const int nb_buckets = range[col].nb;
-    const uint32_t *C = cum + (size_t)col * SEL_NB;
+    for (int b = threadIdx.x; b < nb_buckets; b += 256) C[b] = cum[(size_t)col * SEL_NB + b];
+    __syncthreads();
     const uint64_t *segs = coll + (size_t)col * n;
     uint64_t *t = thr + (size_t)col * GRX_MAX_BINS;
+    const int lane = threadIdx.x & 63;
     int64_t done = 0;
     int nb = 0;
     while (done < n && nb < GRX_MAX_BINS) {
         int64_t size = (int64_t)(frac * (double)(n - done));
         if (size < 1) size = 1;
         const int64_t pos = done + size - 1;
-        int lo = 0, hi = nb_buckets - 1;                         // first bucket whose inclusive prefix exceeds pos
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)C[mid] > pos) hi = mid; else lo = mid + 1; }
-        const int j = lo;
+        // first bucket whose inclusive prefix exceeds pos: two 64-ary ballot steps over the 4096 prefixes
+        int j;
+        {
+            const int coarse = lane * 64 + 63;
+            const bool gt = coarse < nb_buckets ? (int64_t)C[coarse] > pos : true;
+            const int blk = __ffsll((long long)__ballot(gt)) - 1;
+            const int fine = blk * 64 + lane;
+            const bool gt2 = fine < nb_buckets ? (int64_t)C[fine] > pos : true;
+            j = blk * 64 + __ffsll((long long)__ballot(gt2)) - 1;
+        }
         const int64_t before = j ? (int64_t)C[j - 1] : 0;
         const int64_t len = (int64_t)C[j] - before;
-        if (!mark[(size_t)col * SEL_NB + j]) {                   // cannot happen: the interval walk covers every exact walk
+        const size_t cell = (size_t)col * SEL_NB + j;
+        if (!mark[cell]) {                                      // cannot happen: the interval walk covers every exact walk
             if (threadIdx.x == 0) atomicAdd(fault, 1);
             break;
         }
         uint64_t tk;
         int64_t le;
-        sel_segment_select(segs + seg_off[(size_t)col * SEL_NB + j], len, pos - before, &tk, &le, s_red, s_hist, s_pick);
+        sel_segment_select(segs + seg_off[cell], len, pos - before, bmin[cell], bmax[cell], &tk, &le, s_hist, s_wsum, s_pick);
         if (threadIdx.x == 0) t[nb] = tk;
         ++nb;
         done = before + le;
@@ -1568,15 +1615,17 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t range, hist, cum, seg_off, cursor, mark, coll, thr, nbins, fault, total; };
+struct SelLayout { size_t range, hist, cum, seg_off, cursor, bmax, bmin, mark, coll, thr, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
     L.range = take((size_t)ncols * sizeof(SelRange));
-    L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist and cursor are zeroed together
+    L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist, cursor, bmax (zeroed together)
     L.cursor = take((size_t)ncols * SEL_NB * 4);
+    L.bmax = take((size_t)ncols * SEL_NB * 8);
+    L.bmin = take((size_t)ncols * SEL_NB * 8);                  // all ones
     L.cum = take((size_t)ncols * SEL_NB * 4);
     L.seg_off = take((size_t)ncols * SEL_NB * 4);
     L.mark = take((size_t)ncols * SEL_NB);
@@ -1664,7 +1713,10 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
         int32_t *fault = reinterpret_cast<int32_t *>(ws + L.fault);
-        GRX_CHECK_HIP(hipMemsetAsync(hist, 0, L.cum - L.hist, st));                     // hist + cursor
+        unsigned long long *bmin = reinterpret_cast<unsigned long long *>(ws + L.bmin);
+        unsigned long long *bmax = reinterpret_cast<unsigned long long *>(ws + L.bmax);
+        GRX_CHECK_HIP(hipMemsetAsync(hist, 0, L.bmin - L.hist, st));                    // hist + cursor + bmax
+        GRX_CHECK_HIP(hipMemsetAsync(bmin, 0xFF, L.cum - L.bmin, st));
         GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
         {
             GRX_PROF(GRX_K_KEY_BITS, st);
@@ -1680,11 +1732,11 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         }
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, range, mark, seg_off, cursor, coll, flags);
+            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, range, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
             GRX_PROF(GRX_K_BIN_THRESHOLD, st);
-            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, range, cum, mark, seg_off, coll, thr, nb_ws, fault);
+            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, range, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();
         const int64_t want = grx_ceil_div(n, 256 * 4);
