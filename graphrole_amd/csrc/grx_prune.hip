@@ -1147,6 +1147,7 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 // are identical (both are exact); the sort path stays behind GRX_BIN_SORT=1 and in the A/B test.
 // =======================================================================================
 constexpr int SEL_NB = 4096;
+constexpr int SEL_MAX_IDS = 1024;                          // marked buckets with an LDS slot in the collect pass
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
 struct SelRange { uint64_t kmin; int shift; int nb; };
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 // segment offsets of the marked buckets.  One workgroup of 1024 threads per column (four buckets per thread).
 __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
                                                          const uint32_t *__restrict__ hist, uint32_t *__restrict__ cum,
-                                                         uint8_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
+                                                         uint16_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
 {
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t S[SEL_NB];
@@ -1314,25 +1315,43 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
         const int b = 4 * t + j;
         if (b < nb) {
             cum[(size_t)col * SEL_NB + b] = C[b];
-            mark[(size_t)col * SEL_NB + b] = M[b];
             seg_off[(size_t)col * SEL_NB + b] = S[b] - v[j];    // exclusive
+        }
+    }
+    // compact ids of the marked buckets (1-based; SEL_MAX_IDS and beyond share the last id: the collect pass serves
+    // those through global atomics)
+    uint32_t m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = M[4 * t + j] ? 1u : 0u;
+    scan4(m, S);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * t + j;
+        if (b < nb) {
+            const uint32_t id = S[b];                            // inclusive count = 1-based id
+            mark[(size_t)col * SEL_NB + b] = (uint16_t)(m[j] ? (id < SEL_MAX_IDS ? id : SEL_MAX_IDS) : 0u);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                          const SelRange *__restrict__ range, const uint8_t *__restrict__ mark,
+                                                          const SelRange *__restrict__ range, const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                           uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
                                                           unsigned long long *__restrict__ bmax, ColFlags flags)
 {
-    __shared__ uint32_t cnt[SEL_NB];
-    __shared__ uint32_t basev[SEL_NB];
-    __shared__ uint8_t M[SEL_NB];
+    // per marked bucket (compact id): how many keys of this tile, their smallest and largest, the bucket itself
+    __shared__ uint32_t cnt[SEL_MAX_IDS];
+    __shared__ uint32_t basev[SEL_MAX_IDS];
+    __shared__ uint16_t bucket_of_id[SEL_MAX_IDS];
+    __shared__ unsigned long long lo_id[SEL_MAX_IDS];
+    __shared__ unsigned long long hi_id[SEL_MAX_IDS];
+    __shared__ uint16_t M[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
     const SelRange r = range[col];
-    for (int b = threadIdx.x; b < r.nb; b += 256) { cnt[b] = 0; M[b] = mark[(size_t)col * SEL_NB + b]; }
+    for (int b = threadIdx.x; b < r.nb; b += 256) M[b] = mark[(size_t)col * SEL_NB + b];
+    for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
@@ -1344,52 +1363,49 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
         raw[i] = x[idx < n ? idx : last];
     }
     __builtin_amdgcn_sched_barrier(0);
+    uint64_t *dst = coll + (size_t)col * n;
+    uint32_t *cur = cursor + (size_t)col * SEL_NB;
+    const uint32_t *off = seg_off + (size_t)col * SEL_NB;
     uint64_t keys[SORT_ITEMS];
-    int rank[SORT_ITEMS], bucket[SORT_ITEMS];
+    int rank[SORT_ITEMS], id[SORT_ITEMS];
     bool any = false;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
         keys[i] = value_key(raw[i], i64);
-        bucket[i] = sel_bucket(keys[i], r.kmin, r.shift, r.nb);
+        const int b = sel_bucket(keys[i], r.kmin, r.shift, r.nb);
+        const int m = valid ? (int)M[b] : 0;
+        id[i] = m - 1;
         rank[i] = -1;
-        const bool want = valid && M[bucket[i]];
-        if (want) { rank[i] = (int)atomicAdd(&cnt[bucket[i]], 1u); any = true; }
-        // smallest / largest key of every marked bucket (the exact walk recognises a block of ties without reading it):
-        // one pair of atomics per wavefront when its wanted keys share a bucket -- the tie-heavy case -- else per key
-        const uint64_t active = __ballot(want);
-        if (active) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)active) - 1;
-            const int b0 = __shfl(bucket[i], leader, 64);
-            if (__ballot(want && bucket[i] != b0) == 0) {
-                uint64_t lo = want ? keys[i] : ~0ull, hi = want ? keys[i] : 0ull;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const uint64_t a = __shfl_xor(lo, off, 64), c = __shfl_xor(hi, off, 64);
-                    lo = a < lo ? a : lo;
-                    hi = c > hi ? c : hi;
-                }
-                if (lane == leader) {
-                    atomicMin(&bmin[(size_t)col * SEL_NB + b0], (unsigned long long)lo);
-                    atomicMax(&bmax[(size_t)col * SEL_NB + b0], (unsigned long long)hi);
-                }
-            } else if (want) {
-                atomicMin(&bmin[(size_t)col * SEL_NB + bucket[i]], (unsigned long long)keys[i]);
-                atomicMax(&bmax[(size_t)col * SEL_NB + bucket[i]], (unsigned long long)keys[i]);
-            }
+        if (m > 0 && m < SEL_MAX_IDS) {
+            rank[i] = (int)atomicAdd(&cnt[m - 1], 1u);
+            atomicMin(&lo_id[m - 1], (unsigned long long)keys[i]);
+            atomicMax(&hi_id[m - 1], (unsigned long long)keys[i]);
+            bucket_of_id[m - 1] = (uint16_t)b;                  // the same value from every writer
+            any = true;
+        } else if (m == SEL_MAX_IDS) {
+            // more marked buckets than LDS slots (a huge unresolved bucket followed by thousands of thin ones):
+            // straight to the segment through global atomics
+            const size_t cell = (size_t)col * SEL_NB + b;
+            dst[off[b] + atomicAdd(&cur[b], 1u)] = keys[i];
+            atomicMin(&bmin[cell], (unsigned long long)keys[i]);
+            atomicMax(&bmax[cell], (unsigned long long)keys[i]);
         }
     }
-    if (__syncthreads_or(any) == 0) return;                     // nothing of this tile is wanted
-    uint32_t *cur = cursor + (size_t)col * SEL_NB;
-    const uint32_t *off = seg_off + (size_t)col * SEL_NB;
-    for (int b = threadIdx.x; b < r.nb; b += 256)
-        if (cnt[b]) basev[b] = off[b] + atomicAdd(&cur[b], cnt[b]);
+    if (__syncthreads_or(any) == 0) return;                     // nothing of this tile has an LDS slot
+    for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) {
+        if (cnt[k]) {
+            const int b = bucket_of_id[k];
+            const size_t cell = (size_t)col * SEL_NB + b;
+            basev[k] = off[b] + atomicAdd(&cur[b], cnt[k]);
+            atomicMin(&bmin[cell], lo_id[k]);
+            atomicMax(&bmax[cell], hi_id[k]);
+        }
+    }
     __syncthreads();
-    uint64_t *dst = coll + (size_t)col * n;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i)
-        if (rank[i] >= 0) dst[basev[bucket[i]] + (uint32_t)rank[i]] = keys[i];
+        if (rank[i] >= 0) dst[basev[id[i]] + (uint32_t)rank[i]] = keys[i];
 }
 
 // the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
@@ -1472,7 +1488,7 @@ __device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len
 }
 
 __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
-                                                        const uint32_t *__restrict__ cum, const uint8_t *__restrict__ mark,
+                                                        const uint32_t *__restrict__ cum, const uint16_t *__restrict__ mark,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
                                                         const unsigned long long *__restrict__ bmin,
                                                         const unsigned long long *__restrict__ bmax,
@@ -1628,7 +1644,7 @@ SelLayout sel_layout(int64_t n, int ncols)
     L.bmin = take((size_t)ncols * SEL_NB * 8);                  // all ones
     L.cum = take((size_t)ncols * SEL_NB * 4);
     L.seg_off = take((size_t)ncols * SEL_NB * 4);
-    L.mark = take((size_t)ncols * SEL_NB);
+    L.mark = take((size_t)ncols * SEL_NB * 2);
     L.coll = take((size_t)ncols * (size_t)n * 8);
     L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
     L.nbins = take((size_t)ncols * 4);
@@ -1708,7 +1724,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.cursor);
         uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
         uint32_t *seg_off = reinterpret_cast<uint32_t *>(ws + L.seg_off);
-        uint8_t *mark = reinterpret_cast<uint8_t *>(ws + L.mark);
+        uint16_t *mark = reinterpret_cast<uint16_t *>(ws + L.mark);
         uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
