@@ -1147,65 +1147,76 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 // are identical (both are exact); the sort path stays behind GRX_BIN_SORT=1 and in the A/B test.
 // =======================================================================================
 constexpr int SEL_NB = 4096;
-constexpr int SEL_MAX_IDS = 1024;                          // marked buckets with an LDS slot in the collect pass
+constexpr int SEL_MAX_IDS = 512;                           // marked buckets with an LDS slot in the collect pass
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
-struct SelRange { uint64_t kmin; int shift; int nb; };
+constexpr int SEL_NSPLIT = SEL_NB - 1;                     // splitters per column; bucket = number of splitters < key
 
-__device__ __forceinline__ int sel_bucket(uint64_t key, uint64_t kmin, int shift, int nb)
+// bucket of a key: lower_bound over the sorted splitters in LDS (12 steps).  Keys equal to a splitter value share
+// the bucket of its first occurrence, so a heavily tied value fills ONE bucket and nothing else does.
+__device__ __forceinline__ int sel_bucket(const uint64_t *__restrict__ sp, uint64_t key)
 {
-    if (key <= kmin) return 0;
-    const uint64_t b = (key - kmin) >> shift;
-    return b >= (uint64_t)nb ? nb - 1 : (int)b;
+    int lo = 0, n = SEL_NSPLIT;                                // invariant: answer in [lo, lo + n]
+#pragma unroll
+    for (int step = 0; step < 12; ++step) {
+        const int half = n >> 1;
+        const bool right = sp[lo + half] < key;
+        lo = right ? lo + half + 1 : lo;
+        n = right ? n - half - 1 : half;
+    }
+    return lo;
 }
 
-__global__ __launch_bounds__(256) void sel_range_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                        SelRange *__restrict__ range, ColFlags flags)
+// 4095 strided samples of a column, sorted (bitonic, one workgroup of 1024 threads): the bucket boundaries.  Sampled
+// boundaries adapt to the distribution -- a bucket holds ~n / 4096 keys wherever the data is dense, unless they are
+// ties -- so the segments the exact walk selects in stay short; a linear map of the key range (tried first) left
+// tens of thousands of unequal keys in the buckets around the median of a 5 M-row column.
+__global__ __launch_bounds__(1024) void sel_splitters_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                             uint64_t *__restrict__ splitters, ColFlags flags)
 {
-    const int col = blockIdx.x;
+    __shared__ uint64_t s[SEL_NB];
+    const int col = blockIdx.x, t = threadIdx.x;
     const bool i64 = col_is_i64(flags, col);
     const double *x = cols + (size_t)col * ld;
-    uint64_t mn = ~0ull, mx = 0ull;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int64_t s = (int64_t)threadIdx.x * 4 + j;
-        int64_t idx;
-        if (n <= 1024) { if (s >= n) continue; idx = s; }
-        else idx = (s * (n - 1)) / 1023;
-        const uint64_t k = value_key(x[idx], i64);
-        mn = k < mn ? k : mn;
-        mx = k > mx ? k : mx;
+        const int64_t k = (int64_t)t * 4 + j;                  // sample number 0 .. 4095 (the last one is padding)
+        uint64_t key = ~0ull;
+        if (k < SEL_NSPLIT) {
+            if (n <= SEL_NSPLIT) { if (k < n) key = value_key(x[k], i64); }
+            else key = value_key(x[(k * (n - 1)) / (SEL_NSPLIT - 1)], i64);
+        }
+        s[k] = key;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    __shared__ uint64_t red[8];
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mn; red[4 + (threadIdx.x >> 6)] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
-        const uint64_t span = mx - mn;
-        const int bits = span ? 64 - __clzll((long long)span) : 0;
-        SelRange r;
-        r.kmin = mn;
-        r.shift = bits > 12 ? bits - 12 : 0;
-        r.nb = (int)(span >> r.shift) + 1;
-        range[col] = r;
+    for (int size = 2; size <= SEL_NB; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pair = t + j * 1024;                  // 2048 compare-exchanges per step
+                const int i = 2 * pair - (pair & (stride - 1));
+                const int k = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = s[i], b = s[k];
+                if ((a > b) == up) { s[i] = b; s[k] = a; }
+            }
+            __syncthreads();
+        }
     }
+    uint64_t *out = splitters + (size_t)col * SEL_NB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[t * 4 + j] = s[t * 4 + j];
 }
 
 __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                       const SelRange *__restrict__ range, uint32_t *__restrict__ hist,
+                                                       const uint64_t *__restrict__ splitters, uint32_t *__restrict__ hist,
                                                        ColFlags flags)
 {
     __shared__ uint32_t h[SEL_NB];
+    __shared__ uint64_t sp[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
-    const SelRange r = range[col];
-    for (int b = threadIdx.x; b < r.nb; b += 256) h[b] = 0;
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { h[b] = 0; sp[b] = splitters[(size_t)col * SEL_NB + b]; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)blockIdx.x * SEL_HIST_TILE;
@@ -1222,7 +1233,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
-            const int b = sel_bucket(value_key(raw[j], i64), r.kmin, r.shift, r.nb);
+            const int b = sel_bucket(sp, value_key(raw[j], i64));
             // heavy ties put a whole wavefront into one bucket: one atomic for all of it
             const uint64_t active = __ballot(valid);
             if (active == 0) continue;
@@ -1236,13 +1247,13 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
     }
     __syncthreads();
     uint32_t *out = hist + (size_t)col * SEL_NB;
-    for (int b = threadIdx.x; b < r.nb; b += 256)
+    for (int b = threadIdx.x; b < SEL_NB; b += 256)
         if (h[b]) atomicAdd(&out[b], h[b]);
 }
 
 // prefix sums of the bucket counts, the interval walk that marks the buckets a threshold can fall into, and the
 // segment offsets of the marked buckets.  One workgroup of 1024 threads per column (four buckets per thread).
-__global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
+__global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
                                                          const uint32_t *__restrict__ hist, uint32_t *__restrict__ cum,
                                                          uint16_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
 {
@@ -1251,7 +1262,7 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
     __shared__ uint8_t M[SEL_NB];
     __shared__ uint32_t wsum[16];
     const int col = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int nb = range[col].nb;
+    constexpr int nb = SEL_NB;
     const uint32_t *h = hist + (size_t)col * SEL_NB;
     auto scan4 = [&](uint32_t (&v)[4], uint32_t *dst) {            // inclusive scan of 4096 values, 4 per thread, into dst
         const uint32_t local = v[0] + v[1] + v[2] + v[3];
@@ -1335,7 +1346,7 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
 }
 
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                          const SelRange *__restrict__ range, const uint16_t *__restrict__ mark,
+                                                          const uint64_t *__restrict__ splitters, const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                           uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
                                                           unsigned long long *__restrict__ bmax, ColFlags flags)
@@ -1347,10 +1358,10 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     __shared__ unsigned long long lo_id[SEL_MAX_IDS];
     __shared__ unsigned long long hi_id[SEL_MAX_IDS];
     __shared__ uint16_t M[SEL_NB];
+    __shared__ uint64_t sp[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
-    const SelRange r = range[col];
-    for (int b = threadIdx.x; b < r.nb; b += 256) M[b] = mark[(size_t)col * SEL_NB + b];
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; sp[b] = splitters[(size_t)col * SEL_NB + b]; }
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
@@ -1373,7 +1384,7 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
         keys[i] = value_key(raw[i], i64);
-        const int b = sel_bucket(keys[i], r.kmin, r.shift, r.nb);
+        const int b = sel_bucket(sp, keys[i]);
         const int m = valid ? (int)M[b] : 0;
         id[i] = m - 1;
         rank[i] = -1;
@@ -1487,7 +1498,7 @@ __device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len
     *le_out = below + equal;
 }
 
-__global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac, const SelRange *__restrict__ range,
+__global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
                                                         const uint32_t *__restrict__ cum, const uint16_t *__restrict__ mark,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
                                                         const unsigned long long *__restrict__ bmin,
@@ -1500,7 +1511,7 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac, 
     __shared__ uint32_t s_wsum[4];
     __shared__ uint64_t s_pick[4];
     const int col = blockIdx.x;
-    const int nb_buckets = range[col].nb;
+    constexpr int nb_buckets = SEL_NB;
     for (int b = threadIdx.x; b < nb_buckets; b += 256) C[b] = cum[(size_t)col * SEL_NB + b];
     __syncthreads();
     const uint64_t *segs = coll + (size_t)col * n;
@@ -1637,7 +1648,7 @@ SelLayout sel_layout(int64_t n, int ncols)
     SelLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
-    L.range = take((size_t)ncols * sizeof(SelRange));
+    L.range = take((size_t)ncols * SEL_NB * 8);                 // sorted sample keys (bucket boundaries)
     L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist, cursor, bmax (zeroed together)
     L.cursor = take((size_t)ncols * SEL_NB * 4);
     L.bmax = take((size_t)ncols * SEL_NB * 8);
@@ -1719,7 +1730,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
     if (!use_sort) {
         // binning without sorting: sample range -> bucket histogram -> interval walk -> collect -> exact walk -> assign
         const SelLayout L = sel_layout(n, ncols);
-        SelRange *range = reinterpret_cast<SelRange *>(ws + L.range);
+        uint64_t *splitters = reinterpret_cast<uint64_t *>(ws + L.range);
         uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
         uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.cursor);
         uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
@@ -1736,23 +1747,23 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
         {
             GRX_PROF(GRX_K_KEY_BITS, st);
-            sel_range_kernel<<<ncols, 256, 0, st>>>(d_cols, ld, n, range, flags);
+            sel_splitters_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, splitters, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, range, hist, flags);
+            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, splitters, hist, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
-            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, range, hist, cum, mark, seg_off);
+            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, hist, cum, mark, seg_off);
         }
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, range, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, splitters, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
             GRX_PROF(GRX_K_BIN_THRESHOLD, st);
-            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, range, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
+            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();
         const int64_t want = grx_ceil_div(n, 256 * 4);
