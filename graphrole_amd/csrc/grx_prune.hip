@@ -1131,8 +1131,10 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 // =======================================================================================
 // Binning WITHOUT sorting (round 3).  prune.py:13-56 needs ~20 order statistics of a column and the ends of their
 // tie runs -- not a sorted column.  Per column:
-//   sel_range_kernel    1024 strided samples -> [kmin, kmax] of the order keys -> a linear map of the key space onto
-//                       <= 4096 buckets (keys outside the sampled range fall into the end buckets: monotone, exact)
+//   sel_map_kernel      4095 strided samples -> [kmin, kmax] of the order keys -> a linear map of the key range onto
+//                       4096 cells, refined by a LUT: a cell with s samples is split into 2^floor(log2 s) buckets,
+//                       empty cells merge into their successor (keys outside the sampled range fall into the end
+//                       buckets: the map is monotone, the counts exact)
 //   sel_hist_kernel     ONE pass: bucket histogram (LDS, wave-aggregated atomics)
 //   sel_walk1_kernel    prefix sums; the threshold walk in INTERVAL arithmetic over the bucket boundaries (the exact
 //                       end of a tie run is unknown yet, so `done` is an interval [lo, hi]): every bucket a threshold
@@ -1150,73 +1152,121 @@ constexpr int SEL_NB = 4096;
 constexpr int SEL_MAX_IDS = 512;                           // marked buckets with an LDS slot in the collect pass
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
-constexpr int SEL_NSPLIT = SEL_NB - 1;                     // splitters per column; bucket = number of splitters < key
+// The bucket map of a column: a LINEAR map of the sampled key range onto 4096 cells, refined by a look-up table built
+// from 4095 strided samples -- a cell that holds s samples is split into 2^floor(log2 s) buckets (<= 4095 in total),
+// empty cells share the first bucket of the next occupied cell.  One LDS read and a few shifts per key (a binary search
+// over sorted sample splitters, tried first, cost 12 dependent LDS reads per key and tripled both streaming passes),
+// and a bucket holds ~n / 4096 keys wherever the data is dense -- unless they are ties.  Monotone in the key, so
+// every bucket is a contiguous range of the order.
+struct SelMap { uint64_t kmin; int shift; int ncells; int nb; };
+constexpr int SEL_NSAMPLE = SEL_NB - 1;
 
-// bucket of a key: lower_bound over the sorted splitters in LDS (12 steps).  Keys equal to a splitter value share
-// the bucket of its first occurrence, so a heavily tied value fills ONE bucket and nothing else does.
-__device__ __forceinline__ int sel_bucket(const uint64_t *__restrict__ sp, uint64_t key)
+// LUT entry of a cell: first bucket | log2(number of buckets) << 16
+__device__ __forceinline__ int sel_bucket(const SelMap &m, const uint32_t *__restrict__ lut, uint64_t key)
 {
-    int lo = 0, n = SEL_NSPLIT;                                // invariant: answer in [lo, lo + n]
-#pragma unroll
-    for (int step = 0; step < 12; ++step) {
-        const int half = n >> 1;
-        const bool right = sp[lo + half] < key;
-        lo = right ? lo + half + 1 : lo;
-        n = right ? n - half - 1 : half;
-    }
-    return lo;
+    if (key <= m.kmin) return 0;
+    const uint64_t rel = key - m.kmin;
+    uint64_t c = rel >> m.shift;
+    if (c >= (uint64_t)m.ncells) return m.nb - 1;               // above the sampled range: the last bucket
+    const uint32_t e = lut[c];
+    const int k = (int)(e >> 16);
+    const uint64_t within = rel - (c << m.shift);               // offset inside the cell, < 2^shift
+    return (int)(e & 0xFFFFu) + (int)(within >> (m.shift - k));
 }
 
-// 4095 strided samples of a column, sorted (bitonic, one workgroup of 1024 threads): the bucket boundaries.  Sampled
-// boundaries adapt to the distribution -- a bucket holds ~n / 4096 keys wherever the data is dense, unless they are
-// ties -- so the segments the exact walk selects in stay short; a linear map of the key range (tried first) left
-// tens of thousands of unequal keys in the buckets around the median of a 5 M-row column.
-__global__ __launch_bounds__(1024) void sel_splitters_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                             uint64_t *__restrict__ splitters, ColFlags flags)
+__global__ __launch_bounds__(1024) void sel_map_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                       SelMap *__restrict__ maps, uint32_t *__restrict__ luts, ColFlags flags)
 {
-    __shared__ uint64_t s[SEL_NB];
-    const int col = blockIdx.x, t = threadIdx.x;
+    __shared__ uint32_t cnt[SEL_NB];
+    __shared__ uint64_t red[32];
+    __shared__ uint32_t wsum[16];
+    __shared__ SelMap s_map;
+    const int col = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool i64 = col_is_i64(flags, col);
     const double *x = cols + (size_t)col * ld;
+    uint64_t key[4];
+    bool have[4];
+    uint64_t mn = ~0ull, mx = 0ull;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int64_t k = (int64_t)t * 4 + j;                  // sample number 0 .. 4095 (the last one is padding)
-        uint64_t key = ~0ull;
-        if (k < SEL_NSPLIT) {
-            if (n <= SEL_NSPLIT) { if (k < n) key = value_key(x[k], i64); }
-            else key = value_key(x[(k * (n - 1)) / (SEL_NSPLIT - 1)], i64);
+        const int64_t k = (int64_t)t * 4 + j;                  // sample number
+        have[j] = k < SEL_NSAMPLE && (n > SEL_NSAMPLE || k < n);
+        key[j] = 0;
+        if (have[j]) {
+            key[j] = value_key(x[n > SEL_NSAMPLE ? (k * (n - 1)) / (SEL_NSAMPLE - 1) : k], i64);
+            mn = key[j] < mn ? key[j] : mn;
+            mx = key[j] > mx ? key[j] : mx;
         }
-        s[k] = key;
+        cnt[4 * t + j] = 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane == 0) { red[wave] = mn; red[16 + wave] = mx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[16 + w] > mx ? red[16 + w] : mx; }
+        const uint64_t span = mx - mn;
+        const int bits = span ? 64 - __clzll((long long)span) : 0;
+        s_map.kmin = mn;
+        s_map.shift = bits > 12 ? bits - 12 : 0;
+        s_map.ncells = (int)(span >> s_map.shift) + 1;
+        s_map.nb = 0;
     }
     __syncthreads();
-    for (int size = 2; size <= SEL_NB; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    const SelMap m = s_map;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pair = t + j * 1024;                  // 2048 compare-exchanges per step
-                const int i = 2 * pair - (pair & (stride - 1));
-                const int k = i + stride;
-                const bool up = (i & size) == 0;
-                const uint64_t a = s[i], b = s[k];
-                if ((a > b) == up) { s[i] = b; s[k] = a; }
-            }
-            __syncthreads();
-        }
+    for (int j = 0; j < 4; ++j)
+        if (have[j]) atomicAdd(&cnt[(key[j] - m.kmin) >> m.shift], 1u);
+    __syncthreads();
+    // buckets per cell: 2^min(floor(log2 s), shift) for s samples, none for an empty cell; exclusive prefix = first bucket
+    uint32_t alloc[4], kk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t sc = cnt[4 * t + j];
+        int k = sc ? 31 - __clz((int)sc) : 0;
+        if (k > m.shift) k = m.shift;
+        kk[j] = (uint32_t)k;
+        alloc[j] = sc ? (1u << k) : 0u;
     }
-    uint64_t *out = splitters + (size_t)col * SEL_NB;
+    const uint32_t local = alloc[0] + alloc[1] + alloc[2] + alloc[3];
+    uint32_t inc = local;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[t * 4 + j] = s[t * 4 + j];
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - local;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    uint32_t *lut = luts + (size_t)col * SEL_NB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lut[4 * t + j] = run | (kk[j] << 16);
+        run += alloc[j];
+    }
+    if (t == 1023) {
+        // one more bucket behind the last cell's: keys above the sampled range and trailing empty cells end there
+        SelMap out = m;
+        out.nb = (int)run + 1;
+        maps[col] = out;
+    }
 }
 
 __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                       const uint64_t *__restrict__ splitters, uint32_t *__restrict__ hist,
-                                                       ColFlags flags)
+                                                       const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
+                                                       uint32_t *__restrict__ hist, ColFlags flags)
 {
     __shared__ uint32_t h[SEL_NB];
-    __shared__ uint64_t sp[SEL_NB];
+    __shared__ uint32_t lut[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) { h[b] = 0; sp[b] = splitters[(size_t)col * SEL_NB + b]; }
+    const SelMap m = maps[col];
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { h[b] = 0; lut[b] = luts[(size_t)col * SEL_NB + b]; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)blockIdx.x * SEL_HIST_TILE;
@@ -1233,7 +1283,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
-            const int b = sel_bucket(sp, value_key(raw[j], i64));
+            const int b = sel_bucket(m, lut, value_key(raw[j], i64));
             // heavy ties put a whole wavefront into one bucket: one atomic for all of it
             const uint64_t active = __ballot(valid);
             if (active == 0) continue;
@@ -1346,7 +1396,8 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
 }
 
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                          const uint64_t *__restrict__ splitters, const uint16_t *__restrict__ mark,
+                                                          const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
+                                                          const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                           uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
                                                           unsigned long long *__restrict__ bmax, ColFlags flags)
@@ -1358,10 +1409,11 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     __shared__ unsigned long long lo_id[SEL_MAX_IDS];
     __shared__ unsigned long long hi_id[SEL_MAX_IDS];
     __shared__ uint16_t M[SEL_NB];
-    __shared__ uint64_t sp[SEL_NB];
+    __shared__ uint32_t lut[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; sp[b] = splitters[(size_t)col * SEL_NB + b]; }
+    const SelMap m = maps[col];
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; lut[b] = luts[(size_t)col * SEL_NB + b]; }
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
@@ -1384,17 +1436,17 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
         keys[i] = value_key(raw[i], i64);
-        const int b = sel_bucket(sp, keys[i]);
-        const int m = valid ? (int)M[b] : 0;
-        id[i] = m - 1;
+        const int b = sel_bucket(m, lut, keys[i]);
+        const int mk = valid ? (int)M[b] : 0;
+        id[i] = mk - 1;
         rank[i] = -1;
-        if (m > 0 && m < SEL_MAX_IDS) {
-            rank[i] = (int)atomicAdd(&cnt[m - 1], 1u);
-            atomicMin(&lo_id[m - 1], (unsigned long long)keys[i]);
-            atomicMax(&hi_id[m - 1], (unsigned long long)keys[i]);
-            bucket_of_id[m - 1] = (uint16_t)b;                  // the same value from every writer
+        if (mk > 0 && mk < SEL_MAX_IDS) {
+            rank[i] = (int)atomicAdd(&cnt[mk - 1], 1u);
+            atomicMin(&lo_id[mk - 1], (unsigned long long)keys[i]);
+            atomicMax(&hi_id[mk - 1], (unsigned long long)keys[i]);
+            bucket_of_id[mk - 1] = (uint16_t)b;                 // the same value from every writer
             any = true;
-        } else if (m == SEL_MAX_IDS) {
+        } else if (mk == SEL_MAX_IDS) {
             // more marked buckets than LDS slots (a huge unresolved bucket followed by thousands of thin ones):
             // straight to the segment through global atomics
             const size_t cell = (size_t)col * SEL_NB + b;
@@ -1642,13 +1694,14 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t range, hist, cum, seg_off, cursor, bmax, bmin, mark, coll, thr, nbins, fault, total; };
+struct SelLayout { size_t maps, luts, hist, cum, seg_off, cursor, bmax, bmin, mark, coll, thr, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
-    L.range = take((size_t)ncols * SEL_NB * 8);                 // sorted sample keys (bucket boundaries)
+    L.maps = take((size_t)ncols * sizeof(SelMap));
+    L.luts = take((size_t)ncols * SEL_NB * 4);
     L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist, cursor, bmax (zeroed together)
     L.cursor = take((size_t)ncols * SEL_NB * 4);
     L.bmax = take((size_t)ncols * SEL_NB * 8);
@@ -1730,7 +1783,8 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
     if (!use_sort) {
         // binning without sorting: sample range -> bucket histogram -> interval walk -> collect -> exact walk -> assign
         const SelLayout L = sel_layout(n, ncols);
-        uint64_t *splitters = reinterpret_cast<uint64_t *>(ws + L.range);
+        SelMap *maps = reinterpret_cast<SelMap *>(ws + L.maps);
+        uint32_t *luts = reinterpret_cast<uint32_t *>(ws + L.luts);
         uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
         uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.cursor);
         uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
@@ -1747,11 +1801,11 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
         {
             GRX_PROF(GRX_K_KEY_BITS, st);
-            sel_splitters_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, splitters, flags);
+            sel_map_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, maps, luts, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, splitters, hist, flags);
+            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, hist, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
@@ -1759,7 +1813,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         }
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
-            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, splitters, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
             GRX_PROF(GRX_K_BIN_THRESHOLD, st);
