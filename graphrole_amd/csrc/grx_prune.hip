@@ -1174,9 +1174,17 @@ __device__ __forceinline__ int sel_bucket(const SelMap &m, const uint32_t *__res
     return (int)(e & 0xFFFFu) + (int)(within >> (m.shift - k));
 }
 
+constexpr int SEL_MAX_TIES = 511;                          // tie-block candidates per column (ids 1 .. 511)
+
 __global__ __launch_bounds__(1024) void sel_map_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                       SelMap *__restrict__ maps, uint32_t *__restrict__ luts, ColFlags flags)
+                                                       SelMap *__restrict__ maps, uint32_t *__restrict__ luts,
+                                                       uint16_t *__restrict__ tie_of_bucket, uint64_t *__restrict__ tie_value,
+                                                       ColFlags flags)
 {
+    __shared__ unsigned long long smin[SEL_NB];
+    __shared__ unsigned long long smax[SEL_NB];
+    __shared__ uint32_t scnt[SEL_NB];
+    __shared__ uint32_t s_lut[SEL_NB];
     __shared__ uint32_t cnt[SEL_NB];
     __shared__ uint64_t red[32];
     __shared__ uint32_t wsum[16];
@@ -1246,27 +1254,79 @@ __global__ __launch_bounds__(1024) void sel_map_kernel(const double *__restrict_
     uint32_t *lut = luts + (size_t)col * SEL_NB;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        lut[4 * t + j] = run | (kk[j] << 16);
+        const uint32_t e = run | (kk[j] << 16);
+        lut[4 * t + j] = e;
+        s_lut[4 * t + j] = e;
         run += alloc[j];
+        smin[4 * t + j] = ~0ull; smax[4 * t + j] = 0ull; scnt[4 * t + j] = 0;
     }
     if (t == 1023) {
         // one more bucket behind the last cell's: keys above the sampled range and trailing empty cells end there
-        SelMap out = m;
-        out.nb = (int)run + 1;
-        maps[col] = out;
+        s_map.nb = (int)run + 1;
+        maps[col] = s_map;
+    }
+    __syncthreads();
+    // Tie-block candidates: a bucket whose samples (two or more) are all equal.  The histogram pass CERTIFIES them --
+    // it compares every key that lands in such a bucket with the sampled value and flags the bucket on a mismatch --
+    // so that the interval walk knows exactly where a bin ends when its threshold falls into a block of ties (a
+    // bucket of 30 % equal keys would otherwise leave the next thresholds anywhere in hundreds of buckets).
+    const SelMap mm = s_map;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (have[j]) {
+            const int b = sel_bucket(mm, s_lut, key[j]);
+            atomicAdd(&scnt[b], 1u);
+            atomicMin(&smin[b], (unsigned long long)key[j]);
+            atomicMax(&smax[b], (unsigned long long)key[j]);
+        }
+    }
+    __syncthreads();
+    uint32_t cand[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; cand[j] = (scnt[b] >= 2 && smin[b] == smax[b]) ? 1u : 0u; }
+    const uint32_t lc = cand[0] + cand[1] + cand[2] + cand[3];
+    uint32_t ic = lc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(ic, off, 64);
+        if (lane >= off) ic += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = ic;
+    __syncthreads();
+    uint32_t id = ic - lc;
+    for (int w = 0; w < wave; ++w) id += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * t + j;
+        uint16_t tid = 0;
+        if (cand[j]) {
+            ++id;
+            if (id <= SEL_MAX_TIES) { tid = (uint16_t)id; tie_value[(size_t)col * (SEL_MAX_TIES + 1) + id] = smin[b]; }
+        }
+        tie_of_bucket[(size_t)col * SEL_NB + b] = tid;
     }
 }
 
 __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
                                                        const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
+                                                       const uint16_t *__restrict__ tie_of_bucket,
+                                                       const uint64_t *__restrict__ tie_value, uint8_t *__restrict__ tie_broken,
                                                        uint32_t *__restrict__ hist, ColFlags flags)
 {
     __shared__ uint32_t h[SEL_NB];
     __shared__ uint32_t lut[SEL_NB];
+    __shared__ uint16_t tieb[SEL_NB];
+    __shared__ uint64_t tiev[SEL_MAX_TIES + 1];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
     const SelMap m = maps[col];
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) { h[b] = 0; lut[b] = luts[(size_t)col * SEL_NB + b]; }
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) {
+        h[b] = 0;
+        lut[b] = luts[(size_t)col * SEL_NB + b];
+        tieb[b] = tie_of_bucket[(size_t)col * SEL_NB + b];
+    }
+    for (int k = threadIdx.x; k <= SEL_MAX_TIES; k += 256) tiev[k] = tie_value[(size_t)col * (SEL_MAX_TIES + 1) + k];
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)blockIdx.x * SEL_HIST_TILE;
@@ -1283,7 +1343,10 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
-            const int b = sel_bucket(m, lut, value_key(raw[j], i64));
+            const uint64_t key = value_key(raw[j], i64);
+            const int b = sel_bucket(m, lut, key);
+            const int tid = valid ? (int)tieb[b] : 0;
+            if (tid && tiev[tid] != key) tie_broken[(size_t)col * SEL_NB + b] = 1;     // not a block of ties after all
             // heavy ties put a whole wavefront into one bucket: one atomic for all of it
             const uint64_t active = __ballot(valid);
             if (active == 0) continue;
@@ -1304,9 +1367,11 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 // prefix sums of the bucket counts, the interval walk that marks the buckets a threshold can fall into, and the
 // segment offsets of the marked buckets.  One workgroup of 1024 threads per column (four buckets per thread).
 __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
-                                                         const uint32_t *__restrict__ hist, uint32_t *__restrict__ cum,
+                                                         const uint32_t *__restrict__ hist, const uint16_t *__restrict__ tie_of_bucket,
+                                                         const uint8_t *__restrict__ tie_broken, uint32_t *__restrict__ cum,
                                                          uint16_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
 {
+    __shared__ uint8_t TIE[SEL_NB];                              // certified block of ties
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t S[SEL_NB];
     __shared__ uint8_t M[SEL_NB];
@@ -1334,7 +1399,12 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
     };
     uint32_t v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; v[j] = b < nb ? h[b] : 0u; M[b] = 0; }
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * t + j;
+        v[j] = b < nb ? h[b] : 0u;
+        M[b] = 0;
+        TIE[b] = (tie_of_bucket[(size_t)col * SEL_NB + b] != 0 && tie_broken[(size_t)col * SEL_NB + b] == 0) ? 1 : 0;
+    }
     scan4(v, C);
     if (wave == 0) {
         // first bucket whose inclusive prefix exceeds the rank: two 64-ary ballot steps (the whole wavefront walks)
@@ -1358,8 +1428,10 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
             if (phi < plo) phi = plo;
             const int jlo = bucket_of(plo), jhi = bucket_of(phi);
             for (int j = jlo + lane; j <= jhi; j += 64) M[j] = 1;
-            dlo = plo + 1;                                      // the bin ends at or after its threshold's rank
-            dhi = (int64_t)C[jhi];                              // ... and inside the threshold's bucket
+            // the bin ends at or after its threshold's rank and inside the threshold's bucket -- at the END of the bucket
+            // when that is a certified block of ties
+            dlo = TIE[jlo] ? (int64_t)C[jlo] : plo + 1;
+            dhi = (int64_t)C[jhi];
             if (dhi < dlo) dhi = dlo;
         }
     }
@@ -1694,7 +1766,7 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t maps, luts, hist, cum, seg_off, cursor, bmax, bmin, mark, coll, thr, nbins, fault, total; };
+struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, coll, thr, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
@@ -1702,9 +1774,12 @@ SelLayout sel_layout(int64_t n, int ncols)
     auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
     L.maps = take((size_t)ncols * sizeof(SelMap));
     L.luts = take((size_t)ncols * SEL_NB * 4);
+    L.tieb = take((size_t)ncols * SEL_NB * 2);
+    L.tiev = take((size_t)ncols * (SEL_MAX_TIES + 1) * 8);
     L.hist = take((size_t)ncols * SEL_NB * 4);                  // hist, cursor, bmax (zeroed together)
     L.cursor = take((size_t)ncols * SEL_NB * 4);
     L.bmax = take((size_t)ncols * SEL_NB * 8);
+    L.tbroken = take((size_t)ncols * SEL_NB);                   // (zeroed with the three before it)
     L.bmin = take((size_t)ncols * SEL_NB * 8);                  // all ones
     L.cum = take((size_t)ncols * SEL_NB * 4);
     L.seg_off = take((size_t)ncols * SEL_NB * 4);
@@ -1785,6 +1860,9 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         const SelLayout L = sel_layout(n, ncols);
         SelMap *maps = reinterpret_cast<SelMap *>(ws + L.maps);
         uint32_t *luts = reinterpret_cast<uint32_t *>(ws + L.luts);
+        uint16_t *tieb = reinterpret_cast<uint16_t *>(ws + L.tieb);
+        uint64_t *tiev = reinterpret_cast<uint64_t *>(ws + L.tiev);
+        uint8_t *tbroken = reinterpret_cast<uint8_t *>(ws + L.tbroken);
         uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
         uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.cursor);
         uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
@@ -1801,15 +1879,15 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
         {
             GRX_PROF(GRX_K_KEY_BITS, st);
-            sel_map_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, maps, luts, flags);
+            sel_map_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_COUNT, st);
-            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, hist, flags);
+            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, flags);
         }
         {
             GRX_PROF(GRX_K_SORT_SCAN, st);
-            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, hist, cum, mark, seg_off);
+            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, hist, tieb, tbroken, cum, mark, seg_off);
         }
         {
             GRX_PROF(GRX_K_SORT_SCATTER, st);
