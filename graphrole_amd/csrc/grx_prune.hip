@@ -1545,11 +1545,22 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
 
 // the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
 // its keys <= that key; whole workgroup (256 threads), every thread returns the same values
-__device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
-                                   uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick)
+constexpr int SEL_STAGE = 4096;                            // keys of a segment the exact walk stages in LDS
+
+__device__ void sel_segment_select(const uint64_t *__restrict__ seg_global, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
+                                   uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick,
+                                   uint64_t *s_stage)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (mn == mx) { *tk_out = mn; *le_out = len; return; }      // a block of ties: nothing to read
+    const uint64_t *seg = seg_global;
+    if (len > 64 && len <= SEL_STAGE) {
+        // one trip to memory for the whole segment, the selection passes then run on LDS
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < len; i += 256) s_stage[i] = seg_global[i];
+        __syncthreads();
+        seg = s_stage;
+    }
     if (len <= 64) {
         const uint64_t mine = (lane < len) ? seg[lane] : ~0ull;
         int lt = 0, le = 0;
@@ -1631,12 +1642,19 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
                                                         int32_t *__restrict__ fault)
 {
     __shared__ uint32_t C[SEL_NB];
+    __shared__ uint32_t SO[SEL_NB];
+    __shared__ uint16_t MK[SEL_NB];
+    __shared__ uint64_t s_stage[SEL_STAGE];
     __shared__ uint32_t s_hist[RADIX];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint64_t s_pick[4];
     const int col = blockIdx.x;
     constexpr int nb_buckets = SEL_NB;
-    for (int b = threadIdx.x; b < nb_buckets; b += 256) C[b] = cum[(size_t)col * SEL_NB + b];
+    for (int b = threadIdx.x; b < nb_buckets; b += 256) {
+        C[b] = cum[(size_t)col * SEL_NB + b];
+        SO[b] = seg_off[(size_t)col * SEL_NB + b];
+        MK[b] = mark[(size_t)col * SEL_NB + b];
+    }
     __syncthreads();
     const uint64_t *segs = coll + (size_t)col * n;
     uint64_t *t = thr + (size_t)col * GRX_MAX_BINS;
@@ -1660,13 +1678,13 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
         const int64_t before = j ? (int64_t)C[j - 1] : 0;
         const int64_t len = (int64_t)C[j] - before;
         const size_t cell = (size_t)col * SEL_NB + j;
-        if (!mark[cell]) {                                      // cannot happen: the interval walk covers every exact walk
+        if (!MK[j]) {                                           // cannot happen: the interval walk covers every exact walk
             if (threadIdx.x == 0) atomicAdd(fault, 1);
             break;
         }
         uint64_t tk;
         int64_t le;
-        sel_segment_select(segs + seg_off[cell], len, pos - before, bmin[cell], bmax[cell], &tk, &le, s_hist, s_wsum, s_pick);
+        sel_segment_select(segs + SO[j], len, pos - before, bmin[cell], bmax[cell], &tk, &le, s_hist, s_wsum, s_pick, s_stage);
         if (threadIdx.x == 0) t[nb] = tk;
         ++nb;
         done = before + le;
