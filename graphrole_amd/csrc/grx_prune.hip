@@ -1150,6 +1150,9 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 // =======================================================================================
 constexpr int SEL_NB = 4096;
 constexpr int SEL_MAX_IDS = 512;                           // marked buckets with an LDS slot in the collect pass
+constexpr int SEL_SORT_CAP = 8192;                         // keys of a segment the segment sort holds in LDS
+constexpr uint16_t SEL_MARK_SORTED = 0x8000;               // mark bit: the segment is in ascending order
+constexpr uint16_t SEL_MARK_TIES = 0xFFFF;                 // mark: a certified block of ties, nothing collected
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
 // The bucket map of a column: a LINEAR map of the sampled key range onto 4096 cells, refined by a look-up table built
@@ -1368,8 +1371,12 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
 // segment offsets of the marked buckets.  One workgroup of 1024 threads per column (four buckets per thread).
 __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
                                                          const uint32_t *__restrict__ hist, const uint16_t *__restrict__ tie_of_bucket,
-                                                         const uint8_t *__restrict__ tie_broken, uint32_t *__restrict__ cum,
-                                                         uint16_t *__restrict__ mark, uint32_t *__restrict__ seg_off)
+                                                         const uint8_t *__restrict__ tie_broken,
+                                                         const uint64_t *__restrict__ tie_value, uint32_t *__restrict__ cum,
+                                                         uint16_t *__restrict__ mark, uint32_t *__restrict__ seg_off,
+                                                         uint16_t *__restrict__ idlist, int32_t *__restrict__ nids,
+                                                         unsigned long long *__restrict__ bmin,
+                                                         unsigned long long *__restrict__ bmax)
 {
     __shared__ uint8_t TIE[SEL_NB];                              // certified block of ties
     __shared__ uint32_t C[SEL_NB];
@@ -1436,11 +1443,20 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
         }
     }
     __syncthreads();
+    // a marked bucket that is a certified block of ties needs no keys: its one value is the smallest and the largest
+    bool collect[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = 4 * t + j;
         const uint32_t cnt = b < nb ? (C[b] - (b ? C[b - 1] : 0u)) : 0u;
-        v[j] = M[b] ? cnt : 0u;
+        collect[j] = M[b] && !TIE[b];
+        v[j] = collect[j] ? cnt : 0u;
+        if (M[b] && TIE[b]) {
+            const size_t cell = (size_t)col * SEL_NB + b;
+            const uint64_t value = tie_value[(size_t)col * (SEL_MAX_TIES + 1) + tie_of_bucket[cell]];
+            bmin[cell] = value;
+            bmax[cell] = value;
+        }
     }
     scan4(v, S);
 #pragma unroll
@@ -1451,19 +1467,68 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
             seg_off[(size_t)col * SEL_NB + b] = S[b] - v[j];    // exclusive
         }
     }
-    // compact ids of the marked buckets (1-based; SEL_MAX_IDS and beyond share the last id: the collect pass serves
-    // those through global atomics)
+    // compact ids of the collected buckets (1-based; SEL_MAX_IDS and beyond share the last id: the collect pass serves
+    // those through global atomics) and the list of them for the segment sort
     uint32_t m[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = M[4 * t + j] ? 1u : 0u;
+    for (int j = 0; j < 4; ++j) m[j] = collect[j] ? 1u : 0u;
     scan4(m, S);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = 4 * t + j;
         if (b < nb) {
             const uint32_t id = S[b];                            // inclusive count = 1-based id
-            mark[(size_t)col * SEL_NB + b] = (uint16_t)(m[j] ? (id < SEL_MAX_IDS ? id : SEL_MAX_IDS) : 0u);
+            uint16_t mk = 0;
+            if (m[j]) {
+                mk = (uint16_t)(id < SEL_MAX_IDS ? id : SEL_MAX_IDS);
+                if (id < SEL_MAX_IDS) idlist[(size_t)col * SEL_MAX_IDS + id - 1] = (uint16_t)b;
+            } else if (M[b]) {
+                mk = SEL_MARK_TIES;
+            }
+            mark[(size_t)col * SEL_NB + b] = mk;
         }
+    }
+    if (t == 1023) nids[col] = (int32_t)(S[nb - 1] < (uint32_t)SEL_MAX_IDS ? S[nb - 1] : SEL_MAX_IDS - 1);
+}
+
+// The collected segments in ascending order, each by one workgroup in LDS (bitonic network).  The exact walk then reads
+// a threshold and the end of its tie run with ONE trip to memory instead of a multi-pass selection per threshold -- the
+// walk is a serial chain of ~20 thresholds per column, its latency is the launch's duration.  Segments of <= 64 keys
+// (ranked by shuffles in the walk), blocks of ties and segments beyond the LDS capacity (radix selection in the walk)
+// are left as they are.
+__global__ __launch_bounds__(512) void sel_sort_kernel(const uint32_t *__restrict__ cum, const uint32_t *__restrict__ seg_off,
+                                                       const uint16_t *__restrict__ idlist, const int32_t *__restrict__ nids,
+                                                       const unsigned long long *__restrict__ bmin,
+                                                       const unsigned long long *__restrict__ bmax, int64_t n,
+                                                       uint64_t *__restrict__ coll, uint16_t *__restrict__ mark)
+{
+    __shared__ uint64_t s[SEL_SORT_CAP];
+    const int col = blockIdx.y;
+    const int count = nids[col];
+    for (int id = blockIdx.x; id < count; id += gridDim.x) {
+        const int b = idlist[(size_t)col * SEL_MAX_IDS + id];
+        const size_t cell = (size_t)col * SEL_NB + b;
+        const int64_t len = (int64_t)cum[cell] - (b ? (int64_t)cum[cell - 1] : 0);
+        if (len <= 64 || len > SEL_SORT_CAP || bmin[cell] == bmax[cell]) continue;
+        uint64_t *seg = coll + (size_t)col * n + seg_off[cell];
+        int P = 128;
+        while (P < len) P <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < P; i += 512) s[i] = i < len ? seg[i] : ~0ull;
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < P / 2; i += 512) {
+                    const int lo = 2 * i - (i & (j - 1)), hi = lo + j;
+                    const uint64_t a = s[lo], c = s[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((a > c) == up) { s[lo] = c; s[hi] = a; }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += 512) seg[i] = s[i];
+        if (threadIdx.x == 0) mark[cell] |= SEL_MARK_SORTED;
     }
 }
 
@@ -1545,36 +1610,11 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
 
 // the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
 // its keys <= that key; whole workgroup (256 threads), every thread returns the same values
-constexpr int SEL_STAGE = 4096;                            // keys of a segment the exact walk stages in LDS
-
-__device__ void sel_segment_select(const uint64_t *__restrict__ seg_global, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
-                                   uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick,
-                                   uint64_t *s_stage)
+// q-th smallest key (0-based) of an UNORDERED segment of more than 64 keys and the number of keys <= it
+__device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
+                                   uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (mn == mx) { *tk_out = mn; *le_out = len; return; }      // a block of ties: nothing to read
-    const uint64_t *seg = seg_global;
-    if (len > 64 && len <= SEL_STAGE) {
-        // one trip to memory for the whole segment, the selection passes then run on LDS
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < len; i += 256) s_stage[i] = seg_global[i];
-        __syncthreads();
-        seg = s_stage;
-    }
-    if (len <= 64) {
-        const uint64_t mine = (lane < len) ? seg[lane] : ~0ull;
-        int lt = 0, le = 0;
-        for (int j = 0; j < (int)len; ++j) {
-            const uint64_t other = __shfl(mine, j, 64);
-            lt += other < mine;
-            le += other <= mine;
-        }
-        const uint64_t hit = __ballot(lane < len && lt <= q && q < le);
-        const int src = __ffsll((long long)hit) - 1;
-        *tk_out = __shfl(mine, src, 64);
-        *le_out = __shfl(le, src, 64);
-        return;
-    }
     // radix selection over the bytes in which the segment's keys can differ, most significant first
     const int top = (63 - __clzll((long long)(mn ^ mx))) >> 3;
     uint64_t prefix = top < 7 ? (mn >> (8 * (top + 1))) << (8 * (top + 1)) : 0ull;
@@ -1644,7 +1684,6 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t SO[SEL_NB];
     __shared__ uint16_t MK[SEL_NB];
-    __shared__ uint64_t s_stage[SEL_STAGE];
     __shared__ uint32_t s_hist[RADIX];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint64_t s_pick[4];
@@ -1677,14 +1716,51 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
         }
         const int64_t before = j ? (int64_t)C[j - 1] : 0;
         const int64_t len = (int64_t)C[j] - before;
+        const int64_t q = pos - before;
         const size_t cell = (size_t)col * SEL_NB + j;
-        if (!MK[j]) {                                           // cannot happen: the interval walk covers every exact walk
+        const uint16_t mk = MK[j];
+        if (!mk) {                                              // cannot happen: the interval walk covers every exact walk
             if (threadIdx.x == 0) atomicAdd(fault, 1);
             break;
         }
+        // ONE trip to memory serves the common cases: the bucket's smallest and largest key, and 64 keys of its segment
+        // -- from rank q on when the segment is sorted, all of it when it holds no more than 64
+        const bool ties = mk == SEL_MARK_TIES;
+        const bool sorted = !ties && (mk & SEL_MARK_SORTED);
+        const uint64_t *seg = segs + SO[j];
+        const int64_t at = sorted ? q + lane : lane;
+        const uint64_t mine = ties ? 0ull : seg[at < len ? at : len - 1];
+        const uint64_t mn = bmin[cell], mx = bmax[cell];
         uint64_t tk;
         int64_t le;
-        sel_segment_select(segs + SO[j], len, pos - before, bmin[cell], bmax[cell], &tk, &le, s_hist, s_wsum, s_pick, s_stage);
+        if (mn == mx) {                                         // a block of ties
+            tk = mn;
+            le = len;
+        } else if (sorted) {
+            tk = __shfl(mine, 0, 64);
+            int64_t base = q;
+            uint64_t diff = __ballot(mine != tk || at >= len);
+            while (diff == 0) {                                 // a run of ties longer than a wavefront: keep scanning
+                base += 64;
+                const int64_t i = base + lane;
+                diff = __ballot(i >= len || seg[i < len ? i : len - 1] != tk);
+            }
+            le = base + __ffsll((long long)diff) - 1;
+        } else if (len <= 64) {
+            const uint64_t key = lane < len ? mine : ~0ull;
+            int lt = 0, lq = 0;
+            for (int i = 0; i < (int)len; ++i) {
+                const uint64_t other = __shfl(key, i, 64);
+                lt += other < key;
+                lq += other <= key;
+            }
+            const uint64_t hit = __ballot(lane < len && lt <= q && q < lq);
+            const int src = __ffsll((long long)hit) - 1;
+            tk = __shfl(key, src, 64);
+            le = __shfl(lq, src, 64);
+        } else {
+            sel_segment_select(seg, len, q, mn, mx, &tk, &le, s_hist, s_wsum, s_pick);
+        }
         if (threadIdx.x == 0) t[nb] = tk;
         ++nb;
         done = before + le;
@@ -1784,7 +1860,7 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, coll, thr, nbins, fault, total; };
+struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, idlist, nids, coll, thr, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
@@ -1802,6 +1878,8 @@ SelLayout sel_layout(int64_t n, int ncols)
     L.cum = take((size_t)ncols * SEL_NB * 4);
     L.seg_off = take((size_t)ncols * SEL_NB * 4);
     L.mark = take((size_t)ncols * SEL_NB * 2);
+    L.idlist = take((size_t)ncols * SEL_MAX_IDS * 2);
+    L.nids = take((size_t)ncols * 4);
     L.coll = take((size_t)ncols * (size_t)n * 8);
     L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
     L.nbins = take((size_t)ncols * 4);
@@ -1886,6 +1964,8 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         uint32_t *cum = reinterpret_cast<uint32_t *>(ws + L.cum);
         uint32_t *seg_off = reinterpret_cast<uint32_t *>(ws + L.seg_off);
         uint16_t *mark = reinterpret_cast<uint16_t *>(ws + L.mark);
+        uint16_t *idlist = reinterpret_cast<uint16_t *>(ws + L.idlist);
+        int32_t *nids = reinterpret_cast<int32_t *>(ws + L.nids);
         uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
@@ -1896,23 +1976,27 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         GRX_CHECK_HIP(hipMemsetAsync(bmin, 0xFF, L.cum - L.bmin, st));
         GRX_CHECK_HIP(hipMemsetAsync(fault, 0, 4, st));
         {
-            GRX_PROF(GRX_K_KEY_BITS, st);
+            GRX_PROF(GRX_K_SEL_MAP, st);
             sel_map_kernel<<<ncols, 1024, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, flags);
         }
         {
-            GRX_PROF(GRX_K_SORT_COUNT, st);
+            GRX_PROF(GRX_K_SEL_HIST, st);
             sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, flags);
         }
         {
-            GRX_PROF(GRX_K_SORT_SCAN, st);
-            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, hist, tieb, tbroken, cum, mark, seg_off);
+            GRX_PROF(GRX_K_SEL_WALK1, st);
+            sel_walk1_kernel<<<ncols, 1024, 0, st>>>(n, frac, hist, tieb, tbroken, tiev, cum, mark, seg_off, idlist, nids, bmin, bmax);
         }
         {
-            GRX_PROF(GRX_K_SORT_SCATTER, st);
+            GRX_PROF(GRX_K_SEL_COLLECT, st);
             sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
-            GRX_PROF(GRX_K_BIN_THRESHOLD, st);
+            GRX_PROF(GRX_K_SEL_SEGSORT, st);
+            sel_sort_kernel<<<dim3(64, ncols), 512, 0, st>>>(cum, seg_off, idlist, nids, bmin, bmax, n, coll, mark);
+        }
+        {
+            GRX_PROF(GRX_K_SEL_WALK2, st);
             sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();

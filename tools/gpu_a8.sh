@@ -14,8 +14,8 @@ for w in ("bench","er","dw"):
     try:
         j=json.loads(open(f"$OUT/{w}_{v}.json").read().strip().splitlines()[-1])
         k=j["kernel_ms_per_step"]
-        names=("key_bits_kernel","tile_count_kernel","scan_kernel","scatter_kernel","bin_threshold_kernel","bin_assign_kernel")
-        print(w, "sort" if v else "select", round(j["ms_per_step"],3), round(sum(k.get(x,0) for x in names),3), {x: round(k.get(x,0),3) for x in names})
+        names=("key_bits_kernel","tile_count_kernel","scan_kernel","scatter_kernel","bin_threshold_kernel","bin_assign_kernel","sel_map_kernel","sel_hist_kernel","sel_walk1_kernel","sel_collect_kernel","sel_sort_kernel","sel_walk2_kernel")
+        print(w, "sort" if v else "select", round(j["ms_per_step"],3), round(sum(k.get(x,0) for x in names),3), {x: round(k[x],3) for x in names if k.get(x)})
     except Exception as e:
         print(w, v, "ERR", e, open(f"$OUT/{w}_{v}.err").read()[-500:])
 PY
