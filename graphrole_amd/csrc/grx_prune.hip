@@ -1493,9 +1493,9 @@ __global__ __launch_bounds__(1024) void sel_walk1_kernel(int64_t n, double frac,
 
 // The collected segments in ascending order, each by one workgroup in LDS (bitonic network).  The exact walk then reads
 // a threshold and the end of its tie run with ONE trip to memory instead of a multi-pass selection per threshold -- the
-// walk is a serial chain of ~20 thresholds per column, its latency is the launch's duration.  Segments of <= 64 keys
-// (ranked by shuffles in the walk), blocks of ties and segments beyond the LDS capacity (radix selection in the walk)
-// are left as they are.
+// walk is a serial chain of ~20 thresholds per column, its latency is the launch's duration.  Blocks of ties, segments
+// beyond the LDS capacity and those of the buckets without a compact id stay unordered: the walk ranks up to 64 keys by
+// shuffles and selects by radix passes beyond.
 __global__ __launch_bounds__(512) void sel_sort_kernel(const uint32_t *__restrict__ cum, const uint32_t *__restrict__ seg_off,
                                                        const uint16_t *__restrict__ idlist, const int32_t *__restrict__ nids,
                                                        const unsigned long long *__restrict__ bmin,
@@ -1509,9 +1509,9 @@ __global__ __launch_bounds__(512) void sel_sort_kernel(const uint32_t *__restric
         const int b = idlist[(size_t)col * SEL_MAX_IDS + id];
         const size_t cell = (size_t)col * SEL_NB + b;
         const int64_t len = (int64_t)cum[cell] - (b ? (int64_t)cum[cell - 1] : 0);
-        if (len <= 64 || len > SEL_SORT_CAP || bmin[cell] == bmax[cell]) continue;
+        if (len < 2 || len > SEL_SORT_CAP || bmin[cell] == bmax[cell]) continue;
         uint64_t *seg = coll + (size_t)col * n + seg_off[cell];
-        int P = 128;
+        int P = 2;
         while (P < len) P <<= 1;
         __syncthreads();
         for (int i = threadIdx.x; i < P; i += 512) s[i] = i < len ? seg[i] : ~0ull;
