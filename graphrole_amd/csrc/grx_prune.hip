@@ -1134,19 +1134,25 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
 //   sel_map_kernel      4095 strided samples -> [kmin, kmax] of the order keys -> a linear map of the key range onto
 //                       4096 cells, refined by a LUT: a cell with s samples is split into 2^floor(log2 s) buckets,
 //                       empty cells merge into their successor (keys outside the sampled range fall into the end
-//                       buckets: the map is monotone, the counts exact)
-//   sel_hist_kernel     ONE pass: bucket histogram (LDS, wave-aggregated atomics)
+//                       buckets: the map is monotone, the counts exact).  Buckets whose samples are all equal are
+//                       tie-block CANDIDATES.
+//   sel_hist_kernel     ONE pass: bucket histogram (LDS, wave-aggregated atomics); a candidate bucket that receives a
+//                       key other than its sampled value is struck off -- the rest are CERTIFIED blocks of ties
 //   sel_walk1_kernel    prefix sums; the threshold walk in INTERVAL arithmetic over the bucket boundaries (the exact
-//                       end of a tie run is unknown yet, so `done` is an interval [lo, hi]): every bucket a threshold
-//                       rank can fall into is marked -- typically one or two per threshold
-//   sel_collect_kernel  ONE pass: the keys of the marked buckets, appended to per-bucket segments (unordered)
-//   sel_walk2_kernel    the exact walk: the threshold is the q-th smallest key of its bucket's segment, the bin ends
-//                       after the keys <= it (shuffle ranking up to 64 keys, min/max test for tie blocks, workgroup
-//                       radix selection otherwise) -> thresholds as order keys
+//                       end of a tie run is unknown yet, so `done` is an interval [lo, hi] -- except in a certified
+//                       block of ties, where the bin ends with the bucket): every bucket a threshold rank can fall
+//                       into is marked -- typically one or two per threshold
+//   sel_collect_kernel  ONE pass: the keys of the marked buckets (certified tie blocks excepted), appended to
+//                       per-bucket segments, with each segment's smallest and largest key
+//   sel_sort_kernel     every segment in ascending order, one workgroup each, in LDS
+//   sel_walk2_kernel    the exact walk: the threshold is the q-th key of its bucket's segment and the bin ends with the
+//                       threshold's tie run -- one trip to memory per threshold (segments too large for the LDS sort
+//                       fall back to a workgroup radix selection) -> thresholds as order keys
 //   bin_assign_kernel   as before.
-// Three streaming passes of 8 bytes per key and 6 launches per call instead of key_bits + 4 x (count, scan, scatter) +
-// walk + assign (~70 bytes per key, 15 launches): the binning of a BA 1 M step went from 1.22 to X ms.  The bins
-// are identical (both are exact); the sort path stays behind GRX_BIN_SORT=1 and in the A/B test.
+// Three streaming passes of 8 bytes per key and 7 launches per call instead of key_bits + 4 x (count, scan, scatter) +
+// walk + assign (~70 bytes per key, 15 launches).  Measured per bench step (profiles/r03_binning_ab.txt): BA 1 M
+// 1.23 -> 0.67 ms, ER 100 k 0.64 -> 0.41 ms, directed weighted 5 M / 40 M 25.9 -> 7.3 ms.  The bins are identical
+// (both paths are exact); the sort path stays behind GRX_BIN_SORT=1 and in the A/B tests.
 // =======================================================================================
 constexpr int SEL_NB = 4096;
 constexpr int SEL_MAX_IDS = 512;                           // marked buckets with an LDS slot in the collect pass

@@ -536,12 +536,14 @@ def test_log_bin_window_sort_adversarial(K, n):
 
 @pytest.mark.parametrize('n', [3, 64, 65, 1023, 1025, 50_000, 700_001])
 def test_log_bin_bucket_select_adversarial(K, n):
-    """The default binning does not sort: 1024 strided samples fix a linear map of the key range onto <= 4096 buckets,
-    one pass counts, an interval walk marks the buckets a threshold can fall into, one pass collects their keys, the
-    exact walk selects inside the segments.  Patterns aimed at every step: values outside the sampled range (at
-    positions the samples skip), sorted and reverse-sorted input (samples = quantiles), one dense non-uniform cluster
-    (long segments: radix selection), a column whose every bucket is a candidate, two-valued and constant columns,
-    subnormals / huge magnitudes / negatives, and int64-bits columns over the whole int64 range."""
+    """The default binning does not sort: 4095 strided samples fix a monotone map of the key range onto <= 4096
+    buckets, one pass counts (and certifies blocks of ties), an interval walk marks the buckets a threshold can fall
+    into, one pass collects their keys, the segments are sorted in LDS, the exact walk reads thresholds and tie-run
+    ends from them.  Patterns aimed at every step: values outside the sampled range (at positions the samples skip),
+    sorted and reverse-sorted input (samples = quantiles), one dense non-uniform cluster (segments beyond the LDS
+    capacity: radix selection), tie runs longer than a wavefront inside sorted segments and inside oversized ones, a
+    column whose every bucket is a candidate, two-valued and constant columns, subnormals / huge magnitudes /
+    negatives, and int64-bits columns over the whole int64 range."""
     import torch
     from oracle import ckernels, refex
     rng = np.random.default_rng(n + 99)
@@ -550,7 +552,11 @@ def test_log_bin_bucket_select_adversarial(K, n):
     out_lo = base + 10.0; out_lo[2 % n::max(n // 5, 1)] = -1e-300
     cluster = 1.0 + rng.integers(0, 1 << 30, n) * 2.0 ** -52                         # one bucket, 2^30 distinct keys
     cluster[::max(n // 3, 1)] = 1e6
+    runs = 1.0 + rng.integers(0, max(n // 200, 2), n) * 1e-3                          # tie runs of ~200 in every segment
+    tied_cluster = 1.0 + rng.integers(0, 1 << 12, n) * 2.0 ** -52                     # one bucket, 4096 values, long runs
+    tied_cluster[::max(n // 3, 1)] = 1e6
     cols = [
+        runs, tied_cluster,
         out_hi, out_lo,
         np.sort(rng.pareto(1.3, n)), np.sort(rng.pareto(1.3, n))[::-1].copy(),
         cluster,
