@@ -473,6 +473,92 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
     }
 }
 
+// Second formulation (round 3): the instruction stream, not the memory system, bounded the kernel above -- its
+// per-chunk exact test (eight shuffles, each followed by three compares and a ballot) ran whenever ANY of the eight
+// groups of a wavefront had a filter hit, i.e. nearly always (SQ_ACTIVE_INST_ANY 7x the aggregate kernel's for half
+// its memory traffic).  Here every lane holds the group's 16 ids of N+(u) in registers (broadcast once per source),
+// so the membership test of a chunk of N+(v) is 8 or 16 register compares per lane -- no shuffles, no ballots, no
+// filter -- and the second half of the ids / the second chunk are skipped wavefront-wide when no group needs them.
+__global__ __launch_bounds__(256) void triangle_count_regs_kernel(
+    const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
+    const uint64_t *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
+    unsigned long long *__restrict__ T)
+{
+    constexpr int G = TRI_G;
+    constexpr unsigned long long GMASK = (1ull << G) - 1;
+    const int lane = threadIdx.x % G;
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t u = row_begin + group; u < row_end; u += ngroups) {
+        const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
+        unsigned long long cu = 0;
+        for (int64_t base = ub; base < ue; base += 2 * G) {     // usually a single pass
+            const int64_t i0 = base + lane, i1 = base + G + lane;
+            const int32_t mine0 = (i0 < ue) ? o_col[i0] : -2;
+            const int32_t mine1 = (i1 < ue) ? o_col[i1] : -2;
+            // all sixteen ids in every lane of the group
+            const int32_t p0 = __shfl(mine0, 0, G), p1 = __shfl(mine0, 1, G), p2 = __shfl(mine0, 2, G), p3 = __shfl(mine0, 3, G);
+            const int32_t p4 = __shfl(mine0, 4, G), p5 = __shfl(mine0, 5, G), p6 = __shfl(mine0, 6, G), p7 = __shfl(mine0, 7, G);
+            const bool wide = __ballot(base + G < ue) != 0;     // some group of the wavefront holds more than 8 ids
+            int32_t q0 = -2, q1 = -2, q2 = -2, q3 = -2, q4 = -2, q5 = -2, q6 = -2, q7 = -2;
+            if (wide) {
+                q0 = __shfl(mine1, 0, G); q1 = __shfl(mine1, 1, G); q2 = __shfl(mine1, 2, G); q3 = __shfl(mine1, 3, G);
+                q4 = __shfl(mine1, 4, G); q5 = __shfl(mine1, 5, G); q6 = __shfl(mine1, 6, G); q7 = __shfl(mine1, 7, G);
+            }
+#define TRI_TEST(Y, ACC)                                                                                  \
+            do {                                                                                          \
+                const int32_t y_ = (Y);                                                                   \
+                bool hit_ = (y_ == p0) | (y_ == p1) | (y_ == p2) | (y_ == p3) | (y_ == p4) | (y_ == p5) | \
+                            (y_ == p6) | (y_ == p7);                                                      \
+                if (wide)                                                                                 \
+                    hit_ |= (y_ == q0) | (y_ == q1) | (y_ == q2) | (y_ == q3) | (y_ == q4) | (y_ == q5) | \
+                            (y_ == q6) | (y_ == q7);                                                      \
+                const unsigned long long bal_ = __ballot(hit_);                                           \
+                if (bal_) {                                                 /* rare: a triangle */        \
+                    if (hit_) atomicAdd(&T[y_], 1ull);                                                    \
+                    ACC += (unsigned)__popcll((bal_ >> gshift) & GMASK);                                  \
+                }                                                                                         \
+            } while (0)
+            for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
+                const bool have = k0 + lane < ue;
+                const int32_t v_mine = have ? o_col[k0 + lane] : -1;
+                const unsigned long long d_mine = have ? o_arc[k0 + lane] : 0ull;
+                const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
+#define TRI_LOAD(A, Y0, Y1)                                                                              \
+                const unsigned long long d##A = (a0 + A < nb) ? __shfl(d_mine, a0 + A, G) : 0ull;        \
+                const int64_t vb##A = (int64_t)(d##A & ((1ull << TRI_ARC_SHIFT) - 1));                      \
+                const int len##A = (int)(d##A >> TRI_ARC_SHIFT);                                            \
+                const int32_t Y0 = (lane < len##A) ? o_col[vb##A + lane] : -1;                              \
+                const int32_t Y1 = (lane + G < len##A) ? o_col[vb##A + G + lane] : -1;
+#define TRI_ARC(A, Y0, Y1)                                                                               \
+                {                                                                                         \
+                    unsigned c_arc = 0;                                                                   \
+                    TRI_TEST(Y0, c_arc);                                                                  \
+                    if (__ballot(len##A > G)) {                                                           \
+                        TRI_TEST(Y1, c_arc);                                                              \
+                        for (int j0 = 2 * G; __ballot(j0 < len##A); j0 += G)                              \
+                            TRI_TEST((j0 + lane < len##A) ? o_col[vb##A + j0 + lane] : -1, c_arc);        \
+                    }                                                                                     \
+                    if (__ballot(c_arc != 0)) {                                                           \
+                        const int32_t v = __shfl(v_mine, (a0 + A) & (G - 1), G);                          \
+                        if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);              \
+                        cu += c_arc;                                                                      \
+                    }                                                                                     \
+                }
+                for (int a0 = 0; __ballot(a0 < nb) != 0; a0 += 4) {         // uniform over the wavefront
+                    TRI_LOAD(0, ya0, ya1) TRI_LOAD(1, yb0, yb1) TRI_LOAD(2, yc0, yc1) TRI_LOAD(3, yd0, yd1)
+                    TRI_ARC(0, ya0, ya1) TRI_ARC(1, yb0, yb1) TRI_ARC(2, yc0, yc1) TRI_ARC(3, yd0, yd1)
+                }
+#undef TRI_LOAD
+#undef TRI_ARC
+            }
+#undef TRI_TEST
+        }
+        if (lane == 0 && cu) atomicAdd(&T[u], cu);
+    }
+}
+
 // info[v] = (d'(v) << 1) | L(v)   (int32: the whole table is 4 B/node and stays L2-resident)
 __global__ __launch_bounds__(256) void node_info_kernel(int64_t n, const int64_t *__restrict__ row_ptr,
                                                         const int32_t *__restrict__ col,
@@ -1311,9 +1397,14 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
     GRX_REQUIRE(d_o_row_ptr && d_o_col && d_o_arc && d_T, "grx_triangle_counts: NULL pointer");
     const int64_t want = grx_ceil_div((row_end - row_begin) * TRI_G, 256);
     const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+    static const bool shuffle_variant = [] { const char *e = getenv("GRX_TRIANGLES_SHUFFLE"); return e && e[0] == '1'; }();
     { GRX_PROF(GRX_K_TRIANGLES, grx_stream(stream));
-    triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
-                                                                reinterpret_cast<unsigned long long *>(d_T));
+    if (shuffle_variant)
+        triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
+                                                                    reinterpret_cast<unsigned long long *>(d_T));
+    else
+        triangle_count_regs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
+                                                                         reinterpret_cast<unsigned long long *>(d_T));
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
