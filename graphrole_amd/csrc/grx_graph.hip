@@ -363,7 +363,7 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 // keeps oriented lists <= ~20 on the BASELINE graphs) and tests membership all-to-all with
 // in-group shuffles.  L2 requests per arc drop from ~16 to ~4, which is what bounded this kernel
 // (rocprof: 165 M TCP->TCC requests per launch).  Counting is integer atomics: exact, any order.
-// o_arc[k] = begin | (length << 40) of N+(v) for the k-th oriented arc u->v: the target's list is
+// o_arc[2 k] = begin | (length << 40) of N+(v) for the k-th oriented arc u->v: the target's list is
 // located from the (sequentially read) arc table instead of a dependent, random o_row_ptr[v] lookup,
 // so the group knows the addresses of eight target lists at once and keeps the first two 8-element
 // chunks of each in flight (16 independent loads per lane) before it starts comparing.
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
             for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
                 const bool have = k0 + lane < ue;
                 const int32_t v_mine = have ? GRX_STREAM_LD(o_col[k0 + lane]) : -1;
-                const unsigned long long d_mine = have ? GRX_STREAM_LD(o_arc[k0 + lane]) : 0ull;
+                const unsigned long long d_mine = have ? GRX_STREAM_LD(o_arc[2 * (k0 + lane)]) : 0ull;
                 const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
                 // four target lists at a time: their first two chunks are eight independent loads in
                 // flight per lane (scalars, not arrays: arrays end up in scratch memory here)
@@ -473,89 +473,117 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
     }
 }
 
-// Second formulation (round 3): the instruction stream, not the memory system, bounded the kernel above -- its
-// per-chunk exact test (eight shuffles, each followed by three compares and a ballot) ran whenever ANY of the eight
-// groups of a wavefront had a filter hit, i.e. nearly always (SQ_ACTIVE_INST_ANY 7x the aggregate kernel's for half
-// its memory traffic).  Here every lane holds the group's 16 ids of N+(u) in registers (broadcast once per source),
-// so the membership test of a chunk of N+(v) is 8 or 16 register compares per lane -- no shuffles, no ballots, no
-// filter -- and the second half of the ids / the second chunk are skipped wavefront-wide when no group needs them.
-__global__ __launch_bounds__(256) void triangle_count_regs_kernel(
+// Second formulation (round 3).  The instruction stream and the per-source dependency chain, not the memory system,
+// bounded the kernel above: its per-chunk exact test (eight shuffles, each followed by three compares and a ballot)
+// ran whenever ANY of the eight groups of a wavefront had a filter hit, i.e. nearly always (SQ_ACTIVE_INST_ANY 7x
+// the aggregate kernel's for half its memory traffic), a wavefront waited for its longest source row, and every
+// source cost three dependent round trips (row_ptr -> ids and descriptors -> target lists) at 2.0 TB/s of L2 misses
+// where the aggregate kernel sustains 7.
+// Here the ARCS are the work items: an 8-lane group takes four consecutive arcs u->v, reads their table entries
+// (o_arc now holds two descriptors per arc: where N+(v) lies and where N+(u) lies), has the first sixteen ids of all
+// eight lists in flight at once, and intersects by an all-pairs compare in which the ids of N+(u) rotate through the
+// group's lanes by DPP lane permutations (lane ^ 1..7: quad_perm and row_half_mirror -- VALU moves, no LDS crossbar,
+// no ballots).  Two round trips per arc, no per-source loop, every group always has work.
+__device__ __forceinline__ int32_t tri_dpp(int32_t x, int ctrl_id)
+{
+    // lane ^ r inside every 8-lane group, r = ctrl_id
+    switch (ctrl_id) {
+    case 1: return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    case 2: return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    case 3: return __builtin_amdgcn_mov_dpp(x, 0x1B, 0xF, 0xF, true);      // quad_perm [3,2,1,0]
+    default: return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);    // row_half_mirror: lane ^ 7
+    }
+}
+// does y equal any of the eight ids the group's lanes hold in a?
+__device__ __forceinline__ bool tri_any_equal(int32_t y, int32_t a)
+{
+    const int32_t a1 = tri_dpp(a, 1), a2 = tri_dpp(a, 2), a3 = tri_dpp(a, 3), a7 = tri_dpp(a, 7);
+    const int32_t a6 = tri_dpp(a1, 7), a5 = tri_dpp(a2, 7), a4 = tri_dpp(a3, 7);
+    return (y == a) | (y == a1) | (y == a2) | (y == a3) | (y == a4) | (y == a5) | (y == a6) | (y == a7);
+}
+
+constexpr int TRI_ARCS = 4;                  // arcs per group and iteration
+
+__global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
-    const uint64_t *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
+    const ulonglong2 *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
     unsigned long long *__restrict__ T)
 {
     constexpr int G = TRI_G;
     constexpr unsigned long long GMASK = (1ull << G) - 1;
+    constexpr unsigned long long LOW = (1ull << TRI_ARC_SHIFT) - 1;
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t u = row_begin + group; u < row_end; u += ngroups) {
-        const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
-        unsigned long long cu = 0;
-        for (int64_t base = ub; base < ue; base += 2 * G) {     // usually a single pass
-            const int64_t i0 = base + lane, i1 = base + G + lane;
-            const int32_t mine0 = (i0 < ue) ? o_col[i0] : -2;
-            const int32_t mine1 = (i1 < ue) ? o_col[i1] : -2;
-            // all sixteen ids in every lane of the group
-            const int32_t p0 = __shfl(mine0, 0, G), p1 = __shfl(mine0, 1, G), p2 = __shfl(mine0, 2, G), p3 = __shfl(mine0, 3, G);
-            const int32_t p4 = __shfl(mine0, 4, G), p5 = __shfl(mine0, 5, G), p6 = __shfl(mine0, 6, G), p7 = __shfl(mine0, 7, G);
-            const bool wide = __ballot(base + G < ue) != 0;     // some group of the wavefront holds more than 8 ids
-            int32_t q0 = -2, q1 = -2, q2 = -2, q3 = -2, q4 = -2, q5 = -2, q6 = -2, q7 = -2;
-            if (wide) {
-                q0 = __shfl(mine1, 0, G); q1 = __shfl(mine1, 1, G); q2 = __shfl(mine1, 2, G); q3 = __shfl(mine1, 3, G);
-                q4 = __shfl(mine1, 4, G); q5 = __shfl(mine1, 5, G); q6 = __shfl(mine1, 6, G); q7 = __shfl(mine1, 7, G);
-            }
-#define TRI_TEST(Y, ACC)                                                                                  \
-            do {                                                                                          \
-                const int32_t y_ = (Y);                                                                   \
-                bool hit_ = (y_ == p0) | (y_ == p1) | (y_ == p2) | (y_ == p3) | (y_ == p4) | (y_ == p5) | \
-                            (y_ == p6) | (y_ == p7);                                                      \
-                if (wide)                                                                                 \
-                    hit_ |= (y_ == q0) | (y_ == q1) | (y_ == q2) | (y_ == q3) | (y_ == q4) | (y_ == q5) | \
-                            (y_ == q6) | (y_ == q7);                                                      \
-                const unsigned long long bal_ = __ballot(hit_);                                           \
-                if (bal_) {                                                 /* rare: a triangle */        \
-                    if (hit_) atomicAdd(&T[y_], 1ull);                                                    \
-                    ACC += (unsigned)__popcll((bal_ >> gshift) & GMASK);                                  \
-                }                                                                                         \
-            } while (0)
-            for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
-                const bool have = k0 + lane < ue;
-                const int32_t v_mine = have ? o_col[k0 + lane] : -1;
-                const unsigned long long d_mine = have ? o_arc[k0 + lane] : 0ull;
-                const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
-#define TRI_LOAD(A, Y0, Y1)                                                                              \
-                const unsigned long long d##A = (a0 + A < nb) ? __shfl(d_mine, a0 + A, G) : 0ull;        \
-                const int64_t vb##A = (int64_t)(d##A & ((1ull << TRI_ARC_SHIFT) - 1));                      \
-                const int len##A = (int)(d##A >> TRI_ARC_SHIFT);                                            \
-                const int32_t Y0 = (lane < len##A) ? o_col[vb##A + lane] : -1;                              \
-                const int32_t Y1 = (lane + G < len##A) ? o_col[vb##A + G + lane] : -1;
-#define TRI_ARC(A, Y0, Y1)                                                                               \
-                {                                                                                         \
-                    unsigned c_arc = 0;                                                                   \
-                    TRI_TEST(Y0, c_arc);                                                                  \
-                    if (__ballot(len##A > G)) {                                                           \
-                        TRI_TEST(Y1, c_arc);                                                              \
-                        for (int j0 = 2 * G; __ballot(j0 < len##A); j0 += G)                              \
-                            TRI_TEST((j0 + lane < len##A) ? o_col[vb##A + j0 + lane] : -1, c_arc);        \
-                    }                                                                                     \
-                    if (__ballot(c_arc != 0)) {                                                           \
-                        const int32_t v = __shfl(v_mine, (a0 + A) & (G - 1), G);                          \
-                        if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);              \
-                        cu += c_arc;                                                                      \
-                    }                                                                                     \
-                }
-                for (int a0 = 0; __ballot(a0 < nb) != 0; a0 += 4) {         // uniform over the wavefront
-                    TRI_LOAD(0, ya0, ya1) TRI_LOAD(1, yb0, yb1) TRI_LOAD(2, yc0, yc1) TRI_LOAD(3, yd0, yd1)
-                    TRI_ARC(0, ya0, ya1) TRI_ARC(1, yb0, yb1) TRI_ARC(2, yc0, yc1) TRI_ARC(3, yd0, yd1)
-                }
-#undef TRI_LOAD
-#undef TRI_ARC
-            }
-#undef TRI_TEST
+    const int64_t kb = o_row_ptr[row_begin], ke = o_row_ptr[row_end];
+    for (int64_t k0 = kb + group * TRI_ARCS; __ballot(k0 < ke) != 0; k0 += ngroups * TRI_ARCS) {
+        // the table entries of the four arcs (the same addresses in all eight lanes: one request per group)
+        int64_t vb[TRI_ARCS], ub[TRI_ARCS];
+        int vlen[TRI_ARCS], ulen[TRI_ARCS];
+#pragma unroll
+        for (int j = 0; j < TRI_ARCS; ++j) {
+            const bool have = k0 + j < ke;
+            const ulonglong2 d = have ? o_arc[k0 + j] : make_ulonglong2(0ull, 0ull);
+            vb[j] = (int64_t)(d.x & LOW); vlen[j] = (int)(d.x >> TRI_ARC_SHIFT);
+            ub[j] = (int64_t)(d.y & LOW); ulen[j] = (int)(d.y >> TRI_ARC_SHIFT);
+            if (vlen[j] == 0) ulen[j] = 0;                     // nothing to intersect with: do not fetch N+(u) either
         }
-        if (lane == 0 && cu) atomicAdd(&T[u], cu);
+        // the first sixteen ids of every list: up to sixteen independent loads per lane
+        int32_t y0[TRI_ARCS], y1[TRI_ARCS], a0[TRI_ARCS], a1[TRI_ARCS];
+#pragma unroll
+        for (int j = 0; j < TRI_ARCS; ++j) {
+            y0[j] = (lane < vlen[j]) ? o_col[vb[j] + lane] : -1;
+            y1[j] = (lane + G < vlen[j]) ? o_col[vb[j] + G + lane] : -1;
+            a0[j] = (lane < ulen[j]) ? o_col[ub[j] + lane] : -2;
+            a1[j] = (lane + G < ulen[j]) ? o_col[ub[j] + G + lane] : -2;
+        }
+#pragma unroll
+        for (int j = 0; j < TRI_ARCS; ++j) {
+            const bool wide_u = __ballot(ulen[j] > G) != 0, wide_v = __ballot(vlen[j] > G) != 0;   // wavefront-uniform
+            bool h0 = tri_any_equal(y0[j], a0[j]);
+            if (wide_u) h0 |= tri_any_equal(y0[j], a1[j]);
+            bool h1 = false;
+            if (wide_v) {
+                h1 = tri_any_equal(y1[j], a0[j]);
+                if (wide_u) h1 |= tri_any_equal(y1[j], a1[j]);
+            }
+            unsigned c_arc = 0;
+            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+            if (b0 | b1) {                                      // rare: the arc closes triangles
+                if (h0) atomicAdd(&T[y0[j]], 1ull);
+                if (h1) atomicAdd(&T[y1[j]], 1ull);
+                c_arc = (unsigned)(__popcll((b0 >> gshift) & GMASK) + __popcll((b1 >> gshift) & GMASK));
+            }
+            if (__ballot(ulen[j] > 2 * G || vlen[j] > 2 * G) != 0) {
+                // lists beyond sixteen ids: the remaining chunk pairs, from memory (degree ordering keeps them rare)
+                for (int ja = 0; __ballot(ja < ulen[j]) != 0; ja += G) {
+                    const int32_t a = (ja + lane < ulen[j]) ? o_col[ub[j] + ja + lane] : -2;
+                    for (int jb = (ja < 2 * G) ? 2 * G : 0; __ballot(jb < vlen[j]) != 0; jb += G) {
+                        const int32_t y = (jb + lane < vlen[j]) ? o_col[vb[j] + jb + lane] : -1;
+                        const bool h = tri_any_equal(y, a);
+                        const unsigned long long bh = __ballot(h);
+                        if (bh) {
+                            if (h) atomicAdd(&T[y], 1ull);
+                            c_arc += (unsigned)__popcll((bh >> gshift) & GMASK);
+                        }
+                    }
+                }
+            }
+            if (__ballot(c_arc != 0) != 0) {                    // rare
+                if (c_arc && lane == 0) {
+                    // the arc's two ends: the target from the column array, the source as the row that owns position ub
+                    const int32_t v = o_col[k0 + j];
+                    int64_t lo = row_begin, hi = row_end;       // last row with o_row_ptr[row] <= k0 + j
+                    while (hi - lo > 1) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (o_row_ptr[mid] <= k0 + j) lo = mid; else hi = mid;
+                    }
+                    atomicAdd(&T[v], (unsigned long long)c_arc);
+                    atomicAdd(&T[lo], (unsigned long long)c_arc);
+                }
+            }
+        }
     }
 }
 
@@ -1403,7 +1431,9 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
         triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
                                                                     reinterpret_cast<unsigned long long *>(d_T));
     else
-        triangle_count_regs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
+        triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col,
+                                                                         reinterpret_cast<const ulonglong2 *>(d_o_arc),
+                                                                         row_begin, row_end,
                                                                          reinterpret_cast<unsigned long long *>(d_T));
     }
     GRX_LAUNCH_CHECK();

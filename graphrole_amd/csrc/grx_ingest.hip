@@ -278,14 +278,21 @@ __global__ __launch_bounds__(256) void orient_fill_kernel(int64_t n, const int64
     }
 }
 
-__global__ __launch_bounds__(256) void orient_arc_kernel(int64_t o_nnz, const int64_t *__restrict__ o_row_ptr,
+// per oriented arc u->v two descriptors, begin | (length << 40): where N+(v) lies and where N+(u) lies
+__global__ __launch_bounds__(256) void orient_arc_kernel(int64_t n, const int64_t *__restrict__ o_row_ptr,
                                                          const int32_t *__restrict__ o_col, uint64_t *__restrict__ arc)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= o_nnz) return;
-    const int32_t v = o_col[k];
-    const uint64_t b = (uint64_t)o_row_ptr[v], len = (uint64_t)(o_row_ptr[v + 1] - o_row_ptr[v]);
-    arc[k] = b | (len << 40);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
+        const uint64_t mine = (uint64_t)ub | ((uint64_t)(ue - ub) << 40);
+        for (int64_t k = ub; k < ue; ++k) {
+            const int32_t v = o_col[k];
+            const uint64_t b = (uint64_t)o_row_ptr[v], len = (uint64_t)(o_row_ptr[v + 1] - o_row_ptr[v]);
+            arc[2 * k] = b | (len << 40);
+            arc[2 * k + 1] = mine;
+        }
+    }
 }
 
 // out[c][i] = col_c[idx[i]]: feature columns from the internal row order back to label order, all columns of the
@@ -470,7 +477,10 @@ int grx_orient_fill(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col, c
     const int64_t want = grx_ceil_div(n, 4);
     const int wgrid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
     orient_fill_kernel<<<wgrid, 256, 0, st>>>(n, d_row_ptr, d_col, dprime, d_o_row_ptr, d_o_col);
-    if (o_nnz) orient_arc_kernel<<<(int)grx_ceil_div(o_nnz, 256), 256, 0, st>>>(o_nnz, d_o_row_ptr, d_o_col, d_o_arc);
+    if (o_nnz) {
+        const int64_t awant = grx_ceil_div(n, 256);
+        orient_arc_kernel<<<(int)(awant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : awant), 256, 0, st>>>(n, d_o_row_ptr, d_o_col, d_o_arc);
+    }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
