@@ -479,46 +479,49 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
 // the aggregate kernel's for half its memory traffic), a wavefront waited for its longest source row, and every
 // source cost three dependent round trips (row_ptr -> ids and descriptors -> target lists) at 2.0 TB/s of L2 misses
 // where the aggregate kernel sustains 7.
-// Here the ARCS are the work items: an 8-lane group takes four consecutive arcs u->v, reads their table entries
-// (o_arc now holds two descriptors per arc: where N+(v) lies and where N+(u) lies), has the first sixteen ids of all
-// eight lists in flight at once, and intersects by an all-pairs compare in which the ids of N+(u) rotate through the
-// group's lanes by DPP lane permutations (lane ^ 1..7: quad_perm and row_half_mirror -- VALU moves, no LDS crossbar,
-// no ballots).  Two round trips per arc, no per-source loop, every group always has work.
-__device__ __forceinline__ int32_t tri_dpp(int32_t x, int ctrl_id)
-{
-    // lane ^ r inside every 8-lane group, r = ctrl_id
-    switch (ctrl_id) {
-    case 1: return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-    case 2: return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
-    case 3: return __builtin_amdgcn_mov_dpp(x, 0x1B, 0xF, 0xF, true);      // quad_perm [3,2,1,0]
-    default: return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);    // row_half_mirror: lane ^ 7
-    }
-}
-// does y equal any of the eight ids the group's lanes hold in a?
-__device__ __forceinline__ bool tri_any_equal(int32_t y, int32_t a)
-{
-    const int32_t a1 = tri_dpp(a, 1), a2 = tri_dpp(a, 2), a3 = tri_dpp(a, 3), a7 = tri_dpp(a, 7);
-    const int32_t a6 = tri_dpp(a1, 7), a5 = tri_dpp(a2, 7), a4 = tri_dpp(a3, 7);
-    return (y == a) | (y == a1) | (y == a2) | (y == a3) | (y == a4) | (y == a5) | (y == a6) | (y == a7);
-}
-
+// Here the ARCS are the work items: a 16-lane group takes four consecutive arcs u->v, reads their table entries
+// (o_arc holds two descriptors per arc: where N+(v) lies and where N+(u) lies), has the first sixteen ids of all
+// eight lists in flight at once -- degree ordering keeps 99.5 % of the oriented lists of the BASELINE graphs that
+// short -- and intersects by BINARY SEARCH: the lists are ascending, every lane looks its id of N+(v) up among the
+// sixteen ids of N+(u) spread over the group's lanes (five ds_bpermute probes; the all-pairs compare costs 8 x 8 lane
+// compares per pair of 8-id chunks, four such pairs for two lists of ten).  Two round trips per arc, no per-source
+// loop, every group always has work.
+constexpr int TRI_AG = 16;                   // lanes per arc
 constexpr int TRI_ARCS = 4;                  // arcs per group and iteration
+constexpr int32_t TRI_PAD = 0x7fffffff;      // pads N+(u) to sixteen ascending ids
+
+// is y one of the sixteen ascending ids the group's lanes hold in a?  group_byte = 4 * (first lane of the group)
+__device__ __forceinline__ bool tri_search16(int32_t y, int32_t a, int group_byte)
+{
+    int pos = group_byte;                                       // byte address of lane `lower bound so far`
+    int32_t t = __builtin_amdgcn_ds_bpermute(pos + 7 * 4, a);
+    pos += (t < y) ? 8 * 4 : 0;
+    t = __builtin_amdgcn_ds_bpermute(pos + 3 * 4, a);
+    pos += (t < y) ? 4 * 4 : 0;
+    t = __builtin_amdgcn_ds_bpermute(pos + 1 * 4, a);
+    pos += (t < y) ? 2 * 4 : 0;
+    t = __builtin_amdgcn_ds_bpermute(pos, a);
+    pos += (t < y) ? 4 : 0;
+    t = __builtin_amdgcn_ds_bpermute(pos, a);
+    return t == y;
+}
 
 __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
     const ulonglong2 *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
     unsigned long long *__restrict__ T)
 {
-    constexpr int G = TRI_G;
+    constexpr int G = TRI_AG;
     constexpr unsigned long long GMASK = (1ull << G) - 1;
     constexpr unsigned long long LOW = (1ull << TRI_ARC_SHIFT) - 1;
     const int lane = threadIdx.x % G;
-    const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);          // first lane of this group in the wavefront
+    const int group_byte = gshift * 4;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     const int64_t kb = o_row_ptr[row_begin], ke = o_row_ptr[row_end];
     for (int64_t k0 = kb + group * TRI_ARCS; __ballot(k0 < ke) != 0; k0 += ngroups * TRI_ARCS) {
-        // the table entries of the four arcs (the same addresses in all eight lanes: one request per group)
+        // the table entries of the four arcs (the same address in all lanes of the group: one request)
         int64_t vb[TRI_ARCS], ub[TRI_ARCS];
         int vlen[TRI_ARCS], ulen[TRI_ARCS];
 #pragma unroll
@@ -529,39 +532,29 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
             ub[j] = (int64_t)(d.y & LOW); ulen[j] = (int)(d.y >> TRI_ARC_SHIFT);
             if (vlen[j] == 0) ulen[j] = 0;                     // nothing to intersect with: do not fetch N+(u) either
         }
-        // the first sixteen ids of every list: up to sixteen independent loads per lane
-        int32_t y0[TRI_ARCS], y1[TRI_ARCS], a0[TRI_ARCS], a1[TRI_ARCS];
+        // the first sixteen ids of every list: eight independent loads per lane
+        int32_t y0[TRI_ARCS], a0[TRI_ARCS];
 #pragma unroll
         for (int j = 0; j < TRI_ARCS; ++j) {
             y0[j] = (lane < vlen[j]) ? o_col[vb[j] + lane] : -1;
-            y1[j] = (lane + G < vlen[j]) ? o_col[vb[j] + G + lane] : -1;
-            a0[j] = (lane < ulen[j]) ? o_col[ub[j] + lane] : -2;
-            a1[j] = (lane + G < ulen[j]) ? o_col[ub[j] + G + lane] : -2;
+            a0[j] = (lane < ulen[j]) ? o_col[ub[j] + lane] : TRI_PAD;
         }
 #pragma unroll
         for (int j = 0; j < TRI_ARCS; ++j) {
-            const bool wide_u = __ballot(ulen[j] > G) != 0, wide_v = __ballot(vlen[j] > G) != 0;   // wavefront-uniform
-            bool h0 = tri_any_equal(y0[j], a0[j]);
-            if (wide_u) h0 |= tri_any_equal(y0[j], a1[j]);
-            bool h1 = false;
-            if (wide_v) {
-                h1 = tri_any_equal(y1[j], a0[j]);
-                if (wide_u) h1 |= tri_any_equal(y1[j], a1[j]);
-            }
             unsigned c_arc = 0;
-            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
-            if (b0 | b1) {                                      // rare: the arc closes triangles
+            const bool h0 = tri_search16(y0[j], a0[j], group_byte);
+            const unsigned long long b0 = __ballot(h0);
+            if (b0) {                                           // rare: some arc of the wavefront closes a triangle
                 if (h0) atomicAdd(&T[y0[j]], 1ull);
-                if (h1) atomicAdd(&T[y1[j]], 1ull);
-                c_arc = (unsigned)(__popcll((b0 >> gshift) & GMASK) + __popcll((b1 >> gshift) & GMASK));
+                c_arc = (unsigned)__popcll((b0 >> gshift) & GMASK);
             }
-            if (__ballot(ulen[j] > 2 * G || vlen[j] > 2 * G) != 0) {
+            if (__ballot(ulen[j] > G || vlen[j] > G) != 0) {
                 // lists beyond sixteen ids: the remaining chunk pairs, from memory (degree ordering keeps them rare)
                 for (int ja = 0; __ballot(ja < ulen[j]) != 0; ja += G) {
-                    const int32_t a = (ja + lane < ulen[j]) ? o_col[ub[j] + ja + lane] : -2;
-                    for (int jb = (ja < 2 * G) ? 2 * G : 0; __ballot(jb < vlen[j]) != 0; jb += G) {
+                    const int32_t a = (ja + lane < ulen[j]) ? o_col[ub[j] + ja + lane] : TRI_PAD;
+                    for (int jb = (ja == 0) ? G : 0; __ballot(jb < vlen[j]) != 0; jb += G) {
                         const int32_t y = (jb + lane < vlen[j]) ? o_col[vb[j] + jb + lane] : -1;
-                        const bool h = tri_any_equal(y, a);
+                        const bool h = tri_search16(y, a, group_byte);
                         const unsigned long long bh = __ballot(h);
                         if (bh) {
                             if (h) atomicAdd(&T[y], 1ull);
@@ -572,7 +565,7 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
             }
             if (__ballot(c_arc != 0) != 0) {                    // rare
                 if (c_arc && lane == 0) {
-                    // the arc's two ends: the target from the column array, the source as the row that owns position ub
+                    // the arc's two ends: the target from the column array, the source = the row that owns position k
                     const int32_t v = o_col[k0 + j];
                     int64_t lo = row_begin, hi = row_end;       // last row with o_row_ptr[row] <= k0 + j
                     while (hi - lo > 1) {
