@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void triangle_count_kernel(
             for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
                 const bool have = k0 + lane < ue;
                 const int32_t v_mine = have ? GRX_STREAM_LD(o_col[k0 + lane]) : -1;
-                const unsigned long long d_mine = have ? GRX_STREAM_LD(o_arc[2 * (k0 + lane)]) : 0ull;
+                const unsigned long long d_raw = have ? GRX_STREAM_LD(o_arc[k0 + lane]) : 0ull;
+                const unsigned long long d_mine = (d_raw & 0xFFFFFFFFull) | (((d_raw >> 32) & 1023ull) << TRI_ARC_SHIFT);
                 const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
                 // four target lists at a time: their first two chunks are eight independent loads in
                 // flight per lane (scalars, not arrays: arrays end up in scratch memory here)
@@ -513,19 +514,22 @@ __device__ __forceinline__ unsigned long long tri_bperm64(unsigned long long x, 
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
-// A wavefront takes 64 consecutive arcs per iteration.  Phase A, one LANE per arc: the 16-byte table entry (a coalesced
-// 1 KiB read) and a touch of both lists' first and last line -- 64 random lines in flight per wavefront, which is what
-// the memory system needs to reach its random-line rate (four per 16-lane group left it at a third of that).  Phase B,
-// one 16-lane GROUP per arc, four arcs at a time: the entries come over from the lanes that read them, the lists are
-// read again -- now from L2 -- and intersected by the binary search above.
+// o_arc[k] for the k-th oriented arc u->v (grx.h): begin of N+(v) | |N+(v)| << 32 | |N+(u)| << 42 | (k - begin of
+// N+(u)) << 52, the three 10-bit fields saturating at 1023 -- such arcs (hubs of the ORIENTED graph: out-degree is at
+// most sqrt(2 m)) are looked up from o_row_ptr instead.
+constexpr int TRI_FIELD = 10;
+constexpr unsigned TRI_SAT = (1u << TRI_FIELD) - 1;
+
+// A wavefront takes 64 consecutive arcs per iteration: one LANE per arc reads the 8-byte table entry (a coalesced
+// 512-byte read), then one 16-lane GROUP per arc, four arcs at a time, receives the entries from the lanes that read
+// them, loads the lists and intersects them by the binary search above.
 __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
-    const ulonglong2 *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
-    unsigned long long *__restrict__ T, int32_t *__restrict__ sink_out)
+    const unsigned long long *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
+    unsigned long long *__restrict__ T)
 {
     constexpr int G = TRI_AG;
     constexpr unsigned long long GMASK = (1ull << G) - 1;
-    constexpr unsigned long long LOW = (1ull << TRI_ARC_SHIFT) - 1;
     const int wlane = threadIdx.x & 63;
     const int lane = wlane % G;
     const int gshift = wlane & ~(G - 1);                       // first lane of this group in the wavefront
@@ -534,30 +538,55 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t kb = o_row_ptr[row_begin], ke = o_row_ptr[row_end];
-    int32_t sink = 0;
     for (int64_t base = kb + wave * 64; base < ke; base += nwaves * 64) {
-        // ---- phase A: my arc's table entry, and a touch of the lines its two lists lie in
         const int64_t k_mine = base + wlane;
-        const ulonglong2 d_mine = (k_mine < ke) ? o_arc[k_mine] : make_ulonglong2(0ull, 0ull);
+        unsigned long long d_mine = (k_mine < ke) ? o_arc[k_mine] : 0ull;
+        // ---- arcs with a saturated field (rare): the whole wavefront serves them one by one from o_row_ptr
         {
-            const int64_t vb_m = (int64_t)(d_mine.x & LOW), ub_m = (int64_t)(d_mine.y & LOW);
-            const int vlen_m = (int)(d_mine.x >> TRI_ARC_SHIFT), ulen_m = (int)(d_mine.y >> TRI_ARC_SHIFT);
-            if (vlen_m > 0 && ulen_m > 0) {
-                const int vl = vlen_m < G ? vlen_m : G, ul = ulen_m < G ? ulen_m : G;
-                sink ^= o_col[vb_m] ^ o_col[vb_m + vl - 1] ^ o_col[ub_m] ^ o_col[ub_m + ul - 1];
+            const unsigned vl = (unsigned)(d_mine >> 32) & TRI_SAT, ul = (unsigned)(d_mine >> 42) & TRI_SAT,
+                           ps = (unsigned)(d_mine >> 52) & TRI_SAT;
+            unsigned long long todo = __ballot(vl == TRI_SAT || ul == TRI_SAT || ps == TRI_SAT);
+            if (vl == TRI_SAT || ul == TRI_SAT || ps == TRI_SAT) d_mine = 0ull;      // not for the group phase
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t k = base + src;
+                const int32_t v = o_col[k];
+                int64_t lo = row_begin, hi = row_end;           // u: last row with o_row_ptr[row] <= k
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (o_row_ptr[mid] <= k) lo = mid; else hi = mid;
+                }
+                const int64_t ub = o_row_ptr[lo], ue = o_row_ptr[lo + 1], vb = o_row_ptr[v], ve = o_row_ptr[v + 1];
+                unsigned long long c = 0;
+                for (int64_t j0 = vb; j0 < ve; j0 += 64) {      // every id of N+(v): binary search in N+(u)
+                    const bool have = j0 + wlane < ve;
+                    const int32_t y = have ? o_col[j0 + wlane] : -1;
+                    int64_t a = ub, e = ue;
+                    while (have && a < e) {
+                        const int64_t mid = (a + e) >> 1;
+                        if (o_col[mid] < y) a = mid + 1; else e = mid;
+                    }
+                    const bool hit = have && a < ue && o_col[a] == y;
+                    if (hit) atomicAdd(&T[y], 1ull);
+                    c += (unsigned long long)__popcll(__ballot(hit));
+                }
+                if (c && wlane == 0) { atomicAdd(&T[v], c); atomicAdd(&T[lo], c); }
             }
         }
-        // ---- phase B
+        // ---- the group phase
 #pragma unroll 1
         for (int sub = 0; sub < 64 / ((64 / G) * TRI_ARCS); ++sub) {
-            int64_t vb[TRI_ARCS], ub[TRI_ARCS];
+            uint32_t vb[TRI_ARCS], ub[TRI_ARCS];
             int vlen[TRI_ARCS], ulen[TRI_ARCS];
 #pragma unroll
             for (int j = 0; j < TRI_ARCS; ++j) {
                 const int src = sub * 16 + g * TRI_ARCS + j;    // the lane that holds this arc's entry
-                const unsigned long long dx = tri_bperm64(d_mine.x, src * 4), dy = tri_bperm64(d_mine.y, src * 4);
-                vb[j] = (int64_t)(dx & LOW); vlen[j] = (int)(dx >> TRI_ARC_SHIFT);
-                ub[j] = (int64_t)(dy & LOW); ulen[j] = (int)(dy >> TRI_ARC_SHIFT);
+                const unsigned long long d = tri_bperm64(d_mine, src * 4);
+                vb[j] = (uint32_t)d;
+                vlen[j] = (int)((unsigned)(d >> 32) & TRI_SAT);
+                ulen[j] = (int)((unsigned)(d >> 42) & TRI_SAT);
+                ub[j] = (uint32_t)(base + src) - ((unsigned)(d >> 52) & TRI_SAT);
                 if (vlen[j] == 0) ulen[j] = 0;                 // nothing to intersect with: do not fetch N+(u) either
             }
             int32_t y0[TRI_ARCS], a0[TRI_ARCS];
@@ -607,7 +636,6 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
             }
         }
     }
-    if (sink == 0x5bd1e995 && sink_out) *sink_out = sink;       // never (ids are < 2^31 - 1 ...): keeps the touches alive
 }
 
 // info[v] = (d'(v) << 1) | L(v)   (int32: the whole table is 4 B/node and stays L2-resident)
@@ -1454,10 +1482,9 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
         triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
                                                                     reinterpret_cast<unsigned long long *>(d_T));
     else
-        triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col,
-                                                                         reinterpret_cast<const ulonglong2 *>(d_o_arc),
-                                                                         row_begin, row_end,
-                                                                         reinterpret_cast<unsigned long long *>(d_T), nullptr);
+        triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(
+            d_o_row_ptr, d_o_col, reinterpret_cast<const unsigned long long *>(d_o_arc), row_begin, row_end,
+            reinterpret_cast<unsigned long long *>(d_T));
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

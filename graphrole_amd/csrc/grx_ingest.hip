@@ -278,19 +278,20 @@ __global__ __launch_bounds__(256) void orient_fill_kernel(int64_t n, const int64
     }
 }
 
-// per oriented arc u->v two descriptors, begin | (length << 40): where N+(v) lies and where N+(u) lies
+// per oriented arc k = u->v (grx.h): begin of N+(v) | min(|N+(v)|, 1023) << 32 | min(|N+(u)|, 1023) << 42 |
+// min(k - begin of N+(u), 1023) << 52
 __global__ __launch_bounds__(256) void orient_arc_kernel(int64_t n, const int64_t *__restrict__ o_row_ptr,
                                                          const int32_t *__restrict__ o_col, uint64_t *__restrict__ arc)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
         const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
-        const uint64_t mine = (uint64_t)ub | ((uint64_t)(ue - ub) << 40);
+        const uint64_t ulen = (uint64_t)(ue - ub) < 1023 ? (uint64_t)(ue - ub) : 1023;
         for (int64_t k = ub; k < ue; ++k) {
             const int32_t v = o_col[k];
             const uint64_t b = (uint64_t)o_row_ptr[v], len = (uint64_t)(o_row_ptr[v + 1] - o_row_ptr[v]);
-            arc[2 * k] = b | (len << 40);
-            arc[2 * k + 1] = mine;
+            const uint64_t pos = (uint64_t)(k - ub) < 1023 ? (uint64_t)(k - ub) : 1023;
+            arc[k] = b | ((len < 1023 ? len : 1023) << 32) | (ulen << 42) | (pos << 52);
         }
     }
 }

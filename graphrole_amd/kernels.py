@@ -264,7 +264,7 @@ class DeviceCSR:
         h_ptr = o_ptr.cpu().numpy()
         o_nnz = int(h_ptr[-1])
         o_col = torch.empty(max(o_nnz, 1), dtype=torch.int32, device=device())
-        arc = torch.empty(2 * max(o_nnz, 1), dtype=torch.int64, device=device())
+        arc = torch.empty(max(o_nnz, 1), dtype=torch.int64, device=device())
         _lib.call('grx_orient_fill', n, _ptr(self.row_ptr), _ptr(self.col), _ptr(o_ptr), o_nnz, _ptr(o_col), _ptr(arc),
                   _ptr(ws), ws_bytes, _stream())
         o = DeviceCSR.from_device(o_ptr, o_col, None, None, h_ptr)
@@ -286,15 +286,15 @@ class DeviceCSR:
             o_ptr = np.zeros(n + 1, dtype=np.int64)
             np.cumsum(np.bincount(rows[keep], minlength=n), out=o_ptr[1:])
             self._oriented = DeviceCSR(o_ptr, col[keep])
-            # per oriented arc u->v: where N+(v) and N+(u) lie (begin | length << 40, interleaved), see grx_triangle_counts
+            # per oriented arc k = u->v: begin of N+(v) | d+(v) << 32 | d+(u) << 42 | (k - begin of N+(u)) << 52, the
+            # 10-bit fields saturating at 1023 (see grx_triangle_counts)
             tgt = col[keep].astype(np.int64)
             src = rows[keep]
-            arc = np.empty(2 * max(len(tgt), 1), dtype=np.int64)
-            arc[0::2][:len(tgt)] = o_ptr[tgt] | ((o_ptr[tgt + 1] - o_ptr[tgt]) << 40)
-            arc[1::2][:len(tgt)] = o_ptr[src] | ((o_ptr[src + 1] - o_ptr[src]) << 40)
-            if not len(tgt):
-                arc[:] = 0
-            self._oriented.arc = torch.from_numpy(arc).to(device())
+            k = np.arange(len(tgt), dtype=np.int64)
+            sat = lambda x: np.minimum(x, 1023)
+            arc = (o_ptr[tgt] | (sat(o_ptr[tgt + 1] - o_ptr[tgt]) << 32) | (sat(o_ptr[src + 1] - o_ptr[src]) << 42)
+                   | (sat(k - o_ptr[src]) << 52))
+            self._oriented.arc = torch.from_numpy(arc if len(arc) else np.zeros(1, np.int64)).to(device())
         return self._oriented
 
     def triangle_split(self, rank: int, world: int) -> Tuple[int, int]:

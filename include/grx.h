@@ -237,9 +237,11 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
  * grx_triangle_counts accumulates T (caller zero-fills d_T, uint64[n]) from the degree-oriented
  * graph (CSR that keeps arc u->v iff (d'(u),u) < (d'(v),v), columns ascending); only source rows
  * [row_begin,row_end) are processed, so ranks can split the arcs and all-reduce(SUM) d_T.
- * d_o_arc: TWO uint64 per oriented arc u->v (interleaved, 16-byte aligned): o_row_ptr[v] | ((o_row_ptr[v+1] -
- * o_row_ptr[v]) << 40) and the same for u, i.e. where the target's and the source's own lists lie (read sequentially
- * instead of dependent random lookups; the arcs are the kernel's work items).
+ * d_o_arc: one uint64 per oriented arc k = u->v (the arcs are the kernel's work items; the table is read sequentially
+ * instead of dependent random lookups): o_row_ptr[v] | min(d+(v), 1023) << 32 | min(d+(u), 1023) << 42 |
+ * min(k - o_row_ptr[u], 1023) << 52 -- where the target's own list lies and how long it is, how long the source's
+ * list is and where in it the arc stands (requires o_nnz < 2^32; arcs with a field at 1023 are looked up from
+ * o_row_ptr).
  * grx_egonet_unweighted then writes rows [row_begin,row_end); d_scratch: int32[n] (degree < 2^30).
  * d_hub_rows / n_hub_rows (optional): ascending rows with more than hub_degree neighbours; they get a
  * workgroup each instead of an 8-lane group.

@@ -97,6 +97,44 @@ def test_egonet_hub_rows_powerlaw(K):
     assert np.all(i2.cpu().numpy()[:1000] == 0) and np.all(e2.cpu().numpy()[17000:] == 0)
 
 
+def test_triangle_counts_long_oriented_lists(K):
+    """The per-arc table of the oriented graph keeps list lengths in 10-bit fields; a clique of 1 200 nodes (oriented
+    out-degrees 0 .. 1199) saturates them and takes the row-pointer path, lists of 17 .. 1022 ids take the chunked
+    group path.  T(v) of a clique is C(n - 1, 2); a sparse random part around it keeps the ordinary path busy.  Both
+    builders of the table (device and host) must agree, and source-row ranges must add up."""
+    import torch
+    rng = np.random.default_rng(7)
+    nc, n = 1200, 4000
+    iu = np.triu_indices(nc, 1)
+    extra_s = rng.integers(0, n, 20000)
+    extra_d = rng.integers(nc, n, 20000)                                  # never inside the clique
+    keep = extra_s != extra_d
+    src = np.concatenate([iu[0], extra_s[keep]]).astype(np.int64)
+    dst = np.concatenate([iu[1], extra_d[keep]]).astype(np.int64)
+    key = np.unique(np.minimum(src, dst) * n + np.maximum(src, dst))
+    src, dst = key // n, key % n
+    og = _oracle_graph(n, src, dst, None, False)
+    csr = _dev_csr(K, og)
+    T = K.triangle_counts(csr).cpu().numpy()[:n]
+    # reference: triangles through v from the dense adjacency
+    A = np.zeros((n, n), dtype=np.float32)
+    A[src, dst] = 1; A[dst, src] = 1
+    At = torch.from_numpy(A).cuda()
+    exp = ((At @ At) * At).sum(1).cpu().numpy().astype(np.int64) // 2
+    assert exp[:nc].min() >= (nc - 1) * (nc - 2) // 2
+    assert np.array_equal(T.astype(np.int64), exp)
+    cut = 700
+    Ta = K.triangle_counts(csr, 0, cut).cpu().numpy() + K.triangle_counts(csr, cut, None).cpu().numpy()
+    assert np.array_equal(Ta[:n], T)
+    # the device-built table equals the host-built one
+    dev = K.DeviceCSR.from_device(csr.row_ptr, csr.col, None, None, og.row_ptr) if hasattr(K.DeviceCSR, 'from_device') else None
+    if dev is not None:
+        o = dev.oriented()
+        ref = csr.oriented()
+        o_nnz = int(np.asarray(og.row_ptr)[-1]) // 2
+        assert np.array_equal(o.arc.cpu().numpy()[:o_nnz], ref.arc.cpu().numpy()[:o_nnz])
+
+
 @pytest.mark.parametrize('name', ['karate', 'karate_weighted', 'dw200_attrs', 'loops_dangling150', 'directed120',
                                   'iface7', 'iface7_dw', 'path4', 'er2000', 'ba2000'])
 def test_gen0_vs_reference_golden(K, name):
