@@ -588,20 +588,56 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                 ulen[j] = (int)((unsigned)(d >> 42) & TRI_SAT);
                 ub[j] = (uint32_t)(base + src) - ((unsigned)(d >> 52) & TRI_SAT);
                 if (vlen[j] == 0) ulen[j] = 0;                 // nothing to intersect with: do not fetch N+(u) either
+                if (ulen[j] == 0) ub[j] = 0;                   // (no arc here: keep the unconditional loads in bounds)
             }
+            // eight independent loads per lane (unconditional -- lanes beyond a list read its first id and discard it:
+            // a branch around every load cost more than the redundant reads)
             int32_t y0[TRI_ARCS], a0[TRI_ARCS];
 #pragma unroll
             for (int j = 0; j < TRI_ARCS; ++j) {
-                y0[j] = (lane < vlen[j] && ulen[j] > 0) ? o_col[vb[j] + lane] : -1;
-                a0[j] = (lane < ulen[j]) ? o_col[ub[j] + lane] : TRI_PAD;
+                const bool yv = lane < vlen[j] && ulen[j] > 0, av = lane < ulen[j];
+                const int32_t yr = o_col[vb[j] + (yv ? lane : 0)];
+                const int32_t ar = o_col[ub[j] + (av ? lane : 0)];
+                y0[j] = yv ? yr : -1;
+                a0[j] = av ? ar : TRI_PAD;
             }
+            // the four binary searches step by step TOGETHER: four independent ds_bpermute in flight per step (one
+            // search after the other was twenty serial LDS round trips per group of arcs)
+            bool h[TRI_ARCS];
+            {
+                int pos[TRI_ARCS];
+                int32_t t[TRI_ARCS];
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) t[j] = __builtin_amdgcn_ds_bpermute(group_byte + 7 * 4, a0[j]);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) pos[j] = group_byte + ((t[j] < y0[j]) ? 8 * 4 : 0);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) t[j] = __builtin_amdgcn_ds_bpermute(pos[j] + 3 * 4, a0[j]);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) pos[j] += (t[j] < y0[j]) ? 4 * 4 : 0;
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) t[j] = __builtin_amdgcn_ds_bpermute(pos[j] + 1 * 4, a0[j]);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) pos[j] += (t[j] < y0[j]) ? 2 * 4 : 0;
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) t[j] = __builtin_amdgcn_ds_bpermute(pos[j], a0[j]);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) pos[j] += (t[j] < y0[j]) ? 4 : 0;
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) t[j] = __builtin_amdgcn_ds_bpermute(pos[j], a0[j]);
+#pragma unroll
+                for (int j = 0; j < TRI_ARCS; ++j) h[j] = t[j] == y0[j];
+            }
+            bool longer = false;
+#pragma unroll
+            for (int j = 0; j < TRI_ARCS; ++j) longer |= (ulen[j] > G || vlen[j] > G) && ulen[j] > 0;
+            if (__ballot(h[0] | h[1] | h[2] | h[3] | longer) == 0) continue;     // the usual case: no triangle here
 #pragma unroll
             for (int j = 0; j < TRI_ARCS; ++j) {
                 unsigned c_arc = 0;
-                const bool h0 = tri_search16(y0[j], a0[j], group_byte);
-                const unsigned long long b0 = __ballot(h0);
-                if (b0) {                                       // rare: some arc of the wavefront closes a triangle
-                    if (h0) atomicAdd(&T[y0[j]], 1ull);
+                const unsigned long long b0 = __ballot(h[j]);
+                if (b0) {
+                    if (h[j]) atomicAdd(&T[y0[j]], 1ull);
                     c_arc = (unsigned)__popcll((b0 >> gshift) & GMASK);
                 }
                 if (__ballot((ulen[j] > G || vlen[j] > G) && ulen[j] > 0) != 0) {
@@ -610,16 +646,16 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                         const int32_t a = (ja + lane < ulen[j]) ? o_col[ub[j] + ja + lane] : TRI_PAD;
                         for (int jb = (ja == 0) ? G : 0; __ballot(jb < vlen[j] && ja < ulen[j]) != 0; jb += G) {
                             const int32_t y = (jb + lane < vlen[j] && ja < ulen[j]) ? o_col[vb[j] + jb + lane] : -1;
-                            const bool h = tri_search16(y, a, group_byte);
-                            const unsigned long long bh = __ballot(h);
+                            const bool hh = tri_search16(y, a, group_byte);
+                            const unsigned long long bh = __ballot(hh);
                             if (bh) {
-                                if (h) atomicAdd(&T[y], 1ull);
+                                if (hh) atomicAdd(&T[y], 1ull);
                                 c_arc += (unsigned)__popcll((bh >> gshift) & GMASK);
                             }
                         }
                     }
                 }
-                if (__ballot(c_arc != 0) != 0) {                // rare
+                if (__ballot(c_arc != 0) != 0) {
                     if (c_arc && lane == 0) {
                         // the arc's two ends: the target from the column array, the source = the row that owns position k
                         const int64_t k = base + sub * 16 + g * TRI_ARCS + j;
