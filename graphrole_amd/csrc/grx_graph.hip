@@ -356,137 +356,25 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
 // (networkx.py:71-83 counted edge by edge; all quantities are integers, so this is exact.)
 // T comes from the degree-oriented graph (arc u->v iff (d'(u),u) < (d'(v),v)): every triangle
 // is found exactly once as a common out-neighbour of the two ends of its lowest arc; oriented
-// lists are short even for power-law hubs, so a two-pointer merge per arc is cheap.
-// An 8-lane group owns one source u and walks its oriented arcs u->v TOGETHER: the group reads
-// N+(v) with one coalesced 32-byte load per 8 elements (instead of eight lanes chasing eight
-// different lists), keeps N+(u) in registers (3 entries per lane = 24 per pass; degree ordering
-// keeps oriented lists <= ~20 on the BASELINE graphs) and tests membership all-to-all with
-// in-group shuffles.  L2 requests per arc drop from ~16 to ~4, which is what bounded this kernel
-// (rocprof: 165 M TCP->TCC requests per launch).  Counting is integer atomics: exact, any order.
-// o_arc[2 k] = begin | (length << 40) of N+(v) for the k-th oriented arc u->v: the target's list is
-// located from the (sequentially read) arc table instead of a dependent, random o_row_ptr[v] lookup,
-// so the group knows the addresses of eight target lists at once and keeps the first two 8-element
-// chunks of each in flight (16 independent loads per lane) before it starts comparing.
-constexpr int TRI_ARC_SHIFT = 40;
-constexpr int TRI_G = 8;                     // lanes per source row
-
-// MEASURED AND REJECTED (round 3): an XCD-partitioned variant -- targets split into eight classes of 32-row runs,
-// workgroup b following only the arcs into class b % 8 so that each XCD's private L2 has to hold one eighth of the
-// target lists, the target list located through o_row_ptr[v] instead of the per-arc table.  Counts equal, but
-// 1.74 ms against 0.58 ms at BA 1 M (0.178 against 0.053 ms at ER 100 k): every source list is then read and
-// filtered by all eight XCDs, and that fixed cost (8 M group visits instead of 1 M) outweighs the better hit rate.
-__global__ __launch_bounds__(256) void triangle_count_kernel(
-    const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
-    const uint64_t *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
-    unsigned long long *__restrict__ T)
-{
-    constexpr int G = TRI_G;
-    constexpr unsigned long long GMASK = (1ull << G) - 1;
-    const int lane = threadIdx.x % G;
-    const int gshift = (threadIdx.x & 63) & ~(G - 1);          // bit offset of this group in a ballot
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t u = row_begin + group; u < row_end; u += ngroups) {
-        const int64_t ub = o_row_ptr[u], ue = o_row_ptr[u + 1];
-        unsigned long long cu = 0;
-        for (int64_t base = ub; base < ue; base += 3 * G) {     // usually a single pass
-            int32_t uu[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int64_t idx = base + lane + (int64_t)G * i;
-                uu[i] = (idx < ue) ? GRX_STREAM_LD(o_col[idx]) : -2;
-            }
-            // 256-bit membership filter of the (up to 24) ids of N+(u) held by the group, one bit per
-            // id & 255: an element of N+(v) is compared against the list only when its bit is set --
-            // most are not members (few arcs close a triangle), so most 8-element chunks end after
-            // one bit test and one ballot instead of 8 x (shuffle + 3 compares + ballot)
-            unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (uu[i] >= 0) {
-                    const unsigned long long bit = 1ull << (uu[i] & 63);
-                    const int word = (uu[i] >> 6) & 3;
-                    f0 |= word == 0 ? bit : 0ull; f1 |= word == 1 ? bit : 0ull;
-                    f2 |= word == 2 ? bit : 0ull; f3 |= word == 3 ? bit : 0ull;
-                }
-            }
-#pragma unroll
-            for (int off = 1; off < G; off <<= 1) {
-                f0 |= __shfl_xor(f0, off, G); f1 |= __shfl_xor(f1, off, G);
-                f2 |= __shfl_xor(f2, off, G); f3 |= __shfl_xor(f3, off, G);
-            }
-            // one 8-element chunk of a target list against the ids held by the group (a macro, not a
-            // lambda: the closure object put uu[] and the filter words into scratch memory)
-#define TRI_CHUNK(YEXPR, ACC)                                                                            \
-            do {                                                                                          \
-                const int32_t y_ = (YEXPR);                                                               \
-                const int yw_ = (y_ >> 6) & 3;                                                            \
-                const unsigned long long fw_ = yw_ == 0 ? f0 : yw_ == 1 ? f1 : yw_ == 2 ? f2 : f3;        \
-                const bool maybe_ = y_ >= 0 && ((fw_ >> (y_ & 63)) & 1ull);                               \
-                if (((__ballot(maybe_) >> gshift) & GMASK) != 0) {          /* uniform over the group */  \
-                    unsigned match_ = 0;                                                                  \
-                    _Pragma("unroll") for (int sidx = 0; sidx < G; ++sidx) {                              \
-                        const int32_t ys = __shfl(y_, sidx, G);                                           \
-                        const bool hit = (ys == uu0) | (ys == uu1) | (ys == uu2);                         \
-                        const unsigned long long bal = __ballot(hit);                                     \
-                        if ((bal >> gshift) & GMASK) match_ |= 1u << sidx;                              \
-                    }                                                                                     \
-                    if ((match_ >> lane) & 1u) atomicAdd(&T[y_], 1ull);                                   \
-                    ACC += (unsigned)__popc(match_);                                                      \
-                }                                                                                         \
-            } while (0)
-            const int32_t uu0 = uu[0], uu1 = uu[1], uu2 = uu[2];
-            for (int64_t k0 = ub; k0 < ue; k0 += G) {           // arcs u->v: descriptors eight at a time
-                const bool have = k0 + lane < ue;
-                const int32_t v_mine = have ? GRX_STREAM_LD(o_col[k0 + lane]) : -1;
-                const unsigned long long d_raw = have ? GRX_STREAM_LD(o_arc[k0 + lane]) : 0ull;
-                const unsigned long long d_mine = (d_raw & 0xFFFFFFFFull) | (((d_raw >> 32) & 1023ull) << TRI_ARC_SHIFT);
-                const int nb = (int)((ue - k0) < G ? (ue - k0) : G);
-                // four target lists at a time: their first two chunks are eight independent loads in
-                // flight per lane (scalars, not arrays: arrays end up in scratch memory here)
-#define TRI_LOAD(A, Y0, Y1)                                                                              \
-                const unsigned long long d##A = __shfl(d_mine, a0 + A, G);                                \
-                const int64_t vb##A = (int64_t)(d##A & ((1ull << TRI_ARC_SHIFT) - 1));                      \
-                const int len##A = (int)(d##A >> TRI_ARC_SHIFT);                                            \
-                const int32_t Y0 = (lane < len##A) ? o_col[vb##A + lane] : -1;                              \
-                const int32_t Y1 = (lane + G < len##A) ? o_col[vb##A + G + lane] : -1;
-#define TRI_ARC(A, Y0, Y1)                                                                               \
-                if (a0 + A < nb) {                                                                        \
-                    unsigned c_arc = 0;                                                                   \
-                    if (len##A > 0) TRI_CHUNK(Y0, c_arc);                                                 \
-                    if (len##A > G) TRI_CHUNK(Y1, c_arc);                                                 \
-                    for (int j0 = 2 * G; j0 < len##A; j0 += G)                                            \
-                        TRI_CHUNK((j0 + lane < len##A) ? o_col[vb##A + j0 + lane] : -1, c_arc);           \
-                    const int32_t v = __shfl(v_mine, a0 + A, G);                                          \
-                    if (lane == 0 && c_arc) atomicAdd(&T[v], (unsigned long long)c_arc);                  \
-                    cu += c_arc;                                                                          \
-                }
-                for (int a0 = 0; a0 < nb; a0 += 4) {                        // uniform over the group
-                    TRI_LOAD(0, ya0, ya1) TRI_LOAD(1, yb0, yb1) TRI_LOAD(2, yc0, yc1) TRI_LOAD(3, yd0, yd1)
-                    TRI_ARC(0, ya0, ya1) TRI_ARC(1, yb0, yb1) TRI_ARC(2, yc0, yc1) TRI_ARC(3, yd0, yd1)
-                }
-#undef TRI_LOAD
-#undef TRI_ARC
-#undef TRI_CHUNK
-            }
-        }
-        if (lane == 0 && cu) atomicAdd(&T[u], cu);
-    }
-}
-
-// Second formulation (round 3).  The instruction stream and the per-source dependency chain, not the memory system,
-// bounded the kernel above: its per-chunk exact test (eight shuffles, each followed by three compares and a ballot)
-// ran whenever ANY of the eight groups of a wavefront had a filter hit, i.e. nearly always (SQ_ACTIVE_INST_ANY 7x
-// the aggregate kernel's for half its memory traffic), a wavefront waited for its longest source row, and every
-// source cost three dependent round trips (row_ptr -> ids and descriptors -> target lists) at 2.0 TB/s of L2 misses
-// where the aggregate kernel sustains 7.
-// Here the ARCS are the work items: a 16-lane group takes four consecutive arcs u->v, reads their table entries
-// (o_arc holds two descriptors per arc: where N+(v) lies and where N+(u) lies), has the first sixteen ids of all
-// eight lists in flight at once -- degree ordering keeps 99.5 % of the oriented lists of the BASELINE graphs that
-// short -- and intersects by BINARY SEARCH: the lists are ascending, every lane looks its id of N+(v) up among the
-// sixteen ids of N+(u) spread over the group's lanes (five ds_bpermute probes; the all-pairs compare costs 8 x 8 lane
-// compares per pair of 8-id chunks, four such pairs for two lists of ten).  Two round trips per arc, no per-source
-// loop, every group always has work.
+// lists are short even for power-law hubs.
+// The ARCS are the work items (round 3).  Rounds 1-2 gave every source u an 8-lane group that walked its arcs: N+(u)
+// in registers, a 256-bit membership filter, an all-pairs shuffle compare of 8-id chunks.  Its counters showed the
+// instruction stream and the per-source dependency chain as the bound, not the memory system: the exact test (eight
+// shuffles, each followed by three compares and a ballot) ran whenever ANY of the eight groups of a wavefront had a
+// filter hit, i.e. nearly always (SQ_ACTIVE_INST_ANY 7x the aggregate kernel's for half its memory traffic), a
+// wavefront waited for its longest source row, every source cost three dependent round trips, and only ~4 memory
+// instructions were in flight per CU.  0.58 ms at BA 1 M / 10 M.  Steps from there (profiles/r03_triangles.txt):
+//   N+(u) broadcast into registers, compares instead of shuffles                     0.47 ms
+//   arcs as work items, all-pairs compare by DPP lane rotations, 8 lanes per arc      0.43 ms
+//   16 lanes per arc, binary search across the lanes (ds_bpermute)                   0.44 ms
+//   + a lane-per-arc pass that touches the lists first (64 random lines in flight)   0.52 ms  (rejected)
+//   8-byte table entries read by one lane per arc and passed on by ds_bpermute        0.41 ms
+//   the four searches of a group interleaved, unconditional loads (no exec juggling)  0.39 ms
+// Now: a wavefront takes 64 consecutive arcs u->v; a 16-lane group handles four of them at a time, has the first
+// sixteen ids of all eight lists in flight at once -- degree ordering keeps 99.5 % of the oriented lists of the
+// BASELINE graphs that short -- and intersects by BINARY SEARCH: the lists are ascending, every lane looks its id of
+// N+(v) up among the sixteen ids of N+(u) spread over the group's lanes (five ds_bpermute probes).  Two round trips
+// per arc, no per-source loop, every group always has work; VALU 48 % busy, LDS 29 %, 22 G L2 misses/s.
 constexpr int TRI_AG = 16;                   // lanes per arc
 constexpr int TRI_ARCS = 4;                  // arcs per group and iteration
 constexpr int32_t TRI_PAD = 0x7fffffff;      // pads N+(u) to sixteen ascending ids
@@ -1510,17 +1398,12 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_triangle_counts: bad row range");
     if (row_end == row_begin) return GRX_OK;
     GRX_REQUIRE(d_o_row_ptr && d_o_col && d_o_arc && d_T, "grx_triangle_counts: NULL pointer");
-    const int64_t want = grx_ceil_div((row_end - row_begin) * TRI_G, 256);
+    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);      // ~64 arcs per wavefront and sweep at 8 arcs per row
     const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
-    static const bool shuffle_variant = [] { const char *e = getenv("GRX_TRIANGLES_SHUFFLE"); return e && e[0] == '1'; }();
     { GRX_PROF(GRX_K_TRIANGLES, grx_stream(stream));
-    if (shuffle_variant)
-        triangle_count_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_o_row_ptr, d_o_col, d_o_arc, row_begin, row_end,
-                                                                    reinterpret_cast<unsigned long long *>(d_T));
-    else
-        triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(
-            d_o_row_ptr, d_o_col, reinterpret_cast<const unsigned long long *>(d_o_arc), row_begin, row_end,
-            reinterpret_cast<unsigned long long *>(d_T));
+    triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(
+        d_o_row_ptr, d_o_col, reinterpret_cast<const unsigned long long *>(d_o_arc), row_begin, row_end,
+        reinterpret_cast<unsigned long long *>(d_T));
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
