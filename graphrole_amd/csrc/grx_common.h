@@ -30,11 +30,6 @@ void grx_set_error(const char *fmt, ...);
 
 static inline hipStream_t grx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Wait for a stream whose remaining work is microseconds long (a few-KiB read-back the host decides on): polling the
-// queue returns a few microseconds after the last packet, the interrupt-driven hipStreamSynchronize ~20 us later --
-// seven such waits sit on the critical path of one ReFeX + NMF step.  Falls back to the blocking wait after 200 us.
-int grx_wait_short(hipStream_t st);
-
 // Per-kernel event timing (grx_profile_* in grx.h).  No-ops unless enabled.
 enum GrxKernelId {
     GRX_K_ROW_SUMS = 0, GRX_K_EGONET_WAVE, GRX_K_EGONET_BLOCK, GRX_K_PACK_ROWS, GRX_K_AGGREGATE,

@@ -54,7 +54,8 @@ size_t staging_bytes(int F, int r)
 int fetch(double *h_dst, const double *d_src, size_t count, hipStream_t st)
 {
     GRX_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, count * 8, hipMemcpyDeviceToHost, st));
-    return grx_wait_short(st);
+    GRX_CHECK_HIP(hipStreamSynchronize(st));
+    return GRX_OK;
 }
 
 struct FitLayout {

@@ -225,7 +225,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 void *host = nullptr;
                 GRX_TRY(pinned((size_t)F * F * 4, &host));
                 GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, (size_t)F * F * 4, hipMemcpyDeviceToHost, st));
-                GRX_TRY(grx_wait_short(st));
+                GRX_CHECK_HIP(hipStreamSynchronize(st));
                 // identical distances on every rank -> identical decisions, no further agreement needed
                 drop_idx = prune(cols, work, reinterpret_cast<const int32_t *>(host), generation, recorded);
             }

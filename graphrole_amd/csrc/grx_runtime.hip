@@ -5,8 +5,6 @@
 #include <vector>
 
 #include "grx_common.h"
-#include <chrono>
-#include <cstdlib>
 
 static thread_local char g_err[1024] = "";
 
@@ -40,24 +38,6 @@ const char *const g_prof_names[GRX_K_COUNT] = {
     "key_bits_kernel", "sel_map_kernel", "sel_hist_kernel", "sel_walk1_kernel", "sel_collect_kernel", "sel_sort_kernel",
     "sel_walk2_kernel"};
 }  // namespace
-
-int grx_wait_short(hipStream_t st)
-{
-    static const bool blocking = [] { const char *e = getenv("GRX_BLOCKING_WAITS"); return e && e[0] == '1'; }();
-    if (!blocking) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int spin = 0;; ++spin) {
-            const hipError_t e = hipStreamQuery(st);
-            if (e == hipSuccess) return GRX_OK;
-            if (e != hipErrorNotReady) GRX_CHECK_HIP(e);
-            if ((spin & 15) == 15 &&
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 200.0)
-                break;
-        }
-    }
-    GRX_CHECK_HIP(hipStreamSynchronize(st));
-    return GRX_OK;
-}
 
 static hipEvent_t prof_get_event()
 {
