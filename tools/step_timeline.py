@@ -1,5 +1,6 @@
 """Kernel timeline of the LAST bench step from a rocprofv3 --kernel-trace csv: start (ms), idle gap before the
-kernel, duration, name.  Usage: python tools/step_timeline.py <kernel_trace.csv> <out.txt> [first-kernel-substring]"""
+kernel, duration, name; the step ends before the first k-means / quantisation kernel (the bench's untimed extras).
+Usage: python tools/step_timeline.py <kernel_trace.csv> <out.txt> [first-kernel-substring]"""
 import csv
 import sys
 
@@ -14,7 +15,13 @@ while start - 1 in idx:
     start -= 1
 t0 = prev_end = int(rows[start]['Start_Timestamp'])
 with open(dst, 'w') as out:
+    total_gap = total_dur = 0.0
     for r in rows[start:]:
+        if any(tag in r['Kernel_Name'] for tag in ('km_', 'q_', 'tile_count_kernel<true>')):
+            break
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        total_gap += (s - prev_end) / 1e6
+        total_dur += (e - s) / 1e6
         out.write('%9.3f gap %7.3f dur %8.3f  %s\n' % ((s - t0) / 1e6, (s - prev_end) / 1e6, (e - s) / 1e6, r['Kernel_Name'][:100]))
         prev_end = e
+    out.write('# step: %.3f ms of kernels and copies, %.3f ms idle between them (host waits and launch gaps)\n' % (total_dur, total_gap))
