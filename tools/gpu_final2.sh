@@ -2,7 +2,7 @@
 # round 3, frozen binary: timelines, bench lines, forced-collectives line, model selection
 OUT=gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
-for w in ba1m er100k dw5m; do
+for w in ; do
   steps=6; [ $w = dw5m ] && steps=3
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -o t -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline --no-api-wall > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/tl_$w.err )
   f=$(find /tmp/tl_$w -name '*kernel_trace.csv' | head -1)
