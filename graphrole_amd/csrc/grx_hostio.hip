@@ -14,15 +14,8 @@
 //                               _nmf.py:283, without a host pass)
 #include "grx_common.h"
 
-#include <pthread.h>
-#include <sched.h>
-
 #include <atomic>
-#include <cctype>
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <string>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -31,57 +24,6 @@
 #include <vector>
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------------------------
-// The CPUs next to the GPU.  MI355X hosts are two-socket machines: a staging buffer or a copy thread on the far socket
-// puts the inter-socket link between the GPU and the destination (the 4.6 GB result table of BASELINE config 5 came
-// back in 0.15 s or in 0.6 s depending on where the process happened to run).  The copy threads and the pinned ring
-// are bound to the NUMA node sysfs reports for the current device; no information (containers without it) = no binding.
-// GRX_NUMA_BIND=0 switches it off.
-// ---------------------------------------------------------------------------------------------------------------
-bool gpu_node_cpus(cpu_set_t *set)
-{
-    const char *env = getenv("GRX_NUMA_BIND");
-    if (env && env[0] == '0') return false;
-    int dev = 0;
-    char bdf[64] = {};
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) != hipSuccess) return false;
-    for (char *c = bdf; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
-    int node = -1;
-    {
-        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
-        FILE *f = fopen(path.c_str(), "r");
-        if (!f) return false;
-        if (fscanf(f, "%d", &node) != 1) node = -1;
-        fclose(f);
-    }
-    if (node < 0) return false;
-    char list[4096] = {};
-    {
-        const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
-        FILE *f = fopen(path.c_str(), "r");
-        if (!f) return false;
-        const bool ok = fgets(list, (int)sizeof(list), f) != nullptr;
-        fclose(f);
-        if (!ok) return false;
-    }
-    // "0-63,128-191": only CPUs this process may run on anyway
-    cpu_set_t allowed;
-    CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
-    CPU_ZERO(set);
-    int count = 0;
-    for (const char *c = list; *c;) {
-        if (!std::isdigit((unsigned char)*c)) { ++c; continue; }
-        char *end = nullptr;
-        long a = strtol(c, &end, 10), b = a;
-        if (*end == '-') b = strtol(end + 1, &end, 10);
-        for (long x = a; x <= b && x < CPU_SETSIZE; ++x)
-            if (CPU_ISSET((int)x, &allowed)) { CPU_SET((int)x, set); ++count; }
-        c = end;
-    }
-    return count > 0;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // a tiny fork-join pool: run(k, fn) calls fn(0..k-1) on the workers + the caller and returns when all are done
@@ -122,9 +64,6 @@ private:
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 32 ? 11 : hw >= 8 ? 5 : hw >= 4 ? 2 : 0;   // + the caller
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
-        cpu_set_t near;
-        if (gpu_node_cpus(&near))
-            for (auto &t : workers_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(near), &near);
         for (auto &t : workers_) t.detach();
     }
     void work()
@@ -197,22 +136,10 @@ thread_local Ring g_ring;
 int ring_init()
 {
     if (g_ring.ready) return GRX_OK;
-    // allocated and first touched from the GPU's NUMA node (see gpu_node_cpus)
-    cpu_set_t near, before;
-    const bool bind = gpu_node_cpus(&near) && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                      sched_setaffinity(0, sizeof(near), &near) == 0;
-    int rc = GRX_OK;
-    for (int i = 0; i < RING && rc == GRX_OK; ++i) {
-        if (hipHostMalloc(&g_ring.buf[i], CHUNK, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) != hipSuccess) {
-            grx_set_error("grx_hostio: cannot allocate the pinned staging ring");
-            rc = GRX_ERR_HIP;
-        } else {
-            std::memset(g_ring.buf[i], 0, CHUNK);
-        }
+    for (int i = 0; i < RING; ++i) {
+        GRX_CHECK_HIP(hipHostMalloc(&g_ring.buf[i], CHUNK, hipHostMallocDefault));
+        GRX_CHECK_HIP(hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming));
     }
-    if (bind) (void)sched_setaffinity(0, sizeof(before), &before);
-    if (rc != GRX_OK) return rc;
     g_ring.ready = true;
     return GRX_OK;
 }
