@@ -652,6 +652,9 @@ def _refex_arena_guess(n: int, f0: int, n_aggs: int, max_gens: int) -> int:
 
 
 
+_AGG_NAMES = {v: k for k, v in _lib.AGG_IDS.items()}
+
+
 def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
               aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None,
               gen0_int32: Optional[Sequence[bool]] = None):
@@ -697,15 +700,18 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         _lib.check(rc, 'grx_refex_run')
         break
     base = arena.data_ptr()
-    agg_names = {v: k for k, v in _lib.AGG_IDS.items()}
+    agg_names = _AGG_NAMES
+    # one reinterpretation of the arena, one slice per column: tensor views cost ~2 us each on the host, and this loop
+    # sits between the last kernel of the generation loop and whatever the caller launches next
+    arena64 = arena[:arena.numel() & ~7].view(torch.float64)
     columns = []
     for i in range(n_cols.value):
         c = table[i]
         if c.gen0_index >= 0:
             col = gen0_cols[c.gen0_index]
         else:
-            off = int(c.d_col) - base
-            col = arena[off:off + n * 8].view(torch.float64)
+            off = (int(c.d_col) - base) >> 3
+            col = arena64[off:off + n]
         columns.append(dict(generation=c.generation, parent=c.parent, agg=agg_names.get(c.agg), gen0_index=c.gen0_index,
                             work_position=c.work_position, col=col))
     generations = [dict(generation=g, candidates=gens[g].candidates, working=gens[g].working, dropped=gens[g].dropped,
