@@ -16,7 +16,6 @@
 //   nmf_h_update_kernel     H <- H*A/(B H)
 //   nmf_residual_kernel     ||X - WH||_F^2
 #include "grx_common.h"
-#include <cstdlib>
 
 #include <array>
 #include <utility>
@@ -1621,11 +1620,7 @@ static int w_pass_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, 
     {
         const int FT = (F + 15) / 16;
         const int64_t nsub = grx_ceil_div(row_end - row_begin, 16);
-        // at least four sub-tiles per wave: a workgroup's prologue (H update, H H^T, operand registers) costs about as
-        // much as two sub-tiles, and every workgroup adds a row to the partial sums the next launch reduces -- at
-        // 100 k rows the resident grid gave a wave 1.5 sub-tiles (W pass 12.8 us, reduction 6.9 us per iteration)
-        static const int tiles_per_wave = [] { const char *e = getenv("GRX_NMF_TILES_PER_WAVE"); return e ? atoi(e) : 4; }();
-        const int64_t want = grx_ceil_div(nsub, 4 * (tiles_per_wave > 0 ? tiles_per_wave : 1));
+        const int64_t want = grx_ceil_div(nsub, 4);
         GRX_PROF(GRX_K_NMF_W_PASS, st);
         if (F <= MAX_F) {
             const size_t lds = mfma_lds_doubles(FT) * 8;
