@@ -23,7 +23,8 @@ class RoleExtractor:
     N_ROLE_RANGE = (2, 8)
     MAX_ROLES = 16          # GRX_MAX_ROLES of include/grx.h
     N_BIT_RANGE = (1, 8)
-    #: 'kmeans' = the reference's quantiser reproduced (sklearn KMeans(random_state=1), grx_kmeans1d);
+    #: 'kmeans' = the reference's quantiser reproduced (sklearn KMeans(random_state=1) as scikit-learn >= 1.4 runs it:
+    #: one k-means++ initialisation, n_init='auto'; pinned on 1.7.2 -- grx_kmeans1d);
     #: 'lloyd_max' = the deterministic Lloyd-Max solver (lower error, other numbers).  Class attribute: set it
     #: on the class or on an instance before fitting.
     quantizer = 'kmeans'
