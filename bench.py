@@ -521,11 +521,19 @@ def main():
         if rank == 0 and extra is not None:
             line['sharded_dw5m'] = {k: extra[k] for k in ('value', 'unit', 'ms_per_step', 'n_gpus', 'steps', 'config', 'refex',
                                                          'nmf', 'roofline', 'per_rank') if k in extra}
-    if rank == 0 and line is not None:
-        print(json.dumps(line))
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and line is not None:
+        # the JSON line is the LAST thing on stdout: librccl prints a version banner through C stdio, which would
+        # otherwise be flushed after Python's own buffer when the process exits
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line))
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':
