@@ -1,6 +1,7 @@
 """Differential fuzz on the GPU box: random small graphs (sizes, densities, directed / weighted, self-loops,
 isolated nodes, aggs) through RecursiveFeatureExtractor against the oracle -- bit-exact on unweighted and integer-weighted graphs, generation 0 to
-1e-11 with non-integer weights.  Usage: PYTHONPATH=. python tools/fuzz_refex.py [cases] [seed]"""
+1e-11 with non-integer weights.  Usage: PYTHONPATH=. [FUZZ_BIG=1] python tools/fuzz_refex.py [cases] [seed]"""
+import os
 import sys
 
 import numpy as np
@@ -11,7 +12,10 @@ from oracle import refex
 
 
 def one(rng, case):
-    n = int(rng.choice([5, 17, 64, 300, 1500, 6000]))
+    sizes = [5, 17, 64, 300, 1500, 6000]
+    if os.environ.get('FUZZ_BIG') == '1':                       # medium graphs: the sampled bucket map of the binning at work
+        sizes = [6000, 40_000, 120_000, 400_000]
+    n = int(rng.choice(sizes))
     directed = bool(rng.integers(0, 2))
     weighted = bool(rng.integers(0, 2))
     m = int(n * rng.choice([0.5, 1.5, 4, 12]))
