@@ -23,7 +23,8 @@
 namespace {
 
 constexpr double NMF_EPSILON = 1.1920928955078125e-07;   // np.finfo(np.float32).eps, _nmf.py:39
-constexpr int MAX_R = GRX_MAX_ROLES;                      // 16
+constexpr int MAX_R = GRX_MAX_ROLES;                      // 32
+constexpr int MFMA_R = 16;                                // one MFMA tile of roles: what the fused kernels factor with
 constexpr int MAX_F = 120;                                // single-launch Gram / register-resident W-pass
 constexpr int MAX_F_WIDE = GRX_MAX_NMF_FEATURES;          // 480: r * F * 8 <= 60 KiB of LDS at r = 16
 
@@ -695,11 +696,11 @@ struct ColStat { double maxabs; double signed_val; double idx; double sq_pos; do
 // and combined over the 16 lanes of a column group, the four waves, and then by project_finalize.
 __global__ __launch_bounds__(256) void project_mfma_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                            const double *__restrict__ X, int64_t ldx,
-                                                           const double *__restrict__ Z,
+                                                           const double *__restrict__ Z, int ldz,
                                                            double *__restrict__ U, int64_t ldu,
                                                            double *__restrict__ partial)
 {
-    __shared__ double sred[4][MAX_R][5];
+    __shared__ double sred[4][MFMA_R][5];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int li = lane & 15, lq = lane >> 4;
     const int nq = (F + 3) / 4;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(256) void project_mfma_kernel(int64_t row_begin, in
         for (int q = 0; q < nq; ++q) {
             const int c = 4 * q + lq;
             const double xv = X[(size_t)(c < F ? c : F - 1) * ldx + rowc];
-            const double zv = Z[(size_t)(c < F ? c : F - 1) * r + (li < r ? li : r - 1)];
+            const double zv = Z[(size_t)(c < F ? c : F - 1) * ldz + (li < r ? li : r - 1)];
             u = __builtin_amdgcn_mfma_f64_16x16x4f64((c < F && li < r) ? zv : 0.0, (valid && c < F) ? xv : 0.0, u, 0, 0, 0);
         }
 #pragma unroll
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
             double *sB = fsm + r * F;                            // r x r
             for (int idx = t; idx < r * r; idx += 256) sB[idx] = AB_prev[r * F + idx];
             __syncthreads();
-            constexpr int PER = (MAX_R * MAX_F + 255) / 256;     // 8 outputs per thread at most
+            constexpr int PER = (MFMA_R * MAX_F + 255) / 256;    // 8 outputs per thread at most
             double hn[PER];
 #pragma unroll
             for (int s_ = 0; s_ < PER; ++s_) {
@@ -1100,6 +1101,7 @@ __global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, const d
     }
 }
 
+template <int RMAX>
 __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                            const double *__restrict__ X, int64_t ldx,
                                                            const double *__restrict__ W, int64_t ldw,
@@ -1114,9 +1116,9 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
-        double w[MAX_R];
+        double w[RMAX];
 #pragma unroll
-        for (int k = 0; k < MAX_R; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
+        for (int k = 0; k < RMAX; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
         // eight columns of X in flight per row (a load-use loop waits for every load in turn); the squares are
         // added in column order as before
         for (int c0 = 0; c0 < F; c0 += 8) {
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
                 if (c < F) {
                     double wh = 0.0;
 #pragma unroll
-                    for (int k = 0; k < MAX_R; ++k)
+                    for (int k = 0; k < RMAX; ++k)
                         if (k < r) wh += w[k] * sH[k * F + c];
                     const double d = x[j] - wh;
                     s += d * d;
@@ -1146,6 +1148,7 @@ __global__ __launch_bounds__(256) void nmf_residual_kernel(int64_t row_begin, in
 
 // Generalised KL divergence of X from W H with the zero entries of X masked out
 // (graphrole/roles/description_length.py:44-61): sum_{x != 0} x log(x / v) - x + v, v = (W H)_ic.
+template <int RMAX>
 __global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int64_t row_end, int F, int r,
                                                           const double *__restrict__ X, int64_t ldx,
                                                           const double *__restrict__ W, int64_t ldw,
@@ -1160,15 +1163,15 @@ __global__ __launch_bounds__(256) void nmf_kl_cost_kernel(int64_t row_begin, int
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
-        double w[MAX_R];
+        double w[RMAX];
 #pragma unroll
-        for (int k = 0; k < MAX_R; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
+        for (int k = 0; k < RMAX; ++k) w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0;
         for (int c = 0; c < F; ++c) {
             const double x = X[(size_t)c * ldx + i];
             if (x != 0.0) {
                 double v = 0.0;
 #pragma unroll
-                for (int k = 0; k < MAX_R; ++k)
+                for (int k = 0; k < RMAX; ++k)
                     if (k < r) v += w[k] * sH[k * F + c];
                 s += x * log(x / v) - x + v;
             }
@@ -1323,6 +1326,86 @@ const auto W_PASS_R4 = w_pass_table<4>(std::make_integer_sequence<int, MAX_F / 4
 WPassKernel w_pass_kernel(int F, int r) { return (r <= 8 ? W_PASS_R2 : W_PASS_R4)[(F + 3) / 4 - 1]; }
 
 // one resident generation of workgroups (cached per instantiation)
+// ---------------------------------------------------------------------------------------
+// More than 16 roles (17 .. GRX_MAX_ROLES): the fused kernels above hold the roles in ONE MFMA tile.  Beyond that the
+// multiplicative update is composed from parts that exist: a plain per-row kernel for W <- W * (X H^T) / (W H H^T)
+// (the shape of nmf_residual_kernel: a row of W and its numerators in registers, H read with uniform addresses), then
+// [W^T X | W^T W] as the Gram matrix of the stacked table [W' | X] (the full-width Gram kernels read it once).
+// Several times the traffic of the fused pass -- the reference accepts any rank
+// (graphrole/roles/extract.py:22-33), and a slow exact path beats a refusal.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nmf_hht_kernel(int F, int r, const double *__restrict__ H, double *__restrict__ HH)
+{
+    for (int idx = threadIdx.x; idx < r * r; idx += 256) {
+        const int k = idx / r, l = idx % r;
+        double acc = 0.0;
+        for (int c = 0; c < F; ++c) acc += H[k * F + c] * H[l * F + c];
+        HH[idx] = acc;
+    }
+}
+
+// W' = W * (numer / denom) for rows [row_begin, row_end); W' also goes to the first r rows of the stacked table Y
+__global__ __launch_bounds__(256) void nmf_w_update_generic_kernel(int64_t row_begin, int64_t row_end, int F, int r,
+                                                                   const double *__restrict__ X, int64_t ldx,
+                                                                   double *__restrict__ W, int64_t ldw,
+                                                                   const double *__restrict__ H,
+                                                                   const double *__restrict__ HH,
+                                                                   double *__restrict__ Y, int64_t ldy)
+{
+    __shared__ double sHH[MAX_R * MAX_R];
+    for (int idx = threadIdx.x; idx < r * r; idx += 256) sHH[idx] = HH[idx];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_end; i += stride) {
+        double w[MAX_R], num[MAX_R];
+#pragma unroll
+        for (int k = 0; k < MAX_R; ++k) { w[k] = (k < r) ? W[(size_t)k * ldw + i] : 0.0; num[k] = 0.0; }
+        for (int c0 = 0; c0 < F; c0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = X[(size_t)(c0 + j < F ? c0 + j : F - 1) * ldx + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j;
+                if (c < F) {
+#pragma unroll
+                    for (int k = 0; k < MAX_R; ++k)
+                        if (k < r) num[k] += x[j] * H[k * F + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAX_R; ++k) {
+            if (k < r) {
+                double den = 0.0;
+#pragma unroll
+                for (int l = 0; l < MAX_R; ++l)
+                    if (l < r) den += w[l] * sHH[l * r + k];
+                if (den == 0.0) den = NMF_EPSILON;
+                const double wn = w[k] * (num[k] / den);
+                W[(size_t)k * ldw + i] = wn;
+                Y[(size_t)k * ldy + i] = wn;
+            }
+        }
+    }
+}
+
+// [A | B] from the Gram matrix G (K x K, K = r + F) of the stacked table [W' | X]
+__global__ __launch_bounds__(256) void nmf_ab_from_gram_kernel(int F, int r, const double *__restrict__ G,
+                                                               double *__restrict__ AB)
+{
+    const int K = r + F;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < r * F + r * r; idx += gridDim.x * 256) {
+        if (idx < r * F) {
+            const int k = idx / F, c = idx % F;
+            AB[idx] = G[(size_t)k * K + r + c];
+        } else {
+            const int j = idx - r * F, k = j / r, l = j % r;
+            AB[idx] = G[(size_t)k * K + l];
+        }
+    }
+}
+
 int mfma_resident_grid(int F, int r, size_t lds)
 {
     static int cache[2][MAX_F / 4] = {};
@@ -1341,14 +1424,23 @@ constexpr int RES_GRID = GRX_NUM_CU * 4;
 
 int check_nmf_shape(const char *who, int F, int r)
 {
-    if (F < 1 || r < 1 || F > MAX_F_WIDE || r > MAX_R) {
-        grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d)", who, F, r, MAX_F_WIDE, MAX_R);
+    if (F < 1 || r < 1 || F > MAX_F_WIDE || r > MAX_R || (r > MFMA_R && r + F > MAX_F_WIDE)) {
+        grx_set_error("%s: F=%d r=%d outside the compiled limits (F<=%d, r<=%d, and r+F<=%d when r>%d)", who, F, r,
+                      MAX_F_WIDE, MAX_R, MAX_F_WIDE, MFMA_R);
         return GRX_ERR_UNSUPPORTED;
     }
     return GRX_OK;
 }
 
 }  // namespace
+
+// the wide-rank instantiations keep r * F <= 32 * 448 doubles of H in dynamic LDS: beyond the 64 KB default
+#define GRX_TRY_LDS(kernel)                                                                                     \
+    do {                                                                                                        \
+        static const hipError_t lds_rc__ = hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel),         \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+        GRX_CHECK_HIP(lds_rc__);                                                                                \
+    } while (0)
 
 extern "C" {
 
@@ -1549,12 +1641,18 @@ int grx_project(int64_t n, int F, const double *d_X, int64_t ldx, int64_t row_be
     GRX_CHECK_HIP(hipMemcpyAsync(dZ, h_Z, (size_t)F * r * 8, hipMemcpyHostToDevice, st));
     const int64_t want = grx_ceil_div(grx_ceil_div(row_end - row_begin, 16), 4);
     const int grid = (int)(want > PROJ_GRID ? PROJ_GRID : (want < 1 ? 1 : want));
-    { GRX_PROF(GRX_K_PROJECT, st);
-    project_mfma_kernel<<<grid, 256, 0, st>>>(row_begin, row_end, F, r, d_X, ldx, dZ, d_U, ldu, partial);
+    // one MFMA tile of output columns per launch (a second one for ranks 17 .. 32)
+    for (int j0 = 0; j0 < r; j0 += MFMA_R) {
+        const int rc_ = r - j0 < MFMA_R ? r - j0 : MFMA_R;
+        double *part = partial + (size_t)PROJ_GRID * j0 * 5;
+        { GRX_PROF(GRX_K_PROJECT, st);
+        project_mfma_kernel<<<grid, 256, 0, st>>>(row_begin, row_end, F, rc_, d_X, ldx, dZ + j0, r, d_U + (size_t)j0 * ldu,
+                                                  ldu, part);
+        }
+        GRX_LAUNCH_CHECK();
+        project_finalize_kernel<<<rc_, 64, 0, st>>>(part, grid, rc_, d_stats + (size_t)j0 * 4);
+        GRX_LAUNCH_CHECK();
     }
-    GRX_LAUNCH_CHECK();
-    project_finalize_kernel<<<r, 64, 0, st>>>(partial, grid, r, d_stats);
-    GRX_LAUNCH_CHECK();
     return GRX_OK;
 }
 
@@ -1577,15 +1675,35 @@ int grx_nndsvd_apply(int64_t n, int r, double *d_U, int64_t ldu, int64_t row_beg
     return GRX_OK;
 }
 
+// buffers of the update for more than 16 roles, behind the layout above: H H^T, the stacked table [W' | X]
+// ((r + F) x ld), its Gram matrix and the Gram kernels' own workspace
+struct WideRankLayout { size_t hh, y, g, gram_ws, gram_ws_bytes, total; int64_t ldy; };
+static WideRankLayout wide_rank_layout(int64_t n, int F, int r)
+{
+    WideRankLayout L;
+    const int K = r + F;
+    L.ldy = (n > 0 ? n : 1);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += grx_align_up(bytes, 256); return at; };
+    L.hh = take((size_t)r * r * 8);
+    L.y = take((size_t)K * (size_t)L.ldy * 8);
+    L.g = take(((size_t)K * K + 1) * 8);
+    L.gram_ws_bytes = grx_gram_workspace_bytes(n, K);
+    L.gram_ws = take(L.gram_ws_bytes);
+    L.total = o;
+    return L;
+}
+
 size_t grx_nmf_workspace_bytes(int64_t n, int F, int r)
 {
-    (void)n;
     if (F < 1) F = 1;
     if (r < 1) r = 1;
     const size_t P = (size_t)r * F + (size_t)r * r;
     const size_t a = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256);
     const size_t b = grx_align_up((size_t)RES_GRID * 8, 256);
-    return a + b + 2 * grx_align_up((size_t)r * F * 8, 256);        // + the two H buffers of grx_nmf_iterate
+    size_t bytes = a + b + 2 * grx_align_up((size_t)r * F * 8, 256);        // + the two H buffers of grx_nmf_iterate
+    if (r > MFMA_R) bytes += wide_rank_layout(n, F, r).total;
+    return bytes;
 }
 
 // the two r x F scratch copies of H at the end of the workspace (grx_nmf_iterate)
@@ -1595,6 +1713,41 @@ static double *nmf_h_scratch(void *d_workspace, int F, int r, int which)
     const size_t off = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256) + grx_align_up((size_t)RES_GRID * 8, 256) +
                        (size_t)which * grx_align_up((size_t)r * F * 8, 256);
     return reinterpret_cast<double *>(reinterpret_cast<char *>(d_workspace) + off);
+}
+
+// One W pass for 17 .. 32 roles (see nmf_w_update_generic_kernel): W' in place, then d_AB = [W'^T X | W'^T W'] over the
+// rows [row_begin, row_end) from the Gram matrix of the stacked table.
+static int w_pass_wide_rank(int64_t n, int F, int r, const double *d_X, int64_t ldx, double *d_W, int64_t ldw,
+                            int64_t row_begin, int64_t row_end, const double *d_H, double *d_AB, void *d_workspace,
+                            void *stream)
+{
+    hipStream_t st = grx_stream(stream);
+    const size_t P = (size_t)r * F + (size_t)r * r;
+    const size_t base = grx_align_up((size_t)MU_MAX_GRID * P * 8, 256) + grx_align_up((size_t)RES_GRID * 8, 256) +
+                        2 * grx_align_up((size_t)r * F * 8, 256);
+    const WideRankLayout L = wide_rank_layout(n, F, r);
+    char *ws = reinterpret_cast<char *>(d_workspace) + base;
+    double *dHH = reinterpret_cast<double *>(ws + L.hh);
+    double *dY = reinterpret_cast<double *>(ws + L.y);
+    double *dG = reinterpret_cast<double *>(ws + L.g);
+    const int K = r + F;
+    const int64_t rows = row_end - row_begin;
+    if (rows > 0) {
+        GRX_PROF(GRX_K_NMF_W_PASS, st);
+        nmf_hht_kernel<<<1, 256, 0, st>>>(F, r, d_H, dHH);
+        const int64_t want = grx_ceil_div(rows, 256);
+        nmf_w_update_generic_kernel<<<(int)(want > RES_GRID ? RES_GRID : want), 256, 0, st>>>(
+            row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, dHH, dY, L.ldy);
+        // the X half of the stacked table (this rank's rows)
+        GRX_CHECK_HIP(hipMemcpy2DAsync(dY + (size_t)r * L.ldy + row_begin, (size_t)L.ldy * 8, d_X + row_begin, (size_t)ldx * 8,
+                                       (size_t)rows * 8, (size_t)F, hipMemcpyDeviceToDevice, st));
+    }
+    GRX_LAUNCH_CHECK();
+    int rc = grx_gram(n, K, dY, L.ldy, row_begin, row_end, nullptr, K, dG, ws + L.gram_ws, L.gram_ws_bytes, stream);
+    if (rc != GRX_OK) return rc;
+    nmf_ab_from_gram_kernel<<<(int)grx_ceil_div((int64_t)P, 256), 256, 0, st>>>(F, r, dG, d_AB);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
 }
 
 // d_AB_prev / d_H_out (single-launch kernels only, F <= MAX_F): the kernel first applies the H update of the
@@ -1614,6 +1767,10 @@ static int w_pass_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, 
         return GRX_ERR_WORKSPACE;
     }
     hipStream_t st = grx_stream(stream);
+    if (r > MFMA_R) {
+        GRX_REQUIRE(d_AB_prev == nullptr, "w_pass_impl: more than 16 roles have no fused H update");
+        return w_pass_wide_rank(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H, d_AB, d_workspace, stream);
+    }
     double *partial = reinterpret_cast<double *>(d_workspace);
     const int P = r * F + r * r;
     int grid;
@@ -1662,7 +1819,7 @@ int grx_nmf_w_pass_next(int64_t n, int F, int r, const double *d_X, int64_t ldx,
                         double *d_H_out, double *d_AB, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(d_H_prev && d_AB_prev && d_H_out && d_H_prev != d_H_out, "grx_nmf_w_pass_next: needs distinct H buffers");
-    if (F > MAX_F) {                                            // chunked kernels: the update as a launch of its own
+    if (F > MAX_F || r > MFMA_R) {                              // chunked / wide-rank kernels: the update as a launch of its own
         GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
         nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H_prev, d_H_out, d_AB_prev);
         return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H_out, d_AB, nullptr, nullptr, d_workspace,
@@ -1704,8 +1861,14 @@ int grx_nmf_residual(int64_t n, int F, int r, const double *d_X, int64_t ldx, co
     const int64_t want = grx_ceil_div(row_end - row_begin, 256);
     const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
     { GRX_PROF(GRX_K_NMF_RESIDUAL, st);
-    nmf_residual_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
-                                                             d_H, partial);
+    if (r <= MFMA_R) {
+        nmf_residual_kernel<MFMA_R><<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
+                                                                         d_H, partial);
+    } else {
+        GRX_TRY_LDS(nmf_residual_kernel<MAX_R>);
+        nmf_residual_kernel<MAX_R><<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw,
+                                                                        d_H, partial);
+    }
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
@@ -1735,7 +1898,14 @@ int grx_nmf_kl_cost(int64_t n, int F, int r, const double *d_X, int64_t ldx, con
     const int64_t want = grx_ceil_div(row_end - row_begin, 256);
     const int grid = (int)(want > RES_GRID ? RES_GRID : (want < 1 ? 1 : want));
     { GRX_PROF(GRX_K_NMF_RESIDUAL, st);
-    nmf_kl_cost_kernel<<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H, partial);
+    if (r <= MFMA_R) {
+        nmf_kl_cost_kernel<MFMA_R><<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H,
+                                                                        partial);
+    } else {
+        GRX_TRY_LDS(nmf_kl_cost_kernel<MAX_R>);
+        nmf_kl_cost_kernel<MAX_R><<<grid, 256, (size_t)r * F * 8, st>>>(row_begin, row_end, F, r, d_X, ldx, d_W, ldw, d_H,
+                                                                       partial);
+    }
     }
     GRX_LAUNCH_CHECK();
     { GRX_PROF(GRX_K_REDUCE_PARTIALS, st);
@@ -1753,7 +1923,7 @@ static int nmf_iterate_impl(int64_t n, int F, int r, const double *d_X, int64_t 
                             void *d_workspace, size_t workspace_bytes, void *stream)
 {
     const size_t nAB = (size_t)r * F + (size_t)r * r;
-    if (F <= MAX_F && iters > 0) {
+    if (F <= MAX_F && r <= MFMA_R && iters > 0) {
         // two launches per iteration instead of three: the W pass of iteration i starts by applying the H update
         // of iteration i - 1 (every workgroup recomputes the r x F entries; workgroup 0 stores them, ping-pong
         // between two scratch copies so that no workgroup reads what another is writing); one stand-alone

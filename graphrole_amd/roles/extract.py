@@ -21,7 +21,7 @@ class RoleExtractor:
     """RolX: factor the node-feature table into node-role and role-feature parts (GPU-resident NMF)."""
 
     N_ROLE_RANGE = (2, 8)
-    MAX_ROLES = 16          # GRX_MAX_ROLES of include/grx.h
+    MAX_ROLES = 32          # GRX_MAX_ROLES of include/grx.h (17 .. 32 roles run a slower composed update)
     N_BIT_RANGE = (1, 8)
     #: 'kmeans' = the reference's quantiser reproduced (sklearn KMeans(random_state=1) as scikit-learn >= 1.4 runs it:
     #: one k-means++ initialisation, n_init='auto'; pinned on 1.7.2 -- grx_kmeans1d);

@@ -32,9 +32,10 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 300          /* 0.3.0: grx_comm -- the sharded loops and their exchanges below the ABI */
+#define GRX_VERSION 301          /* 0.3.1: grx_comm -- the sharded loops and their exchanges below the ABI; ranks up to 32 */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
-#define GRX_MAX_ROLES 16         /* NMF rank limit of the device kernels */
+#define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
+                                    a composed update (several times the traffic), then with n_roles + features <= 480 */
 #define GRX_MAX_NMF_FEATURES 480 /* NMF feature-count limit of the device kernels (fast paths: 120) */
 
 typedef enum {

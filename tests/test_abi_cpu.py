@@ -38,7 +38,7 @@ def test_every_header_symbol_is_exported_and_bound():
 def test_version_and_error_string():
     from graphrole_amd import _lib
     lib = _lib.load()
-    assert lib.grx_version() == 300
+    assert lib.grx_version() == 301
     assert isinstance(lib.grx_last_error(), bytes)
     assert lib.grx_profile_kernel_count() >= 20
     names = {lib.grx_profile_kernel_name(i).decode() for i in range(lib.grx_profile_kernel_count())}

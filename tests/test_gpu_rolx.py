@@ -90,6 +90,43 @@ def test_nmf_more_than_120_features_matches_oracle(n, F, r):
     assert _relmax(G, We) < FACTOR_RTOL and _relmax(Fm, He) < FACTOR_RTOL
 
 
+@pytest.mark.parametrize('n,F,r', [(3000, 24, 17), (2000, 40, 32), (1500, 130, 20)])
+def test_nmf_more_than_16_roles_matches_oracle(n, F, r):
+    """Ranks beyond one MFMA tile of roles (the reference accepts any n_roles, roles/extract.py:22-33): NNDSVDa
+    (projection in two role chunks) + the composed multiplicative update against the oracle's sklearn restatement --
+    same iteration count, factors to the tolerance of the fused path."""
+    from graphrole_amd.roles import factor
+    from oracle import rolx
+    rng = np.random.RandomState(n + r)
+    base = np.abs(rng.randn(n, r + 3)) * np.linspace(1, 20, r + 3)
+    mix = np.abs(rng.randn(r + 3, F))
+    X = base @ mix + 0.05 * np.abs(rng.randn(n, F))
+    np.random.seed(5)
+    G, Fm, n_iter = factor.nmf_with_info(X, r)
+    np.random.seed(5)
+    We, He, it = rolx.nmf(X, r)
+    assert n_iter == it
+    assert _relmax(G, We) < FACTOR_RTOL and _relmax(Fm, He) < FACTOR_RTOL
+
+
+def test_role_extractor_with_24_roles():
+    """The public call with a rank above 16: encoded factors of the right shape, roles assigned, and the limit
+    (32) refused at construction."""
+    from graphrole_amd import RoleExtractor
+    import pandas as pd
+    rng = np.random.RandomState(2)
+    X = pd.DataFrame(np.abs(rng.randn(4000, 30)) @ np.abs(rng.randn(30, 36)))
+    np.random.seed(0)
+    rx = RoleExtractor(n_roles=24)
+    rx.extract_role_factors(X)
+    assert rx.node_role_factor.shape == (4000, 24) and rx.role_feature_factor.shape == (24, 36)
+    assert len(rx.roles) == 4000
+    with pytest.raises(ValueError, match='at most 32'):
+        RoleExtractor(n_roles=33)
+    with pytest.raises(ValueError, match='at most 32'):
+        RoleExtractor(n_role_range=(2, 40))
+
+
 def test_nmf_rank_deficient_features():
     """total_degree = in_degree + out_degree is an exact linear dependency (directed graphs)."""
     from graphrole_amd.roles import factor
@@ -107,11 +144,12 @@ def test_nmf_rank_deficient_features():
 
 @pytest.mark.parametrize('n,F,r', [(1, 1, 1), (15, 3, 2), (16, 4, 4), (17, 5, 3), (1000, 16, 6), (1001, 17, 7),
                                    (4099, 20, 6), (5000, 33, 16), (3000, 64, 5), (2500, 100, 9), (2049, 120, 16),
-                                   (3001, 121, 6), (2000, 125, 16), (1500, 250, 5), (900, 257, 12), (700, 480, 16)])
+                                   (3001, 121, 6), (2000, 125, 16), (1500, 250, 5), (900, 257, 12), (700, 480, 16),
+                                   (1000, 5, 17), (4099, 20, 32), (2500, 100, 24), (1200, 130, 20), (600, 448, 32)])
 def test_mu_iteration_kernels_vs_numpy(n, F, r):
     """One multiplicative update (sklearn _nmf.py:540-702, beta = 2) computed by grx_nmf_w_pass (fp64
     MFMA tiles; F > 120: the chunked wide kernel) + grx_nmf_h_update against numpy, over the shape
-    limits (F <= 480, r <= 16), row
+    limits (F <= 480, r <= 16 fused; 17 <= r <= 32 with r + F <= 480: the composed update), row
     counts that are not multiples of the 16-row sub-tile, zero rows / zero denominators, and a
     row range (sharded use)."""
     import torch
