@@ -26,8 +26,14 @@ def _free_port():
     return port
 
 
+def _nmf_rank(kind):
+    """'<graph>_r<k>' factors with k roles (ranks above 16 take the composed update); the default is 4"""
+    return int(kind.rsplit('_r', 1)[1]) if '_r' in kind else 4
+
+
 def _graph(kind):
     from graphrole_amd import synth
+    kind = kind.rsplit('_r', 1)[0] if '_r' in kind else kind
     if kind == 'ba':
         return synth.ba_graph(60_000, 8, seed=3)
     if kind == 'ba1m':
@@ -62,8 +68,9 @@ def _worker(rank, port, kind, driver, out_dir):
         assert plan.comm() is not None
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
-        omega = np.random.RandomState(5).normal(size=(F, 4 + 10))
-        state, n_iter = factor.nmf_device(Xd, G.n, 4, omega, plan=plan)
+        rank_ = _nmf_rank(kind)
+        omega = np.random.RandomState(5).normal(size=(F, rank_ + 10))
+        state, n_iter = factor.nmf_device(Xd, G.n, rank_, omega, plan=plan)
         out = dict(X=X.values.astype(float), cols=np.array(list(X.columns)), gen=fe.generation_count,
                    W=K.to_host(state.W)[:, :G.n], H=K.to_host(state.H), n_iter=n_iter,
                    rb=plan.row_begin, re=plan.row_end)
@@ -72,7 +79,7 @@ def _worker(rank, port, kind, driver, out_dir):
             fe1 = RecursiveFeatureExtractor(G, max_generations=4, attributes=bool(G.attributes))
             X1 = fe1.extract_features()
             Xd1 = K.gather_columns(fe1.device_features()[1], G.n)
-            s1, it1 = factor.nmf_device(Xd1, G.n, 4, omega)
+            s1, it1 = factor.nmf_device(Xd1, G.n, rank_, omega)
             out.update(X1=X1.values.astype(float), cols1=np.array(list(X1.columns)), W1=K.to_host(s1.W)[:, :G.n],
                        H1=K.to_host(s1.H), it1=it1)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **out)
@@ -81,7 +88,8 @@ def _worker(rank, port, kind, driver, out_dir):
 
 
 @pytest.mark.parametrize('kind,driver', [('ba', 'native'), ('ba', 'per_kernel'), ('directed_weighted', 'native'),
-                                         ('directed_weighted', 'per_kernel'), ('ba1m', 'native'), ('dw1m', 'native')])
+                                         ('directed_weighted', 'per_kernel'), ('ba1m', 'native'), ('dw1m', 'native'),
+                                         ('directed_weighted_r20', 'native'), ('directed_weighted_r20', 'per_kernel')])
 def test_two_ranks_one_gpu_equal_single_process(kind, driver, tmp_path):
     mp.spawn(_worker, args=(_free_port(), kind, driver, str(tmp_path)), nprocs=WORLD, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
