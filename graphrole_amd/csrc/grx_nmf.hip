@@ -1080,13 +1080,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 8 ? 3
 
 // H <- H * (A / (B H)), one workgroup; B (r x r) in LDS, A and H (r x F, a few KB, cache resident); every
 // H[l][c] is read before the barrier that precedes the writes, so H_out may be H_in.
+template <int RMAX>
 __global__ __launch_bounds__(256) void nmf_h_update_kernel(int F, int r, const double *H_in, double *H_out,
                                                            const double *__restrict__ AB)
 {
-    __shared__ double sB[MAX_R * MAX_R];
+    __shared__ double sB[RMAX * RMAX];
     for (int idx = threadIdx.x; idx < r * r; idx += 256) sB[idx] = AB[r * F + idx];
     __syncthreads();
-    constexpr int PER = (MAX_R * MAX_F_WIDE + 255) / 256;          // 30 outputs per thread at most
+    constexpr int PER = (RMAX * MAX_F_WIDE + 255) / 256;           // 30 outputs per thread at most (60 above 16 roles)
     double hnew[PER];
 #pragma unroll
     for (int s = 0; s < PER; ++s) {
@@ -1326,6 +1327,12 @@ const auto W_PASS_R4 = w_pass_table<4>(std::make_integer_sequence<int, MAX_F / 4
 WPassKernel w_pass_kernel(int F, int r) { return (r <= 8 ? W_PASS_R2 : W_PASS_R4)[(F + 3) / 4 - 1]; }
 
 // one resident generation of workgroups (cached per instantiation)
+static inline void launch_h_update(int F, int r, const double *h_in, double *h_out, const double *ab, hipStream_t st)
+{
+    if (r <= MFMA_R) nmf_h_update_kernel<MFMA_R><<<1, 256, 0, st>>>(F, r, h_in, h_out, ab);
+    else nmf_h_update_kernel<MAX_R><<<1, 256, 0, st>>>(F, r, h_in, h_out, ab);
+}
+
 // ---------------------------------------------------------------------------------------
 // More than 16 roles (17 .. GRX_MAX_ROLES): the fused kernels above hold the roles in ONE MFMA tile.  Beyond that the
 // multiplicative update is composed from parts that exist: a plain per-row kernel for W <- W * (X H^T) / (W H H^T)
@@ -1821,7 +1828,7 @@ int grx_nmf_w_pass_next(int64_t n, int F, int r, const double *d_X, int64_t ldx,
     GRX_REQUIRE(d_H_prev && d_AB_prev && d_H_out && d_H_prev != d_H_out, "grx_nmf_w_pass_next: needs distinct H buffers");
     if (F > MAX_F || r > MFMA_R) {                              // chunked / wide-rank kernels: the update as a launch of its own
         GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
-        nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H_prev, d_H_out, d_AB_prev);
+        launch_h_update(F, r, d_H_prev, d_H_out, d_AB_prev, grx_stream(stream));
         return w_pass_impl(n, F, r, d_X, ldx, d_W, ldw, row_begin, row_end, d_H_out, d_AB, nullptr, nullptr, d_workspace,
                            workspace_bytes, stream);
     }
@@ -1835,7 +1842,7 @@ int grx_nmf_h_update(int F, int r, double *d_H, const double *d_AB, void *stream
     if (rc != GRX_OK) return rc;
     GRX_REQUIRE(d_H && d_AB, "grx_nmf_h_update: NULL pointer");
     { GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
-    nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, d_H, d_H, d_AB);
+    launch_h_update(F, r, d_H, d_H, d_AB, grx_stream(stream));
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
@@ -1942,7 +1949,7 @@ static int nmf_iterate_impl(int64_t n, int F, int r, const double *d_X, int64_t 
         }
         {
             GRX_PROF(GRX_K_NMF_H_UPDATE, grx_stream(stream));
-            nmf_h_update_kernel<<<1, 256, 0, grx_stream(stream)>>>(F, r, h_in, d_H, d_AB);
+            launch_h_update(F, r, h_in, d_H, d_AB, grx_stream(stream));
         }
         GRX_LAUNCH_CHECK();
     } else {
