@@ -1689,9 +1689,10 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
                                                         const unsigned long long *__restrict__ bmin,
                                                         const unsigned long long *__restrict__ bmax,
-                                                        uint64_t *__restrict__ thr, uint16_t *__restrict__ thr_bucket,
+                                                        uint64_t *__restrict__ thr, uint8_t *__restrict__ bin_lut,
                                                         int32_t *__restrict__ nbins, int32_t *__restrict__ fault)
 {
+    __shared__ uint16_t tb[GRX_MAX_BINS];                        // bucket of every threshold | SEL_THR_EXACT
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t SO[SEL_NB];
     __shared__ uint16_t MK[SEL_NB];
@@ -1775,38 +1776,18 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
         if (threadIdx.x == 0) {
             t[nb] = tk;
             // bucket of the threshold; bit 15: the bucket holds other keys too, so its keys are compared with the thresholds
-            thr_bucket[(size_t)col * GRX_MAX_BINS + nb] = (uint16_t)(j | (mn != mx ? SEL_THR_EXACT : 0));
+            tb[nb] = (uint16_t)(j | (mn != mx ? SEL_THR_EXACT : 0));
         }
         ++nb;
         done = before + le;
     }
     if (threadIdx.x == 0) nbins[col] = (done < n) ? -nb : nb;
-}
-
-// Labels from the stored bucket ids: the map is monotone, so every key of a bucket WITHOUT a threshold lies between
-// the same two thresholds -- its bin is the number of thresholds in earlier buckets -- and so does every key of a
-// bucket that is one block of ties.  Only the keys of the buckets that hold a threshold among other keys (~20 of 4096)
-// are read and compared.  2 + 1 bytes per key instead of 8 + 1.
-__global__ __launch_bounds__(256) void sel_assign_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                         const uint16_t *__restrict__ bid,
-                                                         const uint64_t *__restrict__ thr,
-                                                         const uint16_t *__restrict__ thr_bucket,
-                                                         const int32_t *__restrict__ nbins,
-                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags)
-{
-    __shared__ uint64_t t[GRX_MAX_BINS];
-    __shared__ uint16_t tb[GRX_MAX_BINS];
-    __shared__ uint8_t lut[SEL_NB];                              // bin of the bucket | 0x80: compare exactly
-    const int col = blockIdx.y;
-    const bool i64 = col_is_i64(flags, col);
-    int nb = nbins[col];
-    const bool saturated = nb < 0;                               // more than GRX_MAX_BINS bins: the walk stopped early
-    if (saturated) nb = GRX_MAX_BINS;
-    if (threadIdx.x < GRX_MAX_BINS) {
-        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
-        tb[threadIdx.x] = (threadIdx.x < nb) ? thr_bucket[(size_t)col * GRX_MAX_BINS + threadIdx.x] : (uint16_t)0x7FFF;
-    }
+    // bucket -> label for the assign pass: the map is monotone, so every key of a bucket WITHOUT a threshold lies
+    // between the same two thresholds -- its bin is the number of thresholds in earlier buckets -- and so does every key
+    // of a bucket that is one block of ties; 0x80: the bucket holds a threshold among other keys, compare exactly
+    // (all of them when the walk stopped at GRX_MAX_BINS thresholds)
     __syncthreads();
+    const bool saturated = done < n;
     for (int b = threadIdx.x; b < SEL_NB; b += 256) {
         int lo = 0, hi = nb;                                     // thresholds in earlier buckets (ascending with the index)
         while (lo < hi) {
@@ -1815,15 +1796,42 @@ __global__ __launch_bounds__(256) void sel_assign_kernel(const double *__restric
         }
         bool exact = saturated;
         for (int k = lo; k < nb && (tb[k] & 0x7FFF) == b; ++k) exact |= (tb[k] & SEL_THR_EXACT) != 0;
-        lut[b] = (uint8_t)(lo | (exact ? 0x80 : 0));
+        bin_lut[(size_t)col * SEL_NB + b] = (uint8_t)(lo | (exact ? 0x80 : 0));
+    }
+}
+
+// Labels from the stored bucket ids and the bucket -> label table of the exact walk: only the keys of the buckets that
+// hold a threshold among other keys (~20 of 4096) are read and compared.  2 + 1 bytes per key instead of 8 + 1.
+constexpr int SEL_ASSIGN_ITEMS = 32;                         // keys per thread (the 4 KiB table is loaded per workgroup)
+
+__global__ __launch_bounds__(256) void sel_assign_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                         const uint16_t *__restrict__ bid,
+                                                         const uint64_t *__restrict__ thr,
+                                                         const uint8_t *__restrict__ bin_lut,
+                                                         const int32_t *__restrict__ nbins,
+                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags)
+{
+    __shared__ uint64_t t[GRX_MAX_BINS];
+    __shared__ uint32_t lut4[SEL_NB / 4];
+    const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut4);
+    const int col = blockIdx.y;
+    const bool i64 = col_is_i64(flags, col);
+    int nb = nbins[col];
+    if (nb < 0) nb = GRX_MAX_BINS;                               // more than GRX_MAX_BINS bins: labels saturate
+    if (threadIdx.x < GRX_MAX_BINS)
+        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(bin_lut + (size_t)col * SEL_NB);
+        for (int k = threadIdx.x; k < SEL_NB / 4; k += 256) lut4[k] = src[k];
     }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const uint16_t *bx = bid + (size_t)col * sel_bid_stride(n);
     uint8_t *o = bins + (size_t)col * ld_bins;
     const bool word_stores = (reinterpret_cast<uintptr_t>(o) & 3) == 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    const int64_t tile = (int64_t)256 * SEL_ASSIGN_ITEMS;
+    const int64_t tile_end = ((int64_t)blockIdx.x + 1) * tile < n ? ((int64_t)blockIdx.x + 1) * tile : n;
+    for (int64_t i0 = (int64_t)blockIdx.x * tile + (int64_t)threadIdx.x * 4; i0 < tile_end; i0 += 256 * 4) {
         // four consecutive keys per thread: one 8-byte load of bucket ids, one 4-byte store of labels
         uint16_t b4[4];
         if (i0 + 3 < n) {
@@ -1974,7 +1982,7 @@ SelLayout sel_layout(int64_t n, int ncols)
     L.coll = take((size_t)ncols * (size_t)n * 8);
     L.bid = take((size_t)ncols * (size_t)sel_bid_stride(n) * 2);
     L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
-    L.thrb = take((size_t)ncols * GRX_MAX_BINS * 2);
+    L.thrb = take((size_t)ncols * SEL_NB);                      // bucket -> label table of the assign pass
     L.nbins = take((size_t)ncols * 4);
     L.fault = take(4);
     L.total = o;
@@ -2062,7 +2070,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
         uint16_t *bid = reinterpret_cast<uint16_t *>(ws + L.bid);
-        uint16_t *thrb = reinterpret_cast<uint16_t *>(ws + L.thrb);
+        uint8_t *thrb = reinterpret_cast<uint8_t *>(ws + L.thrb);
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
         int32_t *fault = reinterpret_cast<int32_t *>(ws + L.fault);
         unsigned long long *bmin = reinterpret_cast<unsigned long long *>(ws + L.bmin);
@@ -2095,8 +2103,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
             sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, thrb, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();
-        const int64_t want = grx_ceil_div(n, 256 * 4);
-        const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
+        const dim3 grid((unsigned)grx_ceil_div(n, 256 * SEL_ASSIGN_ITEMS), ncols);
         {
             GRX_PROF(GRX_K_BIN_ASSIGN, st);
             sel_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, bid, thr, thrb, nb_ws, d_bins, ld_bins, flags);
