@@ -1159,8 +1159,6 @@ constexpr int SEL_MAX_IDS = 512;                           // marked buckets wit
 constexpr int SEL_SORT_CAP = 8192;                         // keys of a segment the segment sort holds in LDS
 constexpr uint16_t SEL_MARK_SORTED = 0x8000;               // mark bit: the segment is in ascending order
 constexpr uint16_t SEL_MARK_TIES = 0xFFFF;                 // mark: a certified block of ties, nothing collected
-constexpr uint16_t SEL_THR_EXACT = 0x8000;                 // thr_bucket bit: keys of the bucket need the exact compare
-__host__ __device__ inline int64_t sel_bid_stride(int64_t n) { return (n + 3) & ~(int64_t)3; }   // 8-byte aligned columns
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
 // The bucket map of a column: a LINEAR map of the sampled key range onto 4096 cells, refined by a look-up table built
@@ -1323,8 +1321,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
                                                        const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
                                                        const uint16_t *__restrict__ tie_of_bucket,
                                                        const uint64_t *__restrict__ tie_value, uint8_t *__restrict__ tie_broken,
-                                                       uint32_t *__restrict__ hist, uint16_t *__restrict__ bid,
-                                                       ColFlags flags)
+                                                       uint32_t *__restrict__ hist, ColFlags flags)
 {
     __shared__ uint32_t h[SEL_NB];
     __shared__ uint32_t lut[SEL_NB];
@@ -1357,7 +1354,6 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
             const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
             const uint64_t key = value_key(raw[j], i64);
             const int b = sel_bucket(m, lut, key);
-            if (valid) bid[(size_t)col * sel_bid_stride(n) + base + (int64_t)(i0 + j) * 256 + threadIdx.x] = (uint16_t)b;   // for the two passes below
             const int tid = valid ? (int)tieb[b] : 0;
             if (tid && tiev[tid] != key) tie_broken[(size_t)col * SEL_NB + b] = 1;     // not a block of ties after all
             // heavy ties put a whole wavefront into one bucket: one atomic for all of it
@@ -1543,7 +1539,7 @@ __global__ __launch_bounds__(512) void sel_sort_kernel(const uint32_t *__restric
 }
 
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                          const uint16_t *__restrict__ bid,
+                                                          const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
                                                           const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                           uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
@@ -1556,21 +1552,21 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     __shared__ unsigned long long lo_id[SEL_MAX_IDS];
     __shared__ unsigned long long hi_id[SEL_MAX_IDS];
     __shared__ uint16_t M[SEL_NB];
+    __shared__ uint32_t lut[SEL_NB];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) M[b] = mark[(size_t)col * SEL_NB + b];
+    const SelMap m = maps[col];
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; lut[b] = luts[(size_t)col * SEL_NB + b]; }
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
-    const uint16_t *bx = bid + (size_t)col * sel_bid_stride(n);
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
     const int64_t last = n - 1;
-    // the bucket ids the histogram pass stored (2 bytes per key); a key itself is read only when its bucket is marked
-    uint16_t bv[SORT_ITEMS];
+    double raw[SORT_ITEMS];
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
-        bv[i] = bx[idx < n ? idx : last];
+        raw[i] = x[idx < n ? idx : last];
     }
     __builtin_amdgcn_sched_barrier(0);
     uint64_t *dst = coll + (size_t)col * n;
@@ -1581,15 +1577,13 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     bool any = false;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
-        const bool valid = idx < n;
-        const int b = bv[i];
+        const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
+        keys[i] = value_key(raw[i], i64);
+        const int b = sel_bucket(m, lut, keys[i]);
         const int mk = valid ? (int)M[b] : 0;
         id[i] = mk - 1;
         rank[i] = -1;
-        keys[i] = 0;
         if (mk > 0 && mk < SEL_MAX_IDS) {
-            keys[i] = value_key(x[idx], i64);
             rank[i] = (int)atomicAdd(&cnt[mk - 1], 1u);
             atomicMin(&lo_id[mk - 1], (unsigned long long)keys[i]);
             atomicMax(&hi_id[mk - 1], (unsigned long long)keys[i]);
@@ -1598,7 +1592,6 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
         } else if (mk == SEL_MAX_IDS) {
             // more marked buckets than LDS slots (a huge unresolved bucket followed by thousands of thin ones):
             // straight to the segment through global atomics
-            keys[i] = value_key(x[idx], i64);
             const size_t cell = (size_t)col * SEL_NB + b;
             dst[off[b] + atomicAdd(&cur[b], 1u)] = keys[i];
             atomicMin(&bmin[cell], (unsigned long long)keys[i]);
@@ -1621,6 +1614,8 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
         if (rank[i] >= 0) dst[basev[id[i]] + (uint32_t)rank[i]] = keys[i];
 }
 
+// the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
+// its keys <= that key; whole workgroup (256 threads), every thread returns the same values
 // q-th smallest key (0-based) of an UNORDERED segment of more than 64 keys and the number of keys <= it
 __device__ void sel_segment_select(const uint64_t *__restrict__ seg, int64_t len, int64_t q, uint64_t mn, uint64_t mx,
                                    uint64_t *tk_out, int64_t *le_out, uint32_t *s_hist, uint32_t *s_wsum, uint64_t *s_pick)
@@ -1689,10 +1684,9 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
                                                         const unsigned long long *__restrict__ bmin,
                                                         const unsigned long long *__restrict__ bmax,
-                                                        uint64_t *__restrict__ thr, uint8_t *__restrict__ bin_lut,
-                                                        int32_t *__restrict__ nbins, int32_t *__restrict__ fault)
+                                                        uint64_t *__restrict__ thr, int32_t *__restrict__ nbins,
+                                                        int32_t *__restrict__ fault)
 {
-    __shared__ uint16_t tb[GRX_MAX_BINS];                        // bucket of every threshold | SEL_THR_EXACT
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t SO[SEL_NB];
     __shared__ uint16_t MK[SEL_NB];
@@ -1773,98 +1767,11 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
         } else {
             sel_segment_select(seg, len, q, mn, mx, &tk, &le, s_hist, s_wsum, s_pick);
         }
-        if (threadIdx.x == 0) {
-            t[nb] = tk;
-            // bucket of the threshold; bit 15: the bucket holds other keys too, so its keys are compared with the thresholds
-            tb[nb] = (uint16_t)(j | (mn != mx ? SEL_THR_EXACT : 0));
-        }
+        if (threadIdx.x == 0) t[nb] = tk;
         ++nb;
         done = before + le;
     }
     if (threadIdx.x == 0) nbins[col] = (done < n) ? -nb : nb;
-    // bucket -> label for the assign pass: the map is monotone, so every key of a bucket WITHOUT a threshold lies
-    // between the same two thresholds -- its bin is the number of thresholds in earlier buckets -- and so does every key
-    // of a bucket that is one block of ties; 0x80: the bucket holds a threshold among other keys, compare exactly
-    // (all of them when the walk stopped at GRX_MAX_BINS thresholds)
-    __syncthreads();
-    const bool saturated = done < n;
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) {
-        int lo = 0, hi = nb;                                     // thresholds in earlier buckets (ascending with the index)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((tb[mid] & 0x7FFF) < b) lo = mid + 1; else hi = mid;
-        }
-        bool exact = saturated;
-        for (int k = lo; k < nb && (tb[k] & 0x7FFF) == b; ++k) exact |= (tb[k] & SEL_THR_EXACT) != 0;
-        bin_lut[(size_t)col * SEL_NB + b] = (uint8_t)(lo | (exact ? 0x80 : 0));
-    }
-}
-
-// Labels from the stored bucket ids and the bucket -> label table of the exact walk: only the keys of the buckets that
-// hold a threshold among other keys (~20 of 4096) are read and compared.  2 + 1 bytes per key instead of 8 + 1.
-constexpr int SEL_ASSIGN_ITEMS = 32;                         // keys per thread (the 4 KiB table is loaded per workgroup)
-
-__global__ __launch_bounds__(256) void sel_assign_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
-                                                         const uint16_t *__restrict__ bid,
-                                                         const uint64_t *__restrict__ thr,
-                                                         const uint8_t *__restrict__ bin_lut,
-                                                         const int32_t *__restrict__ nbins,
-                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags)
-{
-    __shared__ uint64_t t[GRX_MAX_BINS];
-    __shared__ uint32_t lut4[SEL_NB / 4];
-    const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut4);
-    const int col = blockIdx.y;
-    const bool i64 = col_is_i64(flags, col);
-    int nb = nbins[col];
-    if (nb < 0) nb = GRX_MAX_BINS;                               // more than GRX_MAX_BINS bins: labels saturate
-    if (threadIdx.x < GRX_MAX_BINS)
-        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(bin_lut + (size_t)col * SEL_NB);
-        for (int k = threadIdx.x; k < SEL_NB / 4; k += 256) lut4[k] = src[k];
-    }
-    __syncthreads();
-    const double *x = cols + (size_t)col * ld;
-    const uint16_t *bx = bid + (size_t)col * sel_bid_stride(n);
-    uint8_t *o = bins + (size_t)col * ld_bins;
-    const bool word_stores = (reinterpret_cast<uintptr_t>(o) & 3) == 0;
-    const int64_t tile = (int64_t)256 * SEL_ASSIGN_ITEMS;
-    const int64_t tile_end = ((int64_t)blockIdx.x + 1) * tile < n ? ((int64_t)blockIdx.x + 1) * tile : n;
-    for (int64_t i0 = (int64_t)blockIdx.x * tile + (int64_t)threadIdx.x * 4; i0 < tile_end; i0 += 256 * 4) {
-        // four consecutive keys per thread: one 8-byte load of bucket ids, one 4-byte store of labels
-        uint16_t b4[4];
-        if (i0 + 3 < n) {
-            const uint2 raw = *reinterpret_cast<const uint2 *>(bx + i0);
-            b4[0] = (uint16_t)(raw.x & 0xFFFF); b4[1] = (uint16_t)(raw.x >> 16);
-            b4[2] = (uint16_t)(raw.y & 0xFFFF); b4[3] = (uint16_t)(raw.y >> 16);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b4[j] = i0 + j < n ? bx[i0 + j] : (uint16_t)0;
-        }
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t lab = lut[b4[j]];
-            if ((lab & 0x80) && i0 + j < n) {
-                const uint64_t v = value_key(x[i0 + j], i64);
-                int lo = 0, hi = nb;                             // first threshold >= v
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (t[mid] < v) lo = mid + 1; else hi = mid;
-                }
-                lab = (uint32_t)lo;
-            }
-            packed |= (lab & 0xFF) << (8 * j);
-        }
-        if (i0 + 3 < n && word_stores) {
-            *reinterpret_cast<uint32_t *>(o + i0) = packed;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (i0 + j < n) o[i0 + j] = (uint8_t)(packed >> (8 * j));
-        }
-    }
 }
 
 struct SortPlan {
@@ -1959,7 +1866,7 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, idlist, nids, coll, bid, thr, thrb, nbins, fault, total; };
+struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, idlist, nids, coll, thr, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
@@ -1980,9 +1887,7 @@ SelLayout sel_layout(int64_t n, int ncols)
     L.idlist = take((size_t)ncols * SEL_MAX_IDS * 2);
     L.nids = take((size_t)ncols * 4);
     L.coll = take((size_t)ncols * (size_t)n * 8);
-    L.bid = take((size_t)ncols * (size_t)sel_bid_stride(n) * 2);
     L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
-    L.thrb = take((size_t)ncols * SEL_NB);                      // bucket -> label table of the assign pass
     L.nbins = take((size_t)ncols * 4);
     L.fault = take(4);
     L.total = o;
@@ -2069,8 +1974,6 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         int32_t *nids = reinterpret_cast<int32_t *>(ws + L.nids);
         uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
-        uint16_t *bid = reinterpret_cast<uint16_t *>(ws + L.bid);
-        uint8_t *thrb = reinterpret_cast<uint8_t *>(ws + L.thrb);
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
         int32_t *fault = reinterpret_cast<int32_t *>(ws + L.fault);
         unsigned long long *bmin = reinterpret_cast<unsigned long long *>(ws + L.bmin);
@@ -2084,7 +1987,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         }
         {
             GRX_PROF(GRX_K_SEL_HIST, st);
-            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, bid, flags);
+            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, flags);
         }
         {
             GRX_PROF(GRX_K_SEL_WALK1, st);
@@ -2092,7 +1995,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         }
         {
             GRX_PROF(GRX_K_SEL_COLLECT, st);
-            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, bid, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
             GRX_PROF(GRX_K_SEL_SEGSORT, st);
@@ -2100,13 +2003,14 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         }
         {
             GRX_PROF(GRX_K_SEL_WALK2, st);
-            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, thrb, nb_ws, fault);
+            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();
-        const dim3 grid((unsigned)grx_ceil_div(n, 256 * SEL_ASSIGN_ITEMS), ncols);
+        const int64_t want = grx_ceil_div(n, 256 * 4);
+        const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
         {
             GRX_PROF(GRX_K_BIN_ASSIGN, st);
-            sel_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, bid, thr, thrb, nb_ws, d_bins, ld_bins, flags);
+            bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags);
         }
         GRX_LAUNCH_CHECK();
         if (d_nbins)
