@@ -1,4 +1,4 @@
-"""Microbenchmark of grx_triangle_counts on the BASELINE BA graph (tools/gpu_b3.sh drives it under rocprofv3)."""
+"""Microbenchmark of grx_triangle_counts on the BASELINE BA graph (tools/pmc_triangles.sh drives it under rocprofv3)."""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
