@@ -336,18 +336,20 @@ def test_end_to_end_karate_roles():
     assert np.allclose(re_.role_percentage.sum(axis=1).values, 1.0)
 
 
-def test_device_mdl_costs_equal_host_formulas():
+@pytest.mark.parametrize('F,r', [(9, 4), (40, 20)])
+def test_device_mdl_costs_equal_host_formulas(F, r):
     """Encoding / error cost computed in HBM (grx_lloyd_max info, grx_nmf_kl_cost) against the host
-    restatement of graphrole/roles/description_length.py:32-61 on the same encoded factors."""
+    restatement of graphrole/roles/description_length.py:32-61 on the same encoded factors (r = 20: the kernels'
+    instantiation for more than 16 roles)."""
     from graphrole_amd import kernels as K
     from graphrole_amd.roles import description_length as dl
     from graphrole_amd.roles import factor
     rng = np.random.RandomState(4)
-    V = np.abs(rng.randn(5000, 9)) * np.linspace(1, 12, 9)
+    V = np.abs(rng.randn(5000, F)) * np.linspace(1, 12, F)
     V[rng.rand(*V.shape) < 0.1] = 0.0                         # zero entries are masked by the KL cost
     Vd = K.to_device(np.ascontiguousarray(V.T))
     np.random.seed(3)
-    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, 4, 5)
+    state, Wq, Hq, uniq_g, uniq_f = factor.encoded_factors_device(Vd, V, r, 5)
     G, F = K.to_host(Wq).T, K.to_host(Hq)
     assert uniq_g == len(np.unique(G)) and uniq_f == len(np.unique(F))
     enc_host, err_host = dl.get_description_length_costs(V, (G, F))
