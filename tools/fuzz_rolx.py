@@ -1,7 +1,9 @@
 """Differential fuzz of the RolX factorisation on the GPU box: random non-negative tables of many shapes
-(n x F, F = 2..140 -- every Gram / W-pass instantiation family -- r = 2..8, dense / sparse / graded / rank-deficient)
+(n x F, F = 2..140 -- every Gram / W-pass instantiation family -- r = 2..8, with FUZZ_WIDE_RANK=1 r = 9..32: the
+second half of one role tile and the composed update beyond it; dense / sparse / graded / rank-deficient)
 through factor.nmf_with_info against oracle.rolx.nmf with the same numpy seed: equal iteration counts, factors to
-1e-7 of their scale.  Usage: PYTHONPATH=. python tools/fuzz_rolx.py [cases] [seed]"""
+1e-7 of their scale.  Usage: PYTHONPATH=. [FUZZ_WIDE_RANK=1] python tools/fuzz_rolx.py [cases] [seed]"""
+import os
 import sys
 
 import numpy as np
@@ -15,6 +17,8 @@ def one(rng, case):
     n = int(rng.choice([F + 1, 2 * F + 3, 500, 3000, 20000]))
     n = max(n, F)
     r = int(rng.integers(2, min(8, F) + 1))
+    if os.environ.get('FUZZ_WIDE_RANK') == '1' and F >= 12:
+        r = int(rng.integers(9, min(32, F) + 1))
     kind = int(rng.integers(0, 4))
     X = np.abs(rng.standard_normal((n, F)))
     if kind == 1:                                               # graded columns (degree-like scales)
