@@ -102,6 +102,7 @@ class CSRGraph:
         self._adjacency = None if adjacency is None else np.ascontiguousarray(adjacency, dtype=np.int32)
         self._host = None
         n_loops = int(np.count_nonzero(src == dst))
+        self.n_loops = n_loops                              # 0: the degree kernels skip their search for the diagonal
         self._nnz = int(len(src)) if directed else 2 * int(len(src)) - n_loops
         if self._adjacency is not None and self._adjacency.shape != (self._nnz,):
             raise ValueError('adjacency must list every neighbour of every row exactly once')

@@ -98,10 +98,15 @@ class DeviceGraphInterface(BaseGraphInterface):
                 out = K.DeviceCSR(host.row_ptr, host.col, host.w, agg_col=host.agg_col)
                 tr = K.DeviceCSR(host.t_row_ptr, host.t_col, host.t_w) if host.directed else None
             self._dev = (host, out, tr)
+            # networkx counts an undirected self-loop twice in the degree (networkx.py:54): the kernel looks every row's
+            # own index up -- a binary search per row that a graph without loops does not need
+            self._has_loops = getattr(g, 'n_loops', 1) > 0
         return self._dev
 
     #: False forces the host-side construction (InternalGraph + upload); tests compare the two
     _device_ingest = True
+    #: set by _device_graph; True = look the diagonal up (always right, slower)
+    _has_loops = True
 
     def _row_range(self) -> Tuple[int, int]:
         """Rows this rank computes (whole graph unless a ShardPlan was attached)."""
@@ -135,7 +140,7 @@ class DeviceGraphInterface(BaseGraphInterface):
             names = ['in_degree', 'out_degree', 'total_degree']
             cols = [ind, outd, K.add_columns(outd, ind)]
         else:
-            deg, = self._finish_columns([K.row_sums(out, True, rb, re)])
+            deg, = self._finish_columns([K.row_sums(out, self._has_loops, rb, re)])
             names, cols = ['degree'], [deg]
         dtypes = [int_dtype] * len(names)
         if self._attrs:
