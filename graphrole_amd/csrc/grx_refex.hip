@@ -195,7 +195,9 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         uint8_t *owned_bins = (comm && n_owned) ? reinterpret_cast<uint8_t *>(arena.take((size_t)n_owned * n)) : nullptr;
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
         const int F = (int)work.size();
-        int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take((size_t)F * F * 4));
+        // (a whole number of 256-byte units: the runtime clears an unaligned tail with a second fill launch)
+        const size_t dist_bytes = grx_align_up((size_t)F * F * 4, 256);
+        int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take(dist_bytes));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
             if (count && !comm) {
@@ -218,7 +220,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             if (F >= 2) {
                 std::vector<const uint8_t *> ptrs(F);
                 for (int j = 0; j < F; ++j) ptrs[j] = cols[work[j]].bins;
-                GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, (size_t)F * F * 4, st));
+                GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
                 // the pruner only asks "distance <= generation number?" (prune.py:110-113)
                 if (re > rb) GRX_TRY(grx_chebyshev(rb, re, F, 0, ptrs.data(), d_dist, generation, stream));
                 if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F, GRX_I32, GRX_MAX, stream));
