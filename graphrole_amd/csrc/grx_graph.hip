@@ -669,6 +669,44 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int f, int ld
     }
 }
 
+// Rows of exactly 64 bytes (ldr = 8: the 5 - 8 retained columns of a generation on the BASELINE graphs).  A wavefront
+// turns 64 rows x 8 columns through its LDS slice so that every store instruction writes 1 KiB of consecutive bytes
+// (lane l: 16 bytes at l * 16 + k * 1024) -- the thread-per-row form writes 8 bytes per lane at a stride of 64, eight
+// times over the same 64 lines.
+__global__ __launch_bounds__(256) void pack_rows8_kernel(int64_t n, int f, GrxPtrTable cols_tab, double *__restrict__ rows)
+{
+    __shared__ double tile[4][64 * 9];                           // [wave][row * 9 + column]: padded against bank conflicts
+    const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *mine = tile[wave];
+    const int64_t nblocks = (n + 63) / 64;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < nblocks; blk += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = blk * 64, i = row0 + lane;
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (c < f && i < n) ? cols[c][i] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mine[lane * 9 + c] = v[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int piece = k * 64 + lane;                     // 16-byte piece of the 4 KiB block
+            const int r = piece >> 2, c = (piece & 3) * 2;
+            if (row0 + r < n) {
+                double2 out;
+                out.x = mine[r * 9 + c];
+                out.y = mine[r * 9 + c + 1];
+                *reinterpret_cast<double2 *>(rows + (row0 + r) * 8 + c) = out;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // The same for ldr a multiple of 16 (rows of whole 128-byte lines): a 64-row x 16-column tile goes through LDS so
 // that both sides are coalesced -- columns are read 64 rows (512 bytes) at a time, rows written a line at a time.
 constexpr int PK_LD = 65;
@@ -1463,6 +1501,10 @@ int grx_pack_rows(int64_t n, int f, const double *const *h_col_ptrs, double *d_r
                 const int64_t tiles = grx_ceil_div(n, 64);
                 const int tgrid = (int)(tiles > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : tiles);
                 pack_rows_tiled_kernel<<<tgrid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
+            } else if (ldr == 8 && c0 == 0 && last && (reinterpret_cast<uintptr_t>(d_rows) & 15) == 0) {
+                const int64_t blocks = grx_ceil_div(grx_ceil_div(n, 64), 4);
+                pack_rows8_kernel<<<(int)(blocks > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : blocks), 256, 0, grx_stream(stream)>>>(
+                    n, fc, tab, d_rows);
             } else {
                 pack_rows_kernel<<<grid, 256, 0, grx_stream(stream)>>>(n, fc, ldr, tab, d_rows, c0, last ? f : ldr);
             }
