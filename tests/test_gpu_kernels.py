@@ -97,6 +97,22 @@ def test_egonet_hub_rows_powerlaw(K):
     assert np.all(i2.cpu().numpy()[:1000] == 0) and np.all(e2.cpu().numpy()[17000:] == 0)
 
 
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 4099, 100003])
+def test_pack_rows_of_64_bytes(K, n):
+    """5 - 8 columns become rows of 8 doubles (pack_rows8_kernel: 64 rows x 8 columns through the wave's LDS slice):
+    values in place, pad columns zero, row counts that are no multiple of the 64-row block."""
+    import torch
+    rng = np.random.default_rng(n)
+    for f in (5, 6, 7, 8):
+        X = rng.standard_normal((n, f))
+        Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+        rows, ldr = K.pack_rows([Xd[c] for c in range(f)], n)
+        assert ldr == 8
+        got = rows.cpu().numpy()
+        assert np.array_equal(got[:n, :f], X)
+        assert not got[:n, f:].any()
+
+
 def test_triangle_counts_long_oriented_lists(K):
     """The per-arc table of the oriented graph keeps list lengths in 10-bit fields; a clique of 1 200 nodes (oriented
     out-degrees 0 .. 1199) saturates them and takes the row-pointer path, lists of 17 .. 1022 ids take the chunked
