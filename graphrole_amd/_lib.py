@@ -206,6 +206,8 @@ _SIGNATURES = {
                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate_rows': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_role_argmax': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    'grx_row_normalise': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }

@@ -37,7 +37,7 @@ enum GrxKernelId {
     GRX_K_BIN_ASSIGN, GRX_K_CHEBYSHEV, GRX_K_GATHER_COLUMNS, GRX_K_GRAM, GRX_K_PROJECT,
     GRX_K_NNDSVD_APPLY, GRX_K_NMF_W_PASS, GRX_K_REDUCE_PARTIALS, GRX_K_NMF_H_UPDATE,
     GRX_K_NMF_RESIDUAL, GRX_K_ADD_COLUMNS, GRX_K_TRIANGLES, GRX_K_EGONET_FINISH, GRX_K_QUANT, GRX_K_KEY_BITS,
-    GRX_K_SEL_MAP, GRX_K_SEL_HIST, GRX_K_SEL_WALK1, GRX_K_SEL_COLLECT, GRX_K_SEL_SEGSORT, GRX_K_SEL_WALK2, GRX_K_COUNT
+    GRX_K_SEL_MAP, GRX_K_SEL_HIST, GRX_K_SEL_WALK1, GRX_K_SEL_COLLECT, GRX_K_SEL_SEGSORT, GRX_K_SEL_WALK2, GRX_K_ROLE_ROWS, GRX_K_COUNT
 };
 bool grx_prof_is_on();
 void grx_prof_begin(int id, hipStream_t st);

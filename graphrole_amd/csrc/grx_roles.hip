@@ -1,0 +1,122 @@
+// grx_roles.hip -- the two row passes over the node-role factor that finish RolX:
+//   grx_role_argmax     RoleExtractor.roles            graphrole/roles/extract.py:38-47  (DataFrame.idxmax(axis=1))
+//   grx_row_normalise   RoleExtractor.role_percentage  graphrole/roles/extract.py:49-57  (row / row.sum() per row)
+//
+// The factor is the n x r row-major matrix the reference holds (r <= GRX_MAX_ROLES): 8 r bytes per node in, 4 (or
+// 8 r) bytes out -- pure HBM streaming.  A workgroup stages 128 consecutive rows through LDS so that the global
+// reads and writes are coalesced 16-byte-per-lane streams whatever r is; one lane then owns one row in LDS (row
+// stride padded to an odd number of doubles: conflict-free ds_read_b64).
+//
+// Exactness.  With 2^n_bits-level quantised factors most rows hold exact ties, so "first maximum wins" IS the
+// result (pandas: nanargmax = NaN -> -inf, then numpy argmax).  The row sum follows the order Series.sum() uses
+// for r contiguous doubles -- numpy's pairwise_sum: fewer than 8 values are added left to right, 8 and more run
+// eight strided accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the r % 8 trailing values one by one;
+// NaN counts as 0 in the sum (nanops.nansum) and stays NaN in the quotient.  0 / 0 is NaN like the reference's.
+#include "grx_common.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int ROWS_PER_WG = 128;        // 128 x (32 | 1) doubles = 33 KB of LDS at the widest factor
+
+__device__ __forceinline__ double numpy_row_sum(const double *__restrict__ a, int r)
+{
+#pragma clang fp contract(off)
+    auto val = [&](int i) { const double x = a[i]; return x != x ? 0.0 : x; };
+    if (r < 8) {
+        double res = 0.0;
+        for (int i = 0; i < r; ++i) res += val(i);
+        return res;
+    }
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = val(j);
+    int i = 8;
+    for (; i < r - (r % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += val(i + j);
+    }
+    double res = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; i < r; ++i) res += val(i);
+    return res;
+}
+
+// ARGMAX: d_first_max[v] = column of the first maximum of row v (-1: every entry is NaN)
+// NORMALISE: d_share[v, :] = row v / its sum
+template <bool ARGMAX, bool NORMALISE>
+__global__ __launch_bounds__(ROWS_PER_WG) void role_rows_kernel(int64_t n, int r, const double *__restrict__ G,
+                                                                int32_t *__restrict__ d_first_max,
+                                                                double *__restrict__ d_share)
+{
+    extern __shared__ double tile[];
+    const int stride = r | 1;
+    for (int64_t base = (int64_t)blockIdx.x * ROWS_PER_WG; base < n; base += (int64_t)gridDim.x * ROWS_PER_WG) {
+        const int rows = (int)((n - base) < ROWS_PER_WG ? (n - base) : ROWS_PER_WG);
+        const double *src = G + base * r;
+        for (int i = threadIdx.x; i < rows * r; i += ROWS_PER_WG) tile[(i / r) * stride + (i % r)] = src[i];
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            double *row = tile + threadIdx.x * stride;
+            if (ARGMAX) {
+                double best = -INFINITY;
+                int arg = 0;
+                bool any = false;
+                for (int c = 0; c < r; ++c) {
+                    const double x = row[c];
+                    const bool nan = x != x;
+                    any |= !nan;
+                    const double v = nan ? -INFINITY : x;
+                    if (c == 0 || v > best) { best = v; arg = c; }
+                }
+                d_first_max[base + threadIdx.x] = any ? arg : -1;
+            }
+            if (NORMALISE) {
+                const double s = numpy_row_sum(row, r);
+                for (int c = 0; c < r; ++c) row[c] = row[c] / s;
+            }
+        }
+        if (NORMALISE) {
+            __syncthreads();
+            double *dst = d_share + base * r;
+            for (int i = threadIdx.x; i < rows * r; i += ROWS_PER_WG) dst[i] = tile[(i / r) * stride + (i % r)];
+        }
+        __syncthreads();
+    }
+}
+
+template <bool ARGMAX, bool NORMALISE>
+int launch_role_rows(int64_t n, int r, const double *d_G, int32_t *d_first_max, double *d_share, hipStream_t st)
+{
+    const size_t shmem = (size_t)ROWS_PER_WG * (r | 1) * sizeof(double);
+    const int64_t want = grx_ceil_div(n, ROWS_PER_WG);
+    const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    GRX_PROF(GRX_K_ROLE_ROWS, st);
+    role_rows_kernel<ARGMAX, NORMALISE><<<grid, ROWS_PER_WG, shmem, st>>>(n, r, d_G, d_first_max, d_share);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_role_argmax(int64_t n, int r, const double *d_G, int32_t *d_first_max, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && r >= 1, "grx_role_argmax: n=%lld r=%d", (long long)n, r);
+    if (r > GRX_MAX_ROLES) { grx_set_error("grx_role_argmax: r=%d > GRX_MAX_ROLES", r); return GRX_ERR_UNSUPPORTED; }
+    if (n == 0) return GRX_OK;
+    GRX_REQUIRE(d_G && d_first_max, "grx_role_argmax: NULL pointer");
+    return launch_role_rows<true, false>(n, r, d_G, d_first_max, nullptr, grx_stream(stream));
+}
+
+int grx_row_normalise(int64_t n, int r, const double *d_G, double *d_share, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && r >= 1, "grx_row_normalise: n=%lld r=%d", (long long)n, r);
+    if (r > GRX_MAX_ROLES) { grx_set_error("grx_row_normalise: r=%d > GRX_MAX_ROLES", r); return GRX_ERR_UNSUPPORTED; }
+    if (n == 0) return GRX_OK;
+    GRX_REQUIRE(d_G && d_share, "grx_row_normalise: NULL pointer");
+    return launch_role_rows<false, true>(n, r, d_G, nullptr, d_share, grx_stream(stream));
+}
+
+}  // extern "C"

@@ -36,7 +36,7 @@ const char *const g_prof_names[GRX_K_COUNT] = {
     "nndsvd_apply_kernel", "nmf_w_pass_kernel", "reduce_partials_kernel", "nmf_h_update_kernel",
     "nmf_residual_kernel", "add_columns_kernel", "triangle_count_kernel", "egonet_from_triangles_kernel", "lloyd_max (scan+dp+lloyd+assign)",
     "key_bits_kernel", "sel_map_kernel", "sel_hist_kernel", "sel_walk1_kernel", "sel_collect_kernel", "sel_sort_kernel",
-    "sel_walk2_kernel"};
+    "sel_walk2_kernel", "role_rows_kernel"};
 }  // namespace
 
 static hipEvent_t prof_get_event()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 301          /* 0.3.1: grx_comm -- the sharded loops and their exchanges below the ABI; ranks up to 32 */
+#define GRX_VERSION 400          /* 0.4.0: + grx_role_argmax / grx_row_normalise (RolX roles / role_percentage) */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
                                     a composed update (several times the traffic), then with n_roles + features <= 480 */
@@ -652,6 +652,22 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                  void *d_workspace, size_t workspace_bytes, void *stream);
 int grx_transpose(int64_t rows, int64_t cols, const double *d_in, int64_t ld_in, double *d_out, int64_t ld_out,
                   void *stream);
+
+
+/* ------------------------------------------------------------------ RolX roles ---------- */
+/*
+ * The two row passes over the fitted node-role factor.  d_G: fp64 n x r row-major (the layout of the reference's
+ * node_role_factor.values), 1 <= r <= GRX_MAX_ROLES.
+ *   grx_role_argmax    replaces RoleExtractor.roles (graphrole/roles/extract.py:38-47, DataFrame.idxmax(axis=1)):
+ *                      d_first_max int32[n] = column of the FIRST maximum of every row (quantised factors are full
+ *                      of exact ties), NaN entries skipped, -1 for a row of NaNs only.
+ *   grx_row_normalise  replaces RoleExtractor.role_percentage (:49-57, apply(lambda row: row / row.sum(), axis=1)):
+ *                      d_share fp64 n x r = every row divided by its sum, the sum evaluated in the order
+ *                      Series.sum() adds r doubles (numpy pairwise_sum: left to right below 8 values, eight strided
+ *                      accumulators from 8 on; NaN counts as 0) -- bit-equal to the reference; 0 / 0 = NaN as there.
+ */
+int grx_role_argmax(int64_t n, int r, const double *d_G, int32_t *d_first_max, void *stream);
+int grx_row_normalise(int64_t n, int r, const double *d_G, double *d_share, void *stream);
 
 #ifdef __cplusplus
 }
