@@ -66,17 +66,81 @@ WORKLOADS = {
     'dw5m': ('dw', 5_000_000, 100_000_000, 'weighted directed power-law, 5 M nodes / 100 M arcs + 8 attributes  [BASELINE config 5, on ONE GPU]'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-GATHER_CEILING_ROWS_PER_S = 56e9   # random 64-byte rows from a 64 MB table, measured (tools/microbench/gather_bw.hip)
+GATHER_PROFILE = os.path.join(ROOT, 'profiles', 'r04_gather_bw.json')   # tools/microbench/gather_bw.hip on MI355X
 N_ROLES = 6
 MAX_GENERATIONS = 4
 
 
-def build_graph(name):
+def generate_graph(name):
     from graphrole_amd import synth
     kind, n, m, _ = WORKLOADS[name]
     if kind == 'dw':
         return synth.directed_weighted_graph(n, m, seed=0)
     return synth.ba_graph(n, m, seed=0) if kind == 'ba' else synth.er_graph(n, m, seed=0)
+
+
+def shared_dir(name):
+    """Where the ranks of one node meet: the generators are seeded, so the content of a workload's directory is a
+    function of its name and of graphrole_amd/synth.py (hashed into the path)."""
+    import hashlib
+    from graphrole_amd import synth
+    tag = hashlib.sha256(open(synth.__file__, 'rb').read()).hexdigest()[:12]
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
+    return os.path.join(base, f'grx_bench_{os.getuid()}', f'{name}_{tag}')
+
+
+def build_graph(name, world=1, local_rank=0):
+    """N = 1: generate.  N > 1: the synthetic graph is generated ONCE per node (local rank 0 -> .npy files in
+    /dev/shm, published by one atomic rename), the other ranks map the same pages -- eight concurrent numpy
+    generations of the 5 M / 100 M graph would cost minutes of host time and 8 x the memory before any GPU work."""
+    if world == 1:
+        return generate_graph(name)
+    from graphrole_amd import synth
+    path = shared_dir(name)
+    if local_rank == 0 and not os.path.exists(os.path.join(path, 'meta.json')):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f'{path}.tmp{os.getpid()}'
+        os.makedirs(tmp, exist_ok=True)
+        synth.save_graph(generate_graph(name), tmp)
+        try:
+            os.rename(tmp, path)
+        except OSError:                                # another launch published the same content first
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    deadline = time.time() + 3600
+    while not os.path.exists(os.path.join(path, 'meta.json')):
+        if time.time() > deadline:
+            raise SystemExit(f'bench.py: rank waited an hour for {path}')
+        time.sleep(0.2)
+    return synth.load_graph(path)
+
+
+def gather_ceiling(table_bytes, dist):
+    """Rows per second the chip gathers from a table of this many bytes with this index distribution
+    (profiles/r04_gather_bw.json, measured with tools/microbench/gather_bw.hip: the gather alone -- no summation
+    order, no writes; the rate depends on the table's BYTES, not on the row width: a 16-, 32- or 64-byte row is one
+    request either way).  Log-linear interpolation between the measured table sizes; None without the file."""
+    try:
+        cells = [json.loads(l) for l in open(GATHER_PROFILE) if l.strip()]
+    except OSError:
+        return None
+    pts = {}
+    for c in cells:
+        if c.get('kind') == 'best' and c['dist'] == dist:
+            mb = c['table_mb']
+            pts[mb] = max(pts.get(mb, 0.0), c['rows_per_s'])
+    if not pts:
+        return None
+    xs = sorted(pts)
+    mb = table_bytes / 1e6
+    if mb <= xs[0]:
+        return pts[xs[0]]
+    if mb >= xs[-1]:
+        return pts[xs[-1]]
+    for lo, hi in zip(xs, xs[1:]):
+        if lo <= mb <= hi:
+            t = (np.log(mb) - np.log(lo)) / (np.log(hi) - np.log(lo))
+            return float(np.exp((1 - t) * np.log(pts[lo]) + t * np.log(pts[hi])))
 
 
 def profile_totals(lib):
@@ -225,6 +289,18 @@ def main():
     ap.add_argument('--cpu-nmf', type=int, default=1)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on the
+        # loopback address -- the container hostname may not resolve)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -247,7 +323,8 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
 
     def run_workload(workload, steps, warmup, light):
         """One measured workload; light = the extra sharded line of an N > 1 run (no breakdown pass, no CPU legs)."""
@@ -257,7 +334,7 @@ def main():
         K = backend.get()
         lib = _lib.load()
 
-        G = build_graph(args_workload)
+        G = build_graph(args_workload, world, int(os.environ.get('LOCAL_RANK', '0')))
         fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=multi,
                                       attributes=bool(G.attributes))
         dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed

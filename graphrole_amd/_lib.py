@@ -43,7 +43,8 @@ class RefexColumn(ctypes.Structure):
 
 class RefexGeneration(ctypes.Structure):
     """grx_refex_generation of include/grx.h."""
-    _fields_ = [('candidates', c_int), ('working', c_int), ('dropped', c_int), ('retained', c_int)]
+    _fields_ = [('candidates', c_int), ('working', c_int), ('dropped', c_int), ('retained', c_int),
+                ('gather_row_bytes', c_int)]
 
 
 AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5, 'prod': 6, 'median': 7, 'count': 8,

@@ -161,13 +161,18 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         GRX_REQUIRE(h_bounds[0] == 0 && h_bounds[P] == n, "grx_refex_run: h_bounds must run from 0 to n");
     const int64_t rb = comm ? h_bounds[me] : 0, re = comm ? h_bounds[me + 1] : n;
     Arena arena{reinterpret_cast<char *>(d_arena), d_arena ? arena_bytes : 0};
-    int64_t nnz_rows = 0;                                    // adjacency entries of this rank's rows (median workspace)
+    // Every allocation below is sized from RANK-INDEPENDENT upper bounds (ceil(count / P) owned columns, the largest
+    // nnz slice of the partition): with the equal capacity the caller agrees on (kernels.refex_run), every rank's arena
+    // overflows at the same allocation or not at all -- so the `if (!arena.overflow)` guards around the exchanges
+    // below take the same branch on every rank and a too-small arena is a joint GRX_ERR_WORKSPACE, never a rank
+    // that restarts while its peers wait inside a collective.
+    int64_t nnz_rows = 0;                                    // adjacency entries of the longest row slice (median workspace)
     if (has[GRX_AGG_MEDIAN]) {
-        int64_t ends[2] = {0, 0};
-        GRX_CHECK_HIP(hipMemcpyAsync(&ends[0], d_row_ptr + rb, 8, hipMemcpyDeviceToHost, st));
-        GRX_CHECK_HIP(hipMemcpyAsync(&ends[1], d_row_ptr + re, 8, hipMemcpyDeviceToHost, st));
+        std::vector<int64_t> ends(P + 1, 0);
+        for (int q = 0; q <= P; ++q)
+            GRX_CHECK_HIP(hipMemcpyAsync(&ends[q], d_row_ptr + (comm ? h_bounds[q] : (q ? n : 0)), 8, hipMemcpyDeviceToHost, st));
         GRX_CHECK_HIP(hipStreamSynchronize(st));
-        nnz_rows = ends[1] - ends[0];
+        for (int q = 0; q < P; ++q) nnz_rows = std::max(nnz_rows, ends[q + 1] - ends[q]);
     }
     std::vector<Column> cols;
     std::vector<int> work;                                   // working set, insertion order (extract.py:128-133)
@@ -177,6 +182,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
 
     // add the new columns to the working set, bin them, prune across the set, record what survives
     // (extract.py:121-142); `block` = the new columns as one contiguous [count, n] block
+    int gather_row_bytes = 0;                                // row width of the gather source of the generation at hand
     auto update = [&](int first_new, int count, const double *block, int generation, bool partial) -> int {
         const size_t scratch_mark = arena.top;
         uint8_t *bins = nullptr;
@@ -189,10 +195,11 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         // sharded: rank q bins columns q, q + P, ... of the new block as WHOLE columns (the threshold walk needs every
         // row), every rank gets back the bins of its own rows of every column -- the only rows its Chebyshev pass reads
         const int n_owned = comm ? (count > me ? (count - me + P - 1) / P : 0) : count;
-        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, n_owned);
-        void *ws = n_owned ? arena.take(ws_bytes) : nullptr;
-        double *owned = (comm && partial && n_owned) ? reinterpret_cast<double *>(arena.take((size_t)n_owned * n * 8)) : nullptr;
-        uint8_t *owned_bins = (comm && n_owned) ? reinterpret_cast<uint8_t *>(arena.take((size_t)n_owned * n)) : nullptr;
+        const int n_owned_max = comm ? (count + P - 1) / P : count;       // what rank 0 owns: the allocation size everywhere
+        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, n_owned_max);
+        void *ws = n_owned_max ? arena.take(ws_bytes) : nullptr;
+        double *owned = (comm && partial && n_owned_max) ? reinterpret_cast<double *>(arena.take((size_t)n_owned_max * n * 8)) : nullptr;
+        uint8_t *owned_bins = (comm && n_owned_max) ? reinterpret_cast<uint8_t *>(arena.take((size_t)n_owned_max * n)) : nullptr;
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
         const int F = (int)work.size();
         // (a whole number of 256-byte units: the runtime clears an unaligned tail with a second fill launch)
@@ -268,6 +275,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             g.working = working_before;
             g.dropped = (int)drop_idx.size();
             g.retained = (int)kept.size();
+            g.gather_row_bytes = gather_row_bytes;
         }
         return GRX_OK;
     };
@@ -313,6 +321,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             bool int_rows = only_sum_mean && grx_aggregate_i32_ok(plan, f);
             for (int j = 0; j < f && int_rows; ++j) int_rows = cols[prev[j]].int32_exact;
             const int ldi = int_rows ? grx_aggregate_ldi(f) : 0;
+            gather_row_bytes = int_rows ? ldi * 4 : ldr * 8;
             double *rows = reinterpret_cast<double *>(arena.take(int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
             double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
                                                                     : nullptr;

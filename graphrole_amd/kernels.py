@@ -679,19 +679,25 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         arena = torch.empty(_refex_arena_guess(n, f0, len(aggs), max_gens), dtype=torch.uint8, device=device())
     max_columns = 256
     while True:
+        # sharded: the library sizes every allocation from rank-independent bounds, so with ONE capacity for all ranks a
+        # too-small arena is a joint -3 (no rank restarts while its peers wait in an exchange); arenas kept from earlier
+        # runs may differ in size, hence the agreement on the smallest
+        capacity = arena.numel() if comm is None else shard.agree_min(arena.numel())
+        if capacity < arena.numel():
+            arena = arena[:capacity]
         table = (_lib.RefexColumn * max_columns)()
         gens = (_lib.RefexGeneration * max_gens)()
         n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         lib = _lib.load()
         rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names, int_flags,
-                               int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), arena.numel(),
+                               int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), capacity,
                                max_columns, table,
                                ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),
                                _stream())
         if rc == -3:                                    # GRX_ERR_WORKSPACE: arena or column table too small
-            if needed.value > arena.numel():
+            if needed.value > capacity:
                 # `needed` is what the run used up to the generation that failed -- a lower bound: grow geometrically
-                want = max(int(needed.value * 1.5), 2 * arena.numel()) + (32 << 20)
+                want = max(int(needed.value * 1.5), 2 * capacity) + (32 << 20)
                 del arena
                 arena = torch.empty(want, dtype=torch.uint8, device=device())
             else:
@@ -715,7 +721,8 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         columns.append(dict(generation=c.generation, parent=c.parent, agg=agg_names.get(c.agg), gen0_index=c.gen0_index,
                             work_position=c.work_position, col=col))
     generations = [dict(generation=g, candidates=gens[g].candidates, working=gens[g].working, dropped=gens[g].dropped,
-                        retained=gens[g].retained) for g in range(gen_count.value + 1)]
+                        retained=gens[g].retained, gather_row_bytes=gens[g].gather_row_bytes)
+                   for g in range(gen_count.value + 1)]
     return columns, generations, int(gen_count.value), arena
 
 
@@ -896,6 +903,26 @@ def transpose(src: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     """[rows, >= cols] row-major (leading dimension src.stride(0)) -> contiguous [cols, rows]."""
     out = torch.empty((cols, rows), dtype=torch.float64, device=device())
     _lib.call('grx_transpose', rows, cols, _ptr(src), _ld(src), _ptr(out), rows, _stream())
+    return out
+
+
+def role_argmax(G: torch.Tensor) -> torch.Tensor:
+    """n x r row-major node-role factor -> int32[n]: column of the first maximum of every row, -1 for an all-NaN
+    row (grx_role_argmax; RoleExtractor.roles, graphrole/roles/extract.py:38-47)."""
+    n, r = G.shape
+    assert G.is_contiguous() and G.dtype == torch.float64
+    out = torch.empty(n, dtype=torch.int32, device=device())
+    _lib.call('grx_role_argmax', n, r, _ptr(G), _ptr(out), _stream())
+    return out
+
+
+def row_normalise(G: torch.Tensor) -> torch.Tensor:
+    """n x r row-major node-role factor -> every row divided by its sum, summed in Series.sum()'s order
+    (grx_row_normalise; RoleExtractor.role_percentage, graphrole/roles/extract.py:49-57)."""
+    n, r = G.shape
+    assert G.is_contiguous() and G.dtype == torch.float64
+    out = torch.empty((n, r), dtype=torch.float64, device=device())
+    _lib.call('grx_row_normalise', n, r, _ptr(G), _ptr(out), _stream())
     return out
 
 

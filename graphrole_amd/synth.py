@@ -135,3 +135,35 @@ def directed_weighted_graph(n: int, m: int, seed: int = 0, n_attr: int = 8) -> C
         else:
             attrs[f'poisson{i}'] = rng.poisson(3.0, n).astype(np.float64)
     return CSRGraph(n, uniq // n, uniq % n, weights=wsum, directed=True, attributes=attrs, validate=False)
+
+
+# ------------------------------------------------------------------ one generation, many processes
+def save_graph(g: CSRGraph, directory: str) -> None:
+    """The edge arrays a CSRGraph was built from (+ weights, + attribute columns) as .npy files: what
+    ``load_graph`` in another process maps back without running the generator again."""
+    import json
+    import os
+    src, dst, w = g.edge_arrays()
+    np.save(os.path.join(directory, 'src.npy'), src)
+    np.save(os.path.join(directory, 'dst.npy'), dst)
+    if w is not None:
+        np.save(os.path.join(directory, 'w.npy'), w)
+    for i, values in enumerate(g.attributes.values()):
+        np.save(os.path.join(directory, f'attr{i}.npy'), np.asarray(values))
+    meta = {'n': g.n, 'directed': g.directed, 'weighted': w is not None, 'integral': g.integral,
+            'attributes': list(g.attributes)}
+    with open(os.path.join(directory, 'meta.json'), 'w') as fh:
+        json.dump(meta, fh)
+
+
+def load_graph(directory: str) -> CSRGraph:
+    """CSRGraph over memory-mapped copies of the arrays ``save_graph`` wrote (read-only, shared page cache)."""
+    import json
+    import os
+    meta = json.load(open(os.path.join(directory, 'meta.json')))
+    src = np.load(os.path.join(directory, 'src.npy'), mmap_mode='r')
+    dst = np.load(os.path.join(directory, 'dst.npy'), mmap_mode='r')
+    w = np.load(os.path.join(directory, 'w.npy'), mmap_mode='r') if meta['weighted'] else None
+    attrs = {name: np.load(os.path.join(directory, f'attr{i}.npy'), mmap_mode='r')
+             for i, name in enumerate(meta['attributes'])}
+    return CSRGraph(meta['n'], src, dst, weights=w, directed=meta['directed'], attributes=attrs or None, validate=False)

@@ -399,7 +399,11 @@ typedef struct {
     int work_position;         /* position in the final working set (extract.py:135-141), -1 if pruned from it */
     const double *d_col;       /* fp64[n]: inside the arena, or the caller's generation-0 column */
 } grx_refex_column;
-typedef struct { int candidates, working, dropped, retained; } grx_refex_generation;
+typedef struct {
+    int candidates, working, dropped, retained;
+    int gather_row_bytes;      /* bytes per row of the generation's gather source (16 / 32: int32 rows, 8 * ldr: fp64
+                                  rows; 0 for generation 0) -- what a gather-rate ceiling has to be looked up with */
+} grx_refex_generation;
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
                   int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,

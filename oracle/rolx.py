@@ -164,3 +164,28 @@ def rescale_costs(costs: np.ndarray) -> np.ndarray:
     """roles/extract.py:163-173."""
     norms = np.sqrt(np.nansum(np.square(costs), axis=1))
     return costs / norms.reshape(costs.shape[0], 1)
+
+
+# ----- roles / role_percentage (roles/extract.py:38-57) --------------------------------------
+def dominant_role_index(G: np.ndarray) -> np.ndarray:
+    """Column of the first maximum of every row of the node-role factor: what DataFrame.idxmax(axis=1) resolves
+    to (roles/extract.py:43-45; pandas nanargmax: NaN -> -inf, then numpy argmax = first maximum).  -1 marks a
+    row of NaNs only."""
+    G = np.asarray(G, dtype=np.float64)
+    nan = np.isnan(G)
+    idx = np.where(nan, -np.inf, G).argmax(axis=1).astype(np.int32)
+    idx[nan.all(axis=1)] = -1
+    return idx
+
+
+def role_percentage(G: np.ndarray) -> np.ndarray:
+    """row / row.sum() for every row (roles/extract.py:55).  Series.sum() of r float64 values is numpy's add.reduce
+    over the row with NaN counted as 0 (pandas nanops.nansum): pairwise_sum -- left to right below 8 values, eight
+    strided accumulators from 8 on; one reduce call per row keeps exactly that order."""
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    filled = np.where(np.isnan(G), 0.0, G)
+    out = np.empty_like(G)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for i in range(G.shape[0]):
+            out[i] = G[i] / np.add.reduce(filled[i])
+    return out

@@ -362,3 +362,11 @@ def nmf_fit(X, n, r, omega, tol, max_iter):
     W0, H0, xx = nmf_init(X, n, r, omega)
     state = NmfState(X, n, W0, H0, x_sq_norm=xx)
     return state, nmf_mu(state, tol, max_iter)
+
+
+def role_argmax(G):
+    return torch.from_numpy(rolx.dominant_role_index(G.numpy()))
+
+
+def row_normalise(G):
+    return torch.from_numpy(rolx.role_percentage(G.numpy()))

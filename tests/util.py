@@ -43,6 +43,10 @@ def load_refex(name):
     return Golden(os.path.join(GOLDEN, f'refex_{name}.npz'))
 
 
+def golden_path(filename):
+    return os.path.join(GOLDEN, filename)
+
+
 def load_roles(name):
     return Golden(os.path.join(GOLDEN, f'roles_{name}.npz'))
 

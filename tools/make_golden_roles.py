@@ -9,7 +9,10 @@ REFERENCE's RoleExtractor in the build container on feature tables that tools/ma
 Per table: the MDL grid of RoleExtractor._select_model (graphrole/roles/extract.py:98-142) -- encoding and
 error costs of every (n_roles, n_bits) cell as the reference computes them (its quantiser is sklearn
 KMeans(random_state=1), graphrole/roles/factor.py:41-48) with numpy's global RNG seeded once before the grid --
-the selected cell, the selected factors, and the fixed-rank result for n_roles = 3.
+the selected cell, the selected factors, and the fixed-rank result for n_roles = 3; for both fits the reference's
+``roles`` dict (stored as the position of every node's label in the factor's columns) and its ``role_percentage``
+table (graphrole/roles/extract.py:38-57).  tests/golden/roles_wide.npz adds fits with 9 and 12 roles (rows of 8
+and more values take the other branch of numpy's pairwise sum).
 The reference is imported here and only here; the fixtures are data.
 """
 import json
@@ -30,16 +33,46 @@ from graphrole.roles.description_length import get_description_length_costs   # 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'tests', 'golden')
+WIDE = [('er2000', 12), ('dw200_attrs', 9), ('er300', 8)]
 CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'directed120', 'loops_dangling150']
 SEED = 0
 
 
+def load_table(name):
+    z = np.load(os.path.join(OUT, f'refex_{name}.npz'))
+    cols = json.loads(str(z['final_columns_json']))
+    labels = json.loads(str(z['labels_json']))
+    return pd.DataFrame(z['final_values'], index=labels, columns=cols)
+
+
+def roles_of(rx):
+    """(position of every node's role label in node_role_factor.columns, role_percentage values), rows in the
+    factor's index order -- from the reference's own properties"""
+    frame = rx.node_role_factor
+    roles = rx.roles
+    pos = {label: i for i, label in enumerate(frame.columns)}
+    index = np.array([pos[roles[node]] for node in frame.index], dtype=np.int32)
+    share = rx.role_percentage
+    assert list(share.index) == list(frame.index) and list(share.columns) == list(frame.columns)
+    return index, np.ascontiguousarray(share.values, dtype=np.float64)
+
+
 def main():
+    wide = {}
+    for name, r in WIDE:
+        X = load_table(name)
+        np.random.seed(SEED)
+        rx = RoleExtractor(n_roles=r)
+        rx.extract_role_factors(X)
+        idx, share = roles_of(rx)
+        wide[f'{name}_r{r}_node_role_factor'] = rx.node_role_factor.values
+        wide[f'{name}_r{r}_role_feature_factor'] = rx.role_feature_factor.values
+        wide[f'{name}_r{r}_roles_index'] = idx
+        wide[f'{name}_r{r}_role_percentage'] = share
+        print(f'roles_wide {name} r={r}: ties in {int((np.sort(rx.node_role_factor.values, axis=1)[:, -1] == np.sort(rx.node_role_factor.values, axis=1)[:, -2]).sum())} of {len(idx)} rows')
+    np.savez_compressed(os.path.join(OUT, 'roles_wide.npz'), seed=SEED, cases=json.dumps([[n, r] for n, r in WIDE]), **wide)
     for name in CASES:
-        z = np.load(os.path.join(OUT, f'refex_{name}.npz'))
-        cols = json.loads(str(z['final_columns_json']))
-        labels = json.loads(str(z['labels_json']))
-        X = pd.DataFrame(z['final_values'], index=labels, columns=cols)
+        X = load_table(name)
         # the grid exactly as RoleExtractor._select_model walks it (one RNG stream for the whole grid)
         rx = RoleExtractor()
         bit_stop = rx.max_bits + 1
@@ -66,8 +99,16 @@ def main():
         np.random.seed(SEED)
         rx3 = RoleExtractor(n_roles=3)
         rx3.extract_role_factors(X)
+        old = np.load(os.path.join(OUT, f'roles_{name}.npz')) if os.path.exists(os.path.join(OUT, f'roles_{name}.npz')) else None
+        if old is not None:                       # a regenerated fixture must reproduce what was pinned before
+            # (to rounding: sklearn's threaded KMeans reductions move the centres by an ulp or two from run to run)
+            assert np.allclose(old['node_role_factor'], rx2.node_role_factor.values, rtol=1e-12, atol=0), name
+            assert np.allclose(old['fixed3_node_role_factor'], rx3.node_role_factor.values, rtol=1e-12, atol=0), name
+        sel_idx, sel_share = roles_of(rx2)
+        fix_idx, fix_share = roles_of(rx3)
         np.savez_compressed(
-            os.path.join(OUT, f'roles_{name}.npz'), seed=SEED, encoding_costs=enc, error_costs=err,
+            os.path.join(OUT, f'roles_{name}.npz'), seed=SEED, roles_index=sel_idx, role_percentage=sel_share,
+            fixed3_roles_index=fix_idx, fixed3_role_percentage=fix_share, encoding_costs=enc, error_costs=err,
             selected=np.array(sel, dtype=np.int64), node_role_factor=rx2.node_role_factor.values,
             role_feature_factor=rx2.role_feature_factor.values, fixed3_node_role_factor=rx3.node_role_factor.values,
             fixed3_role_feature_factor=rx3.role_feature_factor.values,
