@@ -71,6 +71,9 @@ N_ROLES = 6
 MAX_GENERATIONS = 4
 
 
+_PUBLISHED = []            # shared graph directories this process created (removed when it ends)
+
+
 def generate_graph(name):
     from graphrole_amd import synth
     kind, n, m, _ = WORKLOADS[name]
@@ -89,11 +92,12 @@ def shared_dir(name):
     return os.path.join(base, f'grx_bench_{os.getuid()}', f'{name}_{tag}')
 
 
-def build_graph(name, world=1, local_rank=0):
-    """N = 1: generate.  N > 1: the synthetic graph is generated ONCE per node (local rank 0 -> .npy files in
-    /dev/shm, published by one atomic rename), the other ranks map the same pages -- eight concurrent numpy
-    generations of the 5 M / 100 M graph would cost minutes of host time and 8 x the memory before any GPU work."""
-    if world == 1:
+def build_graph(name, world=1, local_rank=0, share=False):
+    """N = 1: generate.  N > 1 (or share=True: the counter passes of --pmc re-run this script): the synthetic graph
+    is generated ONCE per node (local rank 0 -> .npy files in /dev/shm, published by one atomic rename), the other
+    processes map the same pages -- eight concurrent numpy generations of the 5 M / 100 M graph would cost minutes of
+    host time and 8 x the memory before any GPU work."""
+    if world == 1 and not share:
         return generate_graph(name)
     from graphrole_amd import synth
     path = shared_dir(name)
@@ -104,6 +108,7 @@ def build_graph(name, world=1, local_rank=0):
         synth.save_graph(generate_graph(name), tmp)
         try:
             os.rename(tmp, path)
+            _PUBLISHED.append(path)
         except OSError:                                # another launch published the same content first
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
@@ -113,6 +118,82 @@ def build_graph(name, world=1, local_rank=0):
             raise SystemExit(f'bench.py: rank waited an hour for {path}')
         time.sleep(0.2)
     return synth.load_graph(path)
+
+
+PMC_PASSES = ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum TCC_MISS_sum',
+              'SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES')
+
+
+def pmc_counters(workload, timeout_s=240):
+    """Same-run hardware counters: this script re-runs itself (two steps of the same workload on the same graph
+    files, same libgrx.so) under `rocprofv3 --pmc`, one pass per counter group and nothing but --pmc in the command
+    (MI355X_MICROARCH.md, HBM section), and folds the per-launch averages of the aggregation kernels and of the NMF
+    W pass into the line.  Returns None when rocprofv3 is missing or a pass fails (the line then falls back to the
+    committed profiles/traffic_latest.json and says so)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if rocprof is None:
+        return None
+    out_root = tempfile.mkdtemp(prefix='grx_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    sums = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            cmd = [rocprof, '--pmc', *group.split(), '--output-format', 'csv', '-d', os.path.join(out_root, f'p{i}'), '-o', 'pmc',
+                   '--', sys.executable, os.path.abspath(__file__), '--workload', workload, '--pmc-child']
+            proc = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            if proc.returncode != 0:
+                return {'error': f'rocprofv3 --pmc {group}: rc {proc.returncode}: {proc.stderr[-300:]}'}
+            for path in glob.glob(os.path.join(out_root, f'p{i}', '**', '*counter_collection.csv'), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        k = re.sub(r'\(.*$', '', re.sub(r'^void ', '', re.sub(r'\(anonymous namespace\)::', '', row['Kernel_Name'])))
+                        cell = sums[k][row['Counter_Name']]
+                        cell[0] += 1
+                        cell[1] += float(row['Counter_Value'])
+    except Exception as exc:
+        return {'error': repr(exc)}
+    finally:
+        shutil.rmtree(out_root, ignore_errors=True)
+
+    def fold(prefixes):
+        tot, launches = defaultdict(float), 0
+        for k, ctrs in sums.items():
+            if any(k.startswith(p) for p in prefixes):
+                launches += max(v[0] for v in ctrs.values())
+                for c, v in ctrs.items():
+                    tot[c] += v[1]
+        return ({c: v / launches for c, v in tot.items()}, launches) if launches else (None, 0)
+
+    agg, agg_n = fold(('aggregate_kernel', 'aggregate_i32_kernel'))
+    nmf, nmf_n = fold(('nmf_w_pass',))
+    if not agg or 'FETCH_SIZE' not in agg:
+        return {'error': 'no aggregation launches in the counter output'}
+    res = {'passes': list(PMC_PASSES), 'aggregate_launches_sampled': agg_n,
+           # random 16..64-byte row gathers: FETCH_SIZE (KiB) x 1024 equals TCC_MISS_sum x 64 B within 5 % on this pattern,
+           # i.e. the requests are 64-byte and the x2 correction for wide coalesced streams does not apply here
+           'aggregate_fetch_bytes': agg['FETCH_SIZE'] * 1024, 'aggregate_write_bytes': agg.get('WRITE_SIZE', 0.0) * 1024,
+           'aggregate_tcc_miss_x64B': agg.get('TCC_MISS_sum', 0.0) * 64}
+    res['aggregate_traffic_per_launch'] = res['aggregate_fetch_bytes'] + res['aggregate_write_bytes']
+    if agg.get('TCC_HIT_sum', 0) + agg.get('TCC_MISS_sum', 0) > 0:
+        res['aggregate_l2_hit_rate'] = agg['TCC_HIT_sum'] / (agg['TCC_HIT_sum'] + agg['TCC_MISS_sum'])
+    if nmf and 'FETCH_SIZE' in nmf:
+        # wide coalesced streaming reads: FETCH_SIZE reports half the bytes on gfx950 (the guide's correction)
+        res['nmf_w_pass_traffic_per_launch'] = 2.0 * nmf['FETCH_SIZE'] * 1024 + nmf.get('WRITE_SIZE', 0.0) * 1024
+        res['nmf_w_pass_launches_sampled'] = nmf_n
+        if nmf.get('SQ_VALU_MFMA_BUSY_CYCLES') and nmf.get('SQ_BUSY_CU_CYCLES'):
+            res['nmf_w_pass_mfma'] = {'SQ_VALU_MFMA_BUSY_CYCLES': nmf['SQ_VALU_MFMA_BUSY_CYCLES'],
+                                      'SQ_INSTS_VALU_MFMA_MOPS_F64': nmf.get('SQ_INSTS_VALU_MFMA_MOPS_F64'),
+                                      'SQ_BUSY_CU_CYCLES': nmf['SQ_BUSY_CU_CYCLES'],
+                                      # cycles a SIMD's matrix pipe was busy / (cycles a CU was busy x 4 SIMDs)
+                                      'mfma_util': nmf['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * nmf['SQ_BUSY_CU_CYCLES'])}
+    return res
 
 
 def gather_ceiling(table_bytes, dist):
@@ -287,6 +368,13 @@ def main():
     ap.add_argument('--no-sharded-extra', action='store_true',
                     help='N > 1: skip the additional sharded config-5 (dw5m) measurement')
     ap.add_argument('--cpu-nmf', type=int, default=1)
+    ap.add_argument('--pmc', default='auto', choices=['auto', 'on', 'off'],
+                    help='same-run hardware counters: re-run two steps under rocprofv3 --pmc (one pass per counter group) '
+                         'and fold HBM traffic / L2 hit rate / MFMA busy into the line; auto = when N = 1 and rocprofv3 exists')
+    ap.add_argument('--pmc-child', action='store_true', help='internal: the process a --pmc pass profiles (two steps, no output)')
+    ap.add_argument('--soak-seconds', type=float, default=2.5,
+                    help='after the timed region: keep stepping (untimed) for this long so that an external GPU-activity '
+                         'sampler sees the device busy; 0 disables')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -326,6 +414,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
 
+    import shutil
+    have_rocprof = bool(shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3'))
+    under_profiler = any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    use_pmc = (not args.pmc_child and world == 1 and not multi and
+               (args.pmc == 'on' or (args.pmc == 'auto' and have_rocprof and not under_profiler)))
+
     def run_workload(workload, steps, warmup, light):
         """One measured workload; light = the extra sharded line of an N > 1 run (no breakdown pass, no CPU legs)."""
         args_workload = workload
@@ -334,7 +428,7 @@ def main():
         K = backend.get()
         lib = _lib.load()
 
-        G = build_graph(args_workload, world, int(os.environ.get('LOCAL_RANK', '0')))
+        G = build_graph(args_workload, world, int(os.environ.get('LOCAL_RANK', '0')), share=use_pmc or args.pmc_child)
         fe = RecursiveFeatureExtractor(G, max_generations=MAX_GENERATIONS, distributed=multi,
                                       attributes=bool(G.attributes))
         dev_graph = fe.graph._device_graph()[1]        # graph resident in HBM before anything is timed
@@ -370,6 +464,11 @@ def main():
                          F=len(names), W=nmf_state.W)
 
         warm = dict(refex=0.0, nmf=0.0, nmf_iters=0)
+        if args.pmc_child:                              # the process a counter pass profiles: two plain steps
+            step(warm)
+            step(warm)
+            torch.cuda.synchronize()
+            return None
         for _ in range(warmup):
             step(warm)
         # untimed breakdown pass: HIP events around EVERY kernel launch (per-kernel ms per step)
@@ -408,6 +507,16 @@ def main():
             step(plain)
         barrier()
         t_plain = time.perf_counter() - t_plain
+        # untimed soak: the timed region of the small workloads is tens of milliseconds -- an external activity sampler
+        # (the driver polls the SMI once a second) would never see the device busy
+        soak = None
+        if args.soak_seconds > 0 and not light:
+            t_soak, n_soak = time.perf_counter(), 0
+            while time.perf_counter() - t_soak < args.soak_seconds:
+                step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
+                n_soak += 1
+            barrier()
+            soak = {'seconds': time.perf_counter() - t_soak, 'steps': n_soak, 'what': 'untimed steps after the timed region'}
         # N > 1: one more (untimed) step with HIP events around every exchange -> exchange share of a step
         exchange = None
         if plan is not None:
@@ -487,7 +596,17 @@ def main():
                 traffic = nmf_traffic = traffic_source = nmf_mfma = agg_l2 = None
                 traffic_stale = None
                 tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-                if os.path.exists(tpath):
+                pmc = pmc_counters(args_workload) if (use_pmc and not light) else None
+                if pmc and 'error' not in pmc:
+                    traffic = pmc['aggregate_traffic_per_launch']
+                    agg_l2 = pmc.get('aggregate_l2_hit_rate')
+                    nmf_traffic = pmc.get('nmf_w_pass_traffic_per_launch')
+                    nmf_mfma = pmc.get('nmf_w_pass_mfma')
+                    traffic_stale = False
+                    traffic_source = ('measured in this run: rocprofv3 --pmc passes (%s) of two steps of this command on the same '
+                                      'graph files and libgrx.so, started by bench.py itself after the timed region'
+                                      % '; '.join(PMC_PASSES))
+                elif os.path.exists(tpath):
                     try:
                         table = json.load(open(tpath))
                         tj = table.get(args_workload) if 'workload' not in table else \
@@ -514,14 +633,33 @@ def main():
                 roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
                             'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                             'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_source,
-                            'l2_hit_rate': agg_l2,
+                            'l2_hit_rate': agg_l2, 'pmc': pmc,
                             'algorithmic_bytes_per_launch': alg_bytes / launches,
-                            'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen,
-                            # the kernel is a random 64-byte-line gather: what the chip sustains on that pattern was
-                            # measured with tools/microbench/gather_bw.hip
-                            'gather_rows_per_s': nnz_per_rank / (per_launch_ms * 1e-3),
-                            'gather_ceiling_rows_per_s': GATHER_CEILING_ROWS_PER_S,
-                            'frac_of_gather_ceiling': nnz_per_rank / (per_launch_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S}
+                            'avg_launch_ms': per_launch_ms, 'launches': agg_cnt, 'f_prev_per_generation': f_per_gen}
+                # The kernel is a random-row gather: one request per CSR entry, and the chip's request rate -- not its
+                # byte rate -- is what bounds it (profiles/r04_gather_bw.json: 16-, 32- and 64-byte rows gather at the same
+                # rows/s; the rate follows the TABLE's bytes through the L2 hit rate).  Ceiling of this step = the
+                # microbenchmark's time for the same number of gathers from tables of the launches' sizes, with the index
+                # distribution of the workload (power-law hubs first for the preferential-attachment graphs).
+                dist_kind = 'uniform' if WORKLOADS[args_workload][0] == 'er' else 'powerlaw'
+                ceil_s, per_gen = 0.0, []
+                for s_gen in state['stats']:
+                    rb = s_gen.get('gather_row_bytes', 0)
+                    if s_gen['generation'] < 1 or not rb:
+                        continue
+                    n_launch = -(-rb // 128)                        # rows wider than 128 bytes: one launch per 16 columns
+                    rate = gather_ceiling(G.n * min(rb, 128), dist_kind)
+                    per_gen.append({'generation': s_gen['generation'], 'row_bytes': rb, 'table_mb': G.n * rb / 1e6,
+                                    'launches': n_launch, 'ceiling_rows_per_s': rate})
+                    if rate:
+                        ceil_s += n_launch * nnz_per_rank / rate
+                roofline['gather_rows_per_s'] = nnz_per_rank / (per_launch_ms * 1e-3)
+                roofline['gather_ceiling'] = {
+                    'source': 'profiles/r04_gather_bw.json (tools/microbench/gather_bw.hip on MI355X: the gather alone, best of '
+                              'unroll x grid variants; index distribution: %s)' % dist_kind,
+                    'per_generation': per_gen, 'ceiling_ms_per_step': ceil_s * 1e3 if ceil_s else None,
+                    'measured_ms_per_step': (agg_ms + hub_ms) / steps}
+                roofline['frac_of_gather_ceiling'] = (ceil_s * 1e3) / ((agg_ms + hub_ms) / steps) if ceil_s else None
             F, r = state['F'], N_ROLES
             w_ms, w_cnt = breakdown.get('nmf_w_pass_kernel', (0.0, 0))
             roofline_nmf = None
@@ -554,7 +692,7 @@ def main():
                           'generations': state['stats']},
                 'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / steps * 1e3,
                         'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
-                'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
+                'soak': soak, 'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
                 'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
             }
             if per_rank is not None:
@@ -601,6 +739,9 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    for path in _PUBLISHED:                             # mapped copies in other processes stay valid after the unlink
+        import shutil
+        shutil.rmtree(path, ignore_errors=True)
     if rank == 0 and line is not None:
         # the JSON line is the LAST thing on stdout: librccl prints a version banner through C stdio, which would
         # otherwise be flushed after Python's own buffer when the process exits

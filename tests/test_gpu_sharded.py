@@ -45,14 +45,14 @@ def _graph(kind):
     return synth.directed_weighted_graph(40_000, 400_000, seed=4)
 
 
-def _worker(rank, port, kind, driver, out_dir):
+def _worker(rank, port, kind, driver, out_dir, world=WORLD):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from graphrole_amd import RecursiveFeatureExtractor, kernels as K
         from graphrole_amd.roles import factor
@@ -64,7 +64,7 @@ def _worker(rank, port, kind, driver, out_dir):
                                       attributes=bool(G.attributes))
         X = fe.extract_features()
         plan = fe._shard()
-        assert plan is not None and plan.world == WORLD and 0 < plan.row_end - plan.row_begin < G.n
+        assert plan is not None and plan.world == world and 0 < plan.row_end - plan.row_begin < G.n
         assert plan.comm() is not None
         Xd = K.gather_columns(fe.device_features()[1], G.n)
         F = X.shape[1]
@@ -103,6 +103,51 @@ def test_two_ranks_one_gpu_equal_single_process(kind, driver, tmp_path):
         rb, re = int(r['rb']), int(r['re'])
         # entries far below the factor's scale carry the absolute error of the re-ordered partial sums
         np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-12 * np.abs(r0['W1']).max())
+
+
+@pytest.mark.parametrize('kind,driver', [('ba', 'native'), ('directed_weighted', 'native'), ('ba', 'per_kernel')])
+def test_eight_ranks_one_gpu_equal_single_process(kind, driver, tmp_path):
+    """P = 8 -- the partition of BASELINE configs 4 / 5 -- on the real kernels: eight processes share cuda:0 (callback
+    transport).  Generation 0 has 3 (BA) columns for 8 column owners, so five ranks own NO column of the first
+    binning exchange, and the nnz-balanced row cuts are uneven on the power-law graph; every rank must end with the
+    single-process table, bit for bit."""
+    world = 8
+    mp.spawn(_worker, args=(_free_port(), kind, driver, str(tmp_path), world), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / f'rank{q}.npz') for q in range(world)]
+    r0 = ranks[0]
+    sizes = [int(r['re']) - int(r['rb']) for r in ranks]
+    assert sum(sizes) == r0['X'].shape[0] and [int(r['rb']) for r in ranks[1:]] == [int(r['re']) for r in ranks[:-1]]
+    if kind == 'ba':
+        assert max(sizes) > 2 * min(sizes)                   # hubs first: the first ranks hold few, long rows
+    for r in ranks:
+        assert list(r['cols']) == list(r0['cols1'])
+        assert np.array_equal(r['X'], r0['X1'])                    # ReFeX: bit-exact vs one GPU
+        assert int(r['n_iter']) == int(r0['it1'])
+        assert np.array_equal(r['H'], r0['H'])
+        rb, re = int(r['rb']), int(r['re'])
+        np.testing.assert_allclose(r['W'][:, rb:re], r0['W1'][:, rb:re], rtol=1e-9, atol=1e-12 * np.abs(r0['W1']).max())
+    np.testing.assert_allclose(r0['H'], r0['H1'], rtol=1e-9)
+
+
+def test_bench_launches_itself_on_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher (how a driver calls N = 1): the script re-executes itself under
+    torch.distributed.run, the synthetic graph is generated once and shared through /dev/shm, and rank 0 prints one
+    JSON line.  GRX_BENCH_SHARE_GPU=1: both ranks on cuda:0 over gloo (functional check; numbers are meaningless)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['GRX_BENCH_SHARE_GPU'] = '1'
+    proc = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'ba100k', '--steps', '2',
+                           '--warmup', '1', '--no-sharded-extra'], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['config']['workload'] == 'ba100k'
+    assert len(line['per_rank']) == 2 and {pr['rank'] for pr in line['per_rank']} == {0, 1}
+    assert line['value'] > 0 and line['roofline']['frac'] > 0
 
 
 def _worker_rccl(rank, port, kind, driver, out_dir):
