@@ -159,7 +159,10 @@ int exchange_impl(grx_comm *c, int n_ops, const grx_p2p_op *ops, hipStream_t st)
             GRX_CHECK_HIP(hipMemcpyAsync(self_recv[i]->d_ptr, self_send[i]->d_ptr, self_send[i]->bytes,
                                          hipMemcpyDeviceToDevice, st));
     }
-    if (remote.empty()) return GRX_OK;
+    // RCCL sends / receives are point to point: nothing to do without remote transfers.  A callback transport may be
+    // built on a collective (the gloo one is an all_to_all_single): it is entered by every rank of every exchange,
+    // also by a rank that has nothing to move (no rows and no owned column), or its peers would wait for it forever.
+    if (remote.empty() && (c->rccl || c->world == 1)) return GRX_OK;
     if (c->rccl) {
         GRX_CHECK_RCCL(g_rccl.GroupStart());
         for (const grx_p2p_op &op : remote) {

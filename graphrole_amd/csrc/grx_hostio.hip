@@ -42,9 +42,14 @@ public:
         if (tasks == 1 || workers_.empty()) { for (int i = 0; i < tasks; ++i) fn(i); return; }
         std::unique_lock<std::mutex> call(call_mu_);           // one fork-join at a time
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            // the task counter is reset LAST: a straggler of the previous call that draws an index from the new
-            // counter then also sees the new function and the new bound
+            std::unique_lock<std::mutex> lk(mu_);
+            // Nobody may be between "draw an index" and "compare it with the bound" while the bound changes: a
+            // straggler of the previous call holding a stale index (>= the old task count) that resumed after the new
+            // bound was stored would run a task a second time -- pending_ would reach 0 with a task still in flight
+            // and run() would return under it.  Entering and leaving work() is counted under this mutex, and the job
+            // is replaced only while the count is zero; whoever enters afterwards draws from the new counter and
+            // sees the new function and bound.
+            idle_.wait(lk, [&] { return active_ == 0; });
             fn_.store(&fn);
             total_.store(tasks);
             pending_ = tasks;
@@ -68,13 +73,16 @@ private:
     }
     void work()
     {
+        { std::lock_guard<std::mutex> lk(mu_); ++active_; }
         for (;;) {
             const int i = next_.fetch_add(1);
-            if (i >= total_.load()) return;
+            if (i >= total_.load()) break;
             (*fn_.load())(i);
             std::lock_guard<std::mutex> lk(mu_);
             if (--pending_ == 0) done_.notify_all();
         }
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--active_ == 0) idle_.notify_all();
     }
     void loop()
     {
@@ -90,7 +98,8 @@ private:
     }
     std::vector<std::thread> workers_;
     std::mutex mu_, call_mu_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_, done_, idle_;
+    int active_ = 0;                                           // threads inside work() (guarded by mu_)
     std::atomic<const std::function<void(int)> *> fn_{nullptr};
     std::atomic<int> next_{0}, total_{0};
     int pending_ = 0;

@@ -1934,6 +1934,46 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
                         reinterpret_cast<uint32_t *>(ws + p.keys_bytes), grx_stream(stream));
 }
 
+}  // extern "C"
+
+namespace {
+// one wave: bit 0 = the sort-free walk met a bucket it had not marked (an invariant of the interval walk broke),
+// bit 1 = a column needs more than GRX_MAX_BINS bins (labels would saturate).  OR-ed into *status.
+__global__ __launch_bounds__(64) void log_bin_status_kernel(const int32_t *__restrict__ nbins, int ncols,
+                                                            const int32_t *__restrict__ fault, int32_t *__restrict__ status)
+{
+    int bad = 0;
+    for (int c = threadIdx.x; c < ncols; c += 64) bad |= nbins[c] < 0 ? 2 : 0;
+    if (fault && threadIdx.x == 0 && *fault != 0) bad |= 1;
+    if (bad) atomicOr(status, bad);
+}
+}  // namespace
+
+// Internal (grx_refex.hip): fold the outcome flags of the grx_vertical_log_bin call that last used this workspace
+// into *d_status (see log_bin_status_kernel).  The flags live in the workspace, so they must be read before it is
+// reused.  No synchronisation: the caller reads *d_status with whatever it copies back next.
+int grx_internal_log_bin_status(int64_t n, int ncols, void *d_workspace, int32_t *d_status, hipStream_t st)
+{
+    if (n <= 0 || ncols <= 0) return GRX_OK;
+    char *ws = reinterpret_cast<char *>(d_workspace);
+    static const bool use_sort = [] { const char *e = std::getenv("GRX_BIN_SORT"); return e && *e == '1'; }();
+    const int32_t *nb_ws, *fault = nullptr;
+    if (!use_sort) {
+        const SelLayout L = sel_layout(n, ncols);
+        nb_ws = reinterpret_cast<const int32_t *>(ws + L.nbins);
+        fault = reinterpret_cast<const int32_t *>(ws + L.fault);
+    } else {
+        const SortPlan p = make_plan(n, ncols);
+        nb_ws = reinterpret_cast<const int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
+                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
+    }
+    log_bin_status_kernel<<<1, 64, 0, st>>>(nb_ws, ncols, fault, d_status);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+extern "C" {
+
 int grx_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, double frac,
                          uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
                          size_t workspace_bytes, void *stream)

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+int grx_internal_log_bin_status(int64_t n, int ncols, void *d_workspace, int32_t *d_status, hipStream_t st);   // grx_prune.hip
+
 namespace {
 
 const char *const AGG_NAMES[] = {"sum", "mean", "min", "max", "var", "std", "prod", "median", "count", "size"};
@@ -203,12 +205,16 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
         const int F = (int)work.size();
         // (a whole number of 256-byte units: the runtime clears an unaligned tail with a second fill launch)
-        const size_t dist_bytes = grx_align_up((size_t)F * F * 4, 256);
+        // + one status word behind the matrix: the outcome flags of the binning travel (and, sharded, are max-reduced)
+        // with the distances, so a failed binning is a joint error on every rank instead of a silent wrong drop list
+        const size_t dist_bytes = grx_align_up(((size_t)F * F + 1) * 4, 256);
         int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take(dist_bytes));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
+            if (F >= 2) GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
             if (count && !comm) {
                 GRX_TRY(grx_vertical_log_bin(n, count, block, n, 0.5, bins, n, nullptr, ws, ws_bytes, stream));
+                if (F >= 2) GRX_TRY(grx_internal_log_bin_status(n, count, ws, d_dist + (size_t)F * F, st));
             } else if (count) {
                 const double *src = block + (size_t)me * n;       // complete columns: the owned ones are a strided view
                 int64_t ld_src = (int64_t)P * n;
@@ -218,8 +224,10 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     src = owned;
                     ld_src = n;
                 }
-                if (n_owned)
+                if (n_owned) {
                     GRX_TRY(grx_vertical_log_bin(n, n_owned, src, ld_src, 0.5, owned_bins, n, nullptr, ws, ws_bytes, stream));
+                    if (F >= 2) GRX_TRY(grx_internal_log_bin_status(n, n_owned, ws, d_dist + (size_t)F * F, st));
+                }
                 // step 2: the owners' bins of this rank's rows come back
                 GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));
             }
@@ -227,14 +235,21 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             if (F >= 2) {
                 std::vector<const uint8_t *> ptrs(F);
                 for (int j = 0; j < F; ++j) ptrs[j] = cols[work[j]].bins;
-                GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
                 // the pruner only asks "distance <= generation number?" (prune.py:110-113)
                 if (re > rb) GRX_TRY(grx_chebyshev(rb, re, F, 0, ptrs.data(), d_dist, generation, stream));
-                if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F, GRX_I32, GRX_MAX, stream));
+                if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F + 1, GRX_I32, GRX_MAX, stream));
                 void *host = nullptr;
-                GRX_TRY(pinned((size_t)F * F * 4, &host));
-                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, (size_t)F * F * 4, hipMemcpyDeviceToHost, st));
+                GRX_TRY(pinned(((size_t)F * F + 1) * 4, &host));
+                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, ((size_t)F * F + 1) * 4, hipMemcpyDeviceToHost, st));
                 GRX_CHECK_HIP(hipStreamSynchronize(st));
+                const int32_t bin_status = reinterpret_cast<const int32_t *>(host)[(size_t)F * F];
+                if (bin_status != 0) {
+                    grx_set_error("grx_refex_run: generation %d: vertical log binning failed on some rank (%s%s); "
+                                  "GRX_BIN_SORT=1 selects the sort-based binning", generation,
+                                  (bin_status & 1) ? "the sort-free threshold walk met an unmarked bucket" : "",
+                                  (bin_status & 2) ? " a column needs more than GRX_MAX_BINS bins" : "");
+                    return GRX_ERR_UNSUPPORTED;
+                }
                 // identical distances on every rank -> identical decisions, no further agreement needed
                 drop_idx = prune(cols, work, reinterpret_cast<const int32_t *>(host), generation, recorded);
             }

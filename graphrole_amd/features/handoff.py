@@ -11,6 +11,13 @@ back, ``lookup`` re-hashes the frame's column buffers (threaded, ~memory speed: 
 device block only if every column still holds exactly the bytes that were handed out -- any in-place edit, column
 replacement, reordering or dtype change is a miss and the table takes the ordinary upload path.  Correctness never
 depends on pandas internals: a frame that does not expose plain contiguous column buffers is simply a miss.
+
+Retention.  A registered block keeps [F, n] fp64 of HBM alive (about 4 GB for 5 M x 100) for as long as its frame
+lives.  The registry therefore holds at most ``MAX_BLOCKS`` blocks (default 2, environment ``GRX_HANDOFF_BLOCKS``;
+0 switches the hand-off off): registering one more drops the oldest, whose frame then simply takes the upload path.
+``clear()`` releases all of them at once.  The content check is a 64-bit multiply-add hash per column -- it catches
+accidental edits (bit flips, swaps, shifts: tests/test_hostio_cpu.py) with probability 1 - 2^-64 per edit, it is
+not a cryptographic guarantee against a frame crafted to collide.
 """
 from __future__ import annotations
 
@@ -19,7 +26,15 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-_REGISTRY: dict = {}
+import os
+
+_REGISTRY: dict = {}                    # id(frame) -> _Entry, oldest first (dicts keep insertion order)
+MAX_BLOCKS = int(os.environ.get('GRX_HANDOFF_BLOCKS', '2'))
+
+
+def clear() -> None:
+    """Release every retained device block (the frames stay valid: they take the upload path next time)."""
+    _REGISTRY.clear()
 
 
 class _Entry:
@@ -57,11 +72,13 @@ def _checksums(K, cols: Sequence[np.ndarray]) -> np.ndarray:
 def register(K, frame, device_block) -> None:
     """frame: the DataFrame about to be returned to the caller; device_block: [F, n] fp64 device tensor holding the
     same values (integer-typed columns as their fp64 values), row i = column i of the frame."""
-    if not hasattr(K, 'host_checksums'):
+    if not hasattr(K, 'host_checksums') or MAX_BLOCKS <= 0:
         return
     cols = _column_buffers(frame)
     if cols is None or not cols:
         return
+    while len(_REGISTRY) >= MAX_BLOCKS:                          # bounded retention: the oldest block goes first
+        _REGISTRY.pop(next(iter(_REGISTRY)))
     e = _Entry()
     e.block = device_block
     e.n = frame.shape[0]

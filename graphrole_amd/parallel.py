@@ -194,6 +194,8 @@ class ShardPlan:
     def columns_to_owners(self, block: torch.Tensor) -> torch.Tensor:
         """block [ncols, n] with only this rank's row slice valid -> the WHOLE columns this rank owns
         (columns rank, rank + world, ...) as a [n_owned, n] tensor."""
+        if block.is_cuda and self._solo:
+            return block[:, :self.n]                       # a one-rank group owns every column, rows complete
         if block.is_cuda:
             from graphrole_amd import _lib
             ncols = block.shape[0]
@@ -232,6 +234,9 @@ class ShardPlan:
         """Inverse direction for per-column results (uint8 bins): owned [n_owned, n] whole columns ->
         [ncols, n] with this rank's row slice of EVERY column valid (other rows: unspecified on the device path,
         zero on the host path -- each rank only ever scans its own rows)."""
+        if owned.is_cuda and self._solo:
+            assert owned.shape[0] == ncols
+            return owned[:, :self.n]
         if owned.is_cuda:
             from graphrole_amd import _lib
             out = torch.empty((ncols, max(self.n, 1)), dtype=owned.dtype, device=owned.device)
@@ -428,7 +433,11 @@ def _communicator(group):
     backend = dist.get_backend(group)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     forced = _force_collectives()
-    key = (id(group) if group is not None else 0, backend, rank, world, forced)
+    # keyed on the process-group OBJECT (the default group resolved to its object), which the cache entry keeps alive:
+    # an id() cannot be recycled by a group created after this one was destroyed, and a re-initialised default group
+    # is a new object -- it gets a new communicator instead of the stale one
+    pg = group if group is not None else dist.group.WORLD
+    key = (id(pg), backend, rank, world, forced)
     hit = _COMMUNICATORS.get(key)
     if hit is not None:
         return hit[0]
@@ -449,7 +458,7 @@ def _communicator(group):
         keep = _StagedTransport(group)
         _lib.call('grx_comm_create_callbacks', rank, world, keep.callbacks[0], keep.callbacks[1], None,
                   ctypes.byref(handle))
-    _COMMUNICATORS[key] = (handle, keep)
+    _COMMUNICATORS[key] = (handle, keep, pg)
     return handle
 
 

@@ -65,3 +65,32 @@ def test_uniform_choice_equals_numpy_searchsorted_of_the_cumulative_sum():
         draws += [(k + eps) / m for k in (0, 1, m // 2, m - 1) for eps in (0.0, 1e-12, -1e-12, 0.5) if 0 <= (k + eps) / m < 1]
         for u in draws:
             assert ours(m, u) == numpy_way(m, u), (m, u)
+
+
+def test_pool_back_to_back_fork_joins_stay_exact():
+    """The fork-join pool behind grx_host_checksums / grx_download is re-armed thousands of times with CHANGING task
+    counts (a straggler of call N must never run a task of call N + 1 twice: the hashes of a call would then be
+    combined from the wrong parts or returned while a part is still being written).  Two Python threads hammer it
+    with tables of different widths; every answer must equal the single-column answer computed up front."""
+    import threading
+    rng = np.random.default_rng(7)
+    tables = [rng.random((w, 40_000 + 64 * w)) for w in (1, 2, 3, 5, 8, 13)]
+    expect = [np.array([_sums(t[j:j + 1])[0] for j in range(t.shape[0])], dtype=np.uint64) for t in tables]
+    errors = []
+
+    def hammer(offset):
+        try:
+            for it in range(400):
+                k = (it + offset) % len(tables)
+                if not np.array_equal(_sums(tables[k]), expect[k]):
+                    errors.append((offset, it, k))
+                    return
+        except Exception as exc:                                  # pragma: no cover
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=hammer, args=(o,)) for o in (0, 3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
