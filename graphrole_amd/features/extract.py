@@ -30,13 +30,29 @@ _INT_SAFE_ON_EMPTY = ('sum', 'prod', 'count', 'size')                # integers 
 
 
 def _agg_name(agg) -> str:
-    """'sum' / np.sum / pd.DataFrame.sum -> 'sum' (the name pandas puts in the result index)."""
+    """'sum' / np.sum / pd.DataFrame.sum / a user function -> the name pandas puts in the result index
+    (pandas.core.common.get_callable_name: __name__, the wrapped function of a functools.partial, else the class)."""
     if isinstance(agg, str):
         return agg
-    name = getattr(agg, '__name__', None)
-    if name is None:
-        raise TypeError(f'cannot interpret aggregation {agg!r}')
-    return name
+    import functools
+    if hasattr(agg, '__name__'):
+        return agg.__name__
+    if isinstance(agg, functools.partial):
+        return _agg_name(agg.func)
+    if callable(agg):
+        return type(agg).__name__
+    raise TypeError(f'cannot interpret aggregation {agg!r}')
+
+
+def _has_kernel(agg) -> bool:
+    """True for the spellings of the ten aggregations that have device kernels: their names as strings, and the numpy /
+    pandas / builtin functions pandas itself maps to those names (np.sum, pd.DataFrame.mean, max, ...).  Any OTHER
+    callable -- also a user function that happens to be called 'sum' -- is evaluated on the host (extract.py:111)."""
+    if isinstance(agg, str):
+        return agg in _SUPPORTED_AGGS
+    module = getattr(agg, '__module__', None) or ''
+    return (callable(agg) and getattr(agg, '__name__', None) in _SUPPORTED_AGGS and
+            (module.split('.')[0] in ('numpy', 'pandas', 'builtins')))
 
 
 class RecursiveFeatureExtractor:
@@ -62,8 +78,11 @@ class RecursiveFeatureExtractor:
         :param max_generations: maximum levels of recursion
         :param aggs: optional list of aggregations for each recursive generation
           ('sum', 'mean', 'min', 'max', 'std', 'var', 'prod', 'median', 'count', 'size' in any spelling pandas
-          accepts; arbitrary callables and the remaining pandas names raise NotImplementedError: there is no CPU
-          fallback).  With 'prod' the integer columns of an unweighted graph follow the reference's wrapping int64
+          accepts run as device kernels; the remaining pandas NAMES raise NotImplementedError).  Any other CALLABLE
+          -- what the reference hands to ``DataFrame.agg`` (extract.py:26,111) -- is evaluated by pandas on the
+          host, node by node, over neighbour rows the device gathered: the reference's own procedure at the
+          reference's speed (~0.5 ms per node and generation), single GPU only, documented in DESIGN.md section 7.
+          With 'prod' the integer columns of an unweighted graph follow the reference's wrapping int64
           arithmetic (csrc/grx_aggx.hip)
         :kwargs: attributes / attributes_include / attributes_exclude for the graph interface;
           distributed=True|ProcessGroup shards node ranges over the ranks of torch.distributed;
@@ -130,12 +149,19 @@ class RecursiveFeatureExtractor:
 
     def _agg_names(self) -> List[str]:
         names = [_agg_name(a) for a in self.aggs]
-        bad = [a for a in names if a not in _SUPPORTED_AGGS]
+        bad = [nm for a, nm in zip(self.aggs, names) if isinstance(a, str) and nm not in _SUPPORTED_AGGS]
         if bad:
             raise NotImplementedError(
-                f'aggregations {bad} have no device kernel (supported: {list(_SUPPORTED_AGGS)}); '
-                f'graphrole_amd has no CPU fallback')
+                f'aggregations {bad} have no device kernel (supported: {list(_SUPPORTED_AGGS)}); pass a callable to '
+                f'have pandas evaluate it on the host')
+        if self._host_callables() and len(set(names)) != len(names):
+            # pandas: SpecificationError('Function names must be unique if there is no new column names assigned')
+            raise ValueError(f'Function names must be unique: {names}')
         return names
+
+    def _host_callables(self) -> Dict[str, object]:
+        """name -> callable for the entries of ``aggs`` that have no device kernel"""
+        return {_agg_name(a): a for a in self.aggs if not _has_kernel(a) and not isinstance(a, str)}
 
     # ------------------------------------------------------------------ public API
     def extract_features(self) -> DataFrameLike:
@@ -170,7 +196,7 @@ class RecursiveFeatureExtractor:
                 raise NotImplementedError("'prod' over integer features needs the int64 kernels of libgrx.so")
             cols = [K.convert_f64_to_i64(c) if np.dtype(dt).kind in 'iu' else c for c, dt in zip(cols, dtypes)]
             self._i64 = {nm for nm, dt in zip(names, dtypes) if np.dtype(dt).kind in 'iu'}
-        if native and self._native_loop and not wrapping and len(set(aggs)) == len(aggs):
+        if native and self._native_loop and not wrapping and len(set(aggs)) == len(aggs) and not self._host_callables():
             # the whole generation loop runs below the ABI (grx_refex_run); with a ShardPlan it aggregates this rank's
             # rows and issues the exchanges itself
             self._run_native(names, cols, dtypes, aggs)
@@ -288,7 +314,13 @@ class RecursiveFeatureExtractor:
         f64 = np.dtype('float64')
         names = [f'{c}({a})' for a in aggs for c in prev]
         dtypes = [self._candidate_dtype(self._dtypes.get(c, f64), aggs, no_empty_rows) for a in aggs for c in prev]
-        if set(aggs) <= set(_FAST_AGGS) and not (self._i64 & set(prev)):
+        callables = self._host_callables()
+        if callables:
+            if plan is not None:
+                raise NotImplementedError('callable aggregations are evaluated on the host of ONE process; '
+                                          'distributed= is not supported with them')
+            sub, dtypes = self._aggregate_with_callables(K, dev_graph, prev, aggs, callables, names, dtypes, n)
+        elif set(aggs) <= set(_FAST_AGGS) and not (self._i64 & set(prev)):
             sub = self._aggregate_fast(K, dev_graph, prev, aggs, n, rb, re)
         else:
             sub = self._aggregate_general(K, dev_graph, prev, aggs, names, dtypes, n, rb, re)
@@ -398,6 +430,92 @@ class RecursiveFeatureExtractor:
             if flag:
                 self._i64.add(nm)
         return self._as_block(picked, n)
+
+    def _aggregate_with_callables(self, K, dev_graph, prev, aggs, callables, names, dtypes, n):
+        """
+        ``aggs`` holds callables without a device kernel.  The kernel-backed entries run on the device as always; for
+        the callables the reference's own expression is evaluated (extract.py:104-113): per node, the frame of its
+        neighbours' previous-generation features -- index = neighbour labels in adjacency order, columns = feature
+        names -- goes through ``DataFrame.agg([f])`` and ``fillna(0)``.  The neighbour rows are gathered ON THE
+        DEVICE (grx_permute_columns over the adjacency-ordered index list) and downloaded once; pandas then works
+        on slices of that table.  This is the reference's per-node pandas loop at the reference's speed; it exists
+        so that no constructor input of the reference raises here, not to be fast.  Never routed through oracle/.
+        A callable pandas can only apply ELEMENT-wise (np.ptp under pandas 2: the result is not one row per
+        function) is refused with a TypeError instead of reproducing the reference's garbled column names.
+        """
+        import torch
+        f = len(prev)
+        host = self.graph._device_graph()[0]
+        known = [a for a in aggs if a not in callables]
+        pieces = {}
+        if known:
+            if any(c in self._i64 for c in prev):
+                raise NotImplementedError("callable aggregations together with wrapping integer 'prod' columns")
+            known_names = [f'{c}({a})' for a in known for c in prev]
+            known_dtypes = [np.dtype('float64')] * len(known_names)
+            if set(known) <= set(_FAST_AGGS):
+                blk = self._aggregate_fast(K, dev_graph, prev, known, n, 0, n)
+            else:
+                blk = self._aggregate_general(K, dev_graph, prev, known, known_names, known_dtypes, n, 0, n)
+            for k, a in enumerate(known):
+                pieces[a] = [blk[k * f + j] for j in range(f)]
+        # neighbour rows in adjacency order, gathered on the device: E[c, e] = X_prev[c][agg_col[e]]
+        cols = [self._work[c] for c in prev]
+        nnz = int(host.row_ptr[-1])
+        E = K.to_host(K.permute_columns(cols, dev_graph.agg_col, nnz)) if nnz else np.zeros((f, 0))
+        nbr = dev_graph.agg_col
+        nbr = (K.to_host(nbr) if hasattr(nbr, 'detach') else np.asarray(nbr))[:nnz]
+        labels = np.asarray(list(host.labels), dtype=object)[np.asarray(host.perm)]      # label of every internal row
+        funcs = [callables[a] for a in aggs if a in callables]
+        order = [a for a in aggs if a in callables]
+        out = {a: np.zeros((f, n)) for a in order}
+        all_int = {a: np.ones(f, dtype=bool) for a in order}
+        prev_dt = [np.dtype(self._dtypes.get(c, 'float64')) for c in prev]
+        row_ptr = host.row_ptr
+        # A node without neighbours: the reference aggregates an EMPTY frame with the whole list (extract.py:108-113).
+        # pandas either raises there (a list mixing names and callables: "cannot combine transform and aggregation
+        # operations" -- the reference raises the same, so this propagates), or hands back nothing for the callables
+        # (-> the node's candidates are NaN -> 0, extract.py:132), or real rows (a callable that copes with an empty Series).
+        empty_rows = None
+        if n and int(np.diff(row_ptr).min()) == 0:
+            res0 = pd.DataFrame({c: np.zeros(0, dtype=prev_dt[j]) for j, c in enumerate(prev)}, columns=prev).agg(list(self.aggs))
+            empty_rows = {a: (res0.loc[a].to_numpy(dtype=np.float64, na_value=0.0)
+                              if isinstance(res0, pd.DataFrame) and a in res0.index and res0.shape[1] == f else np.zeros(f))
+                          for a in order}
+        for v in range(n):
+            b, e = int(row_ptr[v]), int(row_ptr[v + 1])
+            if e == b:
+                for a in order:
+                    out[a][:, v] = empty_rows[a]
+                    all_int[a][:] = False                                   # NaN -> 0.0: the column is float
+                continue
+            frame = pd.DataFrame({c: E[j, b:e].astype(prev_dt[j], copy=False) for j, c in enumerate(prev)},
+                                 index=labels[nbr[b:e]], columns=prev)
+            res = frame.agg(funcs)
+            if not isinstance(res, pd.DataFrame) or list(res.index) != order:
+                raise TypeError(
+                    f'aggregation callables {order}: DataFrame.agg did not return one row per function (pandas applied a '
+                    f'function element-wise: it does not reduce a Series) -- pass a function of a Series that returns a scalar')
+            for a in order:
+                vals = res.loc[a]
+                for j in range(f):
+                    x = vals.iloc[j]
+                    if not isinstance(x, (int, np.integer)) or isinstance(x, (bool, np.bool_)):
+                        all_int[a][j] = False
+                out[a][:, v] = vals.to_numpy(dtype=np.float64, na_value=0.0)      # .fillna(0), extract.py:113
+        for a in order:
+            block = K.to_device(np.ascontiguousarray(out[a]))
+            pieces[a] = [block[j] for j in range(f)]
+        # dtypes as pandas infers them from the per-node dicts: a candidate stays integer only if every function of the
+        # list returned integers for its parent (the agg frame's column is one dtype) -- see _candidate_dtype
+        f64 = np.dtype('float64')
+        base = self._candidate_dtype(np.dtype('int64'), known, self._no_empty_rows(host)) if known else np.dtype('int64')
+        new_dtypes = []
+        for a in aggs:
+            for j in range(f):
+                ints = (prev_dt[j].kind in 'iu' and base.kind in 'iu' and all(all_int[c][j] for c in order))
+                new_dtypes.append(np.dtype('int64') if ints else f64)
+        return self._as_block([pieces[a][j] for a in aggs for j in range(f)], n), new_dtypes
 
     def _update_columns(self, names: Sequence[str], cols: Sequence, dtypes: Sequence[np.dtype],
                         block=None) -> None:

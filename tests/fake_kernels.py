@@ -281,7 +281,7 @@ def kmeans1d(values, n_bins, max_iter=300, rel_tol=1e-4):
 
 
 def permute_columns(cols, index, n):
-    idx = index.long()
+    idx = torch.as_tensor(np.asarray(index)).long() if not hasattr(index, 'long') else index.long()
     return torch.stack([c[idx] for c in cols]) if len(cols) else torch.zeros((0, n), dtype=torch.float64)
 
 

@@ -116,3 +116,28 @@ BUILDERS = {
     'er2000': lambda: er(2000, 20000, 0),
     'ba2000': lambda: ba(2000, 10, 0),
 }
+
+
+# ---- aggregation CALLABLES (features/extract.py:26,111: anything DataFrame.agg accepts).  Functions of a Series that
+# return a scalar; shared by tools/make_golden_callables.py (the reference runs them) and the tests (graphrole_amd does).
+def spread(s):
+    return s.max() - s.min()
+
+
+def second_largest(s):
+    values = np.sort(s.to_numpy())
+    return float(values[-2]) if len(values) > 1 else np.nan
+
+
+CALLABLE_CASES = {
+    # name: (graph builder name, aggs with callables by registry name, max_generations)
+    'karate_sum_spread': ('karate', ['sum', 'callable:spread'], 4),
+    'ba300_second_mean': ('ba300', ['callable:second_largest', 'mean'], 3),
+    'loops_dangling150_spread': ('loops_dangling150', ['callable:spread'], 3),
+    'er300_spread_max': ('er300', ['callable:spread', 'max'], 3),
+}
+CALLABLES = {'spread': spread, 'second_largest': second_largest}
+
+
+def resolve_aggs(spec):
+    return [CALLABLES[a.split(':', 1)[1]] if isinstance(a, str) and a.startswith('callable:') else a for a in spec]

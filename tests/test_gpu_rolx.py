@@ -551,3 +551,49 @@ def test_stopping_rule_adversarial(seed):
         rel = np.linalg.norm(X - K.to_host(st2.W)[:, :n].T @ K.to_host(st2.H)) / np.linalg.norm(X)
         if rel < 1e-5:
             assert st2.info.direct_residuals >= 1
+
+
+# ---------------------------------------------------------------- conditioning of the initialisation
+def _ill_conditioned(kind, seed):
+    """Feature tables that stress the Gram-matrix + eigh whitening of the NNDSVDa start (it squares the condition
+    number of X; sklearn's range finder works on X itself): near-duplicate columns and extreme column scales."""
+    rng = np.random.RandomState(seed)
+    n, F, r = 4000, 14, 6
+    base = np.abs(rng.randn(n, r)) @ np.abs(rng.randn(r, F)) + 0.05 * np.abs(rng.randn(n, F))
+    if kind == 'near_duplicate_columns':
+        # two pairs of columns equal to 1e-7 relative: kappa(X) ~ 1e7, kappa(X^T X) ~ 1e14
+        base[:, 5] = base[:, 2] * (1.0 + 1e-7 * rng.randn(n))
+        base[:, 11] = base[:, 7] * (1.0 + 1e-7 * rng.randn(n))
+    elif kind == 'scale_spread_1e10':
+        base = base * np.logspace(-5, 5, F)                           # column scales from 1e-5 to 1e5
+    elif kind == 'both':
+        base[:, 5] = base[:, 2] * (1.0 + 1e-7 * rng.randn(n))
+        base = base * np.logspace(-5, 5, F)
+    elif kind == 'degree_like':
+        # what ReFeX tables look like: heavy-tailed integer-ish columns, one a near-multiple of another
+        base = np.floor(rng.pareto(1.5, (n, F)) * 10.0)
+        base[:, 3] = 2.0 * base[:, 1] + (rng.rand(n) < 1e-3)
+    return np.ascontiguousarray(base), r
+
+
+@pytest.mark.parametrize('kind', ['near_duplicate_columns', 'scale_spread_1e10', 'both', 'degree_like'])
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_nmf_on_ill_conditioned_tables_matches_oracle(kind, seed):
+    """equal iteration count and factors within the stated 1e-8 of oracle.rolx.nmf (sklearn's procedure restated:
+    randomized range finder on X itself) on tables whose Gram matrix has a condition number up to ~1e14 and beyond"""
+    from graphrole_amd.roles import factor
+    from oracle import rolx
+    X, r = _ill_conditioned(kind, seed)
+    omega = np.random.RandomState(100 + seed).normal(size=(X.shape[1], r + 10))
+    # the same Gaussian test matrix on both sides (the reference draws it from numpy's global stream)
+    from graphrole_amd import kernels as K
+    Xd = K.to_device(np.ascontiguousarray(X.T))
+    st, n_iter = factor.nmf_device(Xd, X.shape[0], r, omega)
+    G = K.to_host(st.W)[:, :X.shape[0]].T
+    Fm = K.to_host(st.H)
+    We, He, it = rolx.nmf(X, r, omega)
+    cond = np.linalg.cond(X)
+    _record('nmf_conditioning.json', f'{kind}_{seed}', {'cond_X': float(cond), 'n_iter': int(n_iter), 'oracle_n_iter': int(it),
+                                                       'W_rel': float(_relmax(G, We)), 'H_rel': float(_relmax(Fm, He))})
+    assert n_iter == it, (n_iter, it, cond)
+    assert _relmax(G, We) < FACTOR_RTOL and _relmax(Fm, He) < FACTOR_RTOL, (cond, _relmax(G, We), _relmax(Fm, He))
