@@ -51,6 +51,12 @@ AGG_IDS = {'sum': 0, 'mean': 1, 'min': 2, 'max': 3, 'var': 4, 'std': 5, 'prod': 
            'size': 9}                                                           # grx_agg
 
 
+class PackedLayout(ctypes.Structure):
+    """grx_packed_layout of include/grx.h."""
+    _fields_ = [('n_fields', c_int), ('field_bits', c_int * 8), ('degree_bits', c_int), ('n_out', c_int),
+                ('out_field', c_int * 8), ('out_is_mean', c_int * 8)]
+
+
 class P2pOp(ctypes.Structure):
     """grx_p2p_op of include/grx.h."""
     _fields_ = [('is_recv', c_int), ('peer', c_int), ('d_ptr', c_void_p), ('bytes', c_size_t)]
@@ -207,6 +213,11 @@ _SIGNATURES = {
                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate_rows': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'grx_packed_row_bytes': (c_int, [c_void_p]),
+    'grx_column_bits': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
+    'grx_pack_fields': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'grx_aggregate_packed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                     c_int64, c_void_p]),
     'grx_role_argmax': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'grx_row_normalise': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'grx_nmf_iterate': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

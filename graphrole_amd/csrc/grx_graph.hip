@@ -1156,6 +1156,242 @@ __global__ __launch_bounds__(256) void aggregate_i32_combine_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// neighbour aggregation from BIT-PACKED integer rows (generations 1 and 2 of unweighted graphs)
+// ---------------------------------------------------------------------------------------
+// The gather is bound by the chip's REQUEST rate, and how many requests miss an XCD's 4 MiB L2 is set by the bytes of
+// the gather table (profiles/r04_gather_bw.json: 16-, 32- and 64-byte rows gather at the same rows/s; a 64 MB table
+// at 62 G rows/s, a 16 MB one at 92, an L2-resident one at 250).  So the table is made as small as exactness allows:
+//   * every summand the reference adds in generation g is either an exact integer S (a degree / ego-net count of
+//     generation 0, or a neighbour SUM of such a column) or the mean fl(S / d) of one over d neighbours;
+//   * the row of node u therefore only has to carry the integers S_k(u) of the distinct base columns and d(u), each in
+//     as many bits as the column's maximum needs (grx_column_bits) -- 8 or 16 bytes instead of 16 / 64;
+//   * the kernel rebuilds every summand in registers -- double(S), or double(S) / double(d) with the same correctly
+//     rounded division that produced the stored mean -- and adds them in numpy's pairwise order exactly like
+//     aggregate_kernel does (for integer summands any order gives the same bits; one code path serves both).
+// Lane = slot: G = 8 lanes per output row, lane s owns the strided accumulator r[s] of EVERY output column (a whole
+// neighbour row is one 8- / 16-byte load of one lane).  Rows longer than 128 neighbours reuse the plan's block list and
+// aggregate_combine_kernel unchanged.
+struct PackedDesc {
+    int n_out;
+    uint8_t word[8], shift[8], bits[8], is_mean[8];    // per output: where its source field sits
+    uint8_t d_word, d_shift, d_bits;                     // the neighbour-count field (d_bits = 0: none)
+};
+
+template <int WORDS>
+struct PackedRow { unsigned long long w[WORDS]; };
+
+template <int WORDS>
+__device__ __forceinline__ PackedRow<WORDS> packed_load(const unsigned long long *__restrict__ rows, int64_t u)
+{
+    PackedRow<WORDS> r;
+    if constexpr (WORDS == 1) {
+        r.w[0] = rows[u];
+    } else {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rows + 2 * u);
+        r.w[0] = v.x; r.w[1] = v.y;
+    }
+    return r;
+}
+
+template <int WORDS>
+__device__ __forceinline__ unsigned long long packed_field(const PackedRow<WORDS> &r, int word, int shift, int bits)
+{
+    const unsigned long long w = (WORDS == 2 && word) ? r.w[WORDS - 1] : r.w[0];
+    return bits >= 64 ? w : ((w >> shift) & ((1ull << bits) - 1ull));
+}
+
+// the F summands of one neighbour row
+// Means: fl(S / d) for F columns that share the divisor.  The compiler's fp64 division is, for operands that need no
+// scaling (here 0 <= S < 2^53, 1 <= d < 2^31), exactly: y = rcp(d) refined by two Newton steps, q = S * y,
+// r = fma(-d, q, S), q' = fma(r, y, q) -- correctly rounded.  The reciprocal and its refinement do not depend on S, so
+// they are done ONCE per neighbour row and every column pays three instructions instead of a whole division; the
+// result is the same correctly rounded quotient (tests/test_gpu_packed.py compares ~10^8 quotients with the divisions
+// aggregate_kernel's sources were produced by).
+template <int WORDS, int F>
+__device__ __forceinline__ void packed_values(const PackedRow<WORDS> &r, const PackedDesc &d, double (&x)[F])
+{
+#pragma clang fp contract(off)
+    double cnt = 1.0, y = 0.0;
+    if (d.d_bits) {
+        cnt = (double)(int)packed_field<WORDS>(r, d.d_word, d.d_shift, d.d_bits);       // < 2^31 (place_fields)
+        y = __builtin_amdgcn_rcp(cnt);
+        double e = __builtin_fma(-cnt, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-cnt, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        const unsigned long long f = packed_field<WORDS>(r, d.word[j], d.shift[j], d.bits[j]);
+        const double s = d.bits[j] <= 31 ? (double)(int)f : (double)(long long)f;
+        if (d.is_mean[j]) {
+            // the stored mean of a node without neighbours is 0 (NaN -> 0, extract.py:113)
+            const double q = s * y;
+            const double rem = __builtin_fma(-cnt, q, s);
+            x[j] = cnt > 0.0 ? __builtin_fma(rem, y, q) : 0.0;
+        } else {
+            x[j] = s;
+        }
+    }
+}
+
+// numpy's pairwise sum of one segment of cnt <= 128 neighbours for F columns, G = 8 lanes (slot = lane):
+//   r[j] = x[j] + x[j+8] + ...;  ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7));  then the cnt % 8 trailing elements one by one
+template <int WORDS, int F>
+__device__ __forceinline__ void packed_segment(const int32_t *__restrict__ col, const unsigned long long *__restrict__ rows,
+                                               const PackedDesc &d, int64_t b, int cnt, int slot, double (&res)[F])
+{
+#pragma clang fp contract(off)
+    constexpr int G = 8;
+    const int c8 = cnt & ~7, rem = cnt - c8;
+#pragma unroll
+    for (int j = 0; j < F; ++j) res[j] = 0.0;
+    // the trailing neighbour of this lane: its index and row are requested first, used last
+    PackedRow<WORDS> tail;
+    if (rem) {
+        const int idx = c8 + slot;
+        const int64_t ut = GRX_STREAM_LD(col[b + (idx < cnt ? idx : cnt - 1)]);
+        tail = packed_load<WORDS>(rows, ut);
+    }
+    if (c8) {
+        double r[F];
+        {
+            const int64_t u = GRX_STREAM_LD(col[b + slot]);
+            packed_values<WORDS, F>(packed_load<WORDS>(rows, u), d, r);
+        }
+        int i = 8;
+        for (; i + 24 < c8; i += 32) {                        // four trips of 8 per iteration: four gathers in flight per lane
+            int64_t u[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) u[t] = GRX_STREAM_LD(col[b + i + 8 * t + slot]);
+            PackedRow<WORDS> pr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pr[t] = packed_load<WORDS>(rows, u[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double x[F];
+                packed_values<WORDS, F>(pr[t], d, x);
+#pragma unroll
+                for (int j = 0; j < F; ++j) r[j] += x[j];
+            }
+        }
+        for (; i < c8; i += 8) {
+            const int64_t u = GRX_STREAM_LD(col[b + i + slot]);
+            double x[F];
+            packed_values<WORDS, F>(packed_load<WORDS>(rows, u), d, x);
+#pragma unroll
+            for (int j = 0; j < F; ++j) r[j] += x[j];
+        }
+        // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): level `bit` pairs slot ^ (1 << bit)
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) r[j] += __shfl_xor(r[j], 1 << bit, G);
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) res[j] = r[j];
+    }
+    if (rem) {
+        double x[F];
+        packed_values<WORDS, F>(tail, d, x);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const double v = __shfl(x[j], i, G);
+                if (i < rem) res[j] += v;
+            }
+        }
+    }
+}
+
+template <int WORDS, int F>
+__global__ __launch_bounds__(256) void aggregate_packed_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const unsigned long long *__restrict__ rows,
+    PackedDesc d, int64_t row_begin, int64_t row_end, double *__restrict__ out_sum, double *__restrict__ out_mean,
+    int64_t ld, BlockWork bw)
+{
+    constexpr int G = 8;
+    const int slot = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    double a[F];
+    for (int64_t k = group; k < bw.n_blocks; k += ngroups) {
+        const int64_t v = bw.long_rows[bw.blk_row[k]];
+        if (v < row_begin || v >= row_end) continue;
+        packed_segment<WORDS, F>(col, rows, d, bw.blk_begin[k], bw.blk_len[k], slot, a);
+        if (slot == 0) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) bw.blk_sums[k * 16 + j] = a[j];
+        }
+    }
+    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
+        const int64_t cntl = e - b;
+        if (cntl > PW_BLOCK) continue;                     // the block loop above + aggregate_combine_kernel
+        packed_segment<WORDS, F>(col, rows, d, b, (int)cntl, slot, a);
+        // lane j of the group stores column j: eight 8-byte stores of one wave-instruction instead of F by lane 0
+        const double cnt = (double)cntl;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            if (slot == j) {
+                if (out_sum) GRX_STREAM_ST(out_sum[(int64_t)j * ld + v], a[j]);
+                if (out_mean) GRX_STREAM_ST(out_mean[(int64_t)j * ld + v], (cntl > 0) ? a[j] / cnt : 0.0);
+            }
+        }
+    }
+}
+
+// bit-packed gather source: row u = the fields' integers of node u (+ its neighbour count), see PackedDesc
+struct PackFieldsArgs {
+    const double *src[8];
+    uint8_t word[8], shift[8];
+    int n_fields;
+    uint8_t d_word, d_shift, d_bits;
+};
+
+template <int WORDS>
+__global__ __launch_bounds__(256) void pack_fields_kernel(int64_t n, PackFieldsArgs a, const int64_t *__restrict__ row_ptr,
+                                                          unsigned long long *__restrict__ rows)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned long long w[2] = {0ull, 0ull};
+        for (int k = 0; k < a.n_fields; ++k)
+            w[a.word[k]] |= (unsigned long long)(long long)a.src[k][i] << a.shift[k];
+        if (a.d_bits) w[a.d_word] |= (unsigned long long)(row_ptr[i + 1] - row_ptr[i]) << a.d_shift;
+        if constexpr (WORDS == 1) rows[i] = w[0];
+        else *reinterpret_cast<ulonglong2 *>(rows + 2 * i) = make_ulonglong2(w[0], w[1]);
+    }
+}
+
+// bits[c] = max(bits[c], number of bits of max(column c over the workgroup's slice of rows [rb, re))) for the columns
+// flagged in `mask` (exact non-negative integers by construction); bits[] starts at 0.  The width is monotone in the
+// value, so the maximum over the slices' widths is the width of the column maximum -- and it can be max-reduced over
+// ranks as a 32-bit integer.  grid = (row slices, columns).
+__global__ __launch_bounds__(256) void column_bits_kernel(const double *__restrict__ block, int64_t ld, int64_t rb, int64_t re,
+                                                          unsigned long long mask, int32_t *__restrict__ bits)
+{
+    const int c = blockIdx.y;
+    if (!((mask >> c) & 1ull)) return;
+    const double *x = block + (int64_t)c * ld;
+    double m = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = rb + (int64_t)blockIdx.x * 256 + threadIdx.x; i < re; i += stride) m = fmax(m, x[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+        // a column whose maximum is not below 2^62 (or not finite) cannot be packed: 64 says so
+        const unsigned long long v = (m >= 0.0 && m < 4.6e18) ? (unsigned long long)m : ~0ull;
+        atomicMax(bits + c, v ? 64 - __clzll((long long)v) : 1);
+    }
+}
+
 // product over the neighbours (agg 'prod'): np.multiply.reduce is a plain left-to-right product, so
 // one lane per (row, column) multiplies in adjacency order; the empty product is 1.  Not a tuned
 // kernel: the lanes of a row read adjacent doubles of each neighbour row, nothing more.
@@ -1354,6 +1590,41 @@ int aggregate_dispatch(bool minmax, const grx_aggregate_plan *plan, const int64_
     return GRX_OK;
 }
 
+}  // namespace
+
+namespace {
+struct PackedPlacement { int row_bytes; uint8_t word[8], shift[8]; uint8_t d_word, d_shift; };
+
+// fields in order, first into word 0 while they fit, then word 1; the neighbour count last; no field straddles a word
+bool place_fields(const grx_packed_layout *L, PackedPlacement *P)
+{
+    if (!L || L->n_fields < 1 || L->n_fields > 7 || L->n_out < 1 || L->n_out > 8 || L->degree_bits < 0 || L->degree_bits > 31)
+        return false;
+    int used[2] = {0, 0}, w = 0;
+    auto put = [&](int bits, uint8_t *word, uint8_t *shift) {
+        if (bits < 1 || bits > 62) return false;
+        if (used[w] + bits > 64) { if (w == 1) return false; w = 1; }
+        *word = (uint8_t)w; *shift = (uint8_t)used[w];
+        used[w] += bits;
+        return true;
+    };
+    for (int k = 0; k < L->n_fields; ++k)
+        if (!put(L->field_bits[k], &P->word[k], &P->shift[k])) return false;
+    P->d_word = P->d_shift = 0;
+    if (L->degree_bits && !put(L->degree_bits, &P->d_word, &P->d_shift)) return false;
+    for (int j = 0; j < L->n_out; ++j)
+        if (L->out_field[j] < 0 || L->out_field[j] >= L->n_fields) return false;
+    P->row_bytes = used[1] ? 16 : 8;
+    return true;
+}
+
+template <int WORDS, int F>
+void launch_packed(int grid, hipStream_t st, const int64_t *row_ptr, const int32_t *col, const void *rows, const PackedDesc &d,
+                   int64_t rb, int64_t re, double *s, double *m, int64_t ld, const BlockWork &bw)
+{
+    aggregate_packed_kernel<WORDS, F><<<grid, 256, 0, st>>>(row_ptr, col, reinterpret_cast<const unsigned long long *>(rows), d, rb,
+                                                            re, s, m, ld, bw);
+}
 }  // namespace
 
 extern "C" {
@@ -1697,6 +1968,115 @@ int grx_aggregate_i32(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, 
         aggregate_i32_combine_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
             d_row_ptr, f, row_begin, row_end, plan->d_long_rows, plan->d_blk_ptr, plan->n_long, plan->d_blk_sums, d_sum,
             d_mean, ld);
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+/* ---- bit-packed integer rows (see PackedDesc above) ---------------------------------------------------------- */
+
+}  // extern "C"
+int64_t grx_internal_plan_max_degree(const grx_aggregate_plan *plan) { return plan ? plan->max_degree : 0; }
+extern "C" {
+
+int grx_packed_row_bytes(const grx_packed_layout *layout)
+{
+    PackedPlacement P;
+    return place_fields(layout, &P) ? P.row_bytes : 0;
+}
+
+int grx_column_bits(int64_t n, int ncols, const double *d_block, int64_t ld, int64_t row_begin, int64_t row_end,
+                    uint64_t int_mask, int32_t *d_bits, void *stream)
+{
+    GRX_REQUIRE(n >= 0 && ncols >= 0 && ncols <= 64 && row_begin >= 0 && row_begin <= row_end && row_end <= n && ld >= n,
+                "grx_column_bits: bad shape (at most 64 columns per call)");
+    if (ncols == 0) return GRX_OK;
+    GRX_REQUIRE(d_block && d_bits, "grx_column_bits: NULL pointer");
+    // d_bits accumulates by atomicMax: the CALLER zeroes it (grx_refex_run clears it with its distance matrix)
+    const int64_t want = grx_ceil_div(row_end - row_begin, 256 * 16);
+    const dim3 grid((unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want)), (unsigned)ncols);
+    column_bits_kernel<<<grid, 256, 0, grx_stream(stream)>>>(d_block, ld, row_begin, row_end, int_mask, d_bits);
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_pack_fields(int64_t n, const grx_packed_layout *layout, const double *const *h_field_cols, const int64_t *d_row_ptr,
+                    void *d_rows, void *stream)
+{
+    PackedPlacement P;
+    GRX_REQUIRE(place_fields(layout, &P), "grx_pack_fields: the fields do not fit two 64-bit words (grx_packed_row_bytes)");
+    GRX_REQUIRE(n >= 0 && h_field_cols && d_rows && (d_row_ptr || !layout->degree_bits), "grx_pack_fields: NULL pointer");
+    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, "grx_pack_fields: d_rows must be 16-byte aligned");
+    if (n == 0) return GRX_OK;
+    PackFieldsArgs a{};
+    a.n_fields = layout->n_fields;
+    for (int k = 0; k < layout->n_fields; ++k) {
+        GRX_REQUIRE(h_field_cols[k] != nullptr, "grx_pack_fields: field column %d is NULL", k);
+        a.src[k] = h_field_cols[k];
+        a.word[k] = P.word[k];
+        a.shift[k] = P.shift[k];
+    }
+    a.d_word = P.d_word; a.d_shift = P.d_shift; a.d_bits = (uint8_t)layout->degree_bits;
+    hipStream_t st = grx_stream(stream);
+    const int64_t want = grx_ceil_div(n, 256);
+    const int grid = (int)(want > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : want);
+    {
+        GRX_PROF(GRX_K_PACK_ROWS, st);
+        if (P.row_bytes == 8) pack_fields_kernel<1><<<grid, 256, 0, st>>>(n, a, d_row_ptr, reinterpret_cast<unsigned long long *>(d_rows));
+        else pack_fields_kernel<2><<<grid, 256, 0, st>>>(n, a, d_row_ptr, reinterpret_cast<unsigned long long *>(d_rows));
+    }
+    GRX_LAUNCH_CHECK();
+    return GRX_OK;
+}
+
+int grx_aggregate_packed(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col,
+                         const grx_packed_layout *layout, const void *d_rows, int64_t row_begin, int64_t row_end,
+                         double *d_sum, double *d_mean, int64_t ld, void *stream)
+{
+    GRX_REQUIRE(plan != nullptr, "grx_aggregate_packed: NULL plan");
+    PackedPlacement P;
+    GRX_REQUIRE(place_fields(layout, &P), "grx_aggregate_packed: the fields do not fit two 64-bit words");
+    const int64_t n = plan->n;
+    GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= n && ld >= n, "grx_aggregate_packed: bad row range");
+    if (row_end == row_begin) return GRX_OK;
+    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate_packed: NULL pointer");
+    PackedDesc d{};
+    d.n_out = layout->n_out;
+    bool any_mean = false;
+    for (int j = 0; j < layout->n_out; ++j) {
+        const int k = layout->out_field[j];
+        d.word[j] = P.word[k]; d.shift[j] = P.shift[k]; d.bits[j] = (uint8_t)layout->field_bits[k];
+        d.is_mean[j] = layout->out_is_mean[j] ? 1 : 0;
+        any_mean = any_mean || d.is_mean[j];
+    }
+    GRX_REQUIRE(!any_mean || layout->degree_bits > 0, "grx_aggregate_packed: mean summands need the neighbour-count field");
+    d.d_word = P.d_word; d.d_shift = P.d_shift; d.d_bits = (uint8_t)layout->degree_bits;
+    hipStream_t st = grx_stream(stream);
+    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
+    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    const BlockWork bw{plan->d_long_rows, plan->d_blk_begin, plan->d_blk_len, plan->d_blk_row,
+                       plan->n_long > 0 ? plan->n_blocks : 0, plan->d_blk_sums};
+    {
+        GRX_PROF(GRX_K_AGGREGATE, st);
+#define GRX_PACKED_CASE(FF)                                                                                           \
+        case FF:                                                                                                      \
+            if (P.row_bytes == 8) launch_packed<1, FF>(grid, st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
+            else launch_packed<2, FF>(grid, st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
+            break;
+        switch (layout->n_out) {
+            GRX_PACKED_CASE(1) GRX_PACKED_CASE(2) GRX_PACKED_CASE(3) GRX_PACKED_CASE(4)
+            GRX_PACKED_CASE(5) GRX_PACKED_CASE(6) GRX_PACKED_CASE(7) GRX_PACKED_CASE(8)
+        default: break;
+        }
+#undef GRX_PACKED_CASE
+    }
+    GRX_LAUNCH_CHECK();
+    if (plan->n_long > 0) {
+        GRX_PROF(GRX_K_AGGREGATE_HUB, st);
+        const int64_t cwant = grx_ceil_div(plan->n_long, 16);
+        aggregate_combine_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
+            d_row_ptr, layout->n_out, row_begin, row_end, plan->d_long_rows, plan->d_blk_ptr, plan->n_long, plan->d_blk_ops,
+            plan->d_blk_sums, d_sum, d_mean, ld, 0);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

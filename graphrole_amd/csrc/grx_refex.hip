@@ -14,10 +14,12 @@
 #include "grx_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
+int64_t grx_internal_plan_max_degree(const grx_aggregate_plan *plan);                                          // grx_graph.hip
 int grx_internal_log_bin_status(int64_t n, int ncols, void *d_workspace, int32_t *d_status, hipStream_t st);   // grx_prune.hip
 
 namespace {
@@ -34,6 +36,13 @@ struct Column {
     const uint8_t *bins;
     int record_index;         // position in the output table, -1 while not recorded
     bool int32_exact = false; // every value an exact integer in [0, 2^31): may travel as an int32 gather source
+    // what the values ARE, for the bit-packed gather source (grx_aggregate_packed):
+    //   kind 1: exact non-negative integers S (a generation-0 count or a neighbour sum of one); bits = width of the maximum
+    //   kind 2: fl(S / d) with S = column `base` (the sum candidate of the same parent) and d the neighbour count
+    //   kind 0: anything else
+    int kind = 0;
+    int base = -1;
+    int bits = -1;            // known after the generation's read-back (-1: not known)
 };
 
 // bump allocator over the caller's arena; keeps counting past the end so that the caller learns how
@@ -207,7 +216,9 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         // (a whole number of 256-byte units: the runtime clears an unaligned tail with a second fill launch)
         // + one status word behind the matrix: the outcome flags of the binning travel (and, sharded, are max-reduced)
         // with the distances, so a failed binning is a joint error on every rank instead of a silent wrong drop list
-        const size_t dist_bytes = grx_align_up(((size_t)F * F + 1) * 4, 256);
+        // ... and one word per new column: the bit width of its maximum when it holds exact integers (kind 1)
+        const size_t tail_words = 1 + (size_t)(count <= 64 ? count : 0);
+        const size_t dist_bytes = grx_align_up(((size_t)F * F + tail_words) * 4, 256);
         int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take(dist_bytes));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
@@ -232,16 +243,27 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));
             }
             for (int j = 0; j < count; ++j) cols[first_new + j].bins = bins + (size_t)j * n;
+            if (F >= 2 && tail_words > 1 && re > rb) {
+                uint64_t mask = 0;
+                for (int j = 0; j < count; ++j)
+                    if (cols[first_new + j].kind == 1) mask |= 1ull << j;
+                if (mask) GRX_TRY(grx_column_bits(n, count, block, n, rb, re, mask, d_dist + (size_t)F * F + 1, stream));
+            }
             if (F >= 2) {
                 std::vector<const uint8_t *> ptrs(F);
                 for (int j = 0; j < F; ++j) ptrs[j] = cols[work[j]].bins;
                 // the pruner only asks "distance <= generation number?" (prune.py:110-113)
                 if (re > rb) GRX_TRY(grx_chebyshev(rb, re, F, 0, ptrs.data(), d_dist, generation, stream));
-                if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F + 1, GRX_I32, GRX_MAX, stream));
+                if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F + tail_words, GRX_I32, GRX_MAX, stream));
                 void *host = nullptr;
-                GRX_TRY(pinned(((size_t)F * F + 1) * 4, &host));
-                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, ((size_t)F * F + 1) * 4, hipMemcpyDeviceToHost, st));
+                GRX_TRY(pinned(((size_t)F * F + tail_words) * 4, &host));
+                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, ((size_t)F * F + tail_words) * 4, hipMemcpyDeviceToHost, st));
                 GRX_CHECK_HIP(hipStreamSynchronize(st));
+                if (tail_words > 1)
+                    for (int j = 0; j < count; ++j) {
+                        const int32_t b = reinterpret_cast<const int32_t *>(host)[(size_t)F * F + 1 + j];
+                        if (cols[first_new + j].kind == 1 && b >= 1 && b <= 62) cols[first_new + j].bits = b;
+                    }
                 const int32_t bin_status = reinterpret_cast<const int32_t *>(host)[(size_t)F * F];
                 if (bin_status != 0) {
                     grx_set_error("grx_refex_run: generation %d: vertical log binning failed on some rank (%s%s); "
@@ -300,7 +322,11 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         GRX_REQUIRE(h_gen0_cols[j] && h_gen0_names[j], "grx_refex_run: generation-0 column %d is NULL", j);
         cols.push_back({h_gen0_names[j], 0, -1, -1, h_gen0_cols[j], nullptr, -1});
         cols.back().int32_exact = h_gen0_int32 && h_gen0_int32[j] != 0;
+        if (cols.back().int32_exact) { cols.back().kind = 1; cols.back().base = j; }
     }
+    int deg_bits = 1;
+    while (deg_bits < 62 && (grx_internal_plan_max_degree(plan) >> deg_bits) != 0) ++deg_bits;
+    static const bool packed_allowed = [] { const char *e = std::getenv("GRX_NO_PACKED_ROWS"); return !(e && *e == '1'); }();
     {
         // binning wants one contiguous block: a scratch copy of the (separately allocated) input columns
         const size_t mark = arena.top;
@@ -320,11 +346,20 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         double *block = count ? reinterpret_cast<double *>(arena.take((size_t)count * n * 8)) : nullptr;
         if (count) {
             // candidate order: every column under the first aggregation, then the second, ... (extract.py:158-162)
+            int a_sum = -1;
+            for (int a = 0; a < n_aggs; ++a)
+                if (h_aggs[a] == GRX_AGG_SUM) a_sum = a;
             for (int a = 0; a < n_aggs; ++a)
                 for (int j = 0; j < f; ++j) {
-                    const Column &p = cols[prev[j]];
-                    cols.push_back({p.name + "(" + AGG_NAMES[h_aggs[a]] + ")", g, prev[j], h_aggs[a],
-                                    block ? block + ((size_t)a * f + j) * n : nullptr, nullptr, -1});
+                    Column child{cols[prev[j]].name + "(" + AGG_NAMES[h_aggs[a]] + ")", g, prev[j], h_aggs[a],
+                                 block ? block + ((size_t)a * f + j) * n : nullptr, nullptr, -1};
+                    // a neighbour sum of exact integers is an exact integer while it stays below 2^53; its mean is
+                    // fl(S / d) of that sum (the sum candidate of the same parent exists when 'sum' is among the aggs)
+                    const Column &par = cols[prev[j]];
+                    const bool exact_sum = par.kind == 1 && par.bits >= 1 && par.bits + deg_bits <= 53;
+                    if (exact_sum && h_aggs[a] == GRX_AGG_SUM) { child.kind = 1; child.base = first_new + a * f + j; }
+                    if (exact_sum && h_aggs[a] == GRX_AGG_MEAN && a_sum >= 0) { child.kind = 2; child.base = first_new + a_sum * f + j; }
+                    cols.push_back(std::move(child));
                 }
             const size_t mark = arena.top;
             const int ldr = grx_aggregate_ldr(f);
@@ -336,8 +371,41 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
             bool int_rows = only_sum_mean && grx_aggregate_i32_ok(plan, f);
             for (int j = 0; j < f && int_rows; ++j) int_rows = cols[prev[j]].int32_exact;
             const int ldi = int_rows ? grx_aggregate_ldi(f) : 0;
-            gather_row_bytes = int_rows ? ldi * 4 : ldr * 8;
-            double *rows = reinterpret_cast<double *>(arena.take(int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
+            // bit-packed integer rows (grx_aggregate_packed): every parent an exact integer column or the mean of one,
+            // column maxima known, fields within two 64-bit words; sharded: the base columns must be complete on this
+            // rank (generation 0, or retained -- those were all-gathered)
+            grx_packed_layout layout{};
+            std::vector<const double *> field_cols;
+            int packed_bytes = 0;
+            if (packed_allowed && only_sum_mean && f <= 8) {
+                std::vector<int> fields;
+                bool ok = true, any_mean = false;
+                for (int j = 0; j < f && ok; ++j) {
+                    const Column &par = cols[prev[j]];
+                    const int b = par.kind == 1 ? prev[j] : (par.kind == 2 ? par.base : -1);
+                    ok = b >= 0 && cols[b].bits >= 1 && cols[b].bits + deg_bits <= 53 &&
+                         (!comm || cols[b].generation == 0 || cols[b].record_index >= 0);
+                    if (!ok) break;
+                    int k = (int)(std::find(fields.begin(), fields.end(), b) - fields.begin());
+                    if (k == (int)fields.size()) { fields.push_back(b); ok = fields.size() <= 7; }
+                    layout.out_field[j] = k;
+                    layout.out_is_mean[j] = par.kind == 2;
+                    any_mean = any_mean || par.kind == 2;
+                }
+                if (ok) {
+                    layout.n_fields = (int)fields.size();
+                    layout.n_out = f;
+                    layout.degree_bits = any_mean ? deg_bits : 0;
+                    for (size_t k = 0; k < fields.size(); ++k) {
+                        layout.field_bits[k] = cols[fields[k]].bits;
+                        field_cols.push_back(cols[fields[k]].data);
+                    }
+                    packed_bytes = grx_packed_row_bytes(&layout);
+                }
+            }
+            gather_row_bytes = packed_bytes ? packed_bytes : (int_rows ? ldi * 4 : ldr * 8);
+            double *rows = reinterpret_cast<double *>(arena.take(packed_bytes ? (size_t)n * packed_bytes
+                                                                 : int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
             double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
                                                                     : nullptr;
             const size_t med_bytes = has[GRX_AGG_MEDIAN] ? grx_aggregate_median_workspace_bytes(nnz_rows) : 0;
@@ -351,7 +419,11 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 std::vector<const double *> ptrs(f);
                 for (int j = 0; j < f; ++j) ptrs[j] = cols[prev[j]].data;
                 double *d_mean = has[GRX_AGG_MEAN] ? out_of(GRX_AGG_MEAN) : mean_scratch;
-                if (int_rows) {
+                if (packed_bytes) {
+                    GRX_TRY(grx_pack_fields(n, &layout, field_cols.data(), d_row_ptr, rows, stream));
+                    GRX_TRY(grx_aggregate_packed(plan, d_row_ptr, d_agg_col, &layout, rows, rb, re, out_of(GRX_AGG_SUM), d_mean, n,
+                                                 stream));
+                } else if (int_rows) {
                     int32_t *irows = reinterpret_cast<int32_t *>(rows);
                     GRX_TRY(grx_pack_rows_i32(n, f, ptrs.data(), irows, ldi, stream));
                     GRX_TRY(grx_aggregate_i32(plan, d_row_ptr, d_agg_col, f, irows, ldi, rb, re, out_of(GRX_AGG_SUM), d_mean, n,

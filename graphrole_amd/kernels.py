@@ -537,6 +537,44 @@ def aggregate_minmax(csr: DeviceCSR, rows: torch.Tensor, f: int, ldr: int, row_b
 
 
 # ---- integer (int64-bits) columns, median, count: csrc/grx_aggx.hip -------------------------------------------------
+def packed_layout(field_bits: Sequence[int], degree_bits: int, out_field: Sequence[int], out_is_mean: Sequence[bool]):
+    """grx_packed_layout + the row width it needs (8 / 16 bytes; 0: does not fit)."""
+    L = _lib.PackedLayout()
+    L.n_fields, L.degree_bits, L.n_out = len(field_bits), int(degree_bits), len(out_field)
+    for k, b in enumerate(field_bits):
+        L.field_bits[k] = int(b)
+    for j, (k, m) in enumerate(zip(out_field, out_is_mean)):
+        L.out_field[j], L.out_is_mean[j] = int(k), int(bool(m))
+    return L, int(_lib.load().grx_packed_row_bytes(ctypes.byref(L)))
+
+
+def column_bits(block: torch.Tensor, n: int, int_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> torch.Tensor:
+    """int32[ncols]: bits of the maximum of every flagged column of a [ncols, >= n] fp64 block (grx_column_bits)."""
+    ncols = block.shape[0]
+    out = zeros(max(ncols, 1), dtype=torch.int32)
+    _lib.call('grx_column_bits', n, ncols, _ptr(block), _ld(block), row_begin, n if row_end is None else row_end,
+              int(int_mask), _ptr(out), _stream())
+    return out[:ncols]
+
+
+def pack_fields(csr: DeviceCSR, layout, row_bytes: int, field_cols: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Bit-packed gather source of grx_aggregate_packed: uint8 [n * row_bytes]."""
+    rows = torch.empty(max(csr.n, 1) * row_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_pack_fields', csr.n, ctypes.byref(layout), ptr_array(list(field_cols)), _ptr(csr.row_ptr), _ptr(rows), _stream())
+    return rows
+
+
+def aggregate_packed(csr: DeviceCSR, layout, rows: torch.Tensor, row_begin: int = 0, row_end: Optional[int] = None,
+                     want_sum: bool = True, want_mean: bool = True) -> torch.Tensor:
+    """[2 * n_out, n] (sums, then means) from bit-packed integer rows: bit-identical to aggregate() on the fp64 columns."""
+    n, f = csr.n, layout.n_out
+    out = torch.zeros((2 * f, max(n, 1)), dtype=torch.float64, device=device())
+    _lib.call('grx_aggregate_packed', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), ctypes.byref(layout), _ptr(rows),
+              row_begin, n if row_end is None else row_end, _ptr(out[:f]) if want_sum else None,
+              _ptr(out[f:]) if want_mean else None, out.stride(0), _stream())
+    return out[:, :n]
+
+
 def convert_i64_to_f64(col: torch.Tensor) -> torch.Tensor:
     """A column of int64 BITS (stored in an fp64 tensor) -> the fp64 values (numpy astype(float64))."""
     out = torch.empty_like(col)

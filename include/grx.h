@@ -384,6 +384,44 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * (grx_comm_all_gather_rows).  Every recorded column is complete on every rank on return; the neighbour sums
  * follow a tree that depends on the row length only, so the bits equal those of a one-GPU run.
  */
+/*
+ * Neighbour sums / means from BIT-PACKED integer rows.  The gather of grx_aggregate is bound by the chip's request
+ * rate, and the share of requests that miss an XCD's L2 follows the BYTES of the gather table (DESIGN.md section 3,
+ * profiles/r04_gather_bw.json).  On an unweighted graph every summand of generations 1 and 2
+ * (graphrole/features/extract.py:104-119) is an exact integer S -- a generation-0 count or a neighbour sum of one --
+ * or the mean fl(S / d) of one; a row that carries only the distinct S_k and the neighbour count d, each in the bits
+ * its column maximum needs, is 8 or 16 bytes instead of 16 / 64, and the kernel rebuilds the summands in registers
+ * (double(S), or double(S) / double(d): the correctly rounded division that produced the stored mean) and adds them
+ * in numpy's pairwise order like grx_aggregate.  Results are bit-identical to grx_aggregate on the fp64 columns.
+ *   grx_column_bits       d_bits[c] = max(d_bits[c], bits of max(column c, rows [row_begin, row_end))) for the columns
+ *                         flagged in int_mask (exact non-negative integers); the caller zeroes d_bits first (the widths
+ *                         of row slices combine by max, also across ranks); <= 64 columns per call
+ *   grx_packed_row_bytes  8 / 16, or 0 when the fields do not fit two 64-bit words (no field straddles a word; every
+ *                         field 1..62 bits)
+ *   grx_pack_fields       row u = fields S_k(u) = (int64) h_field_cols[k][u], then the neighbour count
+ *                         d_row_ptr[u + 1] - d_row_ptr[u] when degree_bits > 0; d_rows 16-byte aligned
+ *   grx_aggregate_packed  output j (column j of d_sum / d_mean, leading dimension ld) sums field out_field[j] of the
+ *                         neighbours, as S or -- out_is_mean[j] -- as fl(S / d); rows of more than 128 neighbours go
+ *                         through the plan's block list like grx_aggregate.  The caller guarantees
+ *                         bits(S) + bits(longest row) <= 53 (sums stay exact integers).
+ */
+typedef struct {
+    int n_fields;              /* 1 .. 7 integer source columns */
+    int field_bits[8];
+    int degree_bits;           /* width of the neighbour-count field, 0 = none (then no output may be a mean) */
+    int n_out;                 /* 1 .. 8 outputs */
+    int out_field[8];
+    int out_is_mean[8];
+} grx_packed_layout;
+int grx_packed_row_bytes(const grx_packed_layout *layout);
+int grx_column_bits(int64_t n, int ncols, const double *d_block, int64_t ld, int64_t row_begin, int64_t row_end,
+                    uint64_t int_mask, int32_t *d_bits, void *stream);
+int grx_pack_fields(int64_t n, const grx_packed_layout *layout, const double *const *h_field_cols, const int64_t *d_row_ptr,
+                    void *d_rows, void *stream);
+int grx_aggregate_packed(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col,
+                         const grx_packed_layout *layout, const void *d_rows, int64_t row_begin, int64_t row_end,
+                         double *d_sum, double *d_mean, int64_t ld, void *stream);
+
 /* The pruning decision of the loop alone, on the host (no device work): FeaturePruner.prune_features given the
  * Chebyshev matrix (prune.py:76-130).  h_recorded_generation[j]: generation that recorded column j, -1 if none (a
  * new candidate); h_dist F x F; h_drop[j] = 1 for every member of a feature group but its oldest. */

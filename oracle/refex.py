@@ -44,6 +44,10 @@ class OracleGraph:
     t_w: Optional[np.ndarray] = None
     attrs: Dict[str, np.ndarray] = field(default_factory=dict)   # 'attribute_<name>' -> float64[n]
     adj_col: Optional[np.ndarray] = None   # int32 [nnz]: rows of `col` in adjacency (insertion) order
+    # what only matters for the ORDER in which the reference adds edge weights (neighborhood_features_networkx_order):
+    node_order: Optional[np.ndarray] = None     # row indices in the order the graph iterates its nodes (default: sorted)
+    pred_ptr: Optional[np.ndarray] = None        # directed: in-neighbours of every row in insertion order (G.pred[v])
+    pred_col: Optional[np.ndarray] = None
 
     @property
     def n(self) -> int:
@@ -224,6 +228,113 @@ def egonet_features(g: OracleGraph) -> Dict[str, np.ndarray]:
         internal[v] = ins
         external[v] = ext
     return {'internal_edges': internal, 'external_edges': external}
+
+
+# --------------------------------------------------------------------------------------
+# generation 0 of WEIGHTED graphs in the reference's own order of additions
+# --------------------------------------------------------------------------------------
+def _weight_lookup(g: OracleGraph):
+    n = g.n
+    key = np.repeat(np.arange(n, dtype=np.int64), np.diff(g.row_ptr)) * n + g.col.astype(np.int64)
+    w = np.ones(g.nnz) if g.w is None else g.w
+    table = dict(zip(key.tolist(), w.tolist()))
+    return lambda a, b: table[a * n + b]
+
+
+def neighborhood_features_networkx_order(g: OracleGraph) -> Tuple[List[str], np.ndarray]:
+    """
+    Generation 0 (graph/interface/networkx.py:48-83,115-123) with every sum evaluated in the order networkx 3.x
+    hands the terms to Python's left-to-right ``sum()`` -- the weighted columns then equal the reference's bit for bit.
+    What that order is (networkx 3.4.2, restated from its published source; labels must be the graph's node objects,
+    here: the sorted labels of an integer-labelled graph, for which Python's set layout does not depend on the process):
+
+      degree            sum over G.adj[v] in insertion order, + the self-loop weight once more (reportviews.py DegreeView);
+                        DiGraph: successors' sum + predecessors' sum, in_degree over G.pred[v] in insertion order
+      internal_edges    ego = nx.ego_graph(G, v): BFS order [v] + G.adj[v] -> ``set`` (filters.show_nodes) -> the COPY's
+                        node order is that set's iteration order when the ego set is smaller than half the graph
+                        (coreviews.FilterAtlas.__iter__), else the graph's node order filtered; the copy's adjacency
+                        lists are filled by add_edge in that node order x G.adj order; ``ego.edges`` walks the copy's
+                        nodes and adjacency lists, an undirected edge reported at its first endpoint
+      external_edges    nx.edge_boundary(G, ego.nodes): a second ``set`` built from the copy's node order, G.edges(nbunch)
+                        over that set x G.adj order, undirected edges deduplicated by ``seen``, kept when exactly one end
+                        is inside
+
+    The two sets are real Python sets here: their iteration order IS the specification (a hash-table layout), which is
+    why no array order reproduces it and why the device path keeps a tolerance on weighted generation-0 sums.  With
+    string labels the layout depends on PYTHONHASHSEED: the reference does not reproduce its own last bits there.
+    """
+    n = g.n
+    labels = list(g.labels)
+    index = {lab: i for i, lab in enumerate(labels)}
+    weight = _weight_lookup(g)
+    order = list(range(n)) if g.node_order is None else [int(i) for i in g.node_order]
+    adj = [[int(u) for u in g.adj_row(v)] for v in range(n)]                       # successors / neighbours, insertion order
+    if g.directed:
+        if g.pred_ptr is not None:
+            pred = [[int(u) for u in g.pred_col[g.pred_ptr[v]:g.pred_ptr[v + 1]]] for v in range(n)]
+        else:
+            pred = [[int(u) for u in g.t_col[g.t_row_ptr[v]:g.t_row_ptr[v + 1]]] for v in range(n)]
+    out: Dict[str, list] = {}
+    if g.directed:
+        ins = [sum(weight(u, v) for u in pred[v]) for v in range(n)]
+        outs = [sum(weight(v, u) for u in adj[v]) for v in range(n)]
+        # DiDegreeView.__iter__: sum over successors + sum over predecessors
+        tot = [sum(weight(v, u) for u in adj[v]) + sum(weight(u, v) for u in pred[v]) for v in range(n)]
+        out['in_degree'], out['out_degree'], out['total_degree'] = ins, outs, tot
+    else:
+        out['degree'] = [sum(weight(v, u) for u in adj[v]) + (weight(v, v) if v in adj[v] else 0) for v in range(n)]
+    internal, external = [0] * n, [0] * n
+    for v in range(n):
+        bfs = [labels[v]] + [labels[u] for u in adj[v] if u != v]
+        inside_set = set(bfs)                                                       # filters.show_nodes: set(nodes)
+        if 2 * len(inside_set) < n:
+            ego_nodes = [index[lab] for lab in inside_set]                           # FilterAtlas: the set's own order
+        else:
+            ego_nodes = [i for i in order if labels[i] in inside_set]
+        member = {i for i in ego_nodes}
+        # Graph.copy(): add_edges_from over (u in ego_nodes) x (G.adj[u] inside) fills the copy's adjacency lists
+        cadj: Dict[int, Dict[int, None]] = {i: {} for i in ego_nodes}
+        for a in ego_nodes:
+            for b in adj[a]:
+                if b in member:
+                    cadj[a][b] = None
+                    if not g.directed:
+                        cadj[b][a] = None
+        terms = []
+        if g.directed:
+            for a in ego_nodes:                                                      # OutEdgeView
+                terms.extend(weight(a, b) for b in cadj[a])
+        else:
+            seen = set()
+            for a in ego_nodes:                                                      # EdgeView: each edge at its first endpoint
+                for b in cadj[a]:
+                    if b not in seen:
+                        terms.append(weight(a, b))
+                seen.add(a)
+        internal[v] = sum(terms)
+        # edge_boundary(G, ego.nodes): nset1 = {n for n in ego.nodes if n in G}
+        nset1 = {labels[i] for i in ego_nodes}
+        terms = []
+        if g.directed:
+            for lab in nset1:                                                        # G.edges(nset1): OutEdgeView over the set
+                a = index[lab]
+                terms.extend(weight(a, b) for b in adj[a] if b not in member)
+        else:
+            seen = set()
+            for lab in nset1:
+                a = index[lab]
+                for b in adj[a]:
+                    if b not in seen and b not in member:
+                        terms.append(weight(a, b))
+                seen.add(a)
+        external[v] = sum(terms)
+    out['internal_edges'], out['external_edges'] = internal, external
+    cols = dict(out)
+    local_names = [k for k in cols if k not in ('internal_edges', 'external_edges')]
+    names = local_names + list(g.attrs) + ['internal_edges', 'external_edges']
+    data = [np.asarray(cols[k], dtype=np.float64) for k in local_names] + [np.asarray(g.attrs[k], dtype=np.float64) for k in g.attrs] + \
+           [np.asarray(cols['internal_edges'], dtype=np.float64), np.asarray(cols['external_edges'], dtype=np.float64)]
+    return names, np.column_stack(data)
 
 
 def local_features_c(g: OracleGraph) -> Dict[str, np.ndarray]:

@@ -289,3 +289,43 @@ def test_typed_oracle_equals_reference_on_any_aggregation_list(name):
     assert res.generation_count == int(g['generation_count'])
     weighted = len(g['w']) > 0
     util.assert_typed_final_equal(g, res.columns, res.arrays, rtol=1e-12 if weighted else 0.0)
+
+
+# ------------------------------------------------------------------ weighted graphs, in the reference's own order of additions
+@pytest.mark.parametrize('name', util.WEIGHTED_ORDER_CASES)
+def test_weighted_generation0_bit_exact_in_networkx_order(name):
+    """oracle.refex.neighborhood_features_networkx_order restates the ORDER in which networkx hands edge weights to
+    Python's sum() (ego-graph copies and edge boundaries iterate over Python sets): the weighted generation-0 columns
+    of the reference come out bit for bit, and with them the whole ReFeX table."""
+    g = util.load_refex(name)
+    og = util.oracle_graph_from_golden(g)
+    util.attach_orders(og, np.load(util.golden_path(f'order_{name}.npz')))
+    names0 = g.js('gen0_names')
+    og.attrs = {nm: g['gen0_values'][:, j] for j, nm in enumerate(names0) if nm.startswith('attribute_')}
+    names, X0 = refex.neighborhood_features_networkx_order(og)
+    assert names == names0
+    assert np.array_equal(X0, g['gen0_values'])                                  # bit-equal, weighted
+    if util.golden_aggs(g) == ['sum', 'mean']:
+        res = refex.extract_features(og, max_generations=int(g['max_generations']), gen0=(names, X0))
+        assert res.columns == g.js('final_columns')
+        assert np.array_equal(res.values, g['final_values'])
+
+
+@pytest.mark.parametrize('name', util.GEN0W_CASES)
+def test_weighted_shuffled_graphs_bit_exact_in_networkx_order(name):
+    """weighted graphs whose nodes and edges were inserted in SHUFFLED order, with a self-loop (tools/make_golden_order.py):
+    the CSR-order sums differ from the reference's in the last bits, the restated order does not"""
+    z = util.Golden(util.golden_path(f'gen0w_{name}.npz'))
+    og = refex.graph_from_arrays(int(z['n']), z['src'], z['dst'], z['w'], bool(z['directed']), z.js('labels'))
+    og.num_edges = int(z['num_edges'])
+    og.adj_col = z['adj_idx'].astype(np.int32)
+    util.attach_orders(og, z)
+    names, X0 = refex.neighborhood_features_networkx_order(og)
+    assert names == z.js('gen0_names')
+    assert np.array_equal(X0, z['gen0_values'])
+    _, X_csr = refex.neighborhood_features(og)
+    assert not np.array_equal(X_csr, z['gen0_values'])                           # what the tolerance elsewhere is for
+    np.testing.assert_allclose(X_csr, z['gen0_values'], rtol=RTOL, atol=0)
+    res = refex.extract_features(og, max_generations=int(z['max_generations']), gen0=(names, X0))
+    assert res.columns == z.js('final_columns') and res.generation_count == int(z['generation_count'])
+    assert np.array_equal(res.values, z['final_values'])

@@ -64,7 +64,21 @@ def oracle_graph_from_golden(g):
         # the adjacency (insertion) order of the graph the reference ran on
         assert np.array_equal(g['adj_ptr'], og.row_ptr)
         og.adj_col = g['adj_idx'].astype(np.int32)
+    attach_orders(og, g)
     return og
+
+
+def attach_orders(og, z):
+    """node iteration order / predecessor insertion order of the graph the reference ran on (tools/make_golden_order.py):
+    what the ORDER of the reference's generation-0 additions depends on besides the adjacency order"""
+    if 'node_order' in z:
+        og.node_order = z['node_order']
+    if 'pred_ptr' in z:
+        og.pred_ptr, og.pred_col = z['pred_ptr'], z['pred_idx'].astype(np.int64)
+
+
+WEIGHTED_ORDER_CASES = ['karate_weighted', 'dw200_attrs', 'iface7_dw', 'dw200_minmax', 'dw200_prod', 'dw200_medianmax']
+GEN0W_CASES = ['rw60', 'rwd80', 'rw400']
 
 
 def typed_gen0(g):
