@@ -1236,91 +1236,134 @@ __device__ __forceinline__ void packed_values(const PackedRow<WORDS> &r, const P
     }
 }
 
-// numpy's pairwise sum of one segment of cnt <= 128 neighbours for F columns, G = 8 lanes (slot = lane):
+// numpy's pairwise sum of one segment of cnt <= 128 neighbours for F columns by S lanes (slot = lane % S), A = 8 / S of the
+// eight strided accumulators per lane (residue j = slot + t * S):
 //   r[j] = x[j] + x[j+8] + ...;  ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7));  then the cnt % 8 trailing elements one by one
-template <int WORDS, int F>
+// Fewer lanes per row = more independent gathers per lane and trip (A of them) and more rows per wavefront.
+template <int WORDS, int F, int S>
 __device__ __forceinline__ void packed_segment(const int32_t *__restrict__ col, const unsigned long long *__restrict__ rows,
                                                const PackedDesc &d, int64_t b, int cnt, int slot, double (&res)[F])
 {
 #pragma clang fp contract(off)
-    constexpr int G = 8;
+    constexpr int A = 8 / S;
+    static_assert(S * A == 8, "S must be 1, 2, 4 or 8");
     const int c8 = cnt & ~7, rem = cnt - c8;
 #pragma unroll
     for (int j = 0; j < F; ++j) res[j] = 0.0;
-    // the trailing neighbour of this lane: its index and row are requested first, used last
-    PackedRow<WORDS> tail;
+    // the trailing neighbours of this lane: indices and rows are requested first, used last
+    PackedRow<WORDS> tail[A];
     if (rem) {
-        const int idx = c8 + slot;
-        const int64_t ut = GRX_STREAM_LD(col[b + (idx < cnt ? idx : cnt - 1)]);
-        tail = packed_load<WORDS>(rows, ut);
+        int64_t ut[A];
+#pragma unroll
+        for (int t = 0; t < A; ++t) {
+            const int idx = c8 + slot + t * S;
+            ut[t] = GRX_STREAM_LD(col[b + (idx < cnt ? idx : cnt - 1)]);
+        }
+#pragma unroll
+        for (int t = 0; t < A; ++t) tail[t] = packed_load<WORDS>(rows, ut[t]);
     }
     if (c8) {
-        double r[F];
+        double r[A][F];
         {
-            const int64_t u = GRX_STREAM_LD(col[b + slot]);
-            packed_values<WORDS, F>(packed_load<WORDS>(rows, u), d, r);
+            int64_t u[A];
+#pragma unroll
+            for (int t = 0; t < A; ++t) u[t] = GRX_STREAM_LD(col[b + slot + t * S]);
+            PackedRow<WORDS> pr[A];
+#pragma unroll
+            for (int t = 0; t < A; ++t) pr[t] = packed_load<WORDS>(rows, u[t]);
+#pragma unroll
+            for (int t = 0; t < A; ++t) packed_values<WORDS, F>(pr[t], d, r[t]);
         }
         int i = 8;
-        for (; i + 24 < c8; i += 32) {                        // four trips of 8 per iteration: four gathers in flight per lane
-            int64_t u[4];
+        if constexpr (A <= 2) {                               // two trips of 8 per iteration: 2 A gathers in flight per lane
+            for (; i + 8 < c8; i += 16) {
+                int64_t u[2 * A];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) u[t] = GRX_STREAM_LD(col[b + i + 8 * t + slot]);
-            PackedRow<WORDS> pr[4];
+                for (int t = 0; t < A; ++t) {
+                    u[t] = GRX_STREAM_LD(col[b + i + slot + t * S]);
+                    u[A + t] = GRX_STREAM_LD(col[b + i + 8 + slot + t * S]);
+                }
+                PackedRow<WORDS> pr[2 * A];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) pr[t] = packed_load<WORDS>(rows, u[t]);
+                for (int t = 0; t < 2 * A; ++t) pr[t] = packed_load<WORDS>(rows, u[t]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                double x[F];
-                packed_values<WORDS, F>(pr[t], d, x);
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int j = 0; j < F; ++j) r[j] += x[j];
+                    for (int t = 0; t < A; ++t) {
+                        double x[F];
+                        packed_values<WORDS, F>(pr[h * A + t], d, x);
+#pragma unroll
+                        for (int j = 0; j < F; ++j) r[t][j] += x[j];
+                    }
+                }
             }
         }
         for (; i < c8; i += 8) {
-            const int64_t u = GRX_STREAM_LD(col[b + i + slot]);
-            double x[F];
-            packed_values<WORDS, F>(packed_load<WORDS>(rows, u), d, x);
+            int64_t u[A];
 #pragma unroll
-            for (int j = 0; j < F; ++j) r[j] += x[j];
+            for (int t = 0; t < A; ++t) u[t] = GRX_STREAM_LD(col[b + i + slot + t * S]);
+            PackedRow<WORDS> pr[A];
+#pragma unroll
+            for (int t = 0; t < A; ++t) pr[t] = packed_load<WORDS>(rows, u[t]);
+#pragma unroll
+            for (int t = 0; t < A; ++t) {
+                double x[F];
+                packed_values<WORDS, F>(pr[t], d, x);
+#pragma unroll
+                for (int j = 0; j < F; ++j) r[t][j] += x[j];
+            }
         }
-        // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): level `bit` pairs slot ^ (1 << bit)
+        // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): residue j = slot + t*S, level `bit` pairs j ^ (1 << bit)
 #pragma unroll
         for (int bit = 0; bit < 3; ++bit) {
+            if ((1 << bit) < S) {
 #pragma unroll
-            for (int j = 0; j < F; ++j) r[j] += __shfl_xor(r[j], 1 << bit, G);
+                for (int t = 0; t < A; ++t)
+#pragma unroll
+                    for (int j = 0; j < F; ++j) r[t][j] += __shfl_xor(r[t][j], 1 << bit, S);
+            } else {
+                const int step = (1 << bit) / S;              // distance between partners in r[]
+#pragma unroll
+                for (int t = 0; t < A; t += 2 * step) {
+                    if (t + step < A) {
+#pragma unroll
+                        for (int j = 0; j < F; ++j) r[t][j] += r[t + step][j];
+                    }
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < F; ++j) res[j] = r[j];
+        for (int j = 0; j < F; ++j) res[j] = r[0][j];
     }
     if (rem) {
-        double x[F];
-        packed_values<WORDS, F>(tail, d, x);
+        double x[A][F];
+#pragma unroll
+        for (int t = 0; t < A; ++t) packed_values<WORDS, F>(tail[t], d, x[t]);
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
 #pragma unroll
             for (int j = 0; j < F; ++j) {
-                const double v = __shfl(x[j], i, G);
+                const double v = S > 1 ? __shfl(x[i / S][j], i % S, S) : x[i / S][j];
                 if (i < rem) res[j] += v;
             }
         }
     }
 }
 
-template <int WORDS, int F>
+template <int WORDS, int F, int S>
 __global__ __launch_bounds__(256) void aggregate_packed_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const unsigned long long *__restrict__ rows,
     PackedDesc d, int64_t row_begin, int64_t row_end, double *__restrict__ out_sum, double *__restrict__ out_mean,
     int64_t ld, BlockWork bw)
 {
-    constexpr int G = 8;
-    const int slot = threadIdx.x % G;
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    const int slot = threadIdx.x % S;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
+    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / S;
     double a[F];
     for (int64_t k = group; k < bw.n_blocks; k += ngroups) {
         const int64_t v = bw.long_rows[bw.blk_row[k]];
         if (v < row_begin || v >= row_end) continue;
-        packed_segment<WORDS, F>(col, rows, d, bw.blk_begin[k], bw.blk_len[k], slot, a);
+        packed_segment<WORDS, F, S>(col, rows, d, bw.blk_begin[k], bw.blk_len[k], slot, a);
         if (slot == 0) {
 #pragma unroll
             for (int j = 0; j < F; ++j) bw.blk_sums[k * 16 + j] = a[j];
@@ -1330,12 +1373,12 @@ __global__ __launch_bounds__(256) void aggregate_packed_kernel(
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         const int64_t cntl = e - b;
         if (cntl > PW_BLOCK) continue;                     // the block loop above + aggregate_combine_kernel
-        packed_segment<WORDS, F>(col, rows, d, b, (int)cntl, slot, a);
-        // lane j of the group stores column j: eight 8-byte stores of one wave-instruction instead of F by lane 0
+        packed_segment<WORDS, F, S>(col, rows, d, b, (int)cntl, slot, a);
+        // every lane of the group holds the totals: lane s stores columns s, s + S, ...
         const double cnt = (double)cntl;
 #pragma unroll
         for (int j = 0; j < F; ++j) {
-            if (slot == j) {
+            if (slot == j % S) {
                 if (out_sum) GRX_STREAM_ST(out_sum[(int64_t)j * ld + v], a[j]);
                 if (out_mean) GRX_STREAM_ST(out_mean[(int64_t)j * ld + v], (cntl > 0) ? a[j] / cnt : 0.0);
             }
@@ -1618,12 +1661,28 @@ bool place_fields(const grx_packed_layout *L, PackedPlacement *P)
     return true;
 }
 
+// lanes per output row (S): fewer lanes = more gathers in flight per lane (8 / S per trip) and more rows per wavefront
+int packed_slots()
+{
+    static const int s = [] {
+        const char *e = std::getenv("GRX_PACKED_SLOTS");
+        const int v = e ? std::atoi(e) : 0;
+        return (v == 2 || v == 4 || v == 8) ? v : 4;
+    }();
+    return s;
+}
+
 template <int WORDS, int F>
-void launch_packed(int grid, hipStream_t st, const int64_t *row_ptr, const int32_t *col, const void *rows, const PackedDesc &d,
+void launch_packed(hipStream_t st, const int64_t *row_ptr, const int32_t *col, const void *rows, const PackedDesc &d,
                    int64_t rb, int64_t re, double *s, double *m, int64_t ld, const BlockWork &bw)
 {
-    aggregate_packed_kernel<WORDS, F><<<grid, 256, 0, st>>>(row_ptr, col, reinterpret_cast<const unsigned long long *>(rows), d, rb,
-                                                            re, s, m, ld, bw);
+    const int S = packed_slots();
+    const int64_t want = grx_ceil_div((re - rb) * S, 256);
+    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
+    const unsigned long long *r = reinterpret_cast<const unsigned long long *>(rows);
+    if (S == 2) aggregate_packed_kernel<WORDS, F, 2><<<grid, 256, 0, st>>>(row_ptr, col, r, d, rb, re, s, m, ld, bw);
+    else if (S == 4) aggregate_packed_kernel<WORDS, F, 4><<<grid, 256, 0, st>>>(row_ptr, col, r, d, rb, re, s, m, ld, bw);
+    else aggregate_packed_kernel<WORDS, F, 8><<<grid, 256, 0, st>>>(row_ptr, col, r, d, rb, re, s, m, ld, bw);
 }
 }  // namespace
 
@@ -2052,16 +2111,14 @@ int grx_aggregate_packed(const grx_aggregate_plan *plan, const int64_t *d_row_pt
     GRX_REQUIRE(!any_mean || layout->degree_bits > 0, "grx_aggregate_packed: mean summands need the neighbour-count field");
     d.d_word = P.d_word; d.d_shift = P.d_shift; d.d_bits = (uint8_t)layout->degree_bits;
     hipStream_t st = grx_stream(stream);
-    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
-    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
     const BlockWork bw{plan->d_long_rows, plan->d_blk_begin, plan->d_blk_len, plan->d_blk_row,
                        plan->n_long > 0 ? plan->n_blocks : 0, plan->d_blk_sums};
     {
         GRX_PROF(GRX_K_AGGREGATE, st);
 #define GRX_PACKED_CASE(FF)                                                                                           \
         case FF:                                                                                                      \
-            if (P.row_bytes == 8) launch_packed<1, FF>(grid, st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
-            else launch_packed<2, FF>(grid, st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
+            if (P.row_bytes == 8) launch_packed<1, FF>(st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
+            else launch_packed<2, FF>(st, d_row_ptr, d_col, d_rows, d, row_begin, row_end, d_sum, d_mean, ld, bw); \
             break;
         switch (layout->n_out) {
             GRX_PACKED_CASE(1) GRX_PACKED_CASE(2) GRX_PACKED_CASE(3) GRX_PACKED_CASE(4)

@@ -101,6 +101,38 @@ W = dW.to_host(np.float64, (r, n)).T
 H = dH.to_host(np.float64, (r, F))
 assert info.n_iter == it, (info.n_iter, it)
 assert np.abs(W - We).max() / np.abs(We).max() < 1e-8 and np.abs(H - He).max() / np.abs(He).max() < 1e-8
+# ---- 2a (packed rows): the same sums / means from 8-byte bit-packed integer rows
+class Layout(C.Structure):
+    _fields_ = [('n_fields', C.c_int), ('field_bits', C.c_int * 8), ('degree_bits', C.c_int), ('n_out', C.c_int),
+                ('out_field', C.c_int * 8), ('out_is_mean', C.c_int * 8)]
+d_block = DeviceArray(np.ascontiguousarray(X0.T))
+d_bits = DeviceArray(np.zeros(f, dtype=np.int32))
+_check(_lib.grx_column_bits(_i64(n), _i32(f), d_block.ptr, _i64(n), _i64(0), _i64(n), C.c_uint64(7), d_bits.ptr, None))
+widths = d_bits.to_host(np.int32, (f,))
+assert list(widths) == [max(int(X0[:, j].max()).bit_length(), 1) for j in range(f)]
+lay = Layout()
+lay.n_fields, lay.degree_bits, lay.n_out = f, 0, f
+for j in range(f):
+    lay.field_bits[j], lay.out_field[j], lay.out_is_mean[j] = int(widths[j]), j, 0
+row_bytes = _lib.grx_packed_row_bytes(C.byref(lay))
+assert row_bytes in (8, 16)
+prow = DeviceArray(nbytes=n * row_bytes)
+_check(_lib.grx_pack_fields(_i64(n), C.byref(lay), ptrs, d_row_ptr.ptr, prow.ptr, None))
+out2 = DeviceArray(nbytes=2 * f * n * 8)
+_check(_lib.grx_aggregate_packed(plan, d_row_ptr.ptr, d_adj.ptr, C.byref(lay), prow.ptr, _i64(0), _i64(n), out2.ptr,
+                                 _vp(out2.ptr.value + f * n * 8), _i64(n), None))
+assert np.array_equal(out2.to_host(np.float64, (2 * f, n)), block)                    # bit-identical to 2a
+
+# ---- 2h: roles / role_percentage of a quantised factor
+levels = np.sort(np.random.RandomState(1).gamma(0.7, 2.0, 8))
+Gq = np.ascontiguousarray(levels[np.random.RandomState(2).randint(0, 8, size=(n, r))])
+dG = DeviceArray(Gq)
+first = DeviceArray(nbytes=4 * n)
+_check(_lib.grx_role_argmax(_i64(n), _i32(r), dG.ptr, first.ptr, None))
+share = DeviceArray(nbytes=8 * n * r)
+_check(_lib.grx_row_normalise(_i64(n), _i32(r), dG.ptr, share.ptr, None))
+assert np.array_equal(first.to_host(np.int32, (n,)), rolx.dominant_role_index(Gq))
+assert np.array_equal(share.to_host(np.float64, (n, r)), rolx.role_percentage(Gq))
 assert 'torch' not in sys.modules
 print('INTEGRATION_STUB_OK', info.n_iter)
 '''
