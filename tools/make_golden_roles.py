@@ -57,6 +57,21 @@ def roles_of(rx):
     return index, np.ascontiguousarray(share.values, dtype=np.float64)
 
 
+def environment():
+    """what the tied cells of the MDL grid depend on: sklearn's k-means++ breaks mathematical ties by the last-bit
+    rounding of its BLAS dot products -- recorded with every fixture so that a changed allow-list
+    (tests/test_gpu_rolx.py::TIED_CELLS) can be traced to a changed build"""
+    import numpy
+    import pandas
+    import scipy
+    import sklearn
+    from threadpoolctl import threadpool_info
+    pools = [{k: p.get(k) for k in ('user_api', 'internal_api', 'version', 'num_threads', 'threading_layer', 'architecture')}
+             for p in threadpool_info()]
+    return json.dumps({'sklearn': sklearn.__version__, 'numpy': numpy.__version__, 'scipy': scipy.__version__,
+                       'pandas': pandas.__version__, 'python': sys.version.split()[0], 'threadpools': pools})
+
+
 def main():
     wide = {}
     for name, r in WIDE:
@@ -70,7 +85,7 @@ def main():
         wide[f'{name}_r{r}_roles_index'] = idx
         wide[f'{name}_r{r}_role_percentage'] = share
         print(f'roles_wide {name} r={r}: ties in {int((np.sort(rx.node_role_factor.values, axis=1)[:, -1] == np.sort(rx.node_role_factor.values, axis=1)[:, -2]).sum())} of {len(idx)} rows')
-    np.savez_compressed(os.path.join(OUT, 'roles_wide.npz'), seed=SEED, cases=json.dumps([[n, r] for n, r in WIDE]), **wide)
+    np.savez_compressed(os.path.join(OUT, 'roles_wide.npz'), seed=SEED, environment_json=environment(), cases=json.dumps([[n, r] for n, r in WIDE]), **wide)
     for name in CASES:
         X = load_table(name)
         # the grid exactly as RoleExtractor._select_model walks it (one RNG stream for the whole grid)
@@ -107,7 +122,7 @@ def main():
         sel_idx, sel_share = roles_of(rx2)
         fix_idx, fix_share = roles_of(rx3)
         np.savez_compressed(
-            os.path.join(OUT, f'roles_{name}.npz'), seed=SEED, roles_index=sel_idx, role_percentage=sel_share,
+            os.path.join(OUT, f'roles_{name}.npz'), seed=SEED, environment_json=environment(), roles_index=sel_idx, role_percentage=sel_share,
             fixed3_roles_index=fix_idx, fixed3_role_percentage=fix_share, encoding_costs=enc, error_costs=err,
             selected=np.array(sel, dtype=np.int64), node_role_factor=rx2.node_role_factor.values,
             role_feature_factor=rx2.role_feature_factor.values, fixed3_node_role_factor=rx3.node_role_factor.values,
