@@ -171,7 +171,7 @@ def pmc_counters(workload, timeout_s=240):
                     tot[c] += v[1]
         return ({c: v / launches for c, v in tot.items()}, launches) if launches else (None, 0)
 
-    agg, agg_n = fold(('aggregate_kernel', 'aggregate_i32_kernel'))
+    agg, agg_n = fold(('aggregate_kernel', 'aggregate_i32_kernel', 'aggregate_packed_kernel'))
     nmf, nmf_n = fold(('nmf_w_pass',))
     if not agg or 'FETCH_SIZE' not in agg:
         return {'error': 'no aggregation launches in the counter output'}
@@ -342,6 +342,19 @@ def api_wall(G, args):
     rx = RoleExtractor(n_roles=N_ROLES)
     rx.extract_role_factors(X)
     t3 = time.perf_counter()
+    # the two properties a user reads next (graphrole/roles/extract.py:38-57): arg-max / row shares on the device
+    # (grx_role_argmax / grx_row_normalise incl. the upload of the factor), then the reference's return types
+    first = rx.dominant_role_index()
+    t4 = time.perf_counter()
+    roles = rx.roles
+    t5 = time.perf_counter()
+    share = rx.role_percentage
+    t6 = time.perf_counter()
+    out['roles'] = {'dominant_role_index_s': t4 - t3, 'roles_dict_s': t5 - t4, 'role_percentage_s': t6 - t5,
+                    'nodes': len(first), 'roles_entries': len(roles), 'shape': list(share.shape),
+                    'what': 'dominant_role_index() = upload + grx_role_argmax + int32 download; roles = the same + a '
+                            'Python dict of n entries (the reference\'s return type); role_percentage = upload + '
+                            'grx_row_normalise + download + DataFrame'}
     out.update({'device_ingest_s': t1 - t0, 'extract_features_s': t2 - t0, 'extract_role_factors_s': t3 - t2,
                 'total_s': t3 - t0, 'features_shape': list(X.shape),
                 'what': 'cold RecursiveFeatureExtractor(CSRGraph).extract_features() -> DataFrame (device_ingest_s = '
@@ -630,7 +643,8 @@ def main():
                                 agg_l2 = tj.get('aggregate_l2_hit_rate')
                     except Exception:
                         traffic = nmf_traffic = None
-                roofline = {'bound': 'hbm', 'kernel': 'aggregate_kernel (+ aggregate_combine_kernel for rows longer than 128)',
+                roofline = {'bound': 'hbm', 'kernel': 'aggregate_packed_kernel (bit-packed integer rows, generations 1-2 of unweighted graphs) / aggregate_kernel '
+                                      '(fp64 rows) + aggregate_combine_kernel for rows longer than 128',
                             'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                             'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_source,
                             'l2_hit_rate': agg_l2, 'pmc': pmc,

@@ -967,12 +967,22 @@ __global__ __launch_bounds__(256) void bin_threshold2_kernel(const double *__res
 __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restrict__ cols, int64_t ld,
                                                          int64_t n, const uint64_t *__restrict__ thr,
                                                          const int32_t *__restrict__ nbins,
-                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags)
+                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags,
+                                                         const int32_t *__restrict__ fault = nullptr,
+                                                         int32_t *__restrict__ status = nullptr)
 {
     __shared__ uint64_t t[GRX_MAX_BINS];
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
     int nb = nbins[col];
+    // outcome flags for a caller that asked for them (grx_internal_log_bin_status_sink): bit 0 = the sort-free walk met
+    // a bucket it had not marked (an invariant of the interval walk broke), bit 1 = a column needs more than
+    // GRX_MAX_BINS bins (its labels saturate below)
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) {
+        int bad = nb < 0 ? 2 : 0;
+        if (col == 0 && fault && *fault != 0) bad |= 1;
+        if (bad) atomicOr(status, bad);
+    }
     if (nb < 0) nb = GRX_MAX_BINS;                    // more than GRX_MAX_BINS bins: labels saturate, the caller is told
     if (threadIdx.x < GRX_MAX_BINS)
         t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
@@ -1937,40 +1947,14 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
 }  // extern "C"
 
 namespace {
-// one wave: bit 0 = the sort-free walk met a bucket it had not marked (an invariant of the interval walk broke),
-// bit 1 = a column needs more than GRX_MAX_BINS bins (labels would saturate).  OR-ed into *status.
-__global__ __launch_bounds__(64) void log_bin_status_kernel(const int32_t *__restrict__ nbins, int ncols,
-                                                            const int32_t *__restrict__ fault, int32_t *__restrict__ status)
-{
-    int bad = 0;
-    for (int c = threadIdx.x; c < ncols; c += 64) bad |= nbins[c] < 0 ? 2 : 0;
-    if (fault && threadIdx.x == 0 && *fault != 0) bad |= 1;
-    if (bad) atomicOr(status, bad);
-}
+thread_local int32_t *g_status_sink = nullptr;
 }  // namespace
 
-// Internal (grx_refex.hip): fold the outcome flags of the grx_vertical_log_bin call that last used this workspace
-// into *d_status (see log_bin_status_kernel).  The flags live in the workspace, so they must be read before it is
-// reused.  No synchronisation: the caller reads *d_status with whatever it copies back next.
-int grx_internal_log_bin_status(int64_t n, int ncols, void *d_workspace, int32_t *d_status, hipStream_t st)
-{
-    if (n <= 0 || ncols <= 0) return GRX_OK;
-    char *ws = reinterpret_cast<char *>(d_workspace);
-    static const bool use_sort = [] { const char *e = std::getenv("GRX_BIN_SORT"); return e && *e == '1'; }();
-    const int32_t *nb_ws, *fault = nullptr;
-    if (!use_sort) {
-        const SelLayout L = sel_layout(n, ncols);
-        nb_ws = reinterpret_cast<const int32_t *>(ws + L.nbins);
-        fault = reinterpret_cast<const int32_t *>(ws + L.fault);
-    } else {
-        const SortPlan p = make_plan(n, ncols);
-        nb_ws = reinterpret_cast<const int32_t *>(ws + 2 * p.keys_bytes + p.hist_bytes +
-                                                  grx_align_up((size_t)ncols * GRX_MAX_BINS * 8, 256));
-    }
-    log_bin_status_kernel<<<1, 64, 0, st>>>(nb_ws, ncols, fault, d_status);
-    GRX_LAUNCH_CHECK();
-    return GRX_OK;
-}
+// Internal (grx_refex.hip): the NEXT grx_vertical_log_bin call of this thread ORs its outcome flags into *d_status
+// (bit 0: the sort-free threshold walk met an unmarked bucket; bit 1: a column needs more than GRX_MAX_BINS bins) from
+// inside its last kernel -- no launch of its own, no synchronisation: the caller reads the word with whatever it
+// copies back next.
+void grx_internal_log_bin_status_sink(int32_t *d_status) { g_status_sink = d_status; }
 
 extern "C" {
 
@@ -1986,6 +1970,8 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
                                uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
                                size_t workspace_bytes, void *stream)
 {
+    int32_t *status = g_status_sink;                          // consumed by this call whatever it returns
+    g_status_sink = nullptr;
     ColFlags flags;
     for (int j = 0; j < 8; ++j) flags.w[j] = 0;
     if (h_is_i64)
@@ -2057,7 +2043,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
         {
             GRX_PROF(GRX_K_BIN_ASSIGN, st);
-            bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags);
+            bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags, fault, status);
         }
         GRX_LAUNCH_CHECK();
         if (d_nbins)
@@ -2105,7 +2091,7 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
     const int64_t want = grx_ceil_div(n, 256 * 4);
     const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
     { GRX_PROF(GRX_K_BIN_ASSIGN, st);
-    bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags);
+    bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags, nullptr, status);
     }
     GRX_LAUNCH_CHECK();
     if (d_nbins)

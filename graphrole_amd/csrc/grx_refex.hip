@@ -20,7 +20,7 @@
 #include <vector>
 
 int64_t grx_internal_plan_max_degree(const grx_aggregate_plan *plan);                                          // grx_graph.hip
-int grx_internal_log_bin_status(int64_t n, int ncols, void *d_workspace, int32_t *d_status, hipStream_t st);   // grx_prune.hip
+void grx_internal_log_bin_status_sink(int32_t *d_status);                                                    // grx_prune.hip
 
 namespace {
 
@@ -193,6 +193,9 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
 
     // add the new columns to the working set, bin them, prune across the set, record what survives
     // (extract.py:121-142); `block` = the new columns as one contiguous [count, n] block
+    int deg_bits = 1;
+    while (deg_bits < 62 && (grx_internal_plan_max_degree(plan) >> deg_bits) != 0) ++deg_bits;
+    static const bool packed_allowed = [] { const char *e = std::getenv("GRX_NO_PACKED_ROWS"); return !(e && *e == '1'); }();
     int gather_row_bytes = 0;                                // row width of the gather source of the generation at hand
     auto update = [&](int first_new, int count, const double *block, int generation, bool partial) -> int {
         const size_t scratch_mark = arena.top;
@@ -217,15 +220,17 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         // + one status word behind the matrix: the outcome flags of the binning travel (and, sharded, are max-reduced)
         // with the distances, so a failed binning is a joint error on every rank instead of a silent wrong drop list
         // ... and one word per new column: the bit width of its maximum when it holds exact integers (kind 1)
-        const size_t tail_words = 1 + (size_t)(count <= 64 ? count : 0);
+        // (not for the last generation the loop can reach: nothing will be gathered from its columns)
+        const bool want_bits = count <= 64 && generation + 1 < max_generations && packed_allowed;
+        const size_t tail_words = 1 + (size_t)(want_bits ? count : 0);
         const size_t dist_bytes = grx_align_up(((size_t)F * F + tail_words) * 4, 256);
         int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take(dist_bytes));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
             if (F >= 2) GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
             if (count && !comm) {
+                if (F >= 2) grx_internal_log_bin_status_sink(d_dist + (size_t)F * F);
                 GRX_TRY(grx_vertical_log_bin(n, count, block, n, 0.5, bins, n, nullptr, ws, ws_bytes, stream));
-                if (F >= 2) GRX_TRY(grx_internal_log_bin_status(n, count, ws, d_dist + (size_t)F * F, st));
             } else if (count) {
                 const double *src = block + (size_t)me * n;       // complete columns: the owned ones are a strided view
                 int64_t ld_src = (int64_t)P * n;
@@ -236,8 +241,8 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     ld_src = n;
                 }
                 if (n_owned) {
+                    if (F >= 2) grx_internal_log_bin_status_sink(d_dist + (size_t)F * F);
                     GRX_TRY(grx_vertical_log_bin(n, n_owned, src, ld_src, 0.5, owned_bins, n, nullptr, ws, ws_bytes, stream));
-                    if (F >= 2) GRX_TRY(grx_internal_log_bin_status(n, n_owned, ws, d_dist + (size_t)F * F, st));
                 }
                 // step 2: the owners' bins of this rank's rows come back
                 GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));
@@ -324,9 +329,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         cols.back().int32_exact = h_gen0_int32 && h_gen0_int32[j] != 0;
         if (cols.back().int32_exact) { cols.back().kind = 1; cols.back().base = j; }
     }
-    int deg_bits = 1;
-    while (deg_bits < 62 && (grx_internal_plan_max_degree(plan) >> deg_bits) != 0) ++deg_bits;
-    static const bool packed_allowed = [] { const char *e = std::getenv("GRX_NO_PACKED_ROWS"); return !(e && *e == '1'); }();
+
     {
         // binning wants one contiguous block: a scratch copy of the (separately allocated) input columns
         const size_t mark = arena.top;

@@ -77,7 +77,7 @@ print(f'pmc kernels: {len(out)}')
 # Calibration for THIS access pattern (random 32-64 B row gathers): FETCH_SIZE(KiB)*1024 equals
 # TCC_MISS_sum * 64 B within 5 %, i.e. the requests are 64-byte and the 2x correction the guide gives
 # for wide coalesced streams does not apply; WRITE_SIZE is taken as reported.
-agg = {k: d for k, d in out.items() if k.startswith('aggregate_kernel') or k.startswith('aggregate_i32_kernel')}
+agg = {k: d for k, d in out.items() if k.startswith(('aggregate_kernel', 'aggregate_i32_kernel', 'aggregate_packed_kernel'))}
 if agg:
     w = sum(d['launches_sampled'] for d in agg.values())
     fetch = sum(d.get('FETCH_SIZE', 0.0) * 1024 * d['launches_sampled'] for d in agg.values()) / w
