@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
 # Outputs go to gpurun_out/prof_<tag>/ ; tools/summarize_rocprof.py condenses them into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 WORKLOAD=${2:-ba1m}
 case "$TAG" in -*) echo "usage: tools/profile_gpu.sh <tag> [workload]  (a tag must not start with '-')"; exit 2;; esac
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
