@@ -397,12 +397,33 @@ int grx_host_eigh(int n, const double *A_in, double *w, double *V)
 }
 
 // Whitening transform of the first Gram matrix G1 = X^T X (F x F):  eigen-pairs above the
-// numerical floor, T1 = V[:, keep] / sqrt(lam[keep]) (F x k, row-major with k columns).
-// lam_keep [k], V_keep [F x k].  Returns k (0: the feature matrix is numerically zero).
+// numerical floor, T1 (F x k, row-major with k columns) with (X T1)^T (X T1) ~ I.
+// lam_keep [k], V_keep [F x k] with X^T X = V_keep diag(lam_keep) V_keep^T on the kept subspace (what
+// grx_host_range_finder rebuilds M = Q^T X from).  Returns k (0: the feature matrix is numerically zero).
+//
+// The Gram matrix squares the condition number of X, and ReFeX tables are GRADED: a degree column next to a mean of
+// means, column norms six and more decades apart.  That part of the conditioning is removed exactly before the
+// eigen-decomposition (round 4): with D = diag(2^e_j), 2^e_j the power of two nearest to the norm of column j, the
+// scaled matrix Gs = D^-1 G1 D^-1 has a diagonal in [1/2, 2] and is formed without rounding; eigh(Gs) = Vs diag(lam)
+// Vs^T gives T1 = D^-1 Vs / sqrt(lam) and V_keep = D Vs.  What is left for the floor to judge is the conditioning of
+// the column-EQUILIBRATED table -- a table whose r-th singular value sits 1e-7 below the first only because one
+// column is 1e7 times another now keeps all its directions (tools/fuzz_rolx.py seed 403 case 103: r = F = 17,
+// cond(X) = 7e6, the seventeenth direction used to fall under the floor).
 int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, double *V_keep, int *k_out)
 {
     GRX_REQUIRE(F >= 1 && G1 && T1 && lam_keep && V_keep && k_out, "grx_host_whiten: bad arguments");
-    Mat A(G1, G1 + (size_t)F * F), V((size_t)F * F);
+    std::vector<double> scale(F, 1.0);
+    for (int j = 0; j < F; ++j) {
+        const double d = G1[(size_t)j * F + j];
+        if (d > 0.0 && std::isfinite(d)) {
+            int e = 0;
+            (void)std::frexp(std::sqrt(d), &e);                  // sqrt(d) = m * 2^e, m in [0.5, 1)
+            scale[j] = std::ldexp(1.0, e - 1);                   // 2^(e-1) <= sqrt(d) < 2^e
+        }
+    }
+    Mat A((size_t)F * F), V((size_t)F * F);
+    for (int i = 0; i < F; ++i)
+        for (int j = 0; j < F; ++j) A[(size_t)i * F + j] = G1[(size_t)i * F + j] / scale[i] / scale[j];   // exact: powers of two
     std::vector<double> w(F);
     sym_eigh(F, A.data(), w.data(), V.data());
     const double lam_max = std::max(w[F - 1], 0.0);
@@ -416,8 +437,8 @@ int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, doubl
         lam_keep[col] = w[j];
         const double inv = 1.0 / std::sqrt(w[j]);
         for (int i = 0; i < F; ++i) {
-            V_keep[(size_t)i * k + col] = V[(size_t)i * F + j];
-            T1[(size_t)i * k + col] = V[(size_t)i * F + j] * inv;
+            V_keep[(size_t)i * k + col] = V[(size_t)i * F + j] * scale[i];
+            T1[(size_t)i * k + col] = V[(size_t)i * F + j] * inv / scale[i];
         }
         ++col;
     }

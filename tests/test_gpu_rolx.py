@@ -597,3 +597,22 @@ def test_nmf_on_ill_conditioned_tables_matches_oracle(kind, seed):
                                                        'W_rel': float(_relmax(G, We)), 'H_rel': float(_relmax(Fm, He))})
     assert n_iter == it, (n_iter, it, cond)
     assert _relmax(G, We) < FACTOR_RTOL and _relmax(Fm, He) < FACTOR_RTOL, (cond, _relmax(G, We), _relmax(Fm, He))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+@pytest.mark.parametrize('shape', [(18, 17, 17), (40, 17, 12), (3000, 20, 6)])
+def test_nmf_on_graded_tables_with_full_rank_request(shape, seed):
+    """column norms six decades apart (what ReFeX tables look like) and up to r = F roles: every singular direction the
+    NNDSVDa start needs survives the Gram whitening (exact power-of-two column equilibration, csrc/grx_host_linalg.hip);
+    found by tools/fuzz_rolx.py (FUZZ_WIDE_RANK=1, seed 403, case 103: the start differed in its seventeenth direction)"""
+    from graphrole_amd.roles import factor
+    from oracle import rolx
+    n, F, r = shape
+    rng = np.random.RandomState(100 * seed + n)
+    X = np.abs(rng.randn(n, F)) * 10.0 ** rng.uniform(-2, 4, F)
+    np.random.seed(seed)
+    G, H, n_iter = factor.nmf_with_info(X, r)
+    np.random.seed(seed)
+    We, He, it = rolx.nmf(X, r)
+    assert n_iter == it
+    assert _relmax(G, We) < 1e-7 and _relmax(H, He) < 1e-7, (_relmax(G, We), _relmax(H, He))

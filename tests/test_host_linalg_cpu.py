@@ -83,7 +83,9 @@ def test_native_small_space_equals_scipy_formulation(n, F, r, deficient):
     keep = lam > max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
     T1, lam_keep, V_keep = K.host_whiten(G1)
     assert T1.shape == (F, int(keep.sum())) and lam_keep.shape == (int(keep.sum()),)
-    np.testing.assert_allclose(lam_keep, lam[keep], rtol=1e-10)
+    # (lam_keep, V_keep) are the eigen-pairs of the column-EQUILIBRATED Gram matrix mapped back (V_keep = D Vs, D powers
+    # of two): they reproduce G1 on the kept subspace, which is all grx_host_range_finder needs of them
+    np.testing.assert_allclose((V_keep * lam_keep) @ V_keep.T, G1, atol=1e-9 * np.abs(G1).max())
     Y = X @ T1
     np.testing.assert_allclose(Y.T @ Y, np.eye(T1.shape[1]), atol=1e-8)          # whitened
     # the scipy formulation on its own basis
@@ -167,3 +169,26 @@ def test_small_svd_of_tables_with_fewer_nodes_than_features(n, F, r):
         sgn = np.sign(U[:, j] @ Ue[:, j])
         np.testing.assert_allclose(sgn * U[:, j], Ue[:, j], atol=1e-8)
         np.testing.assert_allclose(sgn * V[j], Vte[j], atol=1e-8)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_whitening_keeps_every_direction_of_a_graded_table(seed):
+    """Column norms six decades apart (a degree column next to a mean of means) and r = F: without the exact
+    power-of-two column equilibration of grx_host_whiten the Gram matrix's smallest eigenvalues fall under the floor
+    and the last singular directions are lost (tools/fuzz_rolx.py, seed 403 case 103)."""
+    from graphrole_amd import kernels as K
+    rng = np.random.RandomState(seed)
+    n, F = 18, 17
+    X = np.abs(rng.randn(n, F)) * 10.0 ** rng.uniform(-2, 4, F)
+    G1 = X.T @ X
+    T1, lam_keep, V_keep = K.host_whiten(G1)
+    assert T1.shape == (F, F)                                     # nothing dropped
+    Y = X @ T1
+    np.testing.assert_allclose(Y.T @ Y, np.eye(F), atol=1e-6)
+    r = F
+    omega = rng.normal(size=(F, r + 10))
+    Z, S, Vt = K.host_range_finder(T1, lam_keep, V_keep, Y.T @ Y, omega, r, 4)
+    s_true = np.linalg.svd(X, compute_uv=False)
+    np.testing.assert_allclose(S, s_true, rtol=1e-6)             # all seventeen, down to 1e-7 of the largest
+    U = X @ Z
+    np.testing.assert_allclose(U.T @ U, np.eye(r), atol=1e-6)
