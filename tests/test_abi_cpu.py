@@ -134,3 +134,25 @@ def test_every_binding_call_passes_the_declared_number_of_arguments():
                 assert got == want, f'{path}:{node.lineno}: {name} takes {want} arguments, {got} given'
                 checked += 1
     assert checked > 60
+
+
+def test_packed_layout_placement_needs_no_device():
+    """grx_packed_row_bytes is host arithmetic: fields fill word 0, then word 1, none across a word, the neighbour count
+    last and at most 31 bits wide"""
+    from graphrole_amd import _lib
+    lib = _lib.load()
+
+    def row_bytes(field_bits, degree_bits, n_out=1):
+        L = _lib.PackedLayout()
+        L.n_fields, L.degree_bits, L.n_out = len(field_bits), degree_bits, n_out
+        for k, b in enumerate(field_bits):
+            L.field_bits[k] = b
+        return lib.grx_packed_row_bytes(ctypes.byref(L))
+
+    assert row_bytes([14, 15, 20], 0) == 8                      # BA 1 M, generation 1
+    assert row_bytes([20, 20, 28], 14) == 16                    # BA 1 M, generation 2: 68 + 14 bits
+    assert row_bytes([32, 32], 0) == 8 and row_bytes([32, 32], 1) == 16
+    assert row_bytes([40, 30, 30, 30], 4) == 0                  # 40 | 30 + 30 | 30 + 4: the third word does not exist
+    assert row_bytes([62, 62], 31) == 0 and row_bytes([63], 0) == 0 and row_bytes([0], 0) == 0
+    assert row_bytes([10], 32) == 0                             # neighbour counts are below 2^31
+    assert row_bytes([10] * 8, 0) == 0 and row_bytes([9] * 7, 0, n_out=9) == 0
