@@ -82,42 +82,74 @@ def generate_graph(name):
     return synth.ba_graph(n, m, seed=0) if kind == 'ba' else synth.er_graph(n, m, seed=0)
 
 
-def shared_dir(name):
-    """Where the ranks of one node meet: the generators are seeded, so the content of a workload's directory is a
-    function of its name and of graphrole_amd/synth.py (hashed into the path)."""
+def shared_dirs(name):
+    """Where the ranks of one node meet, in order of preference (/dev/shm, then /tmp): the generators are seeded, so the
+    content of a workload's directory is a function of its name and of graphrole_amd/synth.py (hashed into the path).
+    The builder takes the first location with room; the other ranks look in all of them."""
     import hashlib
     from graphrole_amd import synth
     tag = hashlib.sha256(open(synth.__file__, 'rb').read()).hexdigest()[:12]
-    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
-    return os.path.join(base, f'grx_bench_{os.getuid()}', f'{name}_{tag}')
+    bases = [b for b in ('/dev/shm', '/tmp') if os.path.isdir(b) and os.access(b, os.W_OK)]
+    return [os.path.join(b, f'grx_bench_{os.getuid()}', f'{name}_{tag}') for b in bases]
+
+
+def shared_dir(name):
+    return shared_dirs(name)[0]
 
 
 def build_graph(name, world=1, local_rank=0, share=False):
     """N = 1: generate.  N > 1 (or share=True: the counter passes of --pmc re-run this script): the synthetic graph
     is generated ONCE per node (local rank 0 -> .npy files in /dev/shm, published by one atomic rename), the other
     processes map the same pages -- eight concurrent numpy generations of the 5 M / 100 M graph would cost minutes of
-    host time and 8 x the memory before any GPU work."""
+    host time and 8 x the memory before any GPU work.  A builder that fails leaves a marker, so that nobody waits for
+    files that will not come."""
     if world == 1 and not share:
         return generate_graph(name)
+    import shutil
     from graphrole_amd import synth
-    path = shared_dir(name)
-    if local_rank == 0 and not os.path.exists(os.path.join(path, 'meta.json')):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        tmp = f'{path}.tmp{os.getpid()}'
-        os.makedirs(tmp, exist_ok=True)
-        synth.save_graph(generate_graph(name), tmp)
+    places = shared_dirs(name)
+    found = lambda: next((p for p in places if os.path.exists(os.path.join(p, 'meta.json'))), None)
+    failed = places[-1] + '.failed'
+    if local_rank == 0 and found() is None:
         try:
-            os.rename(tmp, path)
-            _PUBLISHED.append(path)
-        except OSError:                                # another launch published the same content first
-            import shutil
-            shutil.rmtree(tmp, ignore_errors=True)
+            if os.path.exists(failed):
+                os.remove(failed)
+            G = generate_graph(name)
+            src, dst, w = G.edge_arrays()
+            need = int(1.25 * (src.nbytes + dst.nbytes + (w.nbytes if w is not None else 0) +
+                               sum(np.asarray(v).nbytes for v in G.attributes.values()))) + (1 << 20)
+            last_error = None
+            for path in places:
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    if shutil.disk_usage(os.path.dirname(path)).free < need:
+                        continue                           # e.g. a container with a 64 MB /dev/shm
+                    tmp = f'{path}.tmp{os.getpid()}'
+                    os.makedirs(tmp, exist_ok=True)
+                    synth.save_graph(G, tmp)
+                    try:
+                        os.rename(tmp, path)
+                        _PUBLISHED.append(path)
+                    except OSError:                        # another launch published the same content first
+                        shutil.rmtree(tmp, ignore_errors=True)
+                    break
+                except OSError as exc:
+                    last_error = exc
+                    shutil.rmtree(f'{path}.tmp{os.getpid()}', ignore_errors=True)
+            else:
+                raise RuntimeError(f'no room for the shared graph files ({need >> 20} MiB) in {places}: {last_error}')
+        except BaseException:
+            os.makedirs(os.path.dirname(failed), exist_ok=True)
+            open(failed, 'w').write('local rank 0 could not publish the graph')
+            raise
     deadline = time.time() + 3600
-    while not os.path.exists(os.path.join(path, 'meta.json')):
+    while found() is None:
+        if os.path.exists(failed):
+            raise SystemExit(f'bench.py: the rank that builds the {name} graph failed ({failed})')
         if time.time() > deadline:
-            raise SystemExit(f'bench.py: rank waited an hour for {path}')
+            raise SystemExit(f'bench.py: rank waited an hour for {places}')
         time.sleep(0.2)
-    return synth.load_graph(path)
+    return synth.load_graph(found())
 
 
 PMC_PASSES = ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum TCC_MISS_sum',
@@ -523,7 +555,9 @@ def main():
         # untimed soak: the timed region of the small workloads is tens of milliseconds -- an external activity sampler
         # (the driver polls the SMI once a second) would never see the device busy
         soak = None
-        if args.soak_seconds > 0 and not light:
+        # (N = 1 only: the loop is bounded by TIME, and ranks that ran different step counts would leave each other
+        # waiting inside an exchange)
+        if args.soak_seconds > 0 and not light and not multi:
             t_soak, n_soak = time.perf_counter(), 0
             while time.perf_counter() - t_soak < args.soak_seconds:
                 step(dict(refex=0.0, nmf=0.0, nmf_iters=0))

@@ -42,7 +42,7 @@ def test_graph_is_generated_once_and_mapped_by_the_other_ranks(tmp_path, monkeyp
     calls = []
     real = bench.generate_graph
     monkeypatch.setattr(bench, 'generate_graph', lambda name: (calls.append(name), real(name))[1])
-    monkeypatch.setattr(bench, 'shared_dir', lambda name: str(tmp_path / 'shared' / name))
+    monkeypatch.setattr(bench, 'shared_dirs', lambda name: [str(tmp_path / 'shared' / name)])
     g0 = bench.build_graph('tiny', world=2, local_rank=0)
     g1 = bench.build_graph('tiny', world=2, local_rank=1)          # finds the published files, generates nothing
     assert calls == ['tiny']
@@ -53,6 +53,37 @@ def test_graph_is_generated_once_and_mapped_by_the_other_ranks(tmp_path, monkeyp
     src = g1.edge_arrays()[0]
     assert not src.flags.owndata                                    # a view of the mapped file, not a private copy
     assert bench._PUBLISHED == [str(tmp_path / 'shared' / 'tiny')]
+    bench._PUBLISHED.clear()
+
+
+def test_a_failing_builder_does_not_leave_the_other_ranks_waiting(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import pytest
+    import bench
+    monkeypatch.setattr(bench, 'shared_dirs', lambda name: [str(tmp_path / 'shared' / name)])
+
+    def boom(name):
+        raise MemoryError('no graph today')
+    monkeypatch.setattr(bench, 'generate_graph', boom)
+    with pytest.raises(MemoryError):
+        bench.build_graph('tiny', world=2, local_rank=0)
+    with pytest.raises(SystemExit, match='failed'):
+        bench.build_graph('tiny', world=2, local_rank=1)        # returns at once, not after an hour
+
+
+def test_the_builder_skips_a_location_without_room(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import collections
+    import shutil
+    import bench
+    small, roomy = tmp_path / 'small' / 'tiny', tmp_path / 'roomy' / 'tiny'
+    monkeypatch.setattr(bench, 'shared_dirs', lambda name: [str(small), str(roomy)])
+    usage = collections.namedtuple('usage', 'total used free')
+    real = shutil.disk_usage
+    monkeypatch.setattr(shutil, 'disk_usage', lambda p: usage(1 << 20, 1 << 20, 0) if 'small' in str(p) else real(p))
+    g = bench.build_graph('tiny', world=2, local_rank=0)
+    assert not (small / 'meta.json').exists() and (roomy / 'meta.json').exists()
+    assert bench.build_graph('tiny', world=2, local_rank=1).n == g.n
     bench._PUBLISHED.clear()
 
 
