@@ -162,6 +162,7 @@ _SIGNATURES = {
     'grx_chebyshev': (c_int, [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_gather_columns': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     'grx_host_whiten': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'grx_host_whiten_for_rank': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'grx_host_range_finder': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_void_p, c_void_p, c_void_p]),
     'grx_host_small_svd': (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -264,7 +264,7 @@ static int nmf_init_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx
     if (x_sq_norm) *x_sq_norm = trace;
     std::vector<double> T1((size_t)F * F), lam(F), V((size_t)F * F);
     int k = 0;
-    GRX_TRY(grx_host_whiten(F, host, T1.data(), lam.data(), V.data(), &k));
+    GRX_TRY(grx_host_whiten_for_rank(F, host, r, T1.data(), lam.data(), V.data(), &k));
     if (k == 0) {
         grx_set_error("NMF initialisation: the feature matrix is numerically zero");
         return GRX_ERR_DEGENERATE;

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -401,19 +402,21 @@ int grx_host_eigh(int n, const double *A_in, double *w, double *V)
 // lam_keep [k], V_keep [F x k] with X^T X = V_keep diag(lam_keep) V_keep^T on the kept subspace (what
 // grx_host_range_finder rebuilds M = Q^T X from).  Returns k (0: the feature matrix is numerically zero).
 //
-// The Gram matrix squares the condition number of X, and ReFeX tables are GRADED: a degree column next to a mean of
-// means, column norms six and more decades apart.  That part of the conditioning is removed exactly before the
-// eigen-decomposition (round 4): with D = diag(2^e_j), 2^e_j the power of two nearest to the norm of column j, the
-// scaled matrix Gs = D^-1 G1 D^-1 has a diagonal in [1/2, 2] and is formed without rounding; eigh(Gs) = Vs diag(lam)
-// Vs^T gives T1 = D^-1 Vs / sqrt(lam) and V_keep = D Vs.  What is left for the floor to judge is the conditioning of
-// the column-EQUILIBRATED table -- a table whose r-th singular value sits 1e-7 below the first only because one
-// column is 1e7 times another now keeps all its directions (tools/fuzz_rolx.py seed 403 case 103: r = F = 17,
-// cond(X) = 7e6, the seventeenth direction used to fall under the floor).
-int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, double *V_keep, int *k_out)
+// equilibrate = false: eigh(G1) itself, floor = lam_max * F * 16 eps.  On a GRADED table (column norms decades
+// apart: a degree column next to a mean of means) that floor is set by the largest column, and the directions of the
+// small columns fall under it -- harmless while the r leading directions survive, and it also keeps the noise
+// directions of exact dependencies out (config 5: 41 of 115 directions dropped, factors 1e-12 from the oracle).
+// equilibrate = true (round 4): the scaling is removed first and EXACTLY -- D = diag(2^e_j), 2^e_j <= ||x_j|| < 2^(e_j+1),
+// Gs = D^-1 G1 D^-1 formed without rounding, eigh(Gs) = Vs diag(lam) Vs^T, T1 = D^-1 Vs / sqrt(lam), V_keep = D Vs --
+// so that the floor judges the column-equilibrated table.  It keeps every direction of a table whose conditioning is
+// pure column scaling (tools/fuzz_rolx.py seed 403 case 103: r = F = 17, the seventeenth direction 1.9e-14 of the
+// first), but also the rounding-noise directions of a wide table with dependent columns (config 5: 113 of 115 kept,
+// factors wrong) -- so it is the FALLBACK: grx_host_whiten_for_rank uses it only when the plain decomposition keeps
+// fewer directions than the factorisation asks for.
+static int whiten_impl(int F, const double *G1, bool equilibrate, double *T1, double *lam_keep, double *V_keep, int *k_out)
 {
-    GRX_REQUIRE(F >= 1 && G1 && T1 && lam_keep && V_keep && k_out, "grx_host_whiten: bad arguments");
     std::vector<double> scale(F, 1.0);
-    for (int j = 0; j < F; ++j) {
+    for (int j = 0; j < F && equilibrate; ++j) {
         const double d = G1[(size_t)j * F + j];
         if (d > 0.0 && std::isfinite(d)) {
             int e = 0;
@@ -442,6 +445,30 @@ int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, doubl
         }
         ++col;
     }
+    return GRX_OK;
+}
+
+int grx_host_whiten(int F, const double *G1, double *T1, double *lam_keep, double *V_keep, int *k_out)
+{
+    GRX_REQUIRE(F >= 1 && G1 && T1 && lam_keep && V_keep && k_out, "grx_host_whiten: bad arguments");
+    return whiten_impl(F, G1, false, T1, lam_keep, V_keep, k_out);
+}
+
+// The whitening for a factorisation of rank r: the plain decomposition; if it keeps fewer than min(r, F) directions
+// (a graded table whose small columns fell under the floor), the column-equilibrated one.
+int grx_host_whiten_for_rank(int F, const double *G1, int r, double *T1, double *lam_keep, double *V_keep, int *k_out)
+{
+    GRX_REQUIRE(F >= 1 && r >= 0 && G1 && T1 && lam_keep && V_keep && k_out, "grx_host_whiten_for_rank: bad arguments");
+    int rc = whiten_impl(F, G1, false, T1, lam_keep, V_keep, k_out);
+    if (rc != GRX_OK || *k_out >= (r < F ? r : F)) return rc;
+    int k2 = 0;
+    std::vector<double> T2((size_t)F * F), lam2(F), V2((size_t)F * F);
+    rc = whiten_impl(F, G1, true, T2.data(), lam2.data(), V2.data(), &k2);
+    if (rc != GRX_OK || k2 <= *k_out) return rc;                 // nothing gained: keep the plain result
+    *k_out = k2;
+    std::memcpy(T1, T2.data(), (size_t)F * k2 * 8);
+    std::memcpy(V_keep, V2.data(), (size_t)F * k2 * 8);
+    std::memcpy(lam_keep, lam2.data(), (size_t)k2 * 8);
     return GRX_OK;
 }
 

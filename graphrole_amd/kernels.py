@@ -825,14 +825,19 @@ def _hp(a: np.ndarray):
     return a.ctypes.data_as(c_void_p)
 
 
-def host_whiten(G1: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Eigen-pairs of the Gram matrix above the numerical floor: (T1 [F, k], lam [k], V [F, k])."""
+def host_whiten(G1: np.ndarray, rank: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Eigen-pairs of the Gram matrix above the numerical floor: (T1 [F, k], lam [k], V [F, k]).  rank > 0
+    (grx_host_whiten_for_rank): when fewer than min(rank, F) directions survive the floor -- a graded table whose small
+    columns fell under it -- the columns are equilibrated exactly before the eigen-decomposition."""
     import ctypes
     F = G1.shape[0]
     G1 = np.ascontiguousarray(G1, dtype=np.float64)
     T1, lam, V = np.empty(F * F), np.empty(F), np.empty(F * F)
     k = ctypes.c_int(0)
-    _lib.call('grx_host_whiten', F, _hp(G1), _hp(T1), _hp(lam), _hp(V), ctypes.byref(k))
+    if rank > 0:
+        _lib.call('grx_host_whiten_for_rank', F, _hp(G1), int(rank), _hp(T1), _hp(lam), _hp(V), ctypes.byref(k))
+    else:
+        _lib.call('grx_host_whiten', F, _hp(G1), _hp(T1), _hp(lam), _hp(V), ctypes.byref(k))
     k = k.value
     return T1[:F * k].reshape(F, k), lam[:k], V[:F * k].reshape(F, k)
 

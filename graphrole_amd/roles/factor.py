@@ -112,7 +112,7 @@ def _init_orchestrated(Xd, n: int, r: int, omega: np.ndarray, plan=None):
     x_mean = xsum / (n * F)
     x_sq_norm = float(np.trace(G1))                                  # ||X||_F^2
     n_iter = 7 if r < 0.1 * min(n, F) else 4                          # extmath.py:557-560
-    T1, lam_keep, V_keep = H_.host_whiten(G1)
+    T1, lam_keep, V_keep = H_.host_whiten(G1, r)
     if T1.shape[1] == 0:
         raise ValueError('NMF initialisation: the feature matrix is numerically zero')
     G2, _ = gram(T1)

@@ -510,6 +510,9 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
   * the columns of h_V.  Exposed for tests. */
 int grx_host_eigh(int n, const double *h_A, double *h_w, double *h_V);
 int grx_host_whiten(int F, const double *h_G1, double *h_T1, double *h_lam_keep, double *h_V_keep, int *k);
+/* the same for a factorisation of rank r: when the plain decomposition keeps fewer than min(r, F) directions (a graded
+ * table: column norms decades apart), the columns are equilibrated exactly (powers of two) before eigh */
+int grx_host_whiten_for_rank(int F, const double *G1, int r, double *T1, double *lam_keep, double *V_keep, int *k_out);
 int grx_host_range_finder(int F, int k, const double *h_T1, const double *h_lam_keep, const double *h_V_keep,
                           const double *h_G2, const double *h_omega, int n_over, int r, int n_iter,
                           double *h_Z, double *h_S, double *h_Vt);

@@ -83,8 +83,8 @@ def test_native_small_space_equals_scipy_formulation(n, F, r, deficient):
     keep = lam > max(lam.max(), 0.0) * F * np.finfo(np.float64).eps * 16
     T1, lam_keep, V_keep = K.host_whiten(G1)
     assert T1.shape == (F, int(keep.sum())) and lam_keep.shape == (int(keep.sum()),)
-    # (lam_keep, V_keep) are the eigen-pairs of the column-EQUILIBRATED Gram matrix mapped back (V_keep = D Vs, D powers
-    # of two): they reproduce G1 on the kept subspace, which is all grx_host_range_finder needs of them
+    np.testing.assert_allclose(lam_keep, lam[keep], rtol=1e-10)
+    # (lam_keep, V_keep) reproduce G1 on the kept subspace, which is all grx_host_range_finder needs of them
     np.testing.assert_allclose((V_keep * lam_keep) @ V_keep.T, G1, atol=1e-9 * np.abs(G1).max())
     Y = X @ T1
     np.testing.assert_allclose(Y.T @ Y, np.eye(T1.shape[1]), atol=1e-8)          # whitened
@@ -173,16 +173,22 @@ def test_small_svd_of_tables_with_fewer_nodes_than_features(n, F, r):
 
 @pytest.mark.parametrize('seed', [0, 1, 2, 3])
 def test_whitening_keeps_every_direction_of_a_graded_table(seed):
-    """Column norms six decades apart (a degree column next to a mean of means) and r = F: without the exact
-    power-of-two column equilibration of grx_host_whiten the Gram matrix's smallest eigenvalues fall under the floor
-    and the last singular directions are lost (tools/fuzz_rolx.py, seed 403 case 103)."""
+    """Column norms six decades apart (a degree column next to a mean of means) and r = F: the plain eigen-decomposition
+    of the Gram matrix drops the smallest directions (its floor is set by the largest column); asked for rank r,
+    grx_host_whiten_for_rank then equilibrates the columns exactly (powers of two) and keeps them all
+    (tools/fuzz_rolx.py, seed 403 case 103)."""
     from graphrole_amd import kernels as K
     rng = np.random.RandomState(seed)
     n, F = 18, 17
     X = np.abs(rng.randn(n, F)) * 10.0 ** rng.uniform(-2, 4, F)
     G1 = X.T @ X
-    T1, lam_keep, V_keep = K.host_whiten(G1)
-    assert T1.shape == (F, F)                                     # nothing dropped
+    k_plain = K.host_whiten(G1)[0].shape[1]
+    assert K.host_whiten(G1, rank=min(6, k_plain))[0].shape[1] == k_plain    # enough directions for the rank: the plain result
+    if seed == 0:
+        assert k_plain < F                                        # the plain decomposition loses directions here ...
+    T1, lam_keep, V_keep = K.host_whiten(G1, rank=F)
+    assert T1.shape == (F, F)                                     # ... and all are kept when all are asked for
+    np.testing.assert_allclose((V_keep * lam_keep) @ V_keep.T, G1, atol=1e-9 * np.abs(G1).max())
     Y = X @ T1
     np.testing.assert_allclose(Y.T @ Y, np.eye(F), atol=1e-6)
     r = F
