@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 400          /* 0.4.0: + grx_role_argmax / grx_row_normalise (RolX roles / role_percentage) */
+#define GRX_VERSION 400          /* 0.4.0: + grx_role_argmax / grx_row_normalise (RolX roles / role_percentage), bit-packed gather rows
+                                    (grx_column_bits / grx_pack_fields / grx_aggregate_packed), grx_host_whiten_for_rank,
+                                    grx_refex_generation.gather_row_bytes */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
                                     a composed update (several times the traffic), then with n_roles + features <= 480 */
@@ -372,9 +374,13 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * h_gens (capacity max_gens >= max_generations): per-generation counts.  *generation_count = the last
  * executed generation (the reference's generation_count).  Synchronises `stream` before returning.
  *
- * h_gen0_int32 (may be NULL): per generation-0 column, non-zero if every value is an exact integer in [0, 2^31) --
- * a generation whose parents all are (generation 1 of an unweighted graph) then gathers 16- / 32-byte integer rows
- * (grx_aggregate_i32) when only sums and means are asked for.
+ * h_gen0_int32 (may be NULL): per generation-0 column, non-zero if every value is an exact integer in [0, 2^31).
+ * The loop then tracks what every later column IS -- an exact integer S (a neighbour sum of such a column, while
+ * bits(S) + bits(longest row) <= 53), the mean fl(S / d) of one, or anything else -- learns the bit width of every
+ * integer column's maximum with the read-back each generation makes anyway, and gathers generations whose parents are
+ * all of the first two kinds from bit-packed rows (grx_aggregate_packed: 8 / 16 bytes per node; generations 1 and 2
+ * of an unweighted graph) when only sums and means are asked for; the fall-back for integer parents whose widths are
+ * not known is the int32 row of grx_aggregate_i32.  GRX_NO_PACKED_ROWS=1 (environment) switches the packed rows off.
  *
  * comm / h_bounds (NULL / NULL = one GPU): node-range sharding.  Every rank calls with the same arguments and the
  * COMPLETE generation-0 columns; it aggregates rows [h_bounds[rank], h_bounds[rank + 1]) only and the loop issues
@@ -397,7 +403,7 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  *                         flagged in int_mask (exact non-negative integers); the caller zeroes d_bits first (the widths
  *                         of row slices combine by max, also across ranks); <= 64 columns per call
  *   grx_packed_row_bytes  8 / 16, or 0 when the fields do not fit two 64-bit words (no field straddles a word; every
- *                         field 1..62 bits)
+ *                         field 1..62 bits, the neighbour count at most 31)
  *   grx_pack_fields       row u = fields S_k(u) = (int64) h_field_cols[k][u], then the neighbour count
  *                         d_row_ptr[u + 1] - d_row_ptr[u] when degree_bits > 0; d_rows 16-byte aligned
  *   grx_aggregate_packed  output j (column j of d_sum / d_mean, leading dimension ld) sums field out_field[j] of the
@@ -439,8 +445,9 @@ typedef struct {
 } grx_refex_column;
 typedef struct {
     int candidates, working, dropped, retained;
-    int gather_row_bytes;      /* bytes per row of the generation's gather source (16 / 32: int32 rows, 8 * ldr: fp64
-                                  rows; 0 for generation 0) -- what a gather-rate ceiling has to be looked up with */
+    int gather_row_bytes;      /* bytes per row of the generation's gather source (8 / 16: bit-packed integer rows,
+                                  16 / 32: int32 rows, 8 * ldr: fp64 rows; 0 for generation 0) -- what a gather-rate
+                                  ceiling has to be looked up with */
 } grx_refex_generation;
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
