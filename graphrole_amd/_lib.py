@@ -57,12 +57,6 @@ class PackedLayout(ctypes.Structure):
                 ('out_field', c_int * 8), ('out_is_mean', c_int * 8)]
 
 
-class DerivedOutputs(ctypes.Structure):
-    """grx_derived_outputs of include/grx.h."""
-    _fields_ = [('plain_sum', c_void_p * 16), ('plain_mean', c_void_p * 16), ('div_sum', c_void_p * 16),
-                ('div_mean', c_void_p * 16)]
-
-
 class P2pOp(ctypes.Structure):
     """grx_p2p_op of include/grx.h."""
     _fields_ = [('is_recv', c_int), ('peer', c_int), ('d_ptr', c_void_p), ('bytes', c_size_t)]
@@ -220,10 +214,6 @@ _SIGNATURES = {
                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_nmf_iterate_rows': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'grx_aggregate_derived_ldr': (c_int, [c_int]),
-    'grx_pack_rows_derived': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    'grx_aggregate_derived': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p,
-                                      c_void_p]),
     'grx_packed_row_bytes': (c_int, [c_void_p]),
     'grx_column_bits': (c_int, [c_int64, c_int, c_void_p, c_int64, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
     'grx_pack_fields': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1435,255 +1435,6 @@ __global__ __launch_bounds__(256) void column_bits_kernel(const double *__restri
     }
 }
 
-// gather source of aggregate_derived_kernel: row u = the base columns' values of node u, zeros, and in the last slot
-// the neighbour count of u as a double; one thread per (row, slot): the writes are one coalesced stream
-__global__ __launch_bounds__(256) void pack_rows_derived_kernel(int64_t n, int nb, int ldr, GrxPtrTable cols_tab,
-                                                                const int64_t *__restrict__ row_ptr, double *__restrict__ rows)
-{
-    const double *const *cols = reinterpret_cast<const double *const *>(cols_tab.p);
-    const int64_t total = n * ldr, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t u = i / ldr;
-        const int c = (int)(i - u * ldr);
-        rows[i] = c < nb ? cols[c][u] : (c == ldr - 1 ? (double)(row_ptr[u + 1] - row_ptr[u]) : 0.0);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// neighbour aggregation with DERIVED means (generations >= 2 of any graph)
-// ---------------------------------------------------------------------------------------
-// From generation 2 on most retained parents come in pairs: the neighbour sum P of a column and its mean fl(P / d).
-// The fp64 gather source then need not carry both: a row holds the distinct BASE columns P_k and, in its last slot,
-// the neighbour count d (as a double); the kernel forms fl(P_k / d) in registers -- the same correctly rounded
-// division that produced the stored mean -- and accumulates Σ P_k and Σ fl(P_k / d) side by side, both in numpy's
-// pairwise order.  One gather of a 128-byte row then serves up to 15 bases = 30 parents instead of 16: BASELINE config 5
-// (weighted, 13 generation-0 columns) needs 1 + 1 + 2 launches per pass instead of 1 + 2 + 3.
-// Lane layout, block list and summation tree are those of aggregate_kernel; every lane additionally fetches its row's d
-// from the lane that loaded the row's last 16 bytes (one shuffle per loaded row).
-struct DerivedOut { double *p[4][16]; };                   // [0 plain sum, 1 plain mean, 2 divided sum, 3 divided mean][slot]
-
-// fl(p / cnt), cnt an integer-valued double in [1, 2^31), y = the refined reciprocal of cnt: the compiler's own fp64
-// division is this sequence behind a scaling step that is the identity for 2^-900 <= |p| <= 2^900; anything else
-// (zeros keep their sign, subnormals, infinities, NaN) takes the division itself
-__device__ __forceinline__ double derived_div(double p, double cnt, double y)
-{
-#pragma clang fp contract(off)
-    const double ap = fabs(p);
-    if (ap >= 0x1p-900 && ap <= 0x1p900) {
-        const double q = p * y;
-        const double rem = __builtin_fma(-cnt, q, p);
-        return __builtin_fma(rem, y, q);
-    }
-    return p / cnt;
-}
-
-__device__ __forceinline__ double derived_rcp(double cnt)
-{
-#pragma clang fp contract(off)
-    double y = __builtin_amdgcn_rcp(cnt);
-    double e = __builtin_fma(-cnt, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-cnt, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
-
-// v = (P0, P1, fl(P0 / d), fl(P1 / d)) of one loaded 16-byte piece; d comes from the lane holding the row's last piece
-template <int CL, int G>
-__device__ __forceinline__ void derived_values(double2 x, int slot, double (&v)[4])
-{
-    const double cnt = CL > 1 ? __shfl(x.y, slot * CL + CL - 1, G) : x.y;
-    v[0] = x.x; v[1] = x.y;
-    if (cnt > 0.0) {
-        const double y = derived_rcp(cnt);
-        v[2] = derived_div(x.x, cnt, y);
-        v[3] = derived_div(x.y, cnt, y);
-    } else {
-        v[2] = v[3] = 0.0;                                  // the stored mean of a node without neighbours (NaN -> 0)
-    }
-}
-
-template <int LDR, int G>
-__device__ __forceinline__ void derived_segment(const int32_t *__restrict__ col, const double *__restrict__ rows,
-                                                int64_t row_stride, int64_t b, int cnt, int part, int slot, double (&o)[4])
-{
-#pragma clang fp contract(off)
-    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
-    constexpr int S = G / CL, A = 8 / S;
-    static_assert(S >= 1 && S <= 8 && S * A == 8, "lane group must hold 1..8 neighbour slots");
-    const double *base = rows + 2 * part;
-    double res[4] = {0.0, 0.0, 0.0, 0.0};
-    const int c8 = cnt & ~7, rem = cnt - c8;
-    double2 xt[A];
-    if (rem) {
-        int64_t ut[A];
-#pragma unroll
-        for (int t = 0; t < A; ++t) {
-            const int idx = c8 + slot + t * S;
-            ut[t] = GRX_STREAM_LD(col[b + (idx < cnt ? idx : cnt - 1)]);
-        }
-#pragma unroll
-        for (int t = 0; t < A; ++t) xt[t] = *reinterpret_cast<const double2 *>(base + ut[t] * row_stride);
-    }
-    if (c8) {
-        double r[A][4];
-        {
-            double2 x[A];
-#pragma unroll
-            for (int t = 0; t < A; ++t) {
-                const int64_t u = GRX_STREAM_LD(col[b + slot + t * S]);
-                x[t] = *reinterpret_cast<const double2 *>(base + u * row_stride);
-            }
-#pragma unroll
-            for (int t = 0; t < A; ++t) derived_values<CL, G>(x[t], slot, r[t]);
-        }
-        for (int i = 8; i < c8; i += 8) {
-            double2 x[A];
-#pragma unroll
-            for (int t = 0; t < A; ++t) {
-                const int64_t u = GRX_STREAM_LD(col[b + i + slot + t * S]);
-                x[t] = *reinterpret_cast<const double2 *>(base + u * row_stride);
-            }
-#pragma unroll
-            for (int t = 0; t < A; ++t) {
-                double v[4];
-                derived_values<CL, G>(x[t], slot, v);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) r[t][k] += v[k];
-            }
-        }
-#pragma unroll
-        for (int bit = 0; bit < 3; ++bit) {
-            if ((1 << bit) < S) {
-#pragma unroll
-                for (int t = 0; t < A; ++t)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[t][k] += __shfl_xor(r[t][k], CL << bit, G);
-            } else {
-                const int step = (1 << bit) / S;
-#pragma unroll
-                for (int t = 0; t < A; t += 2 * step) {
-                    if (t + step < A) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) r[t][k] += r[t + step][k];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) res[k] = r[0][k];
-    }
-    if (rem) {
-        double x[A][4];
-#pragma unroll
-        for (int t = 0; t < A; ++t) {
-            derived_values<CL, G>(xt[t], slot, x[t]);
-            const int idx = c8 + slot + t * S;
-            if (idx >= cnt) { x[t][0] = x[t][1] = x[t][2] = x[t][3] = 0.0; }
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int src = (i % S) * CL + part;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double v = __shfl(x[i / S][k], src, G);
-                if (i < rem) res[k] += v;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = res[k];
-}
-
-template <int LDR, int G>
-__global__ __launch_bounds__(256) void aggregate_derived_kernel(
-    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ rows,
-    int64_t row_stride, int64_t row_begin, int64_t row_end, DerivedOut out, BlockWork bw, double *__restrict__ blk_div)
-{
-    constexpr int CL = (LDR >= 16 ? 16 : LDR) / 2;
-    const int lane = threadIdx.x % G;
-    const int part = lane % CL, slot = lane / CL;
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    double a[4];
-    for (int64_t k = group; k < bw.n_blocks; k += ngroups) {
-        const int64_t v = bw.long_rows[bw.blk_row[k]];
-        if (v < row_begin || v >= row_end) continue;
-        derived_segment<LDR, G>(col, rows, row_stride, bw.blk_begin[k], bw.blk_len[k], part, slot, a);
-        if (slot == 0) {
-            bw.blk_sums[k * 16 + 2 * part] = a[0];
-            bw.blk_sums[k * 16 + 2 * part + 1] = a[1];
-            blk_div[k * 16 + 2 * part] = a[2];
-            blk_div[k * 16 + 2 * part + 1] = a[3];
-        }
-    }
-    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
-        const int64_t b = row_ptr[v], e = row_ptr[v + 1];
-        const int64_t d = e - b;
-        if (d > PW_BLOCK) continue;
-        derived_segment<LDR, G>(col, rows, row_stride, b, (int)d, part, slot, a);
-        if (slot == 0) {
-            const double cnt = (double)d;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = 2 * part + h;
-                double *ps = out.p[0][c], *pm = out.p[1][c], *qs = out.p[2][c], *qm = out.p[3][c];
-                if (ps) GRX_STREAM_ST(ps[v], a[h]);
-                if (pm) GRX_STREAM_ST(pm[v], (d > 0) ? a[h] / cnt : 0.0);
-                if (qs) GRX_STREAM_ST(qs[v], a[2 + h]);
-                if (qm) GRX_STREAM_ST(qm[v], (d > 0) ? a[2 + h] / cnt : 0.0);
-            }
-        }
-    }
-}
-
-// the long rows of aggregate_derived_kernel: the stack machine of aggregate_combine_kernel over the plain and the
-// divided block sums, outputs through the pointer table
-__global__ __launch_bounds__(256) void aggregate_combine_derived_kernel(
-    const int64_t *__restrict__ row_ptr, int64_t row_begin, int64_t row_end, const int32_t *__restrict__ long_rows,
-    const int64_t *__restrict__ blk_ptr, int64_t n_long, const uint8_t *__restrict__ blk_ops,
-    const double *__restrict__ blk_sums, const double *__restrict__ blk_div, DerivedOut out)
-{
-    __shared__ double stk[16][PW_MAX_DEPTH][16];
-    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int64_t gstride = (int64_t)gridDim.x * 16;
-    for (int64_t h = (int64_t)blockIdx.x * 16 + grp; h < n_long; h += gstride) {
-        const int64_t v = long_rows[h];
-        if (v < row_begin || v >= row_end) continue;
-        const int64_t n = row_ptr[v + 1] - row_ptr[v];
-        for (int which = 0; which < 2; ++which) {
-            double *ds = out.p[2 * which][c], *dm = out.p[2 * which + 1][c];
-            if (__ballot(ds != nullptr || dm != nullptr) == 0) continue;
-            const double *src = which ? blk_div : blk_sums;
-            const int64_t leaf_end = blk_ptr[h + 1];
-            int64_t leaf = blk_ptr[h];
-            double total = 0.0;
-            int sp = 0;
-            while (leaf < leaf_end) {
-                const int m = (int)((leaf_end - leaf) < 16 ? (leaf_end - leaf) : 16);
-                double buf[16];
-                int ops[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    buf[j] = (j < m) ? src[(leaf + j) * 16 + c] : 0.0;
-                    ops[j] = (j < m) ? (int)blk_ops[leaf + j] : 0;
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (j < m) {
-                        double val = buf[j];
-                        for (int k = ops[j] & 0x7F; k > 0; --k) val = stk[grp][--sp][c] + val;
-                        if (ops[j] & 0x80) total += val;
-                        else stk[grp][sp++][c] = val;
-                    }
-                }
-                leaf += m;
-            }
-            if (ds) ds[v] = total;
-            if (dm) dm[v] = total / (double)n;
-        }
-    }
-}
-
 // product over the neighbours (agg 'prod'): np.multiply.reduce is a plain left-to-right product, so
 // one lane per (row, column) multiplies in adjacency order; the empty product is 1.  Not a tuned
 // kernel: the lanes of a row read adjacent doubles of each neighbour row, nothing more.
@@ -2383,95 +2134,6 @@ int grx_aggregate_packed(const grx_aggregate_plan *plan, const int64_t *d_row_pt
         aggregate_combine_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
             d_row_ptr, layout->n_out, row_begin, row_end, plan->d_long_rows, plan->d_blk_ptr, plan->n_long, plan->d_blk_ops,
             plan->d_blk_sums, d_sum, d_mean, ld, 0);
-    }
-    GRX_LAUNCH_CHECK();
-    return GRX_OK;
-}
-
-/* ---- fp64 rows with derived means (aggregate_derived_kernel above) ------------------------------------------- */
-int grx_aggregate_derived_ldr(int n_bases)
-{
-    if (n_bases < 1 || n_bases > 15) return 0;
-    return n_bases + 1 <= 2 ? 2 : n_bases + 1 <= 4 ? 4 : n_bases + 1 <= 8 ? 8 : 16;
-}
-
-int grx_pack_rows_derived(int64_t n, int n_bases, const double *const *h_base_cols, const int64_t *d_row_ptr, double *d_rows,
-                          int ldr, void *stream)
-{
-    GRX_REQUIRE(n >= 0 && ldr == grx_aggregate_derived_ldr(n_bases) && ldr > 0, "grx_pack_rows_derived: n_bases=%d needs ldr=%d",
-                n_bases, grx_aggregate_derived_ldr(n_bases));
-    if (n == 0) return GRX_OK;
-    GRX_REQUIRE(h_base_cols && d_row_ptr && d_rows, "grx_pack_rows_derived: NULL pointer");
-    GrxPtrTable tab{};
-    for (int c = 0; c < n_bases; ++c) {
-        GRX_REQUIRE(h_base_cols[c] != nullptr, "grx_pack_rows_derived: base column %d is NULL", c);
-        tab.p[c] = h_base_cols[c];
-    }
-    hipStream_t st = grx_stream(stream);
-    const int64_t want = grx_ceil_div(n * ldr, 256 * 4);
-    GRX_PROF(GRX_K_PACK_ROWS, st);
-    pack_rows_derived_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : (want < 1 ? 1 : want)), 256, 0, st>>>(
-        n, n_bases, ldr, tab, d_row_ptr, d_rows);
-    GRX_LAUNCH_CHECK();
-    return GRX_OK;
-}
-
-int grx_aggregate_derived(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int n_bases,
-                          const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, const grx_derived_outputs *outputs,
-                          double *d_block_scratch, void *stream)
-{
-    GRX_REQUIRE(plan != nullptr && outputs != nullptr, "grx_aggregate_derived: NULL plan / outputs");
-    GRX_REQUIRE(ldr == grx_aggregate_derived_ldr(n_bases) && ldr > 0, "grx_aggregate_derived: n_bases=%d / ldr=%d", n_bases, ldr);
-    const int64_t n = plan->n;
-    GRX_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_aggregate_derived: bad row range");
-    if (row_end == row_begin) return GRX_OK;
-    GRX_REQUIRE(d_row_ptr && d_col && d_rows, "grx_aggregate_derived: NULL pointer");
-    GRX_REQUIRE((reinterpret_cast<uintptr_t>(d_rows) & 127) == 0, "grx_aggregate_derived: d_rows must be 128-byte aligned");
-    GRX_REQUIRE(plan->n_long == 0 || d_block_scratch != nullptr,
-                "grx_aggregate_derived: the graph has rows of more than 128 neighbours: d_block_scratch (16 doubles per block) is needed");
-    DerivedOut out{};
-    for (int c = 0; c < n_bases; ++c) {
-        out.p[0][c] = outputs->plain_sum[c];
-        out.p[1][c] = outputs->plain_mean[c];
-        out.p[2][c] = outputs->div_sum[c];
-        out.p[3][c] = outputs->div_mean[c];
-    }
-    hipStream_t st = grx_stream(stream);
-    const int CL = ldr / 2;
-    int G = plan->lanes_per_row;
-    if (G < 2 * CL) G = 2 * CL;                              // at most four of the eight accumulators per lane: each is
-    if (G > 8 * CL) G = 8 * CL;                              // four doubles here (192 VGPRs with all eight in one lane)
-    if (G < 4) G = 4;
-    if (G > 32) G = 32;
-    const int64_t want = grx_ceil_div((row_end - row_begin) * G, 256);
-    const int grid = (int)(want < 1 ? 1 : (want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want));
-    const BlockWork bw{plan->d_long_rows, plan->d_blk_begin, plan->d_blk_len, plan->d_blk_row,
-                       plan->n_long > 0 ? plan->n_blocks : 0, plan->d_blk_sums};
-    bool launched = false;
-    {
-        GRX_PROF(GRX_K_AGGREGATE, st);
-#define GRX_DERIVED_CASE(LL, GG)                                                                                      \
-        if (!launched && ldr == LL && G == GG) {                                                                      \
-            if constexpr (GG >= LL / 2 && GG <= 4 * LL && (GG / (LL / 2)) <= 8) {                                     \
-                aggregate_derived_kernel<LL, GG><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_rows, ldr, row_begin, row_end, out, \
-                                                                       bw, d_block_scratch);                          \
-                launched = true;                                                                                      \
-            }                                                                                                         \
-        }
-        GRX_DERIVED_CASE(2, 4) GRX_DERIVED_CASE(2, 8)
-        GRX_DERIVED_CASE(4, 4) GRX_DERIVED_CASE(4, 8) GRX_DERIVED_CASE(4, 16)
-        GRX_DERIVED_CASE(8, 4) GRX_DERIVED_CASE(8, 8) GRX_DERIVED_CASE(8, 16) GRX_DERIVED_CASE(8, 32)
-        GRX_DERIVED_CASE(16, 8) GRX_DERIVED_CASE(16, 16) GRX_DERIVED_CASE(16, 32)
-#undef GRX_DERIVED_CASE
-    }
-    if (!launched) { grx_set_error("grx_aggregate_derived: no kernel for ldr=%d lanes_per_row=%d", ldr, G); return GRX_ERR_UNSUPPORTED; }
-    GRX_LAUNCH_CHECK();
-    if (plan->n_long > 0) {
-        GRX_PROF(GRX_K_AGGREGATE_HUB, st);
-        const int64_t cwant = grx_ceil_div(plan->n_long, 16);
-        aggregate_combine_derived_kernel<<<(unsigned)(cwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : cwant), 256, 0, st>>>(
-            d_row_ptr, row_begin, row_end, plan->d_long_rows, plan->d_blk_ptr, plan->n_long, plan->d_blk_ops, plan->d_blk_sums,
-            d_block_scratch, out);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;

@@ -43,7 +43,6 @@ struct Column {
     int kind = 0;
     int base = -1;
     int bits = -1;            // known after the generation's read-back (-1: not known)
-    int div_base = -1;        // a 'mean' candidate: the 'sum' candidate of the same parent (value = fl(that / d)), else -1
 };
 
 // bump allocator over the caller's arena; keeps counting past the end so that the caller learns how
@@ -363,7 +362,6 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     const bool exact_sum = par.kind == 1 && par.bits >= 1 && par.bits + deg_bits <= 53;
                     if (exact_sum && h_aggs[a] == GRX_AGG_SUM) { child.kind = 1; child.base = first_new + a * f + j; }
                     if (exact_sum && h_aggs[a] == GRX_AGG_MEAN && a_sum >= 0) { child.kind = 2; child.base = first_new + a_sum * f + j; }
-                    if (h_aggs[a] == GRX_AGG_MEAN && a_sum >= 0) child.div_base = first_new + a_sum * f + j;
                     cols.push_back(std::move(child));
                 }
             const size_t mark = arena.top;
@@ -408,38 +406,9 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     packed_bytes = grx_packed_row_bytes(&layout);
                 }
             }
-            // fp64 rows with DERIVED means (grx_aggregate_derived): a parent that is the mean of a column whose sum is
-            // around travels as that sum; the row holds the distinct bases and the neighbour count.  Taken when it
-            // gathers fewer bytes per neighbour than one row of all parents (sharded: a base must be complete here --
-            // generation 0 or retained)
-            std::vector<int> d_bases;                        // distinct base columns, in order of first use
-            std::vector<int> d_slot(f, -1), d_div(f, 0);
-            size_t derived_bytes = 0;
-            if (packed_allowed && !packed_bytes && !int_rows && only_sum_mean) {
-                for (int j = 0; j < f; ++j) {
-                    const Column &par = cols[prev[j]];
-                    int b = prev[j];
-                    if (par.div_base >= 0 && (!comm || cols[par.div_base].generation == 0 || cols[par.div_base].record_index >= 0)) {
-                        b = par.div_base;
-                        d_div[j] = 1;
-                    }
-                    int k = (int)(std::find(d_bases.begin(), d_bases.end(), b) - d_bases.begin());
-                    if (k == (int)d_bases.size()) d_bases.push_back(b);
-                    d_slot[j] = k;
-                }
-                for (size_t s0 = 0; s0 < d_bases.size(); s0 += 15)
-                    derived_bytes += (size_t)grx_aggregate_derived_ldr((int)std::min<size_t>(15, d_bases.size() - s0)) * 8;
-                const size_t plain_bytes = f <= 8 ? (size_t)ldr * 8 : (size_t)((f + 15) / 16) * 128;
-                if (derived_bytes >= plain_bytes) derived_bytes = 0;
-            }
-            int64_t plan_blocks = 0;
-            if (derived_bytes) GRX_TRY(grx_aggregate_plan_info(plan, nullptr, &plan_blocks, nullptr));
-            gather_row_bytes = packed_bytes ? packed_bytes : derived_bytes ? (int)derived_bytes : (int_rows ? ldi * 4 : ldr * 8);
+            gather_row_bytes = packed_bytes ? packed_bytes : (int_rows ? ldi * 4 : ldr * 8);
             double *rows = reinterpret_cast<double *>(arena.take(packed_bytes ? (size_t)n * packed_bytes
-                                                                 : derived_bytes ? (size_t)n * 128
                                                                  : int_rows ? (size_t)n * ldi * 4 : (size_t)n * ldr * 8));
-            double *blk_scratch = derived_bytes ? reinterpret_cast<double *>(arena.take((size_t)(plan_blocks > 0 ? plan_blocks : 1) * 16 * 8))
-                                                : nullptr;
             double *mean_scratch = (need_var && !has[GRX_AGG_MEAN]) ? reinterpret_cast<double *>(arena.take((size_t)f * n * 8))
                                                                     : nullptr;
             const size_t med_bytes = has[GRX_AGG_MEDIAN] ? grx_aggregate_median_workspace_bytes(nnz_rows) : 0;
@@ -457,25 +426,6 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     GRX_TRY(grx_pack_fields(n, &layout, field_cols.data(), d_row_ptr, rows, stream));
                     GRX_TRY(grx_aggregate_packed(plan, d_row_ptr, d_agg_col, &layout, rows, rb, re, out_of(GRX_AGG_SUM), d_mean, n,
                                                  stream));
-                } else if (derived_bytes) {
-                    double *sum_out = out_of(GRX_AGG_SUM);
-                    for (size_t s0 = 0; s0 < d_bases.size(); s0 += 15) {
-                        const int nb = (int)std::min<size_t>(15, d_bases.size() - s0);
-                        const int dl = grx_aggregate_derived_ldr(nb);
-                        std::vector<const double *> bptr(nb);
-                        for (int c = 0; c < nb; ++c) bptr[c] = cols[d_bases[s0 + c]].data;
-                        grx_derived_outputs outs{};
-                        for (int j = 0; j < f; ++j) {
-                            const int c = d_slot[j] - (int)s0;
-                            if (c < 0 || c >= nb) continue;
-                            double *js = sum_out ? sum_out + (size_t)j * n : nullptr;
-                            double *jm = d_mean ? d_mean + (size_t)j * n : nullptr;
-                            if (d_div[j]) { outs.div_sum[c] = js; outs.div_mean[c] = jm; }
-                            else { outs.plain_sum[c] = js; outs.plain_mean[c] = jm; }
-                        }
-                        GRX_TRY(grx_pack_rows_derived(n, nb, bptr.data(), d_row_ptr, rows, dl, stream));
-                        GRX_TRY(grx_aggregate_derived(plan, d_row_ptr, d_agg_col, nb, rows, dl, rb, re, &outs, blk_scratch, stream));
-                    }
                 } else if (int_rows) {
                     int32_t *irows = reinterpret_cast<int32_t *>(rows);
                     GRX_TRY(grx_pack_rows_i32(n, f, ptrs.data(), irows, ldi, stream));

@@ -575,36 +575,6 @@ def aggregate_packed(csr: DeviceCSR, layout, rows: torch.Tensor, row_begin: int 
     return out[:, :n]
 
 
-def aggregate_derived(csr: DeviceCSR, base_cols: Sequence[torch.Tensor], want: Sequence[Tuple[bool, bool, bool, bool]],
-                      row_begin: int = 0, row_end: Optional[int] = None):
-    """Neighbour aggregation with derived means (grx_pack_rows_derived + grx_aggregate_derived): per base column c and
-    want[c] = (plain_sum, plain_mean, div_sum, div_mean) returns a list of four optional fp64[n] tensors -- sums / means
-    over the neighbours of P_c and of fl(P_c / d), bit-identical to aggregate() on the columns themselves."""
-    n, nb = csr.n, len(base_cols)
-    lib = _lib.load()
-    ldr = lib.grx_aggregate_derived_ldr(nb)
-    if not ldr:
-        raise _lib.GrxInvalid(f'aggregate_derived: 1 .. 15 base columns per call, got {nb}')
-    rows = torch.empty(max(n, 1) * ldr, dtype=torch.float64, device=device())
-    _lib.call('grx_pack_rows_derived', n, nb, ptr_array(list(base_cols)), _ptr(csr.row_ptr), _ptr(rows), ldr, _stream())
-    outs = _lib.DerivedOutputs()
-    result = []
-    for c in range(nb):
-        four = []
-        for k, field in enumerate(('plain_sum', 'plain_mean', 'div_sum', 'div_mean')):
-            t = torch.zeros(max(n, 1), dtype=torch.float64, device=device()) if want[c][k] else None
-            if t is not None:
-                getattr(outs, field)[c] = t.data_ptr()
-            four.append(None if t is None else t[:n])
-        result.append(four)
-    n_long, n_blocks = ctypes.c_int64(0), ctypes.c_int64(0)
-    _lib.call('grx_aggregate_plan_info', csr.plan().handle, ctypes.byref(n_long), ctypes.byref(n_blocks), None)
-    scratch = torch.empty(max(n_blocks.value, 1) * 16, dtype=torch.float64, device=device())
-    _lib.call('grx_aggregate_derived', csr.plan().handle, _ptr(csr.row_ptr), _ptr(csr.agg_col), nb, _ptr(rows), ldr, row_begin,
-              n if row_end is None else row_end, ctypes.byref(outs), _ptr(scratch), _stream())
-    return result
-
-
 def convert_i64_to_f64(col: torch.Tensor) -> torch.Tensor:
     """A column of int64 BITS (stored in an fp64 tensor) -> the fp64 values (numpy astype(float64))."""
     out = torch.empty_like(col)

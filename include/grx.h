@@ -391,31 +391,6 @@ int grx_aggregate_prod(const int64_t *d_row_ptr, const int32_t *d_col, int f, co
  * follow a tree that depends on the row length only, so the bits equal those of a one-GPU run.
  */
 /*
- * Neighbour sums / means with DERIVED means (fp64 rows).  From generation 2 on the retained parents mostly come in
- * pairs -- the neighbour sum P of a column and its mean fl(P / d) -- so the gather source carries only the distinct
- * base columns P_k and, in its last slot, the neighbour count d; the kernel forms fl(P_k / d) in registers (the
- * correctly rounded division that produced the stored mean) and accumulates sums of P_k and of fl(P_k / d) side by
- * side in numpy's pairwise order: bit-identical to grx_aggregate on the parents' own columns, with one gather of a row
- * serving up to 15 bases = 30 parents instead of 16 (graphrole/features/extract.py:104-119).
- *   grx_aggregate_derived_ldr   row stride in doubles for n_bases <= 15 base columns (+ 1 slot): 2, 4, 8 or 16
- *   grx_pack_rows_derived       row u = h_base_cols[0..n_bases)[u], zeros, (double)(d_row_ptr[u + 1] - d_row_ptr[u])
- *   grx_aggregate_derived       per base slot c four optional outputs (device columns fp64[n], NULL = not wanted):
- *                               plain_sum = sum of P_c over the neighbours, plain_mean = that / count,
- *                               div_sum = sum of fl(P_c / d) over the neighbours, div_mean = that / count (0 for a
- *                               node without neighbours).  d_block_scratch: 16 doubles per block of the plan
- *                               (grx_aggregate_plan_info), needed when the graph has rows of more than 128 neighbours.
- */
-typedef struct {
-    double *plain_sum[16], *plain_mean[16], *div_sum[16], *div_mean[16];
-} grx_derived_outputs;
-int grx_aggregate_derived_ldr(int n_bases);
-int grx_pack_rows_derived(int64_t n, int n_bases, const double *const *h_base_cols, const int64_t *d_row_ptr, double *d_rows,
-                          int ldr, void *stream);
-int grx_aggregate_derived(const grx_aggregate_plan *plan, const int64_t *d_row_ptr, const int32_t *d_col, int n_bases,
-                          const double *d_rows, int ldr, int64_t row_begin, int64_t row_end, const grx_derived_outputs *outputs,
-                          double *d_block_scratch, void *stream);
-
-/*
  * Neighbour sums / means from BIT-PACKED integer rows.  The gather of grx_aggregate is bound by the chip's request
  * rate, and the share of requests that miss an XCD's L2 follows the BYTES of the gather table (DESIGN.md section 3,
  * profiles/r04_gather_bw.json).  On an unweighted graph every summand of generations 1 and 2
