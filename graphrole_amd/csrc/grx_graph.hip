@@ -147,21 +147,124 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
 constexpr int EGO_SLOTS = 4;                                     // ids per lane
 constexpr int EGO_GROUP_MAX = 8 * EGO_SLOTS;
 
+// Round 5.  What a member a of an ego set contributes needs the ids of row(a), where it begins (weights of matched
+// arcs), its length and its weighted row sum.  Read from the CSR that is two row_ptr entries, rowsum[a] and an
+// unaligned run of ids: 3 - 4 cache-line requests per (v, a) pair, and the REQUEST rate (~50 G/s beyond the caches,
+// profiles/r04_gather_bw.json) is what bounds this kernel.  A streaming pre-pass therefore lays every row out as one
+// aligned 128-byte SLOT -- row sum, begin | min(length, SAT) << 40, the first 28 ids (-1 padded) -- so that a pair
+// costs ONE aligned request that eight lanes read with one 16-byte load each; rows longer than 28 ids continue in the CSR.
+constexpr int EGO_DEG_SHIFT = 40;
+constexpr unsigned long long EGO_BEGIN_MASK = (1ull << EGO_DEG_SHIFT) - 1;
+constexpr unsigned EGO_DEG_SAT = (1u << 24) - 1;                 // longer rows: length from row_ptr
+constexpr int EGO_SLOT_IDS = 28;
+struct __align__(16) EgoSlot {
+    double rs;
+    unsigned long long bd;
+    int32_t ids[EGO_SLOT_IDS];
+};
+static_assert(sizeof(EgoSlot) == 128, "one slot = one 128-byte line");
+
+// slots of all n rows + the rows of [row_begin, row_end) that the wavefront / workgroup kernels own (out-degree
+// above EGO_GROUP_MAX resp. from `hub` on), appended to two lists (their order does not matter: every row's result
+// is computed independently of the others)
+__global__ __launch_bounds__(256) void egonet_prepare_kernel(
+    int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ rowsum,
+    int64_t row_begin, int64_t row_end, int64_t hub, EgoSlot *__restrict__ slots, int32_t *__restrict__ mid_rows,
+    int32_t *__restrict__ hub_rows, unsigned *__restrict__ counts)
+{
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < ((n + 63) & ~(int64_t)63); v += (int64_t)gridDim.x * 256) {
+        const int64_t d = v < n ? row_ptr[v + 1] - row_ptr[v] : 0;
+        const bool owned = v >= row_begin && v < row_end;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const bool take = owned && (which == 0 ? (d > EGO_GROUP_MAX && d < hub) : d >= hub);
+            const unsigned long long bal = __ballot(take);
+            if (bal) {
+                const int lane = threadIdx.x & 63;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&counts[which], (unsigned)__popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (take) (which == 0 ? mid_rows : hub_rows)[base + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)v;
+            }
+        }
+    }
+    // one thread per 4-byte word of a slot: 32 consecutive threads write one line
+    uint32_t *words = reinterpret_cast<uint32_t *>(slots);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n * 32; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx >> 5;
+        const int wi = (int)(idx & 31);
+        const int64_t b = row_ptr[r];
+        const int64_t d = row_ptr[r + 1] - b;
+        uint32_t word;
+        if (wi < 2) {
+            const double rs = rowsum ? rowsum[r] : (double)d;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(rs);
+            word = wi == 0 ? (uint32_t)bits : (uint32_t)(bits >> 32);
+        } else if (wi < 4) {
+            const unsigned long long bd =
+                (unsigned long long)b | ((unsigned long long)(d < (int64_t)EGO_DEG_SAT ? d : (int64_t)EGO_DEG_SAT) << EGO_DEG_SHIFT);
+            word = wi == 2 ? (uint32_t)bd : (uint32_t)(bd >> 32);
+        } else {
+            const int k = wi - 4;
+            word = k < d ? (uint32_t)col[b + k] : 0xffffffffu;
+        }
+        words[idx] = word;
+    }
+}
+
+// membership of the eight ids b (one per lane of the group, -1 = none) in ego(v) = {v} U {uu[0..3] of the group's
+// lanes}: a 1024-bit filter of the ego ids in the group's LDS slice decides whether the exact all-pairs shuffle
+// compare has to run at all -- with at most 33 bits set most chunks end after one LDS read and a ballot
+__device__ __forceinline__ bool ego_chunk_inside(int32_t b, int32_t v, const int32_t (&uu)[EGO_SLOTS],
+                                                 const unsigned long long *flt, int gshift, int lane)
+{
+    constexpr int G = 8;
+    const bool live = b >= 0;
+    const bool maybe = live && ((flt[(b >> 6) & 15] >> (b & 63)) & 1ull);
+    unsigned match = 0;
+    if ((__ballot(maybe) >> gshift) & 0xFFull) {                // uniform over the group
+#pragma unroll
+        for (int sidx = 0; sidx < G; ++sidx) {
+            const int32_t bs = __shfl(b, sidx, G);
+            const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
+            if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
+        }
+    }
+    return live && (((match >> lane) & 1u) || b == v);
+}
+
+// Nodes with at most EGO_GROUP_MAX out-neighbours: eight lanes per node.  Per member a of ego(v) the group reads the
+// slot of a with one 16-byte load per lane (lane 0: row sum, begin | length; lanes 1 - 7: four ids each) and tests
+// the ids for membership; WEIGHTS are read for the MATCHED arcs only (the first version scanned ids + 8-byte weights
+// of every member row from the CSR: 25-50x the compulsory traffic, profiles/r05_dw5m_pmc.json):
+//     internal += w(a -> b)                       for b in ego(v)   (undirected: b >= a, every edge once)
+//     external += rowsum(a)                       no arc of row(a) ends in ego(v)       -- no subtraction
+//              += 0                               every arc does                         -- exactly 0
+//              += rowsum(a) - matched weight      otherwise, unless that difference lost more than six bits to
+//                                                 cancellation: then the unmatched weights are added one by one
+// The members are taken BATCH at a time: the slots of a whole batch are requested before the first is looked at.
+// The external shares are added by lane 0 in member order, the rest are per-lane sequential sums and a fixed
+// butterfly: bitwise reproducible, independent of the launch geometry.
+template <int BATCH>
 __global__ __launch_bounds__(256) void egonet_group_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ w, const double *__restrict__ rowsum, int directed,
+    const double *__restrict__ w, const EgoSlot *__restrict__ slots, int directed,
     int64_t row_begin, int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
 {
     constexpr int G = 8;
     __shared__ unsigned long long ego_filter[256 / G][16];
+    __shared__ int32_t ego_id[256 / G][EGO_GROUP_MAX];
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    unsigned long long *flt = ego_filter[threadIdx.x / G];
+    int32_t *mid = ego_id[threadIdx.x / G];
+    const int4 *slot16 = reinterpret_cast<const int4 *>(slots);
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
-        const int64_t dv = ve - vb;
-        if (dv > EGO_GROUP_MAX) continue;                       // uniform over the group
+        const int dv = (int)(ve - vb);
+        if (ve - vb > EGO_GROUP_MAX) continue;                  // uniform over the group
         int32_t uu[EGO_SLOTS];
 #pragma unroll
         for (int i = 0; i < EGO_SLOTS; ++i) {
@@ -170,13 +273,10 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
         }
         const bool mine_v = (uu[0] == (int32_t)v) | (uu[1] == (int32_t)v) | (uu[2] == (int32_t)v) | (uu[3] == (int32_t)v);
         const bool v_in_row = ((__ballot(mine_v) >> gshift) & 0xFFull) != 0;
-        const int members = (int)dv + (v_in_row ? 0 : 1);
-        // 1024-bit membership filter of ego(v) (one bit per id & 1023) in the group's LDS slice: an arc target is
-        // compared against the ego ids only when its bit is set -- with at most 33 bits set most 8-arc chunks of a
-        // member's row end after one LDS read, a bit test and a ballot (all outside) instead of the all-pairs
-        // shuffle compare
-        unsigned long long *flt = ego_filter[threadIdx.x / G];
         __builtin_amdgcn_wave_barrier();                       // the previous node's readers are done
+#pragma unroll
+        for (int i = 0; i < EGO_SLOTS; ++i)
+            if (uu[i] >= 0) mid[lane + G * i] = uu[i];
         flt[lane] = 0ull;
         flt[lane + G] = 0ull;
         __builtin_amdgcn_wave_barrier();
@@ -187,66 +287,101 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
         }
         __builtin_amdgcn_wave_barrier();
         double ins = 0.0, ext = 0.0;
-        for (int m = 0; m < members; ++m) {
-            int32_t a;
-            if (m < dv) {
-                const int slot = m / G;
-                a = __shfl(slot == 0 ? uu[0] : slot == 1 ? uu[1] : slot == 2 ? uu[2] : uu[3], m % G, G);
-            } else {
-                a = (int32_t)v;
+        // member v itself: every arc of row(v) ends in ego(v)
+#pragma unroll
+        for (int i = 0; i < EGO_SLOTS; ++i)
+            if (uu[i] >= 0 && (directed || uu[i] >= (int32_t)v)) ins += w ? w[vb + lane + (int64_t)G * i] : 1.0;
+
+        for (int mb = 0; mb < dv; mb += BATCH) {
+            int4 q[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                q[k] = make_int4(-1, -1, -1, -1);
+                if (mb + k < dv) {
+                    const int32_t a = mid[mb + k];
+                    if (a != (int32_t)v) q[k] = slot16[(int64_t)a * G + lane];
+                }
             }
-            const int64_t ab = row_ptr[a], ae = row_ptr[a + 1];
-            const int64_t da = ae - ab;
-            if (da <= (int64_t)EGO_SLOTS * G * (ilog2_i64(da) + 2)) {
-                // scan row(a) in chunks of eight arcs
-                for (int64_t j0 = ab; j0 < ae; j0 += G) {
-                    const bool live = j0 + lane < ae;
-                    const int32_t b = live ? col[j0 + lane] : -1;
-                    const double x = live ? (w ? w[j0 + lane] : 1.0) : 0.0;
-                    unsigned match = 0;
-                    const bool maybe = live && ((flt[(b >> 6) & 15] >> (b & 63)) & 1ull);
-                    if ((__ballot(maybe) >> gshift) & 0xFFull) {        // uniform over the group
 #pragma unroll
-                        for (int sidx = 0; sidx < G; ++sidx) {
-                            const int32_t bs = __shfl(b, sidx, G);
-                            const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
-                            if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
-                        }
-                    }
-                    if (live) {
-                        const bool inside = ((match >> lane) & 1u) || b == (int32_t)v;
+            for (int k = 0; k < BATCH; ++k) {
+                const int m = mb + k;
+                if (m >= dv) break;
+                const int32_t a = mid[m];
+                if (a == (int32_t)v) continue;                  // a self-loop: row(v) is counted above
+                // lane 0 of the group holds the header of the slot
+                const unsigned rs_lo = (unsigned)__shfl(q[k].x, 0, G), rs_hi = (unsigned)__shfl(q[k].y, 0, G);
+                const unsigned bd_lo = (unsigned)__shfl(q[k].z, 0, G), bd_hi = (unsigned)__shfl(q[k].w, 0, G);
+                const double rs = __longlong_as_double((long long)(((unsigned long long)rs_hi << 32) | rs_lo));
+                const unsigned long long bd = ((unsigned long long)bd_hi << 32) | bd_lo;
+                const int64_t ab = (int64_t)(bd & EGO_BEGIN_MASK);
+                int64_t da = (int64_t)(bd >> EGO_DEG_SHIFT);
+                if (da == (int64_t)EGO_DEG_SAT) da = row_ptr[a + 1] - ab;
+                if (da == 0) continue;
+                const int64_t ae = ab + da;
+                if (da <= (int64_t)EGO_SLOTS * G * (ilog2_i64(da) + 2)) {
+                    int cnt = 0;
+                    double msum = 0.0;
+                    auto chunk = [&](int32_t b, int64_t j) {
+                        const bool inside = ego_chunk_inside(b, (int32_t)v, uu, flt, gshift, lane);
+                        cnt += __popcll((__ballot(inside) >> gshift) & 0xFFull);
                         if (inside) {
+                            const double x = w ? w[j] : 1.0;
+                            msum += x;
                             if (directed || b >= a) ins += x;
+                        }
+                    };
+                    // ids 4 (lane - 1) .. 4 (lane - 1) + 3 of the row sit in this lane's quarter of the slot
+                    const int64_t j4 = ab + 4 * (lane - 1);
+                    chunk(lane ? q[k].x : -1, j4);
+                    if (da > 1) chunk(lane ? q[k].y : -1, j4 + 1);
+                    if (da > 2) chunk(lane ? q[k].z : -1, j4 + 2);
+                    if (da > 3) chunk(lane ? q[k].w : -1, j4 + 3);
+                    for (int64_t j0 = ab + EGO_SLOT_IDS; j0 < ae; j0 += G)
+                        chunk(j0 + lane < ae ? col[j0 + lane] : -1, j0 + lane);
+                    if (cnt == 0) {
+                        if (lane == 0) ext += rs;
+                    } else if (cnt != da) {
+#pragma unroll
+                        for (int off = 1; off < G; off <<= 1) msum += __shfl_xor(msum, off, G);
+                        const double e = rs - msum;
+                        if (e * 64.0 >= rs) {
+                            if (lane == 0) ext += e;
                         } else {
-                            ext += x;
+                            // nearly closed row: the difference would carry the rounding of the two sums; add the arcs
+                            // that leave the ego set one by one instead
+                            for (int64_t j0 = ab; j0 < ae; j0 += G) {
+                                const int32_t b = j0 + lane < ae ? col[j0 + lane] : -1;
+                                const bool inside = ego_chunk_inside(b, (int32_t)v, uu, flt, gshift, lane);
+                                if (b >= 0 && !inside) ext += w ? w[j0 + lane] : 1.0;
+                            }
                         }
                     }
-                }
-            } else {
-                // long row (a hub): look the ego members up in it
-                int matched = 0;
-                double in_all = 0.0;
+                } else {
+                    // long row (a hub): look the ego members up in it
+                    int matched = 0;
+                    double in_all = 0.0;
 #pragma unroll
-                for (int i = 0; i <= EGO_SLOTS; ++i) {
-                    int32_t key = -2;
-                    if (i < EGO_SLOTS) key = uu[i < EGO_SLOTS ? i : 0];
-                    else if (lane == 0 && !v_in_row) key = (int32_t)v;
-                    if (key >= 0) {
-                        const int64_t pos = lower_bound_row(col, ab, ae, key);
-                        if (pos < ae && col[pos] == key) {
-                            const double x = w ? w[pos] : 1.0;
-                            ++matched;
-                            in_all += x;
-                            if (directed || key >= a) ins += x;
+                    for (int i = 0; i <= EGO_SLOTS; ++i) {
+                        int32_t key = -2;
+                        if (i < EGO_SLOTS) key = uu[i < EGO_SLOTS ? i : 0];
+                        else if (lane == 0 && !v_in_row) key = (int32_t)v;
+                        if (key >= 0) {
+                            const int64_t pos = lower_bound_row(col, ab, ae, key);
+                            if (pos < ae && col[pos] == key) {
+                                const double x = w ? w[pos] : 1.0;
+                                ++matched;
+                                in_all += x;
+                                if (directed || key >= a) ins += x;
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int off = 1; off < G; off <<= 1) {
-                    matched += __shfl_xor(matched, off, G);
-                    in_all += __shfl_xor(in_all, off, G);
+                    for (int off = 1; off < G; off <<= 1) {
+                        matched += __shfl_xor(matched, off, G);
+                        in_all += __shfl_xor(in_all, off, G);
+                    }
+                    if (lane == 0 && matched != da) ext += rs - in_all;
                 }
-                if (lane == 0 && matched != da) ext += (w ? rowsum[a] : (double)da) - in_all;
             }
         }
 #pragma unroll
@@ -262,9 +397,11 @@ template <int TPN>
 __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ w, const double *__restrict__ rowsum, int directed,
-    int64_t row_begin, int64_t row_end, int64_t deg_lo, int64_t deg_hi,
+    const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
     double *__restrict__ internal, double *__restrict__ external)
 {
+    // rows: the nodes of this kernel's degree class (egonet_prepare_kernel; round 5 -- every team of TPN threads used
+    // to walk ALL rows and skip the foreign ones: 2.3 ms per pass at 5 M rows for a few thousand owned ones)
     constexpr int BLOCK = (TPN == 64) ? 256 : TPN;
     constexpr int NODES_PER_BLOCK = BLOCK / TPN;
     constexpr int WAVES = TPN / 64;
@@ -272,11 +409,12 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
     const int lane = threadIdx.x % TPN;
     const int64_t slot = (int64_t)blockIdx.x * NODES_PER_BLOCK + threadIdx.x / TPN;
     const int64_t nslots = (int64_t)gridDim.x * NODES_PER_BLOCK;
+    const int64_t count = (int64_t)n_rows[0];
 
-    for (int64_t v = row_begin + slot; v < row_end; v += nslots) {
+    for (int64_t idx = slot; idx < count; idx += nslots) {
+        const int64_t v = rows[idx];
         const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
         const int64_t dv = ve - vb;
-        if (dv < deg_lo || dv >= deg_hi) continue;          // uniform over the TPN threads
         const bool v_in_row = find_in_row(col, vb, ve, (int32_t)v) >= 0;
         const int64_t members = dv + (v_in_row ? 0 : 1);
         const int lg_dv = ilog2_i64(members) + 2;
@@ -1720,10 +1858,16 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
     return GRX_OK;
 }
 
+size_t grx_egonet_workspace_bytes(int64_t n)
+{
+    const size_t rows = (size_t)((n > 0 ? n : 0) + 64);
+    return rows * sizeof(EgoSlot) + 2 * rows * sizeof(int32_t) + 256;
+}
+
 int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
                         const double *d_w, const double *d_rowsum, int directed,
                         int64_t row_begin, int64_t row_end, double *d_internal,
-                        double *d_external, void *stream)
+                        double *d_external, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n,
                 "grx_egonet_features: bad row range");
@@ -1731,30 +1875,52 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     GRX_REQUIRE(d_row_ptr && d_col && d_internal && d_external, "grx_egonet_features: NULL pointer");
     GRX_REQUIRE(d_w == nullptr || d_rowsum != nullptr,
                 "grx_egonet_features: weighted graphs need d_rowsum (grx_row_sums, add_self_loop=0)");
+    GRX_REQUIRE(d_workspace != nullptr && workspace_bytes >= grx_egonet_workspace_bytes(n),
+                "grx_egonet_features: workspace too small (grx_egonet_workspace_bytes)");
+    GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_egonet_features: more than 2^31 - 1 nodes");
+    hipStream_t st = grx_stream(stream);
     const int64_t nrows = row_end - row_begin;
-    constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup above this
+    constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup from this out-degree on
+    // workspace: row slots | counters (256 bytes) | rows of the wavefront kernel | rows of the workgroup kernel
+    const size_t rows_cap = (size_t)(n + 64);
+    EgoSlot *slots = reinterpret_cast<EgoSlot *>(d_workspace);
+    unsigned *counts = reinterpret_cast<unsigned *>(slots + rows_cap);
+    int32_t *mid_rows = reinterpret_cast<int32_t *>(counts + 64);
+    int32_t *hub_rows = mid_rows + rows_cap;
+    GRX_CHECK_HIP(hipMemsetAsync(counts, 0, 256, st));
     {
+        const int64_t want = grx_ceil_div(n * 32, 256);
+        GRX_PROF(GRX_K_EGONET_WAVE, st);
+        egonet_prepare_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want), 256, 0, st>>>(
+            n, d_row_ptr, d_col, d_w ? d_rowsum : nullptr, row_begin, row_end, HUB, slots, mid_rows, hub_rows, counts);
+        GRX_LAUNCH_CHECK();
         // nodes with at most EGO_GROUP_MAX neighbours: eight lanes each; the rest: a wavefront each
         const int64_t gwant = grx_ceil_div(nrows * 8, 256);
         const int ggrid = (int)(gwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : gwant);
-        const int64_t want = grx_ceil_div(nrows, 4);
-        const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
-        { GRX_PROF(GRX_K_EGONET_WAVE, grx_stream(stream));
-        egonet_group_kernel<<<ggrid, 256, 0, grx_stream(stream)>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin,
-                                                                  row_end, d_internal, d_external);
-        egonet_kernel<64><<<grid, 256, 0, grx_stream(stream)>>>(
-            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, EGO_GROUP_MAX + 1, HUB, d_internal,
-            d_external);
+        // tuning switch (A/B runs only): GRX_EGO_VARIANT = members per batch
+        static const int variant = [] { const char *e = std::getenv("GRX_EGO_VARIANT"); return e ? std::atoi(e) : 0; }();
+#define GRX_EGO_LAUNCH(B)                                                                                                 \
+        egonet_group_kernel<B><<<ggrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end,         \
+                                                      d_internal, d_external)
+        switch (variant) {
+        case 1: GRX_EGO_LAUNCH(1); break;
+        case 2: GRX_EGO_LAUNCH(2); break;
+        case 8: GRX_EGO_LAUNCH(8); break;
+        default: GRX_EGO_LAUNCH(4); break;
         }
+#undef GRX_EGO_LAUNCH
+        GRX_LAUNCH_CHECK();
+        const int64_t want4 = grx_ceil_div(nrows, 4);
+        const int grid = (int)(want4 > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want4);
+        egonet_kernel<64><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, mid_rows, counts + 0, d_internal,
+                                               d_external);
         GRX_LAUNCH_CHECK();
     }
     {
         const int grid = (int)(nrows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : nrows);
-        { GRX_PROF(GRX_K_EGONET_BLOCK, grx_stream(stream));
-        egonet_kernel<512><<<grid, 512, 0, grx_stream(stream)>>>(
-            d_row_ptr, d_col, d_w, d_rowsum, directed, row_begin, row_end, HUB,
-            (int64_t)1 << 62, d_internal, d_external);
-        }
+        GRX_PROF(GRX_K_EGONET_BLOCK, st);
+        egonet_kernel<512><<<grid, 512, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, hub_rows, counts + 1, d_internal,
+                                                d_external);
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;

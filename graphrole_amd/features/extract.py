@@ -13,6 +13,7 @@ Per generation (device kernels in graphrole_amd/csrc, host decisions in features
 """
 from __future__ import annotations
 
+import time
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
@@ -124,6 +125,11 @@ class RecursiveFeatureExtractor:
         self._native_loop = kwargs_native
         #: per-generation statistics (candidates, retained, widths) for benchmarks
         self.stats: List[Dict] = []
+        #: wall-clock breakdown of the last extract_features() call (seconds): device run, permutation, download,
+        #: DataFrame construction, hand-off hashes.  Set ``time_phases = True`` to have the device synchronised
+        #: between the phases (otherwise the asynchronous kernels are charged to the download that waits for them)
+        self.wall: Dict[str, float] = {}
+        self.time_phases = False
 
     # ------------------------------------------------------------------ plumbing
     def _K(self):
@@ -169,9 +175,19 @@ class RecursiveFeatureExtractor:
         Perform recursive feature extraction to return DataFrame of features
         """
         # return already calculated features if stored in state (extract.py:70-71)
+        self.wall = {}
         if not self._final_names:
+            t0 = time.perf_counter()
             self.run_on_device()
+            self._phase_sync()
+            self.wall['device_run_s'] = time.perf_counter() - t0
         return self._finalize_features()
+
+    def _phase_sync(self) -> None:
+        if self.time_phases:
+            sync = getattr(self._K(), 'synchronize', None)
+            if sync is not None:
+                sync()
 
     def run_on_device(self) -> None:
         """
@@ -612,8 +628,12 @@ class RecursiveFeatureExtractor:
         if not names:
             return pd.DataFrame(index=labels)
         names = list(names)
+        t0 = time.perf_counter()
         dev_block = K.permute_columns(list(cols), self._inv_device(), n)                  # [F, n], label order
+        self._phase_sync()
+        t1 = time.perf_counter()
         block = K.to_host(dev_block)
+        t2 = time.perf_counter()
         # one frame per run of equally typed columns, each wrapping its rows of the block (integer runs -- generation 0
         # of unweighted graphs -- as int64 copies), joined without copying: assigning the integer columns one by one
         # into a single float frame cost a block split per column
@@ -632,9 +652,13 @@ class RecursiveFeatureExtractor:
             parts.append(pd.DataFrame(values.T, index=labels, columns=names[a:b], copy=False))
             a = b
         frame = parts[0] if len(parts) == 1 else pd.concat(parts, axis=1, copy=False)
+        t3 = time.perf_counter()
         if handoff and hasattr(K, 'host_checksums') and not (self._i64 & set(names)):
             from graphrole_amd.features import handoff as _handoff
             _handoff.register(K, frame, dev_block)
+        if handoff:
+            self.wall.update(permute_s=t1 - t0, download_s=t2 - t1, frame_s=t3 - t2,
+                             handoff_hash_s=time.perf_counter() - t3, table_bytes=int(block.nbytes))
         return frame
 
     def _inv_device(self):

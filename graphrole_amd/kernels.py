@@ -130,6 +130,11 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     return view.numpy().reshape(tuple(t.shape)).copy()
 
 
+def synchronize() -> None:
+    """Wait for the current HIP stream (phase timing of the API calls)."""
+    torch.cuda.current_stream().synchronize()
+
+
 def empty(shape, dtype=torch.float64) -> torch.Tensor:
     return torch.empty(shape, dtype=dtype, device=device())
 
@@ -367,6 +372,13 @@ def add_columns(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _egonet_call(csr: 'DeviceCSR', directed: bool, rowsum, row_begin: int, row_end: int, internal, external) -> None:
+    ws_bytes = int(_lib.load().grx_egonet_workspace_bytes(csr.n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
+    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
+              int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _ptr(ws), ws_bytes, _stream())
+
+
 def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tensor] = None,
                     row_begin: int = 0, row_end: Optional[int] = None, shard=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """
@@ -387,8 +399,7 @@ def egonet_features(csr: DeviceCSR, directed: bool, rowsum: Optional[torch.Tenso
     external = zeros(csr.n, dtype=torch.float64)
     if csr.w is not None and rowsum is None:
         rowsum = row_sums(csr, False)
-    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
-              int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _stream())
+    _egonet_call(csr, directed, rowsum, row_begin, row_end, internal, external)
     return internal, external
 
 
@@ -424,8 +435,7 @@ def egonet_features_general(csr: DeviceCSR, directed: bool, rowsum: Optional[tor
     external = zeros(csr.n, dtype=torch.float64)
     if csr.w is not None and rowsum is None:
         rowsum = row_sums(csr, False)
-    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
-              int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _stream())
+    _egonet_call(csr, directed, rowsum, row_begin, row_end, internal, external)
     return internal, external
 
 

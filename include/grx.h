@@ -32,9 +32,7 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 400          /* 0.4.0: + grx_role_argmax / grx_row_normalise (RolX roles / role_percentage), bit-packed gather rows
-                                    (grx_column_bits / grx_pack_fields / grx_aggregate_packed), grx_host_whiten_for_rank,
-                                    grx_refex_generation.gather_row_bytes */
+#define GRX_VERSION 500          /* 0.5.0: grx_egonet_features takes a workspace (grx_egonet_workspace_bytes) */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
                                     a composed update (several times the traffic), then with n_roles + features <= 480 */
@@ -225,11 +223,17 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
  * once; directed: every arc); external[v] = weight of edges leaving ego(v).
  * d_rowsum: plain weighted row sums of the same CSR (grx_row_sums with add_self_loop = 0, all n
  * rows); required when d_w != NULL, ignored otherwise.
+ * d_workspace: grx_egonet_workspace_bytes(n) bytes of device scratch (round 5: one aligned 128-byte slot per node --
+ * its row sum, where its row begins, how long it is and its first 28 ids -- so that a member of an ego set costs one
+ * aligned request instead of three or four, and the lists of the rows the wavefront / workgroup kernels own).
+ * Weights are read for the arcs that END inside the ego set only; what leaves it is rowsum(a) minus that, exactly 0
+ * for a closed row, and added arc by arc when the difference would cancel more than six bits.
  */
+size_t grx_egonet_workspace_bytes(int64_t n);
 int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
                         const double *d_w, const double *d_rowsum, int directed,
                         int64_t row_begin, int64_t row_end, double *d_internal,
-                        double *d_external, void *stream);
+                        double *d_external, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Fast path of the same ego-net features for UNWEIGHTED UNDIRECTED graphs (BASELINE configs

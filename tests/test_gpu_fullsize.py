@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 
 
@@ -136,14 +138,14 @@ def test_config5_like_directed_weighted_attributes_matches_oracle():
     assert list(X.columns) == ref.columns and fe.generation_count == ref.generation_count
     for gen, tr in enumerate(ref.trace):
         assert fe._final_names[gen] == tr.retained
-    np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=util.WEIGHTED_RTOL, atol=0)
 
 
 @pytest.mark.skipif(os.environ.get('GRX_SKIP_CONFIG5') == '1', reason='GRX_SKIP_CONFIG5=1')
 def test_config5_full_size_matches_oracle():
     """BASELINE config 5 at its real size on one GPU: directed, weighted, 5 M nodes / 100 M arcs, 8 numeric
     node attributes, attributes=True, max_generations=4 -- ReFeX against the oracle's C port (retained lists
-    exact, values 1e-11: weighted generation-0 sums run in another order than networkx's),
+    exact, values util.WEIGHTED_RTOL (1e-11): weighted generation-0 sums run in another order than networkx's),
     then the RolX NMF of the resulting wide table (n_roles = 6) against oracle.rolx.nmf
     (graphrole/features/extract.py:65-89, graphrole/roles/factor.py:10-26)."""
     from graphrole_amd import RecursiveFeatureExtractor, synth
@@ -159,7 +161,7 @@ def test_config5_full_size_matches_oracle():
     for gen, tr in enumerate(ref.trace):
         assert fe._final_names[gen] == tr.retained
     Xv = X.values.astype(float)
-    np.testing.assert_allclose(Xv, ref.values, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(Xv, ref.values, rtol=util.WEIGHTED_RTOL, atol=0)
     del fe, og, ref
     assert Xv.shape[1] > 64                      # the wide-table NMF path (F above the 64-column fast path)
     np.random.seed(0)

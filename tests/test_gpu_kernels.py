@@ -97,6 +97,84 @@ def test_egonet_hub_rows_powerlaw(K):
     assert np.all(i2.cpu().numpy()[:1000] == 0) and np.all(e2.cpu().numpy()[17000:] == 0)
 
 
+def _clique_graph(seed, directed, leak):
+    """Disjoint cliques of 3 .. 31 nodes (every ego-net closed: external exactly 0) with weights over twelve decades;
+    `leak` adds a few arcs of tiny weight between cliques -- rows whose boundary weight is 1e-13 of their row sum, the
+    case in which rowsum - matched would be rounding noise and the kernel has to add the leaving arcs one by one."""
+    rng = np.random.default_rng(seed)
+    src, dst, w = [], [], []
+    start, firsts = 0, []
+    for k in list(rng.integers(3, 32, size=60)) + [2, 2, 33, 40]:
+        ids = np.arange(start, start + k)
+        firsts.append((start, int(k)))
+        a, b = np.meshgrid(ids, ids, indexing='ij')
+        keep = (a != b) if directed else (a < b)
+        src.append(a[keep]); dst.append(b[keep])
+        w.append(10.0 ** rng.uniform(-6, 6, size=int(keep.sum())))
+        start += k
+    n = start
+    src, dst, w = np.concatenate(src), np.concatenate(dst), np.concatenate(w)
+    if leak:
+        ls = np.array([firsts[i][0] for i in range(0, 40, 2)])
+        ld = np.array([firsts[i + 1][0] + 1 for i in range(0, 40, 2)])
+        src, dst = np.concatenate([src, ls]), np.concatenate([dst, ld])
+        w = np.concatenate([w, np.full(len(ls), 1e-7)])
+    return n, src, dst, w
+
+
+@pytest.mark.parametrize('directed', [False, True])
+@pytest.mark.parametrize('leak', [False, True])
+def test_egonet_closed_rows_and_wide_weight_range(K, directed, leak):
+    """Round 5: the ego-net kernel reads weights for MATCHED arcs only and takes what leaves the ego set as
+    rowsum - matched; closed rows must give exactly 0, and nearly closed rows must not lose their digits."""
+    from oracle import refex
+    n, src, dst, w = _clique_graph(11 + directed, directed, leak)
+    og = _oracle_graph(n, src, dst, w, directed)
+    csr = _dev_csr(K, og)
+    ego = refex.egonet_features_c(og)
+    internal, external = K.egonet_features(csr, directed)
+    np.testing.assert_allclose(internal.cpu().numpy(), ego['internal_edges'], rtol=RTOL, atol=0)
+    got = external.cpu().numpy()
+    assert np.array_equal(got == 0, ego['external_edges'] == 0)
+    np.testing.assert_allclose(got, ego['external_edges'], rtol=util.WEIGHTED_RTOL, atol=0)
+    if not leak:
+        assert not got.any()
+    # row ranges reproduce the full result bit for bit (no dependence on the launch geometry)
+    i2, e2 = K.egonet_features(csr, directed, row_begin=n // 3, row_end=n - 7)
+    assert np.array_equal(i2.cpu().numpy()[n // 3:n - 7], internal.cpu().numpy()[n // 3:n - 7])
+    assert np.array_equal(e2.cpu().numpy()[n // 3:n - 7], got[n // 3:n - 7])
+
+
+def test_egonet_member_rows_of_every_length(K):
+    """Directed weighted graph whose member rows span 0 .. 700 arcs: the prefetched four chunks, the chunk loop
+    beyond them, the binary-search branch for hub members, and the wavefront / workgroup kernels for long ego sets
+    (their rows come from the lists of egonet_prepare_kernel)."""
+    from oracle import refex
+    rng = np.random.default_rng(5)
+    n = 4000
+    deg = np.concatenate([np.arange(0, 80), rng.integers(0, 40, size=n - 80 - 6), [300, 511, 512, 513, 600, 700]])
+    src = np.repeat(np.arange(n), deg)
+    dst = np.concatenate([rng.choice(n, size=int(d), replace=False) for d in deg]) if deg.sum() else np.zeros(0, int)
+    # make the hubs popular members, and close a few triangles
+    extra_s = rng.integers(0, n, size=3000)
+    extra_d = rng.choice(np.arange(n - 6, n), size=3000)
+    key = np.unique(np.concatenate([src * n + dst, extra_s * n + extra_d]))
+    src, dst = key // n, key % n
+    w = rng.uniform(0.1, 5.0, size=len(src))
+    og = _oracle_graph(n, src, dst, w, True)
+    csr = _dev_csr(K, og)
+    ego = refex.egonet_features_c(og)
+    internal, external = K.egonet_features(csr, True)
+    np.testing.assert_allclose(internal.cpu().numpy(), ego['internal_edges'], rtol=RTOL, atol=0)
+    np.testing.assert_allclose(external.cpu().numpy(), ego['external_edges'], rtol=util.WEIGHTED_RTOL, atol=0)
+    # the same rows without weights: exact integers
+    og1 = _oracle_graph(n, src, dst, None, True)
+    ego1 = refex.egonet_features_c(og1)
+    i1, e1 = K.egonet_features(_dev_csr(K, og1), True)
+    assert np.array_equal(i1.cpu().numpy(), ego1['internal_edges'])
+    assert np.array_equal(e1.cpu().numpy(), ego1['external_edges'])
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 4099, 100003])
 def test_pack_rows_of_64_bytes(K, n):
     """5 - 8 columns become rows of 8 doubles (pack_rows8_kernel: 64 rows x 8 columns through the wave's LDS slice):

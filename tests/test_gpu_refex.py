@@ -6,7 +6,7 @@ test_interface.py) restated against the drop-in classes.
 
 Tolerances: column lists, retained sets per generation, dtypes, index order: exact.
 Values: BIT-EXACT for unweighted graphs (the neighbour sums follow numpy's pairwise tree in
-adjacency order, like the reference's Series.sum()); rtol 1e-12 for weighted graphs, whose
+adjacency order, like the reference's Series.sum()); rtol util.WEIGHTED_RTOL (1e-11) for weighted graphs, whose
 generation-0 columns the reference sums with Python's sum() over ego-graph edge views.
 """
 import networkx as nx
@@ -18,7 +18,7 @@ from tests import graphs, util
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-12
+RTOL = util.WEIGHTED_RTOL        # one tolerance for weighted graphs, defined once (tests/util.py)
 
 
 def _check_values(actual, expected, weighted):
@@ -128,7 +128,7 @@ def test_csr_graph_input_equals_networkx_input():
     pd.testing.assert_frame_equal(X1, X2, check_exact=True)
     # without an explicit adjacency the sums run in order of appearance: same table up to re-association
     X3 = RecursiveFeatureExtractor(CSRGraph(int(g['n']), g['src'], g['dst'])).extract_features()
-    pd.testing.assert_frame_equal(X1, X3, rtol=1e-12)
+    pd.testing.assert_frame_equal(X1, X3, rtol=RTOL)
     # weighted + directed + attributes through arrays
     g = util.load_refex('dw200_attrs')
     G, kwargs = _graph_for('dw200_attrs', g)
@@ -378,7 +378,7 @@ class TestPrunerLikeReference:
 
 
 def test_large_powerlaw_matches_oracle_and_is_reproducible():
-    """50k-node power-law graph: full pipeline vs the C oracle (retained sets exact, values 1e-12)."""
+    """50k-node power-law graph: full pipeline vs the C oracle (retained sets exact, values util.WEIGHTED_RTOL)."""
     from graphrole_amd import RecursiveFeatureExtractor
     from graphrole_amd.graph import CSRGraph
     from oracle import refex
@@ -414,7 +414,7 @@ _FUZZ = [dict(n=n, m=m, seed=seed, directed=d, weighted=w, self_loops=sl)
 def test_random_graphs_match_oracle(spec, aggs):
     """Whole pipeline on random graphs of every kind (sparse, dense, directed, weighted, self-loops,
     isolated nodes, rows longer than 128) against the oracle: column lists, per-generation retained
-    lists and generation count exact; values bit-exact on unweighted graphs, 1e-12 on weighted."""
+    lists and generation count exact; values bit-exact on unweighted graphs, util.WEIGHTED_RTOL on weighted."""
     from graphrole_amd import RecursiveFeatureExtractor
     from graphrole_amd.graph import CSRGraph
     from oracle import refex
@@ -431,7 +431,7 @@ def test_random_graphs_match_oracle(spec, aggs):
         assert fe._final_names[gen] == tr.retained, f'generation {gen}'
     got = X.values.astype(np.float64)
     if spec['weighted'] and ('std' in aggs or 'var' in aggs):
-        # generation 0 of a weighted graph agrees to 1e-12 only, and a variance of nearly equal
+        # generation 0 of a weighted graph agrees to util.WEIGHTED_RTOL only, and a variance of nearly equal
         # values amplifies that by its cancellation: compare against the scale of each column
         scale = np.abs(ref.values).max(axis=0, keepdims=True) + 1e-300
         assert np.abs(got - ref.values).max() <= 1e-9 * scale.max()

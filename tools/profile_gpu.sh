@@ -15,7 +15,7 @@ h = lambda p: hashlib.sha256(open(p, 'rb').read()).hexdigest()
 print(json.dumps({'lib_sha256': h('$REPO/graphrole_amd/libgrx.so'), 'bench_sha256': h('$REPO/bench.py'), 'workload': '$WORKLOAD'}))
 PY
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --workload $WORKLOAD --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --workload $WORKLOAD --steps 3 --warmup 1 --no-cpu-baseline --no-api-wall --soak-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 # one --pmc pass per counter group (never combined with a trace domain); the last two groups are the
 # matrix-core counters north_star asks for: fp64 MFMA ops, MFMA busy cycles, and the cycle base they
