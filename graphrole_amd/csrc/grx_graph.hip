@@ -144,8 +144,10 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int64_t *__restrict
 // coalesced chunks of eight arcs, membership by the all-pairs shuffle compare of the triangle
 // kernel, or -- long rows, i.e. hub neighbours -- probed by binary search for the (at most 25) ego
 // members.  Per lane sequential sums, fixed butterfly: bitwise reproducible.
-constexpr int EGO_SLOTS = 4;                                     // ids per lane
+constexpr int EGO_SLOTS = 4;                                     // ids per lane: nodes with at most 32 out-neighbours
 constexpr int EGO_GROUP_MAX = 8 * EGO_SLOTS;
+constexpr int EGO_SLOTS_WIDE = 8;                                // a second instance of the kernel: 33 .. 64 out-neighbours
+constexpr int EGO_GROUP_MAX_WIDE = 8 * EGO_SLOTS_WIDE;
 
 // Round 5.  What a member a of an ego set contributes needs the ids of row(a), where it begins (weights of matched
 // arcs), its length and its weighted row sum.  Read from the CSR that is two row_ptr entries, rowsum[a] and an
@@ -164,27 +166,28 @@ struct __align__(16) EgoSlot {
 };
 static_assert(sizeof(EgoSlot) == 128, "one slot = one 128-byte line");
 
-// slots of all n rows + the rows of [row_begin, row_end) that the wavefront / workgroup kernels own (out-degree
-// above EGO_GROUP_MAX resp. from `hub` on), appended to two lists (their order does not matter: every row's result
-// is computed independently of the others)
+// slots of all n rows + the rows of [row_begin, row_end) beyond the 8-lane kernel's 32 neighbours, appended to three
+// lists by out-degree: 33 .. 64 (the wide instance of the group kernel), 65 .. hub - 1 (a wavefront per row), hub and
+// more (a workgroup per row).  Their order does not matter: every row's result is computed independently of the others.
 __global__ __launch_bounds__(256) void egonet_prepare_kernel(
     int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ rowsum,
-    int64_t row_begin, int64_t row_end, int64_t hub, EgoSlot *__restrict__ slots, int32_t *__restrict__ mid_rows,
-    int32_t *__restrict__ hub_rows, unsigned *__restrict__ counts)
+    int64_t row_begin, int64_t row_end, int64_t hub, EgoSlot *__restrict__ slots, int32_t *__restrict__ wide_rows,
+    int32_t *__restrict__ mid_rows, int32_t *__restrict__ hub_rows, unsigned *__restrict__ counts)
 {
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < ((n + 63) & ~(int64_t)63); v += (int64_t)gridDim.x * 256) {
         const int64_t d = v < n ? row_ptr[v + 1] - row_ptr[v] : 0;
         const bool owned = v >= row_begin && v < row_end;
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const bool take = owned && (which == 0 ? (d > EGO_GROUP_MAX && d < hub) : d >= hub);
+        for (int which = 0; which < 3; ++which) {
+            const bool take = owned && (which == 0 ? (d > EGO_GROUP_MAX && d <= EGO_GROUP_MAX_WIDE)
+                                        : which == 1 ? (d > EGO_GROUP_MAX_WIDE && d < hub) : d >= hub);
             const unsigned long long bal = __ballot(take);
             if (bal) {
                 const int lane = threadIdx.x & 63;
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&counts[which], (unsigned)__popcll(bal));
                 base = __shfl(base, 0, 64);
-                if (take) (which == 0 ? mid_rows : hub_rows)[base + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)v;
+                if (take) (which == 0 ? wide_rows : which == 1 ? mid_rows : hub_rows)[base + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)v;
             }
         }
     }
@@ -212,22 +215,50 @@ __global__ __launch_bounds__(256) void egonet_prepare_kernel(
     }
 }
 
+// The membership filter of ego(v): a Bloom filter of EGO_FILTER_WORDS x 32 bits with TWO bits per member -- bit
+// (id mod 4096) and bit ((id >> 12) mod 4096) -- in the group's LDS slice.  With at most 33 members a foreign id passes
+// both probes with probability ~1e-4 (one probe: 0.8 %, which sent two thirds of all WAVEFRONT steps down the general
+// path: a wavefront takes it when any of its eight groups does).  Graphs below 4096 nodes: the first probe is exact.
+constexpr int EGO_FILTER_WORDS = 128;
+__device__ __forceinline__ unsigned ego_filter_bit(const unsigned *flt, int32_t b)
+{
+    const unsigned u = (unsigned)b;
+    const unsigned w1 = flt[(u >> 5) & (EGO_FILTER_WORDS - 1)] >> (u & 31u);
+    const unsigned w2 = flt[(u >> 17) & (EGO_FILTER_WORDS - 1)] >> ((u >> 12) & 31u);
+    return w1 & w2 & 1u;
+}
+__device__ __forceinline__ void ego_filter_set(unsigned *flt, int32_t b)
+{
+    const unsigned u = (unsigned)b;
+    atomicOr(&flt[(u >> 5) & (EGO_FILTER_WORDS - 1)], 1u << (u & 31u));
+    atomicOr(&flt[(u >> 17) & (EGO_FILTER_WORDS - 1)], 1u << ((u >> 12) & 31u));
+}
+
+// the byte of a wavefront ballot that belongs to this lane's group of eight (gshift = first lane of the group)
+__device__ __forceinline__ unsigned ego_group_bits(unsigned long long ballot, int gshift)
+{
+    const unsigned half = (gshift & 32) ? (unsigned)(ballot >> 32) : (unsigned)ballot;
+    return __builtin_amdgcn_ubfe(half, (unsigned)gshift & 31u, 8u);
+}
+
 // membership of the eight ids b (one per lane of the group, -1 = none) in ego(v) = {v} U {uu[0..3] of the group's
-// lanes}: a 1024-bit filter of the ego ids in the group's LDS slice decides whether the exact all-pairs shuffle
-// compare has to run at all -- with at most 33 bits set most chunks end after one LDS read and a ballot
-__device__ __forceinline__ bool ego_chunk_inside(int32_t b, int32_t v, const int32_t (&uu)[EGO_SLOTS],
-                                                 const unsigned long long *flt, int gshift, int lane)
+// lanes}: the filter decides whether the exact all-pairs shuffle compare has to run at all
+template <int SLOTS>
+__device__ __forceinline__ bool ego_chunk_inside(int32_t b, int32_t v, const int32_t (&uu)[SLOTS],
+                                                 const unsigned *flt, int gshift, int lane)
 {
     constexpr int G = 8;
     const bool live = b >= 0;
-    const bool maybe = live && ((flt[(b >> 6) & 15] >> (b & 63)) & 1ull);
+    const bool maybe = live && ego_filter_bit(flt, b);
     unsigned match = 0;
-    if ((__ballot(maybe) >> gshift) & 0xFFull) {                // uniform over the group
+    if (ego_group_bits(__ballot(maybe), gshift)) {              // uniform over the group
 #pragma unroll
         for (int sidx = 0; sidx < G; ++sidx) {
             const int32_t bs = __shfl(b, sidx, G);
-            const bool hit = (bs == uu[0]) | (bs == uu[1]) | (bs == uu[2]) | (bs == uu[3]);
-            if ((__ballot(hit) >> gshift) & 0xFFull) match |= 1u << sidx;
+            bool hit = false;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) hit |= bs == uu[i];
+            if (ego_group_bits(__ballot(hit), gshift)) match |= 1u << sidx;
         }
     }
     return live && (((match >> lane) & 1u) || b == v);
@@ -243,25 +274,36 @@ __device__ __forceinline__ bool ego_chunk_inside(int32_t b, int32_t v, const int
 //              += rowsum(a) - matched weight      otherwise, unless that difference lost more than six bits to
 //                                                 cancellation: then the unmatched weights are added one by one
 // The members are taken BATCH at a time: the slots of a whole batch are requested before the first is looked at.
+// FAST PATH (the kernel was bound by its VALU instruction stream -- 313 instructions per member, every SIMD 100 % busy,
+// the memory system at 17 G requests/s, profiles/r05_egonet.txt): a member whose ids all miss the filter and whose
+// row fits its slot contributes rowsum(a) to `external` and nothing else -- four filter probes per lane, one ballot,
+// no header broadcast (lane 0 holds the row sum itself).  Everything else -- a filter hit, a row beyond 28 ids, a
+// hub row -- takes the general path below.
 // The external shares are added by lane 0 in member order, the rest are per-lane sequential sums and a fixed
 // butterfly: bitwise reproducible, independent of the launch geometry.
-template <int BATCH>
+template <int BATCH, int SLOTS>
 __global__ __launch_bounds__(256) void egonet_group_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ w, const EgoSlot *__restrict__ slots, int directed,
-    int64_t row_begin, int64_t row_end, double *__restrict__ internal, double *__restrict__ external)
+    int64_t row_begin, int64_t row_end, const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
+    double *__restrict__ internal, double *__restrict__ external)
 {
+    // rows == nullptr: the nodes of [row_begin, row_end) with at most 8 SLOTS neighbours; else: the listed nodes
+    constexpr int EGO_SLOTS = SLOTS;
+    constexpr int EGO_GROUP_MAX = 8 * SLOTS;
     constexpr int G = 8;
-    __shared__ unsigned long long ego_filter[256 / G][16];
+    __shared__ unsigned ego_filter[256 / G][EGO_FILTER_WORDS];
     __shared__ int32_t ego_id[256 / G][EGO_GROUP_MAX];
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
-    unsigned long long *flt = ego_filter[threadIdx.x / G];
+    unsigned *flt = ego_filter[threadIdx.x / G];
     int32_t *mid = ego_id[threadIdx.x / G];
     const int4 *slot16 = reinterpret_cast<const int4 *>(slots);
-    for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
+    const int64_t first = rows ? 0 : row_begin, last = rows ? (int64_t)n_rows[0] : row_end;
+    for (int64_t it = first + group; it < last; it += ngroups) {
+        const int64_t v = rows ? (int64_t)rows[it] : it;
         const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
         const int dv = (int)(ve - vb);
         if (ve - vb > EGO_GROUP_MAX) continue;                  // uniform over the group
@@ -271,19 +313,22 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
             const int64_t idx = vb + lane + (int64_t)G * i;
             uu[i] = (idx < ve) ? col[idx] : -2;
         }
-        const bool mine_v = (uu[0] == (int32_t)v) | (uu[1] == (int32_t)v) | (uu[2] == (int32_t)v) | (uu[3] == (int32_t)v);
-        const bool v_in_row = ((__ballot(mine_v) >> gshift) & 0xFFull) != 0;
+        bool mine_v = false;
+#pragma unroll
+        for (int i = 0; i < EGO_SLOTS; ++i) mine_v |= uu[i] == (int32_t)v;
+        const bool v_in_row = ego_group_bits(__ballot(mine_v), gshift) != 0u;
         __builtin_amdgcn_wave_barrier();                       // the previous node's readers are done
 #pragma unroll
         for (int i = 0; i < EGO_SLOTS; ++i)
             if (uu[i] >= 0) mid[lane + G * i] = uu[i];
-        flt[lane] = 0ull;
-        flt[lane + G] = 0ull;
+#pragma unroll
+        for (int i = 0; i < EGO_FILTER_WORDS / (4 * G); ++i)
+            reinterpret_cast<uint4 *>(flt)[lane + G * i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i <= EGO_SLOTS; ++i) {
             const int32_t id = i < EGO_SLOTS ? uu[i < EGO_SLOTS ? i : 0] : (lane == 0 ? (int32_t)v : -2);
-            if (id >= 0) atomicOr(&flt[(id >> 6) & 15], 1ull << (id & 63));
+            if (id >= 0) ego_filter_set(flt, id);
         }
         __builtin_amdgcn_wave_barrier();
         double ins = 0.0, ext = 0.0;
@@ -308,6 +353,19 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
                 if (m >= dv) break;
                 const int32_t a = mid[m];
                 if (a == (int32_t)v) continue;                  // a self-loop: row(v) is counted above
+                {
+                    // fast path: lanes 1 - 7 probe the filter with their four ids (a pad id -1 probes like any other: a hit
+                    // only costs the general path); lane 0 contributes "the row does not fit its slot" (length in bits
+                    // 8 .. 31 of its fourth word)
+                    const unsigned hit = lane ? (ego_filter_bit(flt, q[k].x) | ego_filter_bit(flt, q[k].y) |
+                                                 ego_filter_bit(flt, q[k].z) | ego_filter_bit(flt, q[k].w))
+                                              : (unsigned)(((unsigned)q[k].w >> 8) > (unsigned)EGO_SLOT_IDS);
+                    if (ego_group_bits(__ballot(hit != 0u), gshift) == 0u) {
+                        if (lane == 0)
+                            ext += __longlong_as_double((long long)(((unsigned long long)(unsigned)q[k].y << 32) | (unsigned)q[k].x));
+                        continue;
+                    }
+                }
                 // lane 0 of the group holds the header of the slot
                 const unsigned rs_lo = (unsigned)__shfl(q[k].x, 0, G), rs_hi = (unsigned)__shfl(q[k].y, 0, G);
                 const unsigned bd_lo = (unsigned)__shfl(q[k].z, 0, G), bd_hi = (unsigned)__shfl(q[k].w, 0, G);
@@ -322,8 +380,8 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
                     int cnt = 0;
                     double msum = 0.0;
                     auto chunk = [&](int32_t b, int64_t j) {
-                        const bool inside = ego_chunk_inside(b, (int32_t)v, uu, flt, gshift, lane);
-                        cnt += __popcll((__ballot(inside) >> gshift) & 0xFFull);
+                        const bool inside = ego_chunk_inside<SLOTS>(b, (int32_t)v, uu, flt, gshift, lane);
+                        cnt += __popc(ego_group_bits(__ballot(inside), gshift));
                         if (inside) {
                             const double x = w ? w[j] : 1.0;
                             msum += x;
@@ -351,7 +409,7 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
                             // that leave the ego set one by one instead
                             for (int64_t j0 = ab; j0 < ae; j0 += G) {
                                 const int32_t b = j0 + lane < ae ? col[j0 + lane] : -1;
-                                const bool inside = ego_chunk_inside(b, (int32_t)v, uu, flt, gshift, lane);
+                                const bool inside = ego_chunk_inside<SLOTS>(b, (int32_t)v, uu, flt, gshift, lane);
                                 if (b >= 0 && !inside) ext += w ? w[j0 + lane] : 1.0;
                             }
                         }
@@ -1861,7 +1919,7 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
 size_t grx_egonet_workspace_bytes(int64_t n)
 {
     const size_t rows = (size_t)((n > 0 ? n : 0) + 64);
-    return rows * sizeof(EgoSlot) + 2 * rows * sizeof(int32_t) + 256;
+    return rows * sizeof(EgoSlot) + 3 * rows * sizeof(int32_t) + 256;
 }
 
 int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
@@ -1881,45 +1939,41 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     hipStream_t st = grx_stream(stream);
     const int64_t nrows = row_end - row_begin;
     constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup from this out-degree on
-    // workspace: row slots | counters (256 bytes) | rows of the wavefront kernel | rows of the workgroup kernel
+    // workspace: row slots | counters (256 bytes) | rows of the wide group kernel, the wavefront and the workgroup kernel
     const size_t rows_cap = (size_t)(n + 64);
     EgoSlot *slots = reinterpret_cast<EgoSlot *>(d_workspace);
     unsigned *counts = reinterpret_cast<unsigned *>(slots + rows_cap);
-    int32_t *mid_rows = reinterpret_cast<int32_t *>(counts + 64);
+    int32_t *wide_rows = reinterpret_cast<int32_t *>(counts + 64);
+    int32_t *mid_rows = wide_rows + rows_cap;
     int32_t *hub_rows = mid_rows + rows_cap;
     GRX_CHECK_HIP(hipMemsetAsync(counts, 0, 256, st));
     {
         const int64_t want = grx_ceil_div(n * 32, 256);
         GRX_PROF(GRX_K_EGONET_WAVE, st);
-        egonet_prepare_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want), 256, 0, st>>>(
-            n, d_row_ptr, d_col, d_w ? d_rowsum : nullptr, row_begin, row_end, HUB, slots, mid_rows, hub_rows, counts);
+        // (one word per thread, no grid-stride cap: the row_ptr -> col chain of a thread is two dependent round trips)
+        egonet_prepare_kernel<<<(int)(want > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : want), 256, 0, st>>>(
+            n, d_row_ptr, d_col, d_w ? d_rowsum : nullptr, row_begin, row_end, HUB, slots, wide_rows, mid_rows, hub_rows, counts);
         GRX_LAUNCH_CHECK();
         // nodes with at most EGO_GROUP_MAX neighbours: eight lanes each; the rest: a wavefront each
         const int64_t gwant = grx_ceil_div(nrows * 8, 256);
         const int ggrid = (int)(gwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : gwant);
-        // tuning switch (A/B runs only): GRX_EGO_VARIANT = members per batch
-        static const int variant = [] { const char *e = std::getenv("GRX_EGO_VARIANT"); return e ? std::atoi(e) : 0; }();
-#define GRX_EGO_LAUNCH(B)                                                                                                 \
-        egonet_group_kernel<B><<<ggrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end,         \
-                                                      d_internal, d_external)
-        switch (variant) {
-        case 1: GRX_EGO_LAUNCH(1); break;
-        case 2: GRX_EGO_LAUNCH(2); break;
-        case 8: GRX_EGO_LAUNCH(8); break;
-        default: GRX_EGO_LAUNCH(4); break;
-        }
-#undef GRX_EGO_LAUNCH
+        egonet_group_kernel<2, EGO_SLOTS><<<ggrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end,
+                                                                 nullptr, nullptr, d_internal, d_external);
+        GRX_LAUNCH_CHECK();
+        const int64_t wwant = grx_ceil_div(nrows * 8, 256 * 16);               // a few per cent of the rows at most
+        egonet_group_kernel<2, EGO_SLOTS_WIDE><<<(int)(wwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (wwant < 1 ? 1 : wwant)), 256, 0, st>>>(
+            d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end, wide_rows, counts + 0, d_internal, d_external);
         GRX_LAUNCH_CHECK();
         const int64_t want4 = grx_ceil_div(nrows, 4);
         const int grid = (int)(want4 > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want4);
-        egonet_kernel<64><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, mid_rows, counts + 0, d_internal,
+        egonet_kernel<64><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, mid_rows, counts + 1, d_internal,
                                                d_external);
         GRX_LAUNCH_CHECK();
     }
     {
         const int grid = (int)(nrows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : nrows);
         GRX_PROF(GRX_K_EGONET_BLOCK, st);
-        egonet_kernel<512><<<grid, 512, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, hub_rows, counts + 1, d_internal,
+        egonet_kernel<512><<<grid, 512, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, hub_rows, counts + 2, d_internal,
                                                 d_external);
         GRX_LAUNCH_CHECK();
     }

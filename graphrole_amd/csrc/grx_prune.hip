@@ -975,13 +975,13 @@ __global__ __launch_bounds__(256) void bin_assign_kernel(const double *__restric
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
     int nb = nbins[col];
-    // outcome flags for a caller that asked for them (grx_internal_log_bin_status_sink): bit 0 = the sort-free walk met
-    // a bucket it had not marked (an invariant of the interval walk broke), bit 1 = a column needs more than
-    // GRX_MAX_BINS bins (its labels saturate below)
+    // outcome flags for a caller that asked for them (grx_internal_vertical_log_bin): status[0] = 1 when the sort-free
+    // walk met a bucket it had not marked (an invariant of the interval walk broke), status[1] = 1 when a column needs
+    // more than GRX_MAX_BINS bins (its labels saturate below).  Two WORDS, not two bits of one: sharded runs combine
+    // them across ranks with a MAX reduction, which keeps each word exact
     if (status && blockIdx.x == 0 && threadIdx.x == 0) {
-        int bad = nb < 0 ? 2 : 0;
-        if (col == 0 && fault && *fault != 0) bad |= 1;
-        if (bad) atomicOr(status, bad);
+        if (col == 0 && fault && *fault != 0) status[0] = 1;
+        if (nb < 0) status[1] = 1;
     }
     if (nb < 0) nb = GRX_MAX_BINS;                    // more than GRX_MAX_BINS bins: labels saturate, the caller is told
     if (threadIdx.x < GRX_MAX_BINS)
@@ -1946,15 +1946,14 @@ int grx_sort_columns(int64_t n, int ncols, const double *d_cols, int64_t ld, dou
 
 }  // extern "C"
 
-namespace {
-thread_local int32_t *g_status_sink = nullptr;
-}  // namespace
-
-// Internal (grx_refex.hip): the NEXT grx_vertical_log_bin call of this thread ORs its outcome flags into *d_status
-// (bit 0: the sort-free threshold walk met an unmarked bucket; bit 1: a column needs more than GRX_MAX_BINS bins) from
-// inside its last kernel -- no launch of its own, no synchronisation: the caller reads the word with whatever it
-// copies back next.
-void grx_internal_log_bin_status_sink(int32_t *d_status) { g_status_sink = d_status; }
+// Internal (grx_refex.hip): grx_vertical_log_bin_typed with an explicit place for the outcome flags -- d_status[0] (the
+// sort-free threshold walk met an unmarked bucket) and d_status[1] (a column needs more than GRX_MAX_BINS bins) are
+// set from inside the call's last kernel: no launch of its own, no synchronisation, the caller reads the two words
+// with whatever it copies back next.  (Round 4 passed the pointer through a thread-local that the next binning call of
+// the thread consumed -- a hidden coupling between two calls; gone.)
+int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, const uint8_t *h_is_i64, double frac,
+                                  uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                                  size_t workspace_bytes, int32_t *d_status, void *stream);
 
 extern "C" {
 
@@ -1970,8 +1969,16 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
                                uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
                                size_t workspace_bytes, void *stream)
 {
-    int32_t *status = g_status_sink;                          // consumed by this call whatever it returns
-    g_status_sink = nullptr;
+    return grx_internal_vertical_log_bin(n, ncols, d_cols, ld, h_is_i64, frac, d_bins, ld_bins, d_nbins, d_workspace,
+                                         workspace_bytes, nullptr, stream);
+}
+
+}  // extern "C"
+
+int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, const uint8_t *h_is_i64, double frac,
+                                  uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                                  size_t workspace_bytes, int32_t *status, void *stream)
+{
     ColFlags flags;
     for (int j = 0; j < 8; ++j) flags.w[j] = 0;
     if (h_is_i64)
@@ -2098,6 +2105,8 @@ int grx_vertical_log_bin_typed(int64_t n, int ncols, const double *d_cols, int64
         GRX_CHECK_HIP(hipMemcpyAsync(d_nbins, nb_ws, (size_t)ncols * 4, hipMemcpyDeviceToDevice, st));
     return GRX_OK;
 }
+
+extern "C" {
 
 int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
                   const uint8_t *const *h_bin_ptrs, int32_t *d_dist, int cap, void *stream)

@@ -20,7 +20,9 @@
 #include <vector>
 
 int64_t grx_internal_plan_max_degree(const grx_aggregate_plan *plan);                                          // grx_graph.hip
-void grx_internal_log_bin_status_sink(int32_t *d_status);                                                    // grx_prune.hip
+int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, int64_t ld, const uint8_t *h_is_i64, double frac,
+                                  uint8_t *d_bins, int64_t ld_bins, int32_t *d_nbins, void *d_workspace,
+                                  size_t workspace_bytes, int32_t *d_status, void *stream);                  // grx_prune.hip
 
 namespace {
 
@@ -217,20 +219,21 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
         const int F = (int)work.size();
         // (a whole number of 256-byte units: the runtime clears an unaligned tail with a second fill launch)
-        // + one status word behind the matrix: the outcome flags of the binning travel (and, sharded, are max-reduced)
-        // with the distances, so a failed binning is a joint error on every rank instead of a silent wrong drop list
+        // + two status words behind the matrix (threshold walk failed | too many bins): the outcome flags of the binning
+        // travel (and, sharded, are max-reduced word by word) with the distances, so a failed binning is a joint error
+        // on every rank instead of a silent wrong drop list
         // ... and one word per new column: the bit width of its maximum when it holds exact integers (kind 1)
         // (not for the last generation the loop can reach: nothing will be gathered from its columns)
         const bool want_bits = count <= 64 && generation + 1 < max_generations && packed_allowed;
-        const size_t tail_words = 1 + (size_t)(want_bits ? count : 0);
+        const size_t tail_words = 2 + (size_t)(want_bits ? count : 0);
         const size_t dist_bytes = grx_align_up(((size_t)F * F + tail_words) * 4, 256);
         int32_t *d_dist = reinterpret_cast<int32_t *>(arena.take(dist_bytes));
         std::vector<int> drop_idx;
         if (!arena.overflow) {
             if (F >= 2) GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
             if (count && !comm) {
-                if (F >= 2) grx_internal_log_bin_status_sink(d_dist + (size_t)F * F);
-                GRX_TRY(grx_vertical_log_bin(n, count, block, n, 0.5, bins, n, nullptr, ws, ws_bytes, stream));
+                GRX_TRY(grx_internal_vertical_log_bin(n, count, block, n, nullptr, 0.5, bins, n, nullptr, ws, ws_bytes,
+                                                      F >= 2 ? d_dist + (size_t)F * F : nullptr, stream));
             } else if (count) {
                 const double *src = block + (size_t)me * n;       // complete columns: the owned ones are a strided view
                 int64_t ld_src = (int64_t)P * n;
@@ -241,18 +244,18 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     ld_src = n;
                 }
                 if (n_owned) {
-                    if (F >= 2) grx_internal_log_bin_status_sink(d_dist + (size_t)F * F);
-                    GRX_TRY(grx_vertical_log_bin(n, n_owned, src, ld_src, 0.5, owned_bins, n, nullptr, ws, ws_bytes, stream));
+                    GRX_TRY(grx_internal_vertical_log_bin(n, n_owned, src, ld_src, nullptr, 0.5, owned_bins, n, nullptr, ws, ws_bytes,
+                                                          F >= 2 ? d_dist + (size_t)F * F : nullptr, stream));
                 }
                 // step 2: the owners' bins of this rank's rows come back
                 GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));
             }
             for (int j = 0; j < count; ++j) cols[first_new + j].bins = bins + (size_t)j * n;
-            if (F >= 2 && tail_words > 1 && re > rb) {
+            if (F >= 2 && tail_words > 2 && re > rb) {
                 uint64_t mask = 0;
                 for (int j = 0; j < count; ++j)
                     if (cols[first_new + j].kind == 1) mask |= 1ull << j;
-                if (mask) GRX_TRY(grx_column_bits(n, count, block, n, rb, re, mask, d_dist + (size_t)F * F + 1, stream));
+                if (mask) GRX_TRY(grx_column_bits(n, count, block, n, rb, re, mask, d_dist + (size_t)F * F + 2, stream));
             }
             if (F >= 2) {
                 std::vector<const uint8_t *> ptrs(F);
@@ -264,17 +267,18 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 GRX_TRY(pinned(((size_t)F * F + tail_words) * 4, &host));
                 GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, ((size_t)F * F + tail_words) * 4, hipMemcpyDeviceToHost, st));
                 GRX_CHECK_HIP(hipStreamSynchronize(st));
-                if (tail_words > 1)
+                if (tail_words > 2)
                     for (int j = 0; j < count; ++j) {
-                        const int32_t b = reinterpret_cast<const int32_t *>(host)[(size_t)F * F + 1 + j];
+                        const int32_t b = reinterpret_cast<const int32_t *>(host)[(size_t)F * F + 2 + j];
                         if (cols[first_new + j].kind == 1 && b >= 1 && b <= 62) cols[first_new + j].bits = b;
                     }
-                const int32_t bin_status = reinterpret_cast<const int32_t *>(host)[(size_t)F * F];
-                if (bin_status != 0) {
+                const int32_t walk_failed = reinterpret_cast<const int32_t *>(host)[(size_t)F * F];
+                const int32_t bins_overflow = reinterpret_cast<const int32_t *>(host)[(size_t)F * F + 1];
+                if (walk_failed != 0 || bins_overflow != 0) {
                     grx_set_error("grx_refex_run: generation %d: vertical log binning failed on some rank (%s%s); "
                                   "GRX_BIN_SORT=1 selects the sort-based binning", generation,
-                                  (bin_status & 1) ? "the sort-free threshold walk met an unmarked bucket" : "",
-                                  (bin_status & 2) ? " a column needs more than GRX_MAX_BINS bins" : "");
+                                  walk_failed ? "the sort-free threshold walk met an unmarked bucket" : "",
+                                  bins_overflow ? " a column needs more than GRX_MAX_BINS bins" : "");
                     return GRX_ERR_UNSUPPORTED;
                 }
                 // identical distances on every rank -> identical decisions, no further agreement needed
