@@ -201,8 +201,12 @@ class RecursiveFeatureExtractor:
         self._shard()
 
         # generation 0: neighbourhood (local + ego-net) features
+        t_gen0 = time.perf_counter()
         names, cols, dtypes = self.graph.neighborhood_feature_columns()
         K = self._K()
+        if self.time_phases:
+            self._phase_sync()
+            self.wall['generation0_s'] = time.perf_counter() - t_gen0
         native = hasattr(K, 'refex_run') and (self._plan is None or getattr(K, 'NATIVE_SHARDING', False))
         # 'prod' over INTEGER columns follows the reference's wrapping int64 arithmetic: those columns are carried as
         # int64 bits from generation 0 on, and the generations are driven from here (the per-kernel driver)
@@ -239,8 +243,15 @@ class RecursiveFeatureExtractor:
         K = self._K()
         _, dev_graph, _ = self.graph._device_graph()
         flags = self._int32_flags(names0, dtypes0)
+        t_loop = time.perf_counter()
         columns, generations, gen_count, self._arena = K.refex_run(dev_graph, cols0, names0, self.max_generations,
                                                                    aggs, self._arena, shard=self._plan, gen0_int32=flags)
+        if self.time_phases:
+            self._phase_sync()
+            self.wall['generation_loop_s'] = time.perf_counter() - t_loop
+            self.wall['arena_bytes'] = int(self._arena.numel()) if self._arena is not None else 0
+            self.wall['generation_loop_attempts'] = int(getattr(K.refex_run, 'attempts', 1))
+            self.wall['generation_loop_trace'] = [[what, round(sec, 6)] for what, sec in getattr(K.refex_run, 'trace', [])]
         host = self.graph._device_graph()[0]
         no_empty_rows = self._no_empty_rows(host)
         names: List[str] = []

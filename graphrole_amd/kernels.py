@@ -723,10 +723,18 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
     names = (ctypes.c_char_p * f0)(*[nm.encode('utf-8') for nm in gen0_names])
     col_ptrs = ptr_array(list(gen0_cols))
     max_gens = max(int(max_generations), 1)
+    _t_first = None
     if arena is None:
+        import time as _time0
+        _t0 = _time0.perf_counter()
         arena = torch.empty(_refex_arena_guess(n, f0, len(aggs), max_gens), dtype=torch.uint8, device=device())
+        _t_first = ('arena %d bytes (first guess)' % arena.numel(), _time0.perf_counter() - _t0)
     max_columns = 256
+    refex_run.attempts = 0                     # diagnostics: how often the library was entered (arena / table grown)
+    refex_run.trace = [_t_first] if _t_first else []     # diagnostics: (what, seconds) of every allocation and library call
+    import time as _time
     while True:
+        refex_run.attempts += 1
         # sharded: the library sizes every allocation from rank-independent bounds, so with ONE capacity for all ranks a
         # too-small arena is a joint -3 (no rank restarts while its peers wait in an exchange); arenas kept from earlier
         # runs may differ in size, hence the agreement on the smallest
@@ -737,17 +745,22 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
         gens = (_lib.RefexGeneration * max_gens)()
         n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         lib = _lib.load()
+        _t0 = _time.perf_counter()
         rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names, int_flags,
                                int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), capacity,
                                max_columns, table,
                                ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),
                                _stream())
+        refex_run.trace.append(('grx_refex_run rc=%d capacity=%d needed=%d' % (rc, capacity, needed.value),
+                                _time.perf_counter() - _t0))
         if rc == -3:                                    # GRX_ERR_WORKSPACE: arena or column table too small
             if needed.value > capacity:
                 # `needed` is what the run used up to the generation that failed -- a lower bound: grow geometrically
                 want = max(int(needed.value * 1.5), 2 * capacity) + (32 << 20)
                 del arena
+                _t0 = _time.perf_counter()
                 arena = torch.empty(want, dtype=torch.uint8, device=device())
+                refex_run.trace.append(('arena %d bytes' % want, _time.perf_counter() - _t0))
             else:
                 max_columns *= 4
             continue
