@@ -97,6 +97,16 @@ def shared_dir(name):
     return shared_dirs(name)[0]
 
 
+def private_dir(path):
+    """The per-user directory in a world-writable place (/dev/shm, /tmp): created 0700, and refused when somebody else
+    owns it or others may write to it (the graph files a rank maps come from there)."""
+    os.makedirs(path, mode=0o700, exist_ok=True)
+    st = os.stat(path)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise OSError(f'{path} is not a private directory of uid {os.getuid()} (owner {st.st_uid}, mode {oct(st.st_mode & 0o777)})')
+    return path
+
+
 def build_graph(name, world=1, local_rank=0, share=False):
     """N = 1: generate.  N > 1 (or share=True: the counter passes of --pmc re-run this script): the synthetic graph
     is generated ONCE per node (local rank 0 -> .npy files in /dev/shm, published by one atomic rename), the other
@@ -108,12 +118,17 @@ def build_graph(name, world=1, local_rank=0, share=False):
     import shutil
     from graphrole_amd import synth
     places = shared_dirs(name)
-    found = lambda: next((p for p in places if os.path.exists(os.path.join(p, 'meta.json'))), None)
-    failed = places[-1] + '.failed'
+    def found():
+        for p in places:
+            if os.path.exists(os.path.join(p, 'meta.json')) and os.stat(os.path.dirname(p)).st_uid == os.getuid():
+                return p
+        return None
+    # the failure marker belongs to THIS launch (the launcher's rendezvous port, else the parent process): a marker left
+    # behind by an earlier crashed launch cannot make the other ranks give up while rank 0 builds the graph
+    launch = os.environ.get('TORCHELASTIC_RUN_ID') or os.environ.get('MASTER_PORT') or str(os.getppid())
+    failed = f'{places[-1]}.failed.{launch}'
     if local_rank == 0 and found() is None:
         try:
-            if os.path.exists(failed):
-                os.remove(failed)
             G = generate_graph(name)
             src, dst, w = G.edge_arrays()
             need = int(1.25 * (src.nbytes + dst.nbytes + (w.nbytes if w is not None else 0) +
@@ -121,7 +136,7 @@ def build_graph(name, world=1, local_rank=0, share=False):
             last_error = None
             for path in places:
                 try:
-                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    private_dir(os.path.dirname(path))
                     if shutil.disk_usage(os.path.dirname(path)).free < need:
                         continue                           # e.g. a container with a 64 MB /dev/shm
                     tmp = f'{path}.tmp{os.getpid()}'
@@ -139,7 +154,7 @@ def build_graph(name, world=1, local_rank=0, share=False):
             else:
                 raise RuntimeError(f'no room for the shared graph files ({need >> 20} MiB) in {places}: {last_error}')
         except BaseException:
-            os.makedirs(os.path.dirname(failed), exist_ok=True)
+            private_dir(os.path.dirname(failed))
             open(failed, 'w').write('local rank 0 could not publish the graph')
             raise
     deadline = time.time() + 3600
@@ -269,12 +284,17 @@ def profile_totals(lib):
 def cpu_baseline(G, args, X_features):
     """Oracle (plain-C port, single thread) on the same graph once, plus the reference-faithful legs of
     BASELINE.md baseline (1) on bounded samples."""
-    from oracle import refex, reference_path
+    from oracle import ckernels, refex, reference_path
     og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=None, directed=False,
                            num_edges=G.num_edges, adj_col=G.adj_col)
+    # ONE thread: the oracle's row-parallel loops (OpenMP, there for the full-size parity tests) and its threaded
+    # binning are switched off for the timing -- `cores` below says 1 and means it
+    ckernels.set_threads(1)
+    refex.BIN_THREADS = 1
     t0 = time.perf_counter()
     res = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
     dt = time.perf_counter() - t0
+    ckernels.set_threads(0)
     gens = res.generation_count
     out = {
         'value': G.nnz * gens / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
@@ -619,6 +639,16 @@ def main():
         if multi:
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
         elapsed, t_refex, t_nmf = [float(x) for x in red.cpu()]
+        # N > 1 soak: bounded by a STEP COUNT every rank derives from the same reduced time (a time-bounded loop would
+        # leave ranks that ran different counts waiting inside an exchange) -- an external sampler sees N busy devices
+        if args.soak_seconds > 0 and not light and multi:
+            n_soak = max(1, min(2000, int(np.ceil(args.soak_seconds / max(elapsed / steps, 1e-6)))))
+            t_soak = time.perf_counter()
+            for _ in range(n_soak):
+                step(dict(refex=0.0, nmf=0.0, nmf_iters=0))
+            barrier()
+            soak = {'seconds': time.perf_counter() - t_soak, 'steps': n_soak,
+                    'what': 'untimed steps after the timed region, the same count on every rank'}
 
         # RolX encode of the node-role factor, outside the timed steps: the reference's quantiser reproduced
         # (grx_kmeans1d, the default of RoleExtractor) and the Lloyd-Max solver (quantizer='lloyd_max')

@@ -65,6 +65,7 @@ class P2pOp(ctypes.Structure):
 # transport callbacks of grx_comm_create_callbacks
 ALL_REDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(P2pOp), c_void_p)
+GROW_FN = ctypes.CFUNCTYPE(c_void_p, c_size_t, c_void_p)          # grx_grow_fn: more arena for grx_refex_run
 COMM_ID_BYTES = 128
 COMM_SELF_VIA_TRANSPORT = 1
 DTYPE_IDS = {'float64': 0, 'int32': 1, 'int64': 2, 'uint8': 3}                 # grx_dtype
@@ -191,8 +192,8 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_host_prune': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, POINTER(c_int), c_int, c_void_p,
-                              POINTER(c_int), POINTER(c_size_t), c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_int),
+                              c_int, c_void_p, POINTER(c_int), POINTER(c_size_t), c_void_p]),
     'grx_kmeans1d_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'grx_kmeans1d': (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),

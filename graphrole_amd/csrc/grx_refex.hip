@@ -47,19 +47,58 @@ struct Column {
     int bits = -1;            // known after the generation's read-back (-1: not known)
 };
 
-// bump allocator over the caller's arena; keeps counting past the end so that the caller learns how
-// much would have been needed
+// Bump allocator over the caller's arena.  The arena is a CHAIN of chunks (round 5): the first is the block the caller
+// passed; when a request does not fit, the caller's grow function hands out another chunk (allocations only need to be
+// contiguous in themselves, never across chunks), so a run is never repeated because a first size was a guess.
+// Positions are LOGICAL offsets (chunk i covers [start_i, start_i + cap_i)): marks taken for scratch stay valid, a
+// request that does not fit the rest of a chunk skips to the next one.  Without a grow function (or when it fails)
+// the allocator keeps counting past the end so that the caller learns how much would have been needed.
 struct Arena {
-    char *base;
-    size_t cap, top = 0, peak = 0;
+    struct Chunk { char *base; size_t cap, start; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, top = 0, peak = 0, grow_min = 0;
     bool overflow = false;
+    grx_grow_fn grow = nullptr;
+    void *grow_user = nullptr;
+    Arena(void *base, size_t cap, grx_grow_fn fn, void *user) : grow(fn), grow_user(user)
+    {
+        chunks.push_back({reinterpret_cast<char *>(base), base ? cap : 0, 0});
+        grow_min = cap / 4 > ((size_t)64 << 20) ? cap / 4 : ((size_t)64 << 20);
+    }
+    size_t capacity() const { return chunks.back().start + chunks.back().cap; }
+    void rewind(size_t mark)
+    {
+        top = mark;
+        while (cur > 0 && chunks[cur].start > mark) --cur;
+        while (cur + 1 < chunks.size() && chunks[cur + 1].start <= mark) ++cur;
+    }
     void *take(size_t bytes)
     {
-        const size_t at = grx_align_up(top, 256);
-        top = at + bytes;
-        if (top > peak) peak = top;
-        if (top > cap) { overflow = true; return nullptr; }
-        return base + at;
+        for (;;) {
+            const Chunk &c = chunks[cur];
+            const size_t at = grx_align_up(top > c.start ? top - c.start : 0, 256);
+            if (!overflow && at + bytes <= c.cap) {
+                top = c.start + at + bytes;
+                if (top > peak) peak = top;
+                return c.base + at;
+            }
+            if (!overflow && cur + 1 < chunks.size()) { ++cur; top = chunks[cur].start; continue; }
+            if (!overflow && grow) {
+                const size_t want = grx_align_up(bytes + 256 > grow_min ? bytes + 256 : grow_min, 256);
+                void *p = grow(want, grow_user);
+                if (p) {
+                    chunks.push_back({reinterpret_cast<char *>(p), want, capacity()});
+                    ++cur;
+                    top = chunks[cur].start;
+                    continue;
+                }
+            }
+            // no room and nobody to ask: count on
+            overflow = true;
+            top = grx_align_up(top, 256) + bytes;
+            if (top > peak) peak = top;
+            return nullptr;
+        }
     }
 };
 
@@ -152,7 +191,7 @@ int grx_host_prune(int F, const char *const *h_names, const int *h_recorded_gene
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
                   int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
-                  size_t arena_bytes, int max_columns,
+                  size_t arena_bytes, grx_grow_fn grow, void *grow_user, int max_columns,
                   grx_refex_column *h_columns, int *n_columns, int max_gens, grx_refex_generation *h_gens,
                   int *generation_count, size_t *arena_needed, void *stream)
 {
@@ -173,9 +212,10 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
     if (comm)
         GRX_REQUIRE(h_bounds[0] == 0 && h_bounds[P] == n, "grx_refex_run: h_bounds must run from 0 to n");
     const int64_t rb = comm ? h_bounds[me] : 0, re = comm ? h_bounds[me + 1] : n;
-    Arena arena{reinterpret_cast<char *>(d_arena), d_arena ? arena_bytes : 0};
+    Arena arena(d_arena, d_arena ? arena_bytes : 0, grow, grow_user);
     // Every allocation below is sized from RANK-INDEPENDENT upper bounds (ceil(count / P) owned columns, the largest
-    // nnz slice of the partition): with the equal capacity the caller agrees on (kernels.refex_run), every rank's arena
+    // nnz slice of the partition): every rank asks for the same sizes at the same points, so with a grow function no
+    // rank ever fails alone, and without one -- with the equal capacity the caller agrees on -- every rank's arena
     // overflows at the same allocation or not at all -- so the `if (!arena.overflow)` guards around the exchanges
     // below take the same branch on every rank and a too-small arena is a joint GRX_ERR_WORKSPACE, never a rank
     // that restarts while its peers wait inside a collective.
@@ -204,7 +244,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         uint8_t *bins = nullptr;
         if (count) {
             // bins are cached for the life of a column: re-binning is result-identical (prune.py:101-104)
-            arena.top = scratch_mark;
+            arena.rewind(scratch_mark);
             bins = reinterpret_cast<uint8_t *>(arena.take((size_t)count * n));
         }
         const size_t persistent_top = arena.top;
@@ -285,7 +325,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 drop_idx = prune(cols, work, reinterpret_cast<const int32_t *>(host), generation, recorded);
             }
         }
-        arena.top = persistent_top;                           // workspace and distance matrix are scratch
+        arena.rewind(persistent_top);                         // workspace and distance matrix are scratch
         std::vector<char> dropped(cols.size(), 0);
         for (int m : drop_idx) dropped[work[m]] = 1;
         const int working_before = F;
@@ -458,14 +498,14 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 if (has[GRX_AGG_SIZE])
                     GRX_TRY(grx_aggregate_count(d_row_ptr, f, rb, re, 0, out_of(GRX_AGG_SIZE), n, stream));
             }
-            arena.top = mark;                                 // the gather source is scratch
+            arena.rewind(mark);                               // the gather source is scratch
         }
         GRX_TRY(update(first_new, count, block, g, comm != nullptr));
         if (recorded[g].empty()) break;                       // extract.py:86-87
     }
     if (arena_needed) *arena_needed = arena.peak;
     if (arena.overflow) {
-        grx_set_error("grx_refex_run: arena of %zu bytes is too small (needs at least %zu so far)", arena.cap, arena.peak);
+        grx_set_error("grx_refex_run: arena of %zu bytes is too small (needs at least %zu so far)", arena.capacity(), arena.peak);
         return GRX_ERR_WORKSPACE;
     }
     if (table_full) {

@@ -45,15 +45,35 @@ def _agg_name(agg) -> str:
     raise TypeError(f'cannot interpret aggregation {agg!r}')
 
 
+def _kernel_functions() -> dict:
+    """id(function) -> name for the function OBJECTS that stand for the ten kernel-backed aggregations: the numpy,
+    pandas and builtin functions pandas itself maps to those names.  Matched by identity: a function that merely
+    carries the name 'sum' in a module starting with numpy / pandas (np.ma.sum, a pandas-internal helper with other NaN
+    or ddof rules, a user function) is NOT one of them and runs on the host like any other callable."""
+    import builtins
+    table = {}
+    for name in _SUPPORTED_AGGS:
+        for owner in (np, pd.DataFrame, pd.Series, builtins):
+            fn = getattr(owner, name, None)
+            if callable(fn) and getattr(fn, '__name__', None) == name:
+                table[id(fn)] = name
+    for alias, name in (('amin', 'min'), ('amax', 'max')):
+        fn = getattr(np, alias, None)
+        if callable(fn):
+            table.setdefault(id(fn), name)
+    return table
+
+
+_KERNEL_FUNCTIONS = _kernel_functions()
+
+
 def _has_kernel(agg) -> bool:
     """True for the spellings of the ten aggregations that have device kernels: their names as strings, and the numpy /
-    pandas / builtin functions pandas itself maps to those names (np.sum, pd.DataFrame.mean, max, ...).  Any OTHER
-    callable -- also a user function that happens to be called 'sum' -- is evaluated on the host (extract.py:111)."""
+    pandas / builtin function objects pandas itself maps to those names (np.sum, pd.DataFrame.mean, max, ...).  Any
+    OTHER callable -- also a user function that happens to be called 'sum' -- is evaluated on the host (extract.py:111)."""
     if isinstance(agg, str):
         return agg in _SUPPORTED_AGGS
-    module = getattr(agg, '__module__', None) or ''
-    return (callable(agg) and getattr(agg, '__name__', None) in _SUPPORTED_AGGS and
-            (module.split('.')[0] in ('numpy', 'pandas', 'builtins')))
+    return callable(agg) and _KERNEL_FUNCTIONS.get(id(agg)) == getattr(agg, '__name__', None)
 
 
 class RecursiveFeatureExtractor:
@@ -249,7 +269,7 @@ class RecursiveFeatureExtractor:
         if self.time_phases:
             self._phase_sync()
             self.wall['generation_loop_s'] = time.perf_counter() - t_loop
-            self.wall['arena_bytes'] = int(self._arena.numel()) if self._arena is not None else 0
+            self.wall['arena_bytes'] = int(sum(c.numel() for c in self._arena)) if self._arena else 0
             self.wall['generation_loop_attempts'] = int(getattr(K.refex_run, 'attempts', 1))
             self.wall['generation_loop_trace'] = [[what, round(sec, 6)] for what, sec in getattr(K.refex_run, 'trace', [])]
         host = self.graph._device_graph()[0]
@@ -509,6 +529,16 @@ class RecursiveFeatureExtractor:
             empty_rows = {a: (res0.loc[a].to_numpy(dtype=np.float64, na_value=0.0)
                               if isinstance(res0, pd.DataFrame) and a in res0.index and res0.shape[1] == f else np.zeros(f))
                           for a in order}
+        # The reference hands the WHOLE list to DataFrame.agg (extract.py:111); here only the callables go through pandas
+        # node by node.  Whatever pandas has to say about the full list -- names mixed with callables that transform
+        # ("cannot combine transform and aggregation operations"), duplicate result names -- it says on the first node
+        # with neighbours, as in the reference: one probe with the real list on that node's frame
+        for v in range(n):
+            b, e = int(row_ptr[v]), int(row_ptr[v + 1])
+            if e > b:
+                pd.DataFrame({c: E[j, b:e].astype(prev_dt[j], copy=False) for j, c in enumerate(prev)},
+                             index=labels[nbr[b:e]], columns=prev).agg(list(self.aggs))
+                break
         for v in range(n):
             b, e = int(row_ptr[v]), int(row_ptr[v + 1])
             if e == b:

@@ -704,17 +704,22 @@ _AGG_NAMES = {v: k for k, v in _lib.AGG_IDS.items()}
 
 
 def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Sequence[str], max_generations: int,
-              aggs: Sequence[str], arena: Optional[torch.Tensor] = None, shard=None,
+              aggs: Sequence[str], arena=None, shard=None,
               gen0_int32: Optional[Sequence[bool]] = None):
     """
     grx_refex_run: the generation loop of RecursiveFeatureExtractor below the ABI (one call, one GPU).
     Returns (columns, generations, generation_count, arena): `columns` = one dict per RECORDED feature in
     record order {generation, parent, agg (name or None), gen0_index, work_position, col (fp64[n] tensor --
-    a view into `arena`, or the caller's generation-0 column)}; `generations` = per-generation counts.
-    The arena (uint8 tensor) is grown until the run fits; pass it back in to reuse it.
+    a view into a chunk of `arena`, or the caller's generation-0 column)}; `generations` = per-generation counts.
+    `arena`: a list of uint8 device tensors (chunks).  The first one is sized by a model of the run; when the run
+    needs more the library asks for it through a grow callback and a chunk is appended -- a run is never repeated
+    because the first size was a guess (round 5; it used to be, and at config 5 always was).  Pass the list back in to
+    reuse the memory.
     shard: a ShardPlan -- the loop aggregates this rank's rows only and issues its own exchanges (RCCL or the
-    plan's callback transport) between the kernels; every rank gets the complete columns.
+    plan's callback transport) between the kernels; every rank gets the complete columns.  Every allocation of the
+    loop is sized from rank-independent bounds, so all ranks grow at the same points: no agreement is needed.
     """
+    import time as _time
     comm, bounds = _shard_args(shard)
     n = csr.n
     f0 = len(gen0_cols)
@@ -723,68 +728,82 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
     names = (ctypes.c_char_p * f0)(*[nm.encode('utf-8') for nm in gen0_names])
     col_ptrs = ptr_array(list(gen0_cols))
     max_gens = max(int(max_generations), 1)
-    _t_first = None
-    if arena is None:
-        import time as _time0
-        _t0 = _time0.perf_counter()
-        arena = torch.empty(_refex_arena_guess(n, f0, len(aggs), max_gens), dtype=torch.uint8, device=device())
-        _t_first = ('arena %d bytes (first guess)' % arena.numel(), _time0.perf_counter() - _t0)
+    refex_run.trace = []                       # diagnostics: (what, seconds) of every allocation and library call
+    if isinstance(arena, torch.Tensor):
+        arena = [arena]
+    chunks = list(arena) if arena else []
+    if not chunks:
+        _t0 = _time.perf_counter()
+        chunks.append(torch.empty(_refex_arena_guess(n, f0, len(aggs), max_gens), dtype=torch.uint8, device=device()))
+        refex_run.trace.append(('arena %d bytes (first chunk)' % chunks[0].numel(), _time.perf_counter() - _t0))
+    # the library walks the chunks in order: the first is passed as the arena, the others are handed out again by the
+    # grow callback before any new memory is allocated
+    spare = chunks[1:]
+    chunks = chunks[:1]
+
+    def _grow(nbytes, _user):
+        try:
+            _t0 = _time.perf_counter()
+            for k, t in enumerate(spare):
+                if t.numel() >= nbytes:
+                    chunk = spare.pop(k)
+                    break
+            else:
+                chunk = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
+            chunks.append(chunk)
+            refex_run.trace.append(('grow %d bytes' % nbytes, _time.perf_counter() - _t0))
+            return chunk.data_ptr()
+        except Exception:                       # out of device memory: the library reports GRX_ERR_WORKSPACE
+            return None
+
+    grow_cb = _lib.GROW_FN(_grow)
     max_columns = 256
-    refex_run.attempts = 0                     # diagnostics: how often the library was entered (arena / table grown)
-    refex_run.trace = [_t_first] if _t_first else []     # diagnostics: (what, seconds) of every allocation and library call
-    import time as _time
+    refex_run.attempts = 0                     # diagnostics: how often the library was entered (column table grown)
     while True:
         refex_run.attempts += 1
-        # sharded: the library sizes every allocation from rank-independent bounds, so with ONE capacity for all ranks a
-        # too-small arena is a joint -3 (no rank restarts while its peers wait in an exchange); arenas kept from earlier
-        # runs may differ in size, hence the agreement on the smallest
-        capacity = arena.numel() if comm is None else shard.agree_min(arena.numel())
-        if capacity < arena.numel():
-            arena = arena[:capacity]
         table = (_lib.RefexColumn * max_columns)()
         gens = (_lib.RefexGeneration * max_gens)()
         n_cols, gen_count, needed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         lib = _lib.load()
         _t0 = _time.perf_counter()
         rc = lib.grx_refex_run(csr.plan().handle, n, _ptr(csr.row_ptr), _ptr(csr.agg_col), f0, col_ptrs, names, int_flags,
-                               int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(arena), capacity,
-                               max_columns, table,
+                               int(max_generations), len(aggs), agg_ids, comm, bounds, _ptr(chunks[0]), chunks[0].numel(),
+                               grow_cb, None, max_columns, table,
                                ctypes.byref(n_cols), max_gens, gens, ctypes.byref(gen_count), ctypes.byref(needed),
                                _stream())
-        refex_run.trace.append(('grx_refex_run rc=%d capacity=%d needed=%d' % (rc, capacity, needed.value),
+        refex_run.trace.append(('grx_refex_run rc=%d chunks=%d needed=%d' % (rc, len(chunks), needed.value),
                                 _time.perf_counter() - _t0))
-        if rc == -3:                                    # GRX_ERR_WORKSPACE: arena or column table too small
-            if needed.value > capacity:
-                # `needed` is what the run used up to the generation that failed -- a lower bound: grow geometrically
-                want = max(int(needed.value * 1.5), 2 * capacity) + (32 << 20)
-                del arena
-                _t0 = _time.perf_counter()
-                arena = torch.empty(want, dtype=torch.uint8, device=device())
-                refex_run.trace.append(('arena %d bytes' % want, _time.perf_counter() - _t0))
-            else:
-                max_columns *= 4
+        if rc == -3 and needed.value <= sum(c.numel() for c in chunks):
+            max_columns *= 4                            # GRX_ERR_WORKSPACE from the column table, not from the arena
+            spare[:0] = chunks[1:]
+            chunks = chunks[:1]
             continue
         _lib.check(rc, 'grx_refex_run')
         break
-    base = arena.data_ptr()
     agg_names = _AGG_NAMES
-    # one reinterpretation of the arena, one slice per column: tensor views cost ~2 us each on the host, and this loop
+    # one reinterpretation per chunk, one slice per column: tensor views cost ~2 us each on the host, and this loop
     # sits between the last kernel of the generation loop and whatever the caller launches next
-    arena64 = arena[:arena.numel() & ~7].view(torch.float64)
+    spans = [(c.data_ptr(), c.data_ptr() + c.numel(), c[:c.numel() & ~7].view(torch.float64)) for c in chunks]
     columns = []
     for i in range(n_cols.value):
         c = table[i]
         if c.gen0_index >= 0:
             col = gen0_cols[c.gen0_index]
         else:
-            off = (int(c.d_col) - base) >> 3
-            col = arena64[off:off + n]
+            ptr = int(c.d_col)
+            for lo, hi, view in spans:
+                if lo <= ptr < hi:
+                    off = (ptr - lo) >> 3
+                    col = view[off:off + n]
+                    break
+            else:
+                raise _lib.GrxError('grx_refex_run returned a column outside every arena chunk')
         columns.append(dict(generation=c.generation, parent=c.parent, agg=agg_names.get(c.agg), gen0_index=c.gen0_index,
                             work_position=c.work_position, col=col))
     generations = [dict(generation=g, candidates=gens[g].candidates, working=gens[g].working, dropped=gens[g].dropped,
                         retained=gens[g].retained, gather_row_bytes=gens[g].gather_row_bytes)
                    for g in range(gen_count.value + 1)]
-    return columns, generations, int(gen_count.value), arena
+    return columns, generations, int(gen_count.value), chunks + spare
 
 
 # ------------------------------------------------------------------------------- NMF

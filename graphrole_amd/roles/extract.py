@@ -103,9 +103,6 @@ class RoleExtractor:
         values = np.ascontiguousarray(self.node_role_factor.to_numpy(dtype=np.float64))
         if values.ndim != 2 or values.shape[1] == 0 or values.shape[0] == 0:
             return K, None
-        if values.shape[1] > self.MAX_ROLES:
-            raise ValueError(f'graphrole_amd handles at most {self.MAX_ROLES} role columns (GRX_MAX_ROLES); '
-                             f'got {values.shape[1]} -- there is no CPU fallback')
         return K, K.to_device(values)
 
     def extract_role_factors(self, features: pd.DataFrame) -> None:

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 500          /* 0.5.0: grx_egonet_features takes a workspace (grx_egonet_workspace_bytes) */
+#define GRX_VERSION 500          /* 0.5.0: grx_egonet_features takes a workspace (grx_egonet_workspace_bytes); grx_refex_run takes a
+                                    grow function (the arena is a chain of chunks); role kernels take any r */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
                                     a composed update (several times the traffic), then with n_roles + features <= 480 */
@@ -453,11 +454,18 @@ typedef struct {
                                   16 / 32: int32 rows, 8 * ldr: fp64 rows; 0 for generation 0) -- what a gather-rate
                                   ceiling has to be looked up with */
 } grx_refex_generation;
+/* grow (may be NULL): called when the arena is full -- returns `bytes` more bytes of device memory (256-byte aligned)
+ * that stay valid as long as the caller uses the returned columns, or NULL.  With it the run never fails for want of
+ * room (round 5: a first size is a guess, and a wrong guess used to cost a whole second run); columns may then lie
+ * in any chunk -- d_col is an absolute pointer either way.  Without it a too-small arena is GRX_ERR_WORKSPACE and
+ * *arena_needed a lower bound of what the run takes. */
+typedef void *(*grx_grow_fn)(size_t bytes, void *user);
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
                   int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
-                  size_t arena_bytes, int max_columns, grx_refex_column *h_columns, int *n_columns, int max_gens,
-                  grx_refex_generation *h_gens, int *generation_count, size_t *arena_needed, void *stream);
+                  size_t arena_bytes, grx_grow_fn grow, void *grow_user, int max_columns, grx_refex_column *h_columns,
+                  int *n_columns, int max_gens, grx_refex_generation *h_gens, int *generation_count, size_t *arena_needed,
+                  void *stream);
 
 /* ------------------------------------------------------------------ pruning ------------- */
 /*

@@ -47,8 +47,16 @@ def lib():
         L.orc_vertical_log_binning.restype = ctypes.c_int64
         L.orc_chebyshev.argtypes = [ctypes.c_int64, ctypes.c_int, _i32p, _i64p]
         L.orc_chebyshev.restype = None
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_threads.restype = None
         _lib = L
     return _lib
+
+
+def set_threads(t: int) -> None:
+    """Threads of the row-parallel C loops (0 = up to 32): any count gives the same values; the CPU-baseline leg of
+    bench.py times with 1."""
+    lib().orc_set_threads(int(t))
 
 
 def _wptr(w):

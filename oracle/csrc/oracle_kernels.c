@@ -8,6 +8,9 @@
  *
  *   gcc -O2 -shared -fPIC -o oracle/liboracle.so oracle/csrc/oracle_kernels.c -lm
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -57,10 +60,26 @@ static void pairwise_rows(const int32_t *col, const double *X, int f, int64_t b,
 
 /* graphrole/features/extract.py:98-119 -- sum and mean over the neighbour rows; `col` lists every
  * row's neighbours in the order the reference visits them.  X, S, M row-major n x f. */
+/* Threads (test speed only): every loop below that is parallel splits over ROWS (or column pairs) whose results do not
+ * depend on each other, so the values are the same for any thread count.  bench.py's cpu_baseline leg sets 1. */
+static int g_threads = 0;
+void orc_set_threads(int t) { g_threads = t; }
+static int orc_threads(void)
+{
+#ifdef _OPENMP
+    if (g_threads > 0) return g_threads;
+    int t = omp_get_max_threads();
+    return t > 32 ? 32 : t;
+#else
+    return 1;
+#endif
+}
+
 void orc_aggregate(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
                    const double *X, double *S, double *M)
 {
     if (f <= 0) return;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(orc_threads())
     for (int64_t v = 0; v < n; ++v) {
         double *s = S + v * f, *m = M + v * f;
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
@@ -84,6 +103,7 @@ void orc_aggregate_var(int64_t n, const int64_t *row_ptr, const int32_t *col, in
                        const double *X, double *VAR, double *STD)
 {
     if (f <= 0) return;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(orc_threads())
     for (int64_t v = 0; v < n; ++v) {
         double *var = VAR + v * f, *sd = STD + v * f;
         const int64_t b = row_ptr[v], e = row_ptr[v + 1], cnt = e - b;
@@ -121,6 +141,7 @@ void orc_aggregate_var(int64_t n, const int64_t *row_ptr, const int32_t *col, in
 void orc_aggregate_prod(int64_t n, const int64_t *row_ptr, const int32_t *col, int f,
                         const double *X, double *P)
 {
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(orc_threads())
     for (int64_t v = 0; v < n; ++v) {
         double *p = P + v * f;
         for (int c = 0; c < f; ++c) p[c] = 1.0;
@@ -177,9 +198,18 @@ void orc_rowsum(int64_t n, const int64_t *row_ptr, const int32_t *col, const dou
 int orc_egonet(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *w,
                int directed, double *internal, double *external)
 {
-    int64_t *mark = (int64_t *)calloc((size_t)n, sizeof(int64_t));
-    if (!mark) return -1;
+    int T = orc_threads();
+    if (T > 16) T = 16;                              /* one n-entry stamp array per thread */
+    if (n < 100000) T = 1;
+    int64_t *marks = (int64_t *)calloc((size_t)n * (size_t)T, sizeof(int64_t));
+    if (!marks) return -1;
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(T)
     for (int64_t v = 0; v < n; ++v) {
+#ifdef _OPENMP
+        int64_t *mark = marks + (size_t)omp_get_thread_num() * (size_t)n;
+#else
+        int64_t *mark = marks;
+#endif
         int64_t stamp = v + 1;
         mark[v] = stamp;
         for (int64_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) mark[col[k]] = stamp;
@@ -205,7 +235,7 @@ int orc_egonet(int64_t n, const int64_t *row_ptr, const int32_t *col, const doub
         internal[v] = ins;
         external[v] = ext;
     }
-    free(mark);
+    free(marks);
     return 0;
 }
 
@@ -259,6 +289,7 @@ int64_t orc_vertical_log_binning(int64_t n, const double *arr, double frac, int3
 /* graphrole/features/prune.py:108 -- pdist(binned.T, 'chebychev').  B column-major F x n. */
 void orc_chebyshev(int64_t n, int F, const int32_t *B, int64_t *D)
 {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads())
     for (int p = 0; p < F; ++p) {
         D[p * F + p] = 0;
         for (int q = p + 1; q < F; ++q) {

@@ -23,7 +23,12 @@ from dataclasses import dataclass, field
 from numbers import Number
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
+import os
+
 import numpy as np
+
+#: threads of the column binning of the full-size runs (0 = up to 32, 1 = serial: bench.py's single-core timing leg)
+BIN_THREADS = 0
 
 
 # --------------------------------------------------------------------------------------
@@ -647,7 +652,15 @@ def extract_features(g: OracleGraph, max_generations: int = 10, fast: bool = Fal
         for j, nm in enumerate(cand_names):
             work[nm] = cand_vals[:, j]
         cols = list(work)
-        B = np.column_stack([bin_fn(work[c]) for c in cols]) if cols else np.zeros((g.n, 0))
+        if fast and g.n >= 200_000 and len(cols) > 1 and BIN_THREADS != 1:
+            # the columns are binned independently (each call sorts a private copy in C, the GIL is released): threads
+            # change the wall-clock of the full-size tests, not a value
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=BIN_THREADS or min(32, os.cpu_count() or 1)) as pool:
+                binned = list(pool.map(lambda c: bin_fn(work[c]), cols))
+            B = np.column_stack(binned)
+        else:
+            B = np.column_stack([bin_fn(work[c]) for c in cols]) if cols else np.zeros((g.n, 0))
         D = cheb_fn(B)
         drop = prune_features(cols, D, thresh, final_names)          # prune.py:76
         for nm in drop:

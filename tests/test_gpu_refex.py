@@ -537,3 +537,25 @@ def test_prod_on_float_features_matches_oracle():
     ref = refex.extract_features(og, max_generations=3, fast=True, aggs=aggs)
     assert list(X.columns) == ref.columns and any('(prod)' in c for c in X.columns)
     np.testing.assert_allclose(X.values.astype(float), ref.values, rtol=1e-9, atol=0)
+
+
+def test_arena_grows_on_demand_and_chunks_are_reused(monkeypatch):
+    """Round 5: the arena of grx_refex_run is a chain of chunks -- a first block far too small makes the library ask
+    for more through the grow callback (no repeated run), the table equals the one from a roomy arena, and a second
+    run of the same extractor takes the chunks it already has."""
+    from graphrole_amd import RecursiveFeatureExtractor, kernels, synth
+    G = synth.ba_graph(400_000, 5, seed=3)        # ~0.3 GB of columns and workspace: several 64 MB chunks
+    ref = RecursiveFeatureExtractor(G, max_generations=4).extract_features()
+    monkeypatch.setattr(kernels, '_refex_arena_guess', lambda *a, **k: 1 << 16)
+    fe = RecursiveFeatureExtractor(G, max_generations=4)
+    X = fe.extract_features()
+    assert kernels.refex_run.attempts == 1
+    grown = [what for what, _ in kernels.refex_run.trace if what.startswith('grow')]
+    assert len(grown) >= 2 and len(fe._arena) == 1 + len(grown)
+    pd.testing.assert_frame_equal(X, ref, check_exact=True)
+    held = sorted(c.data_ptr() for c in fe._arena)
+    fe.reset()
+    X2 = fe.extract_features()
+    pd.testing.assert_frame_equal(X2, ref, check_exact=True)
+    assert not [what for what, _ in kernels.refex_run.trace if what.startswith('arena')]
+    assert set(held) <= {c.data_ptr() for c in fe._arena}

@@ -38,10 +38,14 @@ def test_kernels_on_wide_reference_factors():
         assert np.array_equal(share, z[f'{key}_role_percentage'], equal_nan=True), key
 
 
-@pytest.mark.parametrize('r', [1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 24, 31, 32])
-@pytest.mark.parametrize('n', [1, 127, 128, 129, 70001])
+@pytest.mark.parametrize('n,r', [(1, 1), (129, 1), (70001, 2), (127, 3), (70001, 5), (128, 7), (70001, 8), (129, 9),
+                                 (70001, 16), (1, 17), (70001, 24), (129, 31), (70001, 32),
+                                 # wider than any fitted factor (a frame the caller assigned): fewer rows per LDS tile,
+                                 # numpy's pairwise recursion beyond 128 values, rows that do not fit LDS at all
+                                 (5000, 33), (3001, 59), (3001, 60), (2000, 128), (2000, 129), (700, 300), (300, 1000),
+                                 (40, 7679), (40, 7680), (9, 8193), (9, 20000)])
 def test_kernels_equal_the_oracle(n, r):
-    """every rank up to GRX_MAX_ROLES, ragged row counts around the 128-row tile; quantised-like values (many exact
+    """ranks 1 .. GRX_MAX_ROLES and beyond, ragged row counts around the 128-row tile; quantised-like values (many exact
     ties), all-zero rows (0 / 0 = NaN), NaN entries and all-NaN rows"""
     from oracle import rolx
     rng = np.random.RandomState(1000 * r + n % 997)
@@ -56,11 +60,18 @@ def test_kernels_equal_the_oracle(n, r):
     assert np.array_equal(share, rolx.role_percentage(G), equal_nan=True)
 
 
-def test_kernels_reject_wide_and_empty():
-    from graphrole_amd import _lib, kernels as K
-    with pytest.raises(_lib.GrxError):
-        K.role_argmax(K.to_device(np.ones((4, 33))))
+def test_kernels_take_empty_factors_and_user_assigned_wide_frames():
+    from graphrole_amd import RoleExtractor, kernels as K
     assert K.to_host(K.role_argmax(K.to_device(np.ones((0, 4))))).shape == (0,)
+    # the reference's properties are idxmax / apply on ANY frame (roles/extract.py:38-57): a 40-column frame assigned by
+    # the caller works although no fit produces more than GRX_MAX_ROLES roles
+    rng = np.random.RandomState(3)
+    frame = pd.DataFrame(rng.rand(50, 40), index=[f'n{i}' for i in range(50)], columns=[f'role_{i}' for i in range(40)])
+    rx = RoleExtractor(n_roles=2)
+    rx.node_role_factor = frame
+    assert rx.roles == frame.idxmax(axis=1).to_dict()
+    expect = frame.apply(lambda row: row / row.sum(), axis=1)
+    assert np.array_equal(rx.role_percentage.values, expect.values)
 
 
 @pytest.mark.parametrize('name', util.ROLES_CASES)
