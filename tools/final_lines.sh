@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, frozen binary: timelines, bench lines, forced-collectives line, model selection
+# frozen binary of a round: timelines, bench lines, forced-collectives lines (run ON THE GPU BOX through gpurun)
 OUT=gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 for w in ba1m er100k dw5m; do
