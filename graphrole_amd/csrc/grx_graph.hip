@@ -2,7 +2,7 @@
 //
 // Kernels (all HBM/L2-gather bound; no MFMA -- this is integer-indexed fp64 streaming work):
 //   row_sums_kernel        weighted degree            networkx.py:48-63
-//   egonet_kernel          ego-net internal/external  networkx.py:71-83,115-123
+//   egonet_group_kernel / egonet_big_kernel   ego-net internal/external  networkx.py:71-83,115-123
 //   pack_rows_kernel       column-major -> row-major gather source
 //   aggregate_kernel       sum / mean over neighbours  features/extract.py:98-119
 //   aggregate_combine_kernel                             rows with > 128 neighbours: block sums -> row sums
@@ -281,25 +281,28 @@ __device__ __forceinline__ bool ego_chunk_inside(int32_t b, int32_t v, const int
 // hub row -- takes the general path below.
 // The external shares are added by lane 0 in member order, the rest are per-lane sequential sums and a fixed
 // butterfly: bitwise reproducible, independent of the launch geometry.
-template <int BATCH, int SLOTS>
+template <int BATCH, int SLOTS, bool DIRECTED>
 __global__ __launch_bounds__(256) void egonet_group_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ w, const EgoSlot *__restrict__ slots, int directed,
+    const double *__restrict__ w, const EgoSlot *__restrict__ slots,
     int64_t row_begin, int64_t row_end, const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
     double *__restrict__ internal, double *__restrict__ external)
 {
+    constexpr bool directed = DIRECTED;      // two instances: the undirected one carries the weights of row(v) in LDS
     // rows == nullptr: the nodes of [row_begin, row_end) with at most 8 SLOTS neighbours; else: the listed nodes
     constexpr int EGO_SLOTS = SLOTS;
     constexpr int EGO_GROUP_MAX = 8 * SLOTS;
     constexpr int G = 8;
     __shared__ unsigned ego_filter[256 / G][EGO_FILTER_WORDS];
     __shared__ int32_t ego_id[256 / G][EGO_GROUP_MAX];
+    extern __shared__ double ego_w[];      // undirected graphs only (dynamic: 0 bytes otherwise): the weights of row(v) = w(a -> v)
     const int lane = threadIdx.x % G;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
     unsigned *flt = ego_filter[threadIdx.x / G];
     int32_t *mid = ego_id[threadIdx.x / G];
+    double *mw = ego_w + (threadIdx.x / G) * EGO_GROUP_MAX;
     const int4 *slot16 = reinterpret_cast<const int4 *>(slots);
     const int64_t first = rows ? 0 : row_begin, last = rows ? (int64_t)n_rows[0] : row_end;
     for (int64_t it = first + group; it < last; it += ngroups) {
@@ -325,17 +328,24 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
         for (int i = 0; i < EGO_FILTER_WORDS / (4 * G); ++i)
             reinterpret_cast<uint4 *>(flt)[lane + G * i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_wave_barrier();
+        // UNDIRECTED graphs: every member's row holds the arc back to v (the CSR is symmetric), so v stays OUT of the
+        // filter -- a member whose only arc into ego(v) is that one still takes the fast path below, with the arc's
+        // weight from row(v) (w(a -> v) = w(v -> a), the same double); the exact test finds b == v without the filter
 #pragma unroll
         for (int i = 0; i <= EGO_SLOTS; ++i) {
-            const int32_t id = i < EGO_SLOTS ? uu[i < EGO_SLOTS ? i : 0] : (lane == 0 ? (int32_t)v : -2);
-            if (id >= 0) ego_filter_set(flt, id);
+            const int32_t id = i < EGO_SLOTS ? uu[i < EGO_SLOTS ? i : 0] : ((lane == 0 && directed) ? (int32_t)v : -2);
+            if (id >= 0 && (directed || id != (int32_t)v)) ego_filter_set(flt, id);
         }
-        __builtin_amdgcn_wave_barrier();
         double ins = 0.0, ext = 0.0;
         // member v itself: every arc of row(v) ends in ego(v)
 #pragma unroll
         for (int i = 0; i < EGO_SLOTS; ++i)
-            if (uu[i] >= 0 && (directed || uu[i] >= (int32_t)v)) ins += w ? w[vb + lane + (int64_t)G * i] : 1.0;
+            if (uu[i] >= 0) {
+                const double x = w ? w[vb + lane + (int64_t)G * i] : 1.0;
+                if (!directed) mw[lane + G * i] = x;
+                if (directed || uu[i] >= (int32_t)v) ins += x;
+            }
+        __builtin_amdgcn_wave_barrier();
 
         for (int mb = 0; mb < dv; mb += BATCH) {
             int4 q[BATCH];
@@ -361,9 +371,22 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
                                                  ego_filter_bit(flt, q[k].z) | ego_filter_bit(flt, q[k].w))
                                               : (unsigned)(((unsigned)q[k].w >> 8) > (unsigned)EGO_SLOT_IDS);
                     if (ego_group_bits(__ballot(hit != 0u), gshift) == 0u) {
-                        if (lane == 0)
-                            ext += __longlong_as_double((long long)(((unsigned long long)(unsigned)q[k].y << 32) | (unsigned)q[k].x));
-                        continue;
+                        const double rs0 = __longlong_as_double((long long)(((unsigned long long)(unsigned)q[k].y << 32) | (unsigned)q[k].x));
+                        if (directed) {
+                            if (lane == 0) ext += rs0;
+                            continue;
+                        }
+                        // undirected: exactly one arc of row(a) ends in ego(v), the one back to v
+                        const double wva = mw[m];
+                        const double e = rs0 - wva;
+                        const bool cancelled = lane == 0 && !(e * 64.0 >= rs0);
+                        if (ego_group_bits(__ballot(cancelled), gshift) == 0u) {
+                            if (lane == 0) {
+                                ext += e;
+                                if ((int32_t)v >= a) ins += wva;
+                            }
+                            continue;
+                        }
                     }
                 }
                 // lane 0 of the group holds the header of the slot
@@ -451,83 +474,174 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
     }
 }
 
-template <int TPN>
-__global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
-    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ w, const double *__restrict__ rowsum, int directed,
-    const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
-    double *__restrict__ internal, double *__restrict__ external)
+// Nodes with more than 64 out-neighbours (round 5; replaces the wavefront / workgroup kernels of rounds 1 - 4, which
+// searched ego(v) in global memory for every arc of every member: 38 ms for the hubs of a weighted BA 1 M / 10 M graph).
+// WAVES = 1: a wavefront per node (four nodes per workgroup), WAVES = 4: a 256-thread workgroup per node.
+//   * ego(v) as a Bloom filter in LDS (two bits per member, 16+ bits of filter per member while it fits); an id that
+//     passes both probes is confirmed by a binary search in row(v) itself (ascending ids);
+//   * ONE LANE PER MEMBER a: the lane reads the member's slot (row sum, begin | length, first 28 ids) and tests the
+//     ids one after the other -- a filter hit costs that lane a search, not the whole group (eight lanes per member
+//     made every group wait for the group with a hit);
+//   * members whose rows do not fit a slot are taken afterwards by the whole wavefront, 64 ids per step -- or, when the
+//     member is the far bigger hub, by looking ego(v) up in row(a), as before;
+//   * weights only for the arcs that end in ego(v); external = rowsum(a) - matched with the guards of the group kernel.
+// Lane <-> member and lane <-> chunk position are functions of the row alone: bitwise reproducible.
+__device__ __forceinline__ bool ego_big_member(const unsigned *flt, unsigned bit_mask, const int32_t *__restrict__ col,
+                                               int64_t vb, int64_t ve, int32_t v, int32_t b)
 {
-    // rows: the nodes of this kernel's degree class (egonet_prepare_kernel; round 5 -- every team of TPN threads used
-    // to walk ALL rows and skip the foreign ones: 2.3 ms per pass at 5 M rows for a few thousand owned ones)
-    constexpr int BLOCK = (TPN == 64) ? 256 : TPN;
-    constexpr int NODES_PER_BLOCK = BLOCK / TPN;
-    constexpr int WAVES = TPN / 64;
-    __shared__ double red[2][WAVES > 1 ? WAVES : 1];
-    const int lane = threadIdx.x % TPN;
-    const int64_t slot = (int64_t)blockIdx.x * NODES_PER_BLOCK + threadIdx.x / TPN;
-    const int64_t nslots = (int64_t)gridDim.x * NODES_PER_BLOCK;
-    const int64_t count = (int64_t)n_rows[0];
+    const unsigned h1 = (unsigned)b & bit_mask, h2 = (((unsigned)b * 0x9E3779B1u) >> 7) & bit_mask;
+    if (!((flt[h1 >> 5] >> (h1 & 31u)) & (flt[h2 >> 5] >> (h2 & 31u)) & 1u)) return false;
+    return b == v || find_in_row(col, vb, ve, b) >= 0;
+}
 
-    for (int64_t idx = slot; idx < count; idx += nslots) {
-        const int64_t v = rows[idx];
-        const int64_t vb = row_ptr[v], ve = row_ptr[v + 1];
-        const int64_t dv = ve - vb;
-        const bool v_in_row = find_in_row(col, vb, ve, (int32_t)v) >= 0;
-        const int64_t members = dv + (v_in_row ? 0 : 1);
-        const int lg_dv = ilog2_i64(members) + 2;
+template <int WAVES>
+__global__ __launch_bounds__(256) void egonet_big_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ w,
+    const EgoSlot *__restrict__ slots, int directed, const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
+    int filter_words, double *__restrict__ internal, double *__restrict__ external)
+{
+    extern __shared__ unsigned ego_big_lds[];
+    __shared__ double red[2][4];
+    constexpr int T = 64 * WAVES;                               // lanes per node
+    constexpr int NODES = 4 / WAVES;                            // nodes per workgroup
+    const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x % T;
+    unsigned *flt = ego_big_lds + (size_t)(threadIdx.x / T) * filter_words;
+    const unsigned bit_mask = (unsigned)filter_words * 32u - 1u;
+    const int4 *slot16 = reinterpret_cast<const int4 *>(slots);
+    const int64_t count = (int64_t)n_rows[0];
+    auto node_sync = [&] { if (WAVES > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    for (int64_t it = (int64_t)blockIdx.x * NODES + threadIdx.x / T; it < count; it += (int64_t)gridDim.x * NODES) {
+        const int32_t v = rows[it];
+        const int64_t vb = row_ptr[v], ve = row_ptr[v + 1], dv = ve - vb;
+        node_sync();                                            // the previous node's readers are done
+        for (int i = tid; i < filter_words; i += T) flt[i] = 0u;
+        node_sync();
+        for (int64_t m = tid; m <= dv; m += T) {
+            const int32_t id = m < dv ? col[vb + m] : v;
+            const unsigned h1 = (unsigned)id & bit_mask, h2 = (((unsigned)id * 0x9E3779B1u) >> 7) & bit_mask;
+            atomicOr(&flt[h1 >> 5], 1u << (h1 & 31u));
+            atomicOr(&flt[h2 >> 5], 1u << (h2 & 31u));
+        }
+        node_sync();
         double ins = 0.0, ext = 0.0;
-        for (int64_t m = lane; m < members; m += TPN) {
-            const int64_t a = (m < dv) ? (int64_t)col[vb + m] : v;
-            const int64_t ab = row_ptr[a], ae = row_ptr[a + 1];
-            const int64_t da = ae - ab;
-            if (da * lg_dv <= members * (int64_t)(ilog2_i64(da) + 2)) {
-                for (int64_t j = ab; j < ae; ++j) {
-                    const int32_t b = col[j];
-                    const double x = w ? w[j] : 1.0;
-                    const bool inside = (b == (int32_t)v) || find_in_row(col, vb, ve, b) >= 0;
-                    if (inside) {
-                        if (directed || b >= a) ins += x;
-                    } else {
-                        ext += x;
+        // member v itself: every arc of row(v) ends in ego(v)
+        for (int64_t m = tid; m < dv; m += T)
+            if (directed || col[vb + m] >= v) ins += w ? w[vb + m] : 1.0;
+        for (int64_t m0 = 0; m0 < dv; m0 += T) {
+            const int64_t m = m0 + tid;
+            int32_t a = m < dv ? col[vb + m] : -1;
+            if (a == v) a = -1;                                 // a self-loop: counted above
+            int64_t ab = 0, da = 0;
+            double rs = 0.0;
+            if (a >= 0) {
+                const int4 h = slot16[(int64_t)a * 8];
+                rs = __longlong_as_double((long long)(((unsigned long long)(unsigned)h.y << 32) | (unsigned)h.x));
+                const unsigned long long bd = ((unsigned long long)(unsigned)h.w << 32) | (unsigned)h.z;
+                ab = (int64_t)(bd & EGO_BEGIN_MASK);
+                da = (int64_t)(bd >> EGO_DEG_SHIFT);
+                if (da == (int64_t)EGO_DEG_SAT) da = row_ptr[a + 1] - ab;
+                // the first id sits behind the header in the same quarter of the slot
+            }
+            const bool is_long = a >= 0 && da > EGO_SLOT_IDS;
+            if (a >= 0 && !is_long && da > 0) {
+                int cnt = 0;
+                double msum = 0.0;
+                for (int q = 0; q * 4 < da; ++q) {
+                    const int4 ids = slot16[(int64_t)a * 8 + 1 + q];
+                    const int32_t b4[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = q * 4 + j;
+                        if (k < da && ego_big_member(flt, bit_mask, col, vb, ve, v, b4[j])) {
+                            const double x = w ? w[ab + k] : 1.0;
+                            ++cnt;
+                            msum += x;
+                            if (directed || b4[j] >= a) ins += x;
+                        }
                     }
                 }
-            } else {
-                int64_t matched = 0;
-                double in_all = 0.0;
-                int64_t lo = ab;
-                // look one ego member up in the not-yet-passed tail of row(a)
-                auto probe = [&](int32_t b) {
-                    const int64_t pos = lower_bound_row(col, lo, ae, b);
-                    if (pos < ae && col[pos] == b) {
-                        const double x = w ? w[pos] : 1.0;
-                        ++matched;
-                        in_all += x;
-                        if (directed || b >= a) ins += x;
-                        lo = pos + 1;
-                    } else {
-                        lo = pos;
+                if (cnt == 0) ext += rs;
+                else if (cnt != da) {
+                    const double e = rs - msum;
+                    if (e * 64.0 >= rs) ext += e;
+                    else {
+                        // nearly closed row: add the arcs that leave the ego set one by one
+                        for (int64_t k = 0; k < da; ++k) {
+                            const int32_t b = col[ab + k];
+                            if (!ego_big_member(flt, bit_mask, col, vb, ve, v, b)) ext += w ? w[ab + k] : 1.0;
+                        }
                     }
-                };
-                bool v_pending = !v_in_row;                  // v merged at its sorted position
-                for (int64_t t = 0; t < dv && lo < ae; ++t) {
-                    const int32_t b = col[vb + t];
-                    if (v_pending && (int32_t)v < b) {
-                        probe((int32_t)v);
-                        v_pending = false;
-                        if (lo >= ae) break;
-                    }
-                    probe(b);
                 }
-                if (v_pending && lo < ae) probe((int32_t)v);
-                if (matched != da) ext += (w ? rowsum[a] : (double)da) - in_all;
+            }
+            // members whose rows do not fit a slot: the whole wavefront takes them one after the other
+            unsigned long long todo = __ballot(is_long);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int32_t a_s = __shfl(a, src, 64);
+                const int64_t ab_s = __shfl(ab, src, 64), da_s = __shfl(da, src, 64);
+                const double rs_s = __shfl(rs, src, 64);
+                const int64_t members = dv + 1;
+                if (da_s * (ilog2_i64(members) + 2) <= members * (int64_t)(ilog2_i64(da_s) + 2) * 4) {
+                    // scan row(a), 64 ids per step
+                    unsigned long long cnt = 0;
+                    double msum = 0.0;
+                    for (int64_t k0 = 0; k0 < da_s; k0 += 64) {
+                        const int64_t k = k0 + wlane;
+                        const int32_t b = k < da_s ? col[ab_s + k] : -1;
+                        const bool inside = b >= 0 && ego_big_member(flt, bit_mask, col, vb, ve, v, b);
+                        cnt += (unsigned long long)__popcll(__ballot(inside));
+                        if (inside) {
+                            const double x = w ? w[ab_s + k] : 1.0;
+                            msum += x;
+                            if (directed || b >= a_s) ins += x;
+                        }
+                    }
+                    if (cnt != 0 && (int64_t)cnt != da_s) {
+                        msum = grx_group_sum<64>(msum);
+                        const double e = rs_s - msum;
+                        if (e * 64.0 >= rs_s) {
+                            if (wlane == src) ext += e;
+                        } else {
+                            for (int64_t k0 = 0; k0 < da_s; k0 += 64) {
+                                const int64_t k = k0 + wlane;
+                                const int32_t b = k < da_s ? col[ab_s + k] : -1;
+                                if (b >= 0 && !ego_big_member(flt, bit_mask, col, vb, ve, v, b)) ext += w ? w[ab_s + k] : 1.0;
+                            }
+                        }
+                    } else if (cnt == 0 && wlane == src) {
+                        ext += rs_s;
+                    }
+                } else {
+                    // a is by far the bigger hub: look the members of ego(v) up in row(a)
+                    long long matched = 0;
+                    double in_all = 0.0;
+                    for (int64_t t0 = 0; t0 <= dv; t0 += 64) {
+                        const int64_t t = t0 + wlane;
+                        int32_t key = -1;
+                        if (t < dv) key = col[vb + t];
+                        else if (t == dv && find_in_row(col, vb, ve, v) < 0) key = v;      // v itself, once
+                        if (key >= 0) {
+                            const int64_t pos = find_in_row(col, ab_s, ab_s + da_s, key);
+                            if (pos >= 0) {
+                                const double x = w ? w[pos] : 1.0;
+                                ++matched;
+                                in_all += x;
+                                if (directed || key >= a_s) ins += x;
+                            }
+                        }
+                    }
+                    matched = (long long)grx_group_sum<64>((double)matched);
+                    in_all = grx_group_sum<64>(in_all);
+                    if (wlane == src && matched != da_s) ext += rs_s - in_all;
+                }
             }
         }
         ins = grx_group_sum<64>(ins);
         ext = grx_group_sum<64>(ext);
         if constexpr (WAVES > 1) {
-            const int wv = threadIdx.x / 64;
-            if ((threadIdx.x & 63) == 0) { red[0][wv] = ins; red[1][wv] = ext; }
+            if (wlane == 0) { red[0][wave] = ins; red[1][wave] = ext; }
             __syncthreads();
             if (threadIdx.x == 0) {
                 double si = 0.0, se = 0.0;
@@ -535,9 +649,8 @@ __global__ __launch_bounds__(TPN == 64 ? 256 : TPN) void egonet_kernel(
                 internal[v] = si;
                 external[v] = se;
             }
-            __syncthreads();
         } else {
-            if (lane == 0) { internal[v] = ins; external[v] = ext; }
+            if (wlane == 0) { internal[v] = ins; external[v] = ext; }
         }
     }
 }
@@ -1957,24 +2070,37 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
         // nodes with at most EGO_GROUP_MAX neighbours: eight lanes each; the rest: a wavefront each
         const int64_t gwant = grx_ceil_div(nrows * 8, 256);
         const int ggrid = (int)(gwant > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : gwant);
-        egonet_group_kernel<2, EGO_SLOTS><<<ggrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end,
-                                                                 nullptr, nullptr, d_internal, d_external);
-        GRX_LAUNCH_CHECK();
         const int64_t wwant = grx_ceil_div(nrows * 8, 256 * 16);               // a few per cent of the rows at most
-        egonet_group_kernel<2, EGO_SLOTS_WIDE><<<(int)(wwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (wwant < 1 ? 1 : wwant)), 256, 0, st>>>(
-            d_row_ptr, d_col, d_w, slots, directed, row_begin, row_end, wide_rows, counts + 0, d_internal, d_external);
+        const int wgrid = (int)(wwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (wwant < 1 ? 1 : wwant));
+        if (directed) {
+            egonet_group_kernel<2, EGO_SLOTS, true><<<ggrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, row_begin, row_end, nullptr,
+                                                                           nullptr, d_internal, d_external);
+            GRX_LAUNCH_CHECK();
+            egonet_group_kernel<2, EGO_SLOTS_WIDE, true><<<wgrid, 256, 0, st>>>(d_row_ptr, d_col, d_w, slots, row_begin, row_end,
+                                                                                wide_rows, counts + 0, d_internal, d_external);
+        } else {
+            egonet_group_kernel<2, EGO_SLOTS, false><<<ggrid, 256, (size_t)(256 / 8) * EGO_GROUP_MAX * sizeof(double), st>>>(
+                d_row_ptr, d_col, d_w, slots, row_begin, row_end, nullptr, nullptr, d_internal, d_external);
+            GRX_LAUNCH_CHECK();
+            egonet_group_kernel<2, EGO_SLOTS_WIDE, false><<<wgrid, 256, (size_t)(256 / 8) * EGO_GROUP_MAX_WIDE * sizeof(double), st>>>(
+                d_row_ptr, d_col, d_w, slots, row_begin, row_end, wide_rows, counts + 0, d_internal, d_external);
+        }
         GRX_LAUNCH_CHECK();
-        const int64_t want4 = grx_ceil_div(nrows, 4);
-        const int grid = (int)(want4 > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want4);
-        egonet_kernel<64><<<grid, 256, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, mid_rows, counts + 1, d_internal,
-                                               d_external);
+        // 65 .. HUB - 1 neighbours: a wavefront per node, 32 K filter bits each (>= 64 per member)
+        const int64_t want4 = grx_ceil_div(nrows, 4 * 16);
+        const int grid = (int)(want4 > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : (want4 < 1 ? 1 : want4));
+        egonet_big_kernel<1><<<grid, 256, 4 * 1024 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, mid_rows,
+                                                                             counts + 1, 1024, d_internal, d_external);
         GRX_LAUNCH_CHECK();
     }
     {
-        const int grid = (int)(nrows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : nrows);
+        // HUB and more: a workgroup per node, 256 K filter bits (16 per member up to 16 K neighbours; beyond that more
+        // ids pass the filter and are turned away by the search in row(v))
+        const int64_t hwant = grx_ceil_div(nrows, 64);
+        const int grid = (int)(hwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (hwant < 1 ? 1 : hwant));
         GRX_PROF(GRX_K_EGONET_BLOCK, st);
-        egonet_kernel<512><<<grid, 512, 0, st>>>(d_row_ptr, d_col, d_w, d_rowsum, directed, hub_rows, counts + 2, d_internal,
-                                                d_external);
+        egonet_big_kernel<4><<<grid, 256, 8192 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, hub_rows,
+                                                                         counts + 2, 8192, d_internal, d_external);
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;
