@@ -121,8 +121,8 @@ _SIGNATURES = {
     'grx_comm_timing_reset': (c_int, [c_void_p]),
     'grx_row_sums': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'grx_add_columns': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'grx_egonet_workspace_bytes': (c_size_t, [c_int64]),
-    'grx_egonet_features': (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
+    'grx_egonet_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'grx_egonet_features': (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_pack_rows': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'grx_aggregate_ldr': (c_int, [c_int]),

@@ -166,28 +166,39 @@ struct __align__(16) EgoSlot {
 };
 static_assert(sizeof(EgoSlot) == 128, "one slot = one 128-byte line");
 
-// slots of all n rows + the rows of [row_begin, row_end) beyond the 8-lane kernel's 32 neighbours, appended to three
-// lists by out-degree: 33 .. 64 (the wide instance of the group kernel), 65 .. hub - 1 (a wavefront per row), hub and
-// more (a workgroup per row).  Their order does not matter: every row's result is computed independently of the others.
+// slots of all n rows + the rows of [row_begin, row_end) beyond the 8-lane kernel's 32 neighbours, appended to lists by
+// out-degree: 33 .. 64 (the wide instance of the group kernel), 65 .. hub - 1 (a wavefront per row), hub and more: a
+// workgroup per PART of EGO_PART members (entries {row, part, parts}: a node with 10 000 neighbours is ten work items,
+// not one workgroup that finishes long after the others).  The order of the lists does not matter: every row's result
+// is computed independently of the others, the parts of a row are summed in part order by egonet_combine_kernel.
+constexpr int EGO_PART = 1024;
 __global__ __launch_bounds__(256) void egonet_prepare_kernel(
     int64_t n, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ rowsum,
     int64_t row_begin, int64_t row_end, int64_t hub, EgoSlot *__restrict__ slots, int32_t *__restrict__ wide_rows,
-    int32_t *__restrict__ mid_rows, int32_t *__restrict__ hub_rows, unsigned *__restrict__ counts)
+    int32_t *__restrict__ mid_rows, int32_t *__restrict__ hub_parts, unsigned *__restrict__ counts)
 {
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < ((n + 63) & ~(int64_t)63); v += (int64_t)gridDim.x * 256) {
         const int64_t d = v < n ? row_ptr[v + 1] - row_ptr[v] : 0;
         const bool owned = v >= row_begin && v < row_end;
 #pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            const bool take = owned && (which == 0 ? (d > EGO_GROUP_MAX && d <= EGO_GROUP_MAX_WIDE)
-                                        : which == 1 ? (d > EGO_GROUP_MAX_WIDE && d < hub) : d >= hub);
+        for (int which = 0; which < 2; ++which) {
+            const bool take = owned && (which == 0 ? (d > EGO_GROUP_MAX && d <= EGO_GROUP_MAX_WIDE) : (d > EGO_GROUP_MAX_WIDE && d < hub));
             const unsigned long long bal = __ballot(take);
             if (bal) {
                 const int lane = threadIdx.x & 63;
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&counts[which], (unsigned)__popcll(bal));
                 base = __shfl(base, 0, 64);
-                if (take) (which == 0 ? wide_rows : which == 1 ? mid_rows : hub_rows)[base + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)v;
+                if (take) (which == 0 ? wide_rows : mid_rows)[base + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)v;
+            }
+        }
+        if (owned && d >= hub) {
+            const unsigned parts = (unsigned)((d + EGO_PART - 1) / EGO_PART);
+            const unsigned base = atomicAdd(&counts[2], parts);
+            for (unsigned p = 0; p < parts; ++p) {
+                hub_parts[3 * (size_t)(base + p)] = (int32_t)v;
+                hub_parts[3 * (size_t)(base + p) + 1] = (int32_t)p;
+                hub_parts[3 * (size_t)(base + p) + 2] = (int32_t)parts;
             }
         }
     }
@@ -498,8 +509,10 @@ template <int WAVES>
 __global__ __launch_bounds__(256) void egonet_big_kernel(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ w,
     const EgoSlot *__restrict__ slots, int directed, const int32_t *__restrict__ rows, const unsigned *__restrict__ n_rows,
-    int filter_words, double *__restrict__ internal, double *__restrict__ external)
+    int filter_words, double *__restrict__ internal, double *__restrict__ external, double *__restrict__ part_out)
 {
+    // WAVES == 1: rows = node ids, results to internal / external.  WAVES == 4: rows = {node, part, parts} triples, the
+    // members [part EGO_PART, (part + 1) EGO_PART) of the node, results to part_out[2 entry], [2 entry + 1]
     extern __shared__ unsigned ego_big_lds[];
     __shared__ double red[2][4];
     constexpr int T = 64 * WAVES;                               // lanes per node
@@ -512,8 +525,10 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
     const int64_t count = (int64_t)n_rows[0];
     auto node_sync = [&] { if (WAVES > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     for (int64_t it = (int64_t)blockIdx.x * NODES + threadIdx.x / T; it < count; it += (int64_t)gridDim.x * NODES) {
-        const int32_t v = rows[it];
+        const int32_t v = WAVES > 1 ? rows[3 * it] : rows[it];
         const int64_t vb = row_ptr[v], ve = row_ptr[v + 1], dv = ve - vb;
+        const int64_t m_lo = WAVES > 1 ? (int64_t)rows[3 * it + 1] * EGO_PART : 0;
+        const int64_t m_hi = WAVES > 1 ? (m_lo + EGO_PART < dv ? m_lo + EGO_PART : dv) : dv;
         node_sync();                                            // the previous node's readers are done
         for (int i = tid; i < filter_words; i += T) flt[i] = 0u;
         node_sync();
@@ -526,11 +541,11 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
         node_sync();
         double ins = 0.0, ext = 0.0;
         // member v itself: every arc of row(v) ends in ego(v)
-        for (int64_t m = tid; m < dv; m += T)
+        for (int64_t m = m_lo + tid; m < m_hi; m += T)
             if (directed || col[vb + m] >= v) ins += w ? w[vb + m] : 1.0;
-        for (int64_t m0 = 0; m0 < dv; m0 += T) {
+        for (int64_t m0 = m_lo; m0 < m_hi; m0 += T) {
             const int64_t m = m0 + tid;
-            int32_t a = m < dv ? col[vb + m] : -1;
+            int32_t a = m < m_hi ? col[vb + m] : -1;
             if (a == v) a = -1;                                 // a self-loop: counted above
             int64_t ab = 0, da = 0;
             double rs = 0.0;
@@ -646,12 +661,27 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
             if (threadIdx.x == 0) {
                 double si = 0.0, se = 0.0;
                 for (int i = 0; i < WAVES; ++i) { si += red[0][i]; se += red[1][i]; }
-                internal[v] = si;
-                external[v] = se;
+                part_out[2 * it] = si;
+                part_out[2 * it + 1] = se;
             }
         } else {
             if (wlane == 0) { internal[v] = ins; external[v] = ext; }
         }
+    }
+}
+
+// the parts of a hub row, added in part order (the entries of a row are consecutive in the list)
+__global__ __launch_bounds__(256) void egonet_combine_kernel(const int32_t *__restrict__ parts, const unsigned *__restrict__ n_parts,
+                                                             const double *__restrict__ part_out, double *__restrict__ internal,
+                                                             double *__restrict__ external)
+{
+    const int64_t count = (int64_t)n_parts[0];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
+        if (parts[3 * e + 1] != 0) continue;
+        double si = 0.0, se = 0.0;
+        for (int p = 0; p < parts[3 * e + 2]; ++p) { si += part_out[2 * (e + p)]; se += part_out[2 * (e + p) + 1]; }
+        internal[parts[3 * e]] = si;
+        external[parts[3 * e]] = se;
     }
 }
 
@@ -2029,13 +2059,15 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
     return GRX_OK;
 }
 
-size_t grx_egonet_workspace_bytes(int64_t n)
+static size_t ego_parts_cap(int64_t nnz) { return (size_t)(nnz > 0 ? nnz : 0) / 512 + (size_t)(nnz > 0 ? nnz : 0) / EGO_PART + 64; }
+
+size_t grx_egonet_workspace_bytes(int64_t n, int64_t nnz)
 {
     const size_t rows = (size_t)((n > 0 ? n : 0) + 64);
-    return rows * sizeof(EgoSlot) + 3 * rows * sizeof(int32_t) + 256;
+    return rows * sizeof(EgoSlot) + 2 * rows * sizeof(int32_t) + 256 + ego_parts_cap(nnz) * (3 * sizeof(int32_t) + 2 * sizeof(double)) + 64;
 }
 
-int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
+int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const int32_t *d_col,
                         const double *d_w, const double *d_rowsum, int directed,
                         int64_t row_begin, int64_t row_end, double *d_internal,
                         double *d_external, void *d_workspace, size_t workspace_bytes, void *stream)
@@ -2046,7 +2078,8 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     GRX_REQUIRE(d_row_ptr && d_col && d_internal && d_external, "grx_egonet_features: NULL pointer");
     GRX_REQUIRE(d_w == nullptr || d_rowsum != nullptr,
                 "grx_egonet_features: weighted graphs need d_rowsum (grx_row_sums, add_self_loop=0)");
-    GRX_REQUIRE(d_workspace != nullptr && workspace_bytes >= grx_egonet_workspace_bytes(n),
+    GRX_REQUIRE(nnz >= 0, "grx_egonet_features: nnz < 0");
+    GRX_REQUIRE(d_workspace != nullptr && workspace_bytes >= grx_egonet_workspace_bytes(n, nnz),
                 "grx_egonet_features: workspace too small (grx_egonet_workspace_bytes)");
     GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_egonet_features: more than 2^31 - 1 nodes");
     hipStream_t st = grx_stream(stream);
@@ -2058,14 +2091,15 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
     unsigned *counts = reinterpret_cast<unsigned *>(slots + rows_cap);
     int32_t *wide_rows = reinterpret_cast<int32_t *>(counts + 64);
     int32_t *mid_rows = wide_rows + rows_cap;
-    int32_t *hub_rows = mid_rows + rows_cap;
+    double *part_out = reinterpret_cast<double *>(reinterpret_cast<char *>(mid_rows + rows_cap) + ((16 - (((size_t)(mid_rows + rows_cap)) & 15)) & 15));
+    int32_t *hub_parts = reinterpret_cast<int32_t *>(part_out + 2 * ego_parts_cap(nnz));
     GRX_CHECK_HIP(hipMemsetAsync(counts, 0, 256, st));
     {
         const int64_t want = grx_ceil_div(n * 32, 256);
         GRX_PROF(GRX_K_EGONET_WAVE, st);
         // (one word per thread, no grid-stride cap: the row_ptr -> col chain of a thread is two dependent round trips)
         egonet_prepare_kernel<<<(int)(want > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : want), 256, 0, st>>>(
-            n, d_row_ptr, d_col, d_w ? d_rowsum : nullptr, row_begin, row_end, HUB, slots, wide_rows, mid_rows, hub_rows, counts);
+            n, d_row_ptr, d_col, d_w ? d_rowsum : nullptr, row_begin, row_end, HUB, slots, wide_rows, mid_rows, hub_parts, counts);
         GRX_LAUNCH_CHECK();
         // nodes with at most EGO_GROUP_MAX neighbours: eight lanes each; the rest: a wavefront each
         const int64_t gwant = grx_ceil_div(nrows * 8, 256);
@@ -2090,17 +2124,19 @@ int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_co
         const int64_t want4 = grx_ceil_div(nrows, 4 * 16);
         const int grid = (int)(want4 > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : (want4 < 1 ? 1 : want4));
         egonet_big_kernel<1><<<grid, 256, 4 * 1024 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, mid_rows,
-                                                                             counts + 1, 1024, d_internal, d_external);
+                                                                             counts + 1, 1024, d_internal, d_external, nullptr);
         GRX_LAUNCH_CHECK();
     }
     {
-        // HUB and more: a workgroup per node, 256 K filter bits (16 per member up to 16 K neighbours; beyond that more
-        // ids pass the filter and are turned away by the search in row(v))
-        const int64_t hwant = grx_ceil_div(nrows, 64);
+        // HUB and more: a workgroup per part of 1024 members, 256 K filter bits (16 per member up to 16 K neighbours; beyond
+        // that more ids pass the filter and are turned away by the search in row(v)); then the parts of a row in order
+        const int64_t hwant = grx_ceil_div(nrows, 16);
         const int grid = (int)(hwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (hwant < 1 ? 1 : hwant));
         GRX_PROF(GRX_K_EGONET_BLOCK, st);
-        egonet_big_kernel<4><<<grid, 256, 8192 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, hub_rows,
-                                                                         counts + 2, 8192, d_internal, d_external);
+        egonet_big_kernel<4><<<grid, 256, 8192 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, hub_parts,
+                                                                         counts + 2, 8192, d_internal, d_external, part_out);
+        GRX_LAUNCH_CHECK();
+        egonet_combine_kernel<<<64, 256, 0, st>>>(hub_parts, counts + 2, part_out, d_internal, d_external);
         GRX_LAUNCH_CHECK();
     }
     return GRX_OK;

@@ -373,9 +373,10 @@ def add_columns(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def _egonet_call(csr: 'DeviceCSR', directed: bool, rowsum, row_begin: int, row_end: int, internal, external) -> None:
-    ws_bytes = int(_lib.load().grx_egonet_workspace_bytes(csr.n))
+    nnz = int(csr.nnz)
+    ws_bytes = int(_lib.load().grx_egonet_workspace_bytes(csr.n, nnz))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
-    _lib.call('grx_egonet_features', csr.n, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
+    _lib.call('grx_egonet_features', csr.n, nnz, _ptr(csr.row_ptr), _ptr(csr.col), _ptr(csr.w), _ptr(rowsum),
               int(directed), row_begin, row_end, _ptr(internal), _ptr(external), _ptr(ws), ws_bytes, _stream())
 
 

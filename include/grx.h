@@ -224,14 +224,14 @@ int grx_add_columns(int64_t n, const double *d_a, const double *d_b, double *d_o
  * once; directed: every arc); external[v] = weight of edges leaving ego(v).
  * d_rowsum: plain weighted row sums of the same CSR (grx_row_sums with add_self_loop = 0, all n
  * rows); required when d_w != NULL, ignored otherwise.
- * d_workspace: grx_egonet_workspace_bytes(n) bytes of device scratch (round 5: one aligned 128-byte slot per node --
+ * nnz: number of CSR entries (d_row_ptr[n]); d_workspace: grx_egonet_workspace_bytes(n, nnz) bytes of device scratch (round 5: one aligned 128-byte slot per node --
  * its row sum, where its row begins, how long it is and its first 28 ids -- so that a member of an ego set costs one
  * aligned request instead of three or four, and the lists of the rows the wavefront / workgroup kernels own).
  * Weights are read for the arcs that END inside the ego set only; what leaves it is rowsum(a) minus that, exactly 0
  * for a closed row, and added arc by arc when the difference would cancel more than six bits.
  */
-size_t grx_egonet_workspace_bytes(int64_t n);
-int grx_egonet_features(int64_t n, const int64_t *d_row_ptr, const int32_t *d_col,
+size_t grx_egonet_workspace_bytes(int64_t n, int64_t nnz);
+int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const int32_t *d_col,
                         const double *d_w, const double *d_rowsum, int directed,
                         int64_t row_begin, int64_t row_end, double *d_internal,
                         double *d_external, void *d_workspace, size_t workspace_bytes, void *stream);

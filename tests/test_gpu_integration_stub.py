@@ -45,9 +45,10 @@ _check(_lib.grx_row_sums(_i64(n), d_row_ptr.ptr, d_col.ptr, None, _i32(1), _i64(
 assert np.array_equal(deg.to_host(np.float64, (n,)), X0[:, 0])
 internal, external = DeviceArray(np.zeros(n)), DeviceArray(np.zeros(n))
 _lib.grx_egonet_workspace_bytes.restype = C.c_size_t
-ego_bytes = _lib.grx_egonet_workspace_bytes(_i64(n))
+nnz = int(len(G.col))
+ego_bytes = _lib.grx_egonet_workspace_bytes(_i64(n), _i64(nnz))
 ego_ws = DeviceArray(nbytes=ego_bytes)
-_check(_lib.grx_egonet_features(_i64(n), d_row_ptr.ptr, d_col.ptr, None, None, _i32(0), _i64(0), _i64(n),
+_check(_lib.grx_egonet_features(_i64(n), _i64(nnz), d_row_ptr.ptr, d_col.ptr, None, None, _i32(0), _i64(0), _i64(n),
                                 internal.ptr, external.ptr, ego_ws.ptr, C.c_size_t(ego_bytes), None))
 assert np.array_equal(internal.to_host(np.float64, (n,)), X0[:, 1])
 assert np.array_equal(external.to_host(np.float64, (n,)), X0[:, 2])
