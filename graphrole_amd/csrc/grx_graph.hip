@@ -497,12 +497,32 @@ __global__ __launch_bounds__(256) void egonet_group_kernel(
 //     member is the far bigger hub, by looking ego(v) up in row(a), as before;
 //   * weights only for the arcs that end in ego(v); external = rowsum(a) - matched with the guards of the group kernel.
 // Lane <-> member and lane <-> chunk position are functions of the row alone: bitwise reproducible.
-__device__ __forceinline__ bool ego_big_member(const unsigned *flt, unsigned bit_mask, const int32_t *__restrict__ col,
-                                               int64_t vb, int64_t ve, int32_t v, int32_t b)
+// ... confirmed through a two-level search: every `stride`-th id of row(v) sits in LDS (samp[0 .. ns)), the binary search
+// over the samples costs no memory round trip, the remaining `stride` ids are searched in row(v) itself -- fourteen
+// dependent global loads per confirmed id (a hub's row) made the hub-to-hub pairs of a power-law graph the whole cost
+struct EgoBigSet {
+    const unsigned *flt;
+    unsigned bit_mask;
+    const int32_t *samp;
+    int ns, stride;
+    const int32_t *col;
+    int64_t vb, ve;
+    int32_t v;
+};
+__device__ __forceinline__ bool ego_big_member(const EgoBigSet &S, int32_t b)
 {
-    const unsigned h1 = (unsigned)b & bit_mask, h2 = (((unsigned)b * 0x9E3779B1u) >> 7) & bit_mask;
-    if (!((flt[h1 >> 5] >> (h1 & 31u)) & (flt[h2 >> 5] >> (h2 & 31u)) & 1u)) return false;
-    return b == v || find_in_row(col, vb, ve, b) >= 0;
+    const unsigned h1 = (unsigned)b & S.bit_mask, h2 = (((unsigned)b * 0x9E3779B1u) >> 7) & S.bit_mask;
+    if (!((S.flt[h1 >> 5] >> (h1 & 31u)) & (S.flt[h2 >> 5] >> (h2 & 31u)) & 1u)) return false;
+    if (b == S.v) return true;
+    int lo = 0, hi = S.ns;                                      // first sample > b
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (S.samp[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return false;
+    const int64_t begin = S.vb + (int64_t)(lo - 1) * S.stride;
+    const int64_t end = begin + S.stride < S.ve ? begin + S.stride : S.ve;
+    return find_in_row(S.col, begin, end, b) >= 0;
 }
 
 template <int WAVES>
@@ -519,7 +539,9 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
     constexpr int NODES = 4 / WAVES;                            // nodes per workgroup
     const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tid = threadIdx.x % T;
-    unsigned *flt = ego_big_lds + (size_t)(threadIdx.x / T) * filter_words;
+    constexpr int SAMPLES = WAVES > 1 ? 1024 : 64;              // ids of row(v) kept in LDS for the two-level search
+    unsigned *flt = ego_big_lds + (size_t)(threadIdx.x / T) * (filter_words + SAMPLES);
+    int32_t *samp = reinterpret_cast<int32_t *>(flt + filter_words);
     const unsigned bit_mask = (unsigned)filter_words * 32u - 1u;
     const int4 *slot16 = reinterpret_cast<const int4 *>(slots);
     const int64_t count = (int64_t)n_rows[0];
@@ -538,7 +560,11 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
             atomicOr(&flt[h1 >> 5], 1u << (h1 & 31u));
             atomicOr(&flt[h2 >> 5], 1u << (h2 & 31u));
         }
+        const int stride = (int)((dv + SAMPLES - 1) / SAMPLES) > 0 ? (int)((dv + SAMPLES - 1) / SAMPLES) : 1;
+        const int ns = (int)((dv + stride - 1) / stride);
+        for (int i = tid; i < ns; i += T) samp[i] = col[vb + (int64_t)i * stride];
         node_sync();
+        const EgoBigSet S{flt, bit_mask, samp, ns, stride, col, vb, ve, v};
         double ins = 0.0, ext = 0.0;
         // member v itself: every arc of row(v) ends in ego(v)
         for (int64_t m = m_lo + tid; m < m_hi; m += T)
@@ -568,7 +594,7 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int k = q * 4 + j;
-                        if (k < da && ego_big_member(flt, bit_mask, col, vb, ve, v, b4[j])) {
+                        if (k < da && ego_big_member(S, b4[j])) {
                             const double x = w ? w[ab + k] : 1.0;
                             ++cnt;
                             msum += x;
@@ -584,7 +610,7 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
                         // nearly closed row: add the arcs that leave the ego set one by one
                         for (int64_t k = 0; k < da; ++k) {
                             const int32_t b = col[ab + k];
-                            if (!ego_big_member(flt, bit_mask, col, vb, ve, v, b)) ext += w ? w[ab + k] : 1.0;
+                            if (!ego_big_member(S, b)) ext += w ? w[ab + k] : 1.0;
                         }
                     }
                 }
@@ -605,7 +631,7 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
                     for (int64_t k0 = 0; k0 < da_s; k0 += 64) {
                         const int64_t k = k0 + wlane;
                         const int32_t b = k < da_s ? col[ab_s + k] : -1;
-                        const bool inside = b >= 0 && ego_big_member(flt, bit_mask, col, vb, ve, v, b);
+                        const bool inside = b >= 0 && ego_big_member(S, b);
                         cnt += (unsigned long long)__popcll(__ballot(inside));
                         if (inside) {
                             const double x = w ? w[ab_s + k] : 1.0;
@@ -622,7 +648,7 @@ __global__ __launch_bounds__(256) void egonet_big_kernel(
                             for (int64_t k0 = 0; k0 < da_s; k0 += 64) {
                                 const int64_t k = k0 + wlane;
                                 const int32_t b = k < da_s ? col[ab_s + k] : -1;
-                                if (b >= 0 && !ego_big_member(flt, bit_mask, col, vb, ve, v, b)) ext += w ? w[ab_s + k] : 1.0;
+                                if (b >= 0 && !ego_big_member(S, b)) ext += w ? w[ab_s + k] : 1.0;
                             }
                         }
                     } else if (cnt == 0 && wlane == src) {
@@ -2123,7 +2149,7 @@ int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const 
         // 65 .. HUB - 1 neighbours: a wavefront per node, 32 K filter bits each (>= 64 per member)
         const int64_t want4 = grx_ceil_div(nrows, 4 * 16);
         const int grid = (int)(want4 > GRX_NUM_CU * 16 ? GRX_NUM_CU * 16 : (want4 < 1 ? 1 : want4));
-        egonet_big_kernel<1><<<grid, 256, 4 * 1024 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, mid_rows,
+        egonet_big_kernel<1><<<grid, 256, 4 * (1024 + 64) * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, mid_rows,
                                                                              counts + 1, 1024, d_internal, d_external, nullptr);
         GRX_LAUNCH_CHECK();
     }
@@ -2133,7 +2159,7 @@ int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const 
         const int64_t hwant = grx_ceil_div(nrows, 16);
         const int grid = (int)(hwant > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : (hwant < 1 ? 1 : hwant));
         GRX_PROF(GRX_K_EGONET_BLOCK, st);
-        egonet_big_kernel<4><<<grid, 256, 8192 * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, hub_parts,
+        egonet_big_kernel<4><<<grid, 256, (8192 + 1024) * sizeof(unsigned), st>>>(d_row_ptr, d_col, d_w, slots, directed, hub_parts,
                                                                          counts + 2, 8192, d_internal, d_external, part_out);
         GRX_LAUNCH_CHECK();
         egonet_combine_kernel<<<64, 256, 0, st>>>(hub_parts, counts + 2, part_out, d_internal, d_external);

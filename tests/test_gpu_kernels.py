@@ -152,12 +152,13 @@ def test_egonet_member_rows_of_every_length(K):
     from oracle import refex
     rng = np.random.default_rng(5)
     n = 4000
-    deg = np.concatenate([np.arange(0, 80), rng.integers(0, 40, size=n - 80 - 6), [300, 511, 512, 513, 600, 700]])
+    deg = np.concatenate([np.arange(0, 80), rng.integers(0, 40, size=n - 80 - 9), [300, 511, 512, 513, 600, 700,
+                                                                                    1024, 2500, 3900]])     # hub rows in 1 - 4 parts
     src = np.repeat(np.arange(n), deg)
     dst = np.concatenate([rng.choice(n, size=int(d), replace=False) for d in deg]) if deg.sum() else np.zeros(0, int)
     # make the hubs popular members, and close a few triangles
     extra_s = rng.integers(0, n, size=3000)
-    extra_d = rng.choice(np.arange(n - 6, n), size=3000)
+    extra_d = rng.choice(np.arange(n - 9, n), size=3000)
     key = np.unique(np.concatenate([src * n + dst, extra_s * n + extra_d]))
     src, dst = key // n, key % n
     w = rng.uniform(0.1, 5.0, size=len(src))
@@ -173,6 +174,16 @@ def test_egonet_member_rows_of_every_length(K):
     i1, e1 = K.egonet_features(_dev_csr(K, og1), True)
     assert np.array_equal(i1.cpu().numpy(), ego1['internal_edges'])
     assert np.array_equal(e1.cpu().numpy(), ego1['external_edges'])
+    # the same edges as an UNDIRECTED weighted graph (every member's row holds the arc back: the undirected fast path of
+    # the group kernel, hub rows whose members are hubs themselves)
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    key2, first = np.unique(lo * n + hi, return_index=True)
+    og2 = _oracle_graph(n, key2 // n, key2 % n, w[first], False)
+    ego2 = refex.egonet_features_c(og2)
+    i2, e2 = K.egonet_features(_dev_csr(K, og2), False)
+    np.testing.assert_allclose(i2.cpu().numpy(), ego2['internal_edges'], rtol=RTOL, atol=0)
+    np.testing.assert_allclose(e2.cpu().numpy(), ego2['external_edges'], rtol=util.WEIGHTED_RTOL, atol=0)
+    assert np.array_equal(e2.cpu().numpy() == 0, ego2['external_edges'] == 0)
 
 
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 4099, 100003])
