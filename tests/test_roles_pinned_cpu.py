@@ -74,9 +74,10 @@ def test_properties_through_the_test_double():
         # integer node labels come back as Python ints, like Series.to_dict()
         rx.node_role_factor = pd.DataFrame(G, index=np.arange(4) * 10, columns=['role_0', 'role_1', 'role_2'])
         assert all(type(k) is int for k in rx.roles)
-        wide = pd.DataFrame(np.ones((3, 40)))
+        # a frame wider than any fit (the reference's properties are idxmax / apply on ANY frame): no limit (round 5)
+        wide = pd.DataFrame(np.arange(120.0).reshape(3, 40) % 7)
         rx.node_role_factor = wide
-        with pytest.raises(ValueError, match='at most'):
-            rx.roles
+        assert rx.roles == wide.idxmax(axis=1).to_dict()
+        assert np.array_equal(rx.role_percentage.values, wide.apply(lambda row: row / row.sum(), axis=1).values)
     finally:
         backend.use(None)

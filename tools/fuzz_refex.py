@@ -23,7 +23,10 @@ def one(rng, case):
         dst = np.minimum((rng.pareto(1.0, m) * 2).astype(np.int64), n - 1)
     else:
         dst = rng.integers(0, n, m)
-    src = rng.integers(0, n, m)
+    if rng.random() < 0.3:                                      # power-law-ish SOURCES too: long rows (round 5: the ego-net
+        src = np.minimum((rng.pareto(0.8, m) * 2).astype(np.int64), n - 1)     # kernels for 33 - 64, 65 - 511, 512+ neighbours)
+    else:
+        src = rng.integers(0, n, m)
     if rng.random() < 0.7:                                      # mostly without self-loops
         keep = src != dst
         src, dst = src[keep], dst[keep]
