@@ -191,6 +191,7 @@ _SIGNATURES = {
     'grx_nmf_kl_cost': (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'grx_host_prune': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'grx_refex_bin_batch': (c_int, [c_int64, c_int]),
     'grx_refex_run': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, POINTER(c_int),
                               c_int, c_void_p, POINTER(c_int), POINTER(c_size_t), c_void_p]),

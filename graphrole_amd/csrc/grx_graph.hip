@@ -2104,7 +2104,7 @@ int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const 
     GRX_REQUIRE(d_row_ptr && d_col && d_internal && d_external, "grx_egonet_features: NULL pointer");
     GRX_REQUIRE(d_w == nullptr || d_rowsum != nullptr,
                 "grx_egonet_features: weighted graphs need d_rowsum (grx_row_sums, add_self_loop=0)");
-    GRX_REQUIRE(nnz >= 0, "grx_egonet_features: nnz < 0");
+    GRX_REQUIRE(nnz >= 0 && nnz < ((int64_t)1 << EGO_DEG_SHIFT), "grx_egonet_features: nnz must be in [0, 2^40) (a slot keeps a row's begin in 40 bits)");
     GRX_REQUIRE(d_workspace != nullptr && workspace_bytes >= grx_egonet_workspace_bytes(n, nnz),
                 "grx_egonet_features: workspace too small (grx_egonet_workspace_bytes)");
     GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_egonet_features: more than 2^31 - 1 nodes");

@@ -121,6 +121,7 @@ int pinned(size_t bytes, void **out)
 
 #define GRX_TRY(expr) do { int rc__ = (expr); if (rc__ != GRX_OK) return rc__; } while (0)
 
+
 // prune.py:76-130 on the distance matrix of the working set: indices (into `work`) to drop
 std::vector<int> prune(const std::vector<Column> &cols, const std::vector<int> &work, const int32_t *dist, int thresh,
                        const std::vector<std::vector<int>> &recorded)
@@ -164,6 +165,16 @@ std::vector<int> prune(const std::vector<Column> &cols, const std::vector<int> &
 }  // namespace
 
 extern "C" {
+
+// columns the generation loop bins per call of the binning (its workspace is sized for this many)
+int grx_refex_bin_batch(int64_t n, int ncols)
+{
+    if (ncols <= 0) return 0;
+    const size_t per = grx_log_bin_workspace_bytes(n, 1);
+    int64_t b = per ? (int64_t)(((size_t)4 << 30) / per) : ncols;          // 4 GiB: two calls for the widest generation of config 5
+    if (b < 8) b = 8;
+    return (int)(ncols < b ? ncols : b);
+}
 
 // The pruning decision of grx_refex_run as a host-only entry point (no device work): tests drive it without a GPU
 // against the Python FeaturePruner and the reference's known-answer tables (tests/test_host_logic_cpu.py).
@@ -252,8 +263,20 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         // row), every rank gets back the bins of its own rows of every column -- the only rows its Chebyshev pass reads
         const int n_owned = comm ? (count > me ? (count - me + P - 1) / P : 0) : count;
         const int n_owned_max = comm ? (count + P - 1) / P : count;       // what rank 0 owns: the allocation size everywhere
-        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, n_owned_max);
+        // columns are binned independently, so a wide candidate block goes through the binning in batches: the workspace
+        // (two key buffers per column and more) stays below 4 GiB instead of growing with the block (config 5: 6.7 GB for
+        // 82 columns of 5 M keys -- a third of the run's memory); small graphs keep the single call
+        const int bin_batch = grx_refex_bin_batch(n, n_owned_max);
+        const size_t ws_bytes = grx_log_bin_workspace_bytes(n, bin_batch);
         void *ws = n_owned_max ? arena.take(ws_bytes) : nullptr;
+        auto bin_columns = [&](int ncols, const double *src_cols, int64_t ld_cols, uint8_t *dst_bins, int32_t *d_status) -> int {
+            for (int c0 = 0; c0 < ncols; c0 += bin_batch) {
+                const int b = ncols - c0 < bin_batch ? ncols - c0 : bin_batch;
+                GRX_TRY(grx_internal_vertical_log_bin(n, b, src_cols + (size_t)c0 * ld_cols, ld_cols, nullptr, 0.5,
+                                                      dst_bins + (size_t)c0 * n, n, nullptr, ws, ws_bytes, d_status, stream));
+            }
+            return GRX_OK;
+        };
         double *owned = (comm && partial && n_owned_max) ? reinterpret_cast<double *>(arena.take((size_t)n_owned_max * n * 8)) : nullptr;
         uint8_t *owned_bins = (comm && n_owned_max) ? reinterpret_cast<uint8_t *>(arena.take((size_t)n_owned_max * n)) : nullptr;
         for (int j = 0; j < count; ++j) work.push_back(first_new + j);
@@ -272,8 +295,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
         if (!arena.overflow) {
             if (F >= 2) GRX_CHECK_HIP(hipMemsetAsync(d_dist, 0, dist_bytes, st));
             if (count && !comm) {
-                GRX_TRY(grx_internal_vertical_log_bin(n, count, block, n, nullptr, 0.5, bins, n, nullptr, ws, ws_bytes,
-                                                      F >= 2 ? d_dist + (size_t)F * F : nullptr, stream));
+                GRX_TRY(bin_columns(count, block, n, bins, F >= 2 ? d_dist + (size_t)F * F : nullptr));
             } else if (count) {
                 const double *src = block + (size_t)me * n;       // complete columns: the owned ones are a strided view
                 int64_t ld_src = (int64_t)P * n;
@@ -284,8 +306,7 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                     ld_src = n;
                 }
                 if (n_owned) {
-                    GRX_TRY(grx_internal_vertical_log_bin(n, n_owned, src, ld_src, nullptr, 0.5, owned_bins, n, nullptr, ws, ws_bytes,
-                                                          F >= 2 ? d_dist + (size_t)F * F : nullptr, stream));
+                    GRX_TRY(bin_columns(n_owned, src, ld_src, owned_bins, F >= 2 ? d_dist + (size_t)F * F : nullptr));
                 }
                 // step 2: the owners' bins of this rank's rows come back
                 GRX_TRY(grx_comm_owned_to_rows(comm, h_bounds, count, owned_bins, n, 1, bins, n, stream));

@@ -696,7 +696,7 @@ def _refex_arena_guess(n: int, f0: int, n_aggs: int, max_gens: int) -> int:
     cols = sum(min(c, 400.0) for c in per_gen)
     widest = int(min(max(per_gen) + 1, 400))
     blocks = int(cols * max(n, 1) * 9.2)                               # fp64 columns + uint8 bins, 256-byte slack
-    scratch = max(lib.grx_log_bin_workspace_bytes(n, widest), max(n, 1) * 8 * lib.grx_aggregate_ldr(widest))
+    scratch = max(lib.grx_log_bin_workspace_bytes(n, lib.grx_refex_bin_batch(n, widest)), max(n, 1) * 8 * lib.grx_aggregate_ldr(widest))
     return blocks + int(scratch) + (64 << 20)
 
 

@@ -460,6 +460,9 @@ typedef struct {
  * in any chunk -- d_col is an absolute pointer either way.  Without it a too-small arena is GRX_ERR_WORKSPACE and
  * *arena_needed a lower bound of what the run takes. */
 typedef void *(*grx_grow_fn)(size_t bytes, void *user);
+/* Columns the loop hands to one call of the binning (workspace = grx_log_bin_workspace_bytes(n, this), at most about 4 GiB for
+ * wide blocks of long columns; all of them for small graphs): what a caller's first arena size should assume. */
+int grx_refex_bin_batch(int64_t n, int ncols);
 int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_row_ptr, const int32_t *d_agg_col,
                   int f0, const double *const *h_gen0_cols, const char *const *h_gen0_names, const int *h_gen0_int32,
                   int max_generations, int n_aggs, const int *h_aggs, grx_comm *comm, const int64_t *h_bounds, void *d_arena,
