@@ -794,8 +794,7 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
             ptr = int(c.d_col)
             for lo, hi, view in spans:
                 if lo <= ptr < hi:
-                    off = (ptr - lo) >> 3
-                    col = view[off:off + n]
+                    col = view.narrow(0, (ptr - lo) >> 3, n)       # (narrow: a third of the host cost of a slice)
                     break
             else:
                 raise _lib.GrxError('grx_refex_run returned a column outside every arena chunk')
