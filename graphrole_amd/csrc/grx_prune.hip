@@ -1065,6 +1065,31 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
     }
     __syncthreads();
     const int npairs = filter ? n_listed : all_pairs;
+    if (npairs == 0) return;                                               // second stage: the sample settled every pair
+    // second stage (round 5): only the columns that still have a pair within the cap are staged -- after the sample
+    // stage that is a handful of the up to 128 columns of the set, and filling the LDS tile was what the stage spent its
+    // time on (config 5: 0.6 - 0.8 ms per launch at 1 TB/s)
+    __shared__ uint8_t col_needed[CH_MAX_F];
+    __shared__ uint8_t col_list[CH_MAX_F];
+    __shared__ int n_cols;
+    if (filter) {
+        for (int c = threadIdx.x; c < F; c += 256) col_needed[c] = 0;
+        if (threadIdx.x == 0) n_cols = 0;
+        __syncthreads();
+        for (int id = threadIdx.x; id < npairs; id += 256) {
+            col_needed[pair_pq[id] >> 8] = 1;
+            col_needed[pair_pq[id] & 0xFF] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = 0;
+            for (int c = 0; c < F; ++c)
+                if (col_needed[c]) col_list[k++] = (uint8_t)c;
+            n_cols = k;
+        }
+        __syncthreads();
+    }
+    const int n_stage = filter ? n_cols : F;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t align_or = 0;                                                  // low address bits of all columns
     for (int c = 0; c < F; ++c) align_or |= (int64_t)(reinterpret_cast<uintptr_t>(ptrs[c]) & 3);
@@ -1077,24 +1102,26 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
         if (rows == CH_ROWS && ((r0 | align_or) & 3) == 0) {
             // full tile, 4-byte aligned columns: element e = (column, dword) over all 256 lanes; eight loads per
             // thread are issued before the first LDS store (a load-store loop waits for every load in turn)
-            const int total = F * (CH_ROWS / 4);
+            const int total = n_stage * (CH_ROWS / 4);
             for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
                 uint32_t v[8];
+                int cc[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = e0 + 256 * j < total ? e0 + 256 * j : total - 1;
-                    v[j] = reinterpret_cast<const uint32_t *>(ptrs[e / (CH_ROWS / 4)] + r0)[e % (CH_ROWS / 4)];
+                    cc[j] = filter ? (int)col_list[e / (CH_ROWS / 4)] : e / (CH_ROWS / 4);
+                    v[j] = reinterpret_cast<const uint32_t *>(ptrs[cc[j]] + r0)[e % (CH_ROWS / 4)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = e0 + 256 * j;
-                    if (e < total) reinterpret_cast<uint32_t *>(tile + (e / (CH_ROWS / 4)) * CH_STRIDE)[e % (CH_ROWS / 4)] = v[j];
+                    if (e < total) reinterpret_cast<uint32_t *>(tile + cc[j] * CH_STRIDE)[e % (CH_ROWS / 4)] = v[j];
                 }
             }
         } else {
-            for (int e = threadIdx.x; e < F * CH_ROWS; e += 256) {
-                const int c = e / CH_ROWS, i = e % CH_ROWS;
+            for (int e = threadIdx.x; e < n_stage * CH_ROWS; e += 256) {
+                const int c = filter ? (int)col_list[e / CH_ROWS] : e / CH_ROWS, i = e % CH_ROWS;
                 tile[c * CH_STRIDE + i] = (i < rows) ? ptrs[c][r0 + i] : 0;
             }
         }
