@@ -1032,8 +1032,11 @@ __device__ __forceinline__ uint32_t ch_absdiff_max4(uint32_t x, uint32_t y)
 __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
                                                         int first_new, GrxPtrTable ptr_tab,
                                                         int32_t *__restrict__ dist, int ldF, int a0, int na,
-                                                        int b0, int cap, int tiles_per_block, int filter)
+                                                        int b0, int cap, int tiles_per_block, int filter, int psplit)
 {
+    // psplit > 1 (the sample stage: few tiles, every pair): the grid is psplit times the tile blocks, block b takes
+    // the tiles of block b % (gridDim.x / psplit) and the pairs with id % psplit == b / (gridDim.x / psplit) -- sixteen
+    // workgroups walking thousands of pairs each were 1.6 of the 4.8 ms this kernel cost at config 5
     const uint8_t *const *ptrs = reinterpret_cast<const uint8_t *const *>(ptr_tab.p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *tile = smem;                                            // F * CH_STRIDE
@@ -1046,13 +1049,16 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
     __shared__ int n_listed;
     if (threadIdx.x == 0) n_listed = 0;
     __syncthreads();
+    const int tile_blocks = (int)gridDim.x / psplit;
+    const int part = (int)blockIdx.x / tile_blocks;
     for (int id = threadIdx.x; id < all_pairs; id += 256) {
+        if (psplit > 1 && id % psplit != part) continue;
         const int target = id + tri0;
         int q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)target)) * 0.5f);
         while (q * (q - 1) / 2 > target) --q;
         while ((q + 1) * q / 2 <= target) ++q;
         const int p = target - q * (q - 1) / 2;
-        int slot = id;
+        int slot = psplit > 1 ? id / psplit : id;
         if (filter) {
             // second stage: only the pairs a first stage over a sample of rows left at <= cap
             const int gp = p < na ? a0 + p : b0 + (p - na), gq = q < na ? a0 + q : b0 + (q - na);
@@ -1064,8 +1070,8 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
         }
     }
     __syncthreads();
-    const int npairs = filter ? n_listed : all_pairs;
-    if (npairs == 0) return;                                               // second stage: the sample settled every pair
+    const int npairs = filter ? n_listed : (psplit > 1 ? (all_pairs - part + psplit - 1) / psplit : all_pairs);
+    if (npairs <= 0) return;                                               // second stage: the sample settled every pair
     // second stage (round 5): only the columns that still have a pair within the cap are staged -- after the sample
     // stage that is a handful of the up to 128 columns of the set, and filling the LDS tile was what the stage spent its
     // time on (config 5: 0.6 - 0.8 ms per launch at 1 TB/s)
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t align_or = 0;                                                  // low address bits of all columns
     for (int c = 0; c < F; ++c) align_or |= (int64_t)(reinterpret_cast<uintptr_t>(ptrs[c]) & 3);
-    const int64_t first_tile = (int64_t)blockIdx.x * tiles_per_block;
+    const int64_t first_tile = (int64_t)(blockIdx.x % tile_blocks) * tiles_per_block;
     for (int tl = 0; tl < tiles_per_block; ++tl) {
         const int64_t r0 = row_begin + (first_tile + tl) * CH_ROWS;
         if (r0 >= row_end) break;
@@ -1127,26 +1133,45 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
         }
         // rows beyond `rows` are zero in every column -> contribute distance 0
         __syncthreads();
-        for (int id = wave; id < npairs; id += 4) {
-            const uint32_t cur = pair_max[id];
-            if ((int)cur > cap) continue;                                  // uniform over the wavefront
-            const uint32_t pq = pair_pq[id];
-            const uint2 x = *reinterpret_cast<const uint2 *>(tile + (pq >> 8) * CH_STRIDE + lane * 8);
-            const uint2 y = *reinterpret_cast<const uint2 *>(tile + (pq & 0xFF) * CH_STRIDE + lane * 8);
-            uint32_t m = ch_absdiff_max4(x.x, y.x);
-            const uint32_t m2 = ch_absdiff_max4(x.y, y.y);
-            m = m2 > m ? m2 : m;
-            if (__ballot((int)m > cap) != 0) {
-                // beyond the cap: the exact value is not needed, one ballot settles the pair
-                if (lane == 0) pair_max[id] = (uint8_t)(cap + 1);
-                continue;
+        // four pairs per wavefront and trip: their state and tile reads are issued together (with 64 KB of LDS per
+        // workgroup two waves share a SIMD, and one pair at a time was a chain of four dependent LDS round trips)
+        constexpr int U = 4;
+        for (int id0 = wave; id0 < npairs; id0 += 4 * U) {
+            uint32_t cur[U], pq[U];
+            bool act[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = id0 + 4 * u;
+                act[u] = id < npairs;
+                cur[u] = act[u] ? pair_max[id] : 0u;
+                pq[u] = act[u] ? pair_pq[id] : 0u;
+            }
+            uint2 x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                act[u] = act[u] && (int)cur[u] <= cap;                     // uniform over the wavefront
+                x[u] = *reinterpret_cast<const uint2 *>(tile + (pq[u] >> 8) * CH_STRIDE + lane * 8);
+                y[u] = *reinterpret_cast<const uint2 *>(tile + (pq[u] & 0xFF) * CH_STRIDE + lane * 8);
             }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(m, off, 64);
-                m = o > m ? o : m;
+            for (int u = 0; u < U; ++u) {
+                if (!act[u]) continue;
+                const int id = id0 + 4 * u;
+                uint32_t m = ch_absdiff_max4(x[u].x, y[u].x);
+                const uint32_t m2 = ch_absdiff_max4(x[u].y, y[u].y);
+                m = m2 > m ? m2 : m;
+                if (__ballot((int)m > cap) != 0) {
+                    // beyond the cap: the exact value is not needed, one ballot settles the pair
+                    if (lane == 0) pair_max[id] = (uint8_t)(cap + 1);
+                    continue;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(m, off, 64);
+                    m = o > m ? o : m;
+                }
+                if (lane == 0 && m > cur[u]) pair_max[id] = (uint8_t)m;
             }
-            if (lane == 0 && m > cur) pair_max[id] = (uint8_t)m;
         }
     }
     __syncthreads();
@@ -2165,14 +2190,18 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
         const size_t lds = lds_bytes(Fl, fn);
         if (cap < 254 && tiles > 8 * SAMPLE_TILES && Fl > 4) {
             const int64_t split = row_begin + (int64_t)SAMPLE_TILES * CH_ROWS;
-            chebyshev_kernel<<<SAMPLE_TILES, 256, lds, st>>>(row_begin, split, Fl, fn, tab, d_dist, F, a0, na, b0, cap, 1, 0);
+            const int q0l = fn > 1 ? fn : 1;
+            const int np = Fl * (Fl - 1) / 2 - q0l * (q0l - 1) / 2;
+            const int psplit = np >= 256 ? 16 : (np >= 32 ? 4 : 1);        // the sample stage's pairs over 16 x psplit workgroups
+            chebyshev_kernel<<<SAMPLE_TILES * psplit, 256, lds, st>>>(row_begin, split, Fl, fn, tab, d_dist, F, a0, na, b0, cap, 1,
+                                                                      0, psplit);
             const int64_t rest = tiles - SAMPLE_TILES;
             const int tpb = (int)(rest <= GRX_NUM_CU * 8 ? 1 : grx_ceil_div(rest, GRX_NUM_CU * 8));
             chebyshev_kernel<<<(int)grx_ceil_div(rest, tpb), 256, lds, st>>>(split, row_end, Fl, fn, tab, d_dist, F, a0, na,
-                                                                             b0, cap, tpb, 1);
+                                                                             b0, cap, tpb, 1, 1);
         } else {
             chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, Fl, fn, tab, d_dist, F, a0, na, b0, cap,
-                                                     tiles_per_block, 0);
+                                                     tiles_per_block, 0, 1);
         }
         GRX_LAUNCH_CHECK();
         return GRX_OK;
