@@ -1032,8 +1032,11 @@ __device__ __forceinline__ uint32_t ch_absdiff_max4(uint32_t x, uint32_t y)
 __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64_t row_end, int F,
                                                         int first_new, GrxPtrTable ptr_tab,
                                                         int32_t *__restrict__ dist, int ldF, int a0, int na,
-                                                        int b0, int cap, int tiles_per_block, int filter, int psplit)
+                                                        int b0, int cap, int tiles_per_block, int filter, int psplit,
+                                                        int64_t tile_stride)
 {
+    // tile_stride > 1 (the sample stage): the block's tile t lies at rows row_begin + t * tile_stride * CH_ROWS -- a
+    // sample SPREAD over the row range instead of its first rows
     // psplit > 1 (the sample stage: few tiles, every pair): the grid is psplit times the tile blocks, block b takes
     // the tiles of block b % (gridDim.x / psplit) and the pairs with id % psplit == b / (gridDim.x / psplit) -- sixteen
     // workgroups walking thousands of pairs each were 1.6 of the 4.8 ms this kernel cost at config 5
@@ -1101,7 +1104,7 @@ __global__ __launch_bounds__(256) void chebyshev_kernel(int64_t row_begin, int64
     for (int c = 0; c < F; ++c) align_or |= (int64_t)(reinterpret_cast<uintptr_t>(ptrs[c]) & 3);
     const int64_t first_tile = (int64_t)(blockIdx.x % tile_blocks) * tiles_per_block;
     for (int tl = 0; tl < tiles_per_block; ++tl) {
-        const int64_t r0 = row_begin + (first_tile + tl) * CH_ROWS;
+        const int64_t r0 = row_begin + (first_tile + tl) * tile_stride * CH_ROWS;
         if (r0 >= row_end) break;
         const int rows = (int)((row_end - r0 < CH_ROWS) ? (row_end - r0) : CH_ROWS);
         __syncthreads();
@@ -2181,27 +2184,29 @@ int grx_chebyshev(int64_t row_begin, int64_t row_end, int F, int first_new,
         return (size_t)Fl * CH_STRIDE + (size_t)(np > 0 ? np : 0) * 3 + 16;
     };
     // one column set (<= CH_MAX_F columns: the global columns [a0, a0+na) then [b0, ...)): pairs with
-    // q >= fn.  Two stages when a cap is given and the range is long: all pairs on a sample of rows (the
-    // first rows of the range: with the degree-descending node order these are the hubs, where features
-    // differ most), then the whole range for the few pairs that are still within the cap.
+    // q >= fn.  Two stages when a cap is given and the range is long: all pairs on a sample of sixteen tiles SPREAD
+    // over the range (round 5; rounds 2 - 4 took the first rows -- with the degree-descending node order the hubs,
+    // where the features of a power-law graph differ most; on config 5 the sums of every generation grow with the
+    // degree together, their bins agree on the hubs, and thousands of pairs survived to die on the other rows), then
+    // the whole range for the pairs that are still within the cap.
     constexpr int SAMPLE_TILES = 16;
     auto run = [&](int Fl, int fn, const GrxPtrTable &tab, int a0, int na, int b0) -> int {
         GRX_PROF(GRX_K_CHEBYSHEV, st);
         const size_t lds = lds_bytes(Fl, fn);
         if (cap < 254 && tiles > 8 * SAMPLE_TILES && Fl > 4) {
-            const int64_t split = row_begin + (int64_t)SAMPLE_TILES * CH_ROWS;
+            const int64_t sample_stride = tiles / SAMPLE_TILES;               // >= 8
             const int q0l = fn > 1 ? fn : 1;
             const int np = Fl * (Fl - 1) / 2 - q0l * (q0l - 1) / 2;
             const int psplit = np >= 256 ? 16 : (np >= 32 ? 4 : 1);        // the sample stage's pairs over 16 x psplit workgroups
-            chebyshev_kernel<<<SAMPLE_TILES * psplit, 256, lds, st>>>(row_begin, split, Fl, fn, tab, d_dist, F, a0, na, b0, cap, 1,
-                                                                      0, psplit);
-            const int64_t rest = tiles - SAMPLE_TILES;
-            const int tpb = (int)(rest <= GRX_NUM_CU * 8 ? 1 : grx_ceil_div(rest, GRX_NUM_CU * 8));
-            chebyshev_kernel<<<(int)grx_ceil_div(rest, tpb), 256, lds, st>>>(split, row_end, Fl, fn, tab, d_dist, F, a0, na,
-                                                                             b0, cap, tpb, 1, 1);
+            chebyshev_kernel<<<SAMPLE_TILES * psplit, 256, lds, st>>>(row_begin, row_end, Fl, fn, tab, d_dist, F, a0, na, b0, cap, 1,
+                                                                      0, psplit, sample_stride);
+            // (the sampled tiles are simply visited again: sixteen of thousands)
+            const int tpb = (int)(tiles <= GRX_NUM_CU * 8 ? 1 : grx_ceil_div(tiles, GRX_NUM_CU * 8));
+            chebyshev_kernel<<<(int)grx_ceil_div(tiles, tpb), 256, lds, st>>>(row_begin, row_end, Fl, fn, tab, d_dist, F, a0, na,
+                                                                              b0, cap, tpb, 1, 1, 1);
         } else {
             chebyshev_kernel<<<grid, 256, lds, st>>>(row_begin, row_end, Fl, fn, tab, d_dist, F, a0, na, b0, cap,
-                                                     tiles_per_block, 0, 1);
+                                                     tiles_per_block, 0, 1, 1);
         }
         GRX_LAUNCH_CHECK();
         return GRX_OK;
