@@ -1,5 +1,6 @@
-"""A/B of the general ego-net path (grx_egonet_features) on the config-5 graph: one process per GRX_EGO_VARIANT
-(the library reads the switch once).  Prints one JSON line: ms per call (HIP events, best / median of 7), checksum."""
+"""Timing of the general ego-net path (grx_egonet_features) on the config-5 graph (during round 5 one process per kernel
+variant, selected by an environment switch that is gone with the variants; `variant` below is a free label from
+GRX_EGO_VARIANT).  Prints one JSON line: ms per call (HIP events, best / median of 7), checksums."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
