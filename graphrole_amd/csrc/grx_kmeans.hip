@@ -10,30 +10,61 @@
 //   * the caller draws the random numbers exactly as RandomState(1) hands them to sklearn (they do not depend
 //     on the data): the first seed index and n_trials uniforms per further seed;
 //   * mean-centring, tolerance, squared distances in sklearn's operation order (-2 x c + c^2 + x^2, clipped);
-//   * k-means++: cumulative sum of the closest distances -> searchsorted of uniform * potential -> the candidate
-//     with the smallest potential wins;  per seed: update + tile sums, pick, potentials, choose (4 launches, no
-//     host round trip);
+//   * k-means++: cumulative sum of the closest distances IN INDEX ORDER -> searchsorted of uniform * potential ->
+//     the candidate with the smallest potential wins;
 //   * Lloyd on the sorted values with prefix sums (labels are intervals): first-minimum E step decided with
 //     sklearn's own expression c^2 - 2 x c at the interval ends, centres = sum * (1 / count), relocation of
 //     empty clusters to the farthest points, stop on unchanged labels or total squared centre shift <= tol,
 //     a last E step when the labels had not settled.
-// What cannot be bit-identical: sums are reduced in another order than numpy's cumsum / BLAS / OpenMP partials
-// (relative 1e-13), so a uniform draw that lands within that distance of a boundary of the cumulative sum picks a
-// neighbouring point (probability ~1e-6 per draw at 6 M values), and tied candidate potentials are recognised
-// with a 1e-12 tolerance (see km_choose_kernel).  Centres agree with sklearn to ~1e-12 otherwise.
+//
+// The seeding in one dimension (round 6).  sklearn's formulation touches every value for every seed (distances to
+// the candidates, minimum with the closest distance, potentials): O(m k) -- 0.6 TB of traffic for the 30 M entries
+// and 512 levels of a wide table.  On the line a candidate c between the seeds s_L < c < s_R can only lower the
+// closest distance of values between the two midpoints, a CONTIGUOUS RANGE of the sorted values.  So:
+//   * the values are sorted once together with their indices (perm: sorted position -> index, rank: its inverse);
+//     the closest distances live in SORTED order (ds);
+//   * potentials: potential(c) = potential - sum over c's range of (d - min(d, dist(c, x))) -- one pass over the
+//     union of the candidates' ranges (km_gain_kernel);  update: the winner's range only (km_update_kernel);
+//   * the range is a SUPERSET of the values the full pass would change: midpoints widened by a bound on the
+//     rounding error of the two fp distances (see km_prep_kernel), and inside it every value is tested with the very
+//     expression the full pass uses -- GRX_KMEANS_FULL_RANGE=1 makes every range [0, m) and must give the same bits
+//     (tests/test_gpu_encode.py);
+//   * sums are EXACT: a distance is split into three fixed-point limbs (units 2^(E-32), 2^(E-64), 2^(E-96), E from
+//     the largest possible distance; the rest, < 2^-96 of it, is dropped -- a function of the value alone), limb sums
+//     are integers, integer addition is associative: per-tile (1024 indices) and per-super-tile (64 tiles) sums of
+//     the closest distances IN INDEX ORDER are kept by integer atomics from the range update, in any order, and the
+//     cumulative sum sklearn searches is their prefix;  gains likewise.  Nothing depends on the order of a reduction,
+//     so grids and chunking are free to change and every run gives the same bits;
+//   * per seed three launches, no host round trip: prep (one workgroup: winner of the previous seed, prefix of the
+//     super-tile sums, the n_trials candidates by searchsorted, their neighbours among the seeds, their ranges),
+//     gain (potentials), update (winner's range).
+// What cannot be bit-identical to sklearn: it sums in floating point (cumsum, BLAS), relative 1e-13, so a uniform
+// draw that lands within that distance of a boundary of the cumulative sum picks a neighbouring index (probability
+// ~1e-6 per draw at 6 M values), and tied candidate potentials are recognised with a 1e-12 tolerance (km_best).
+// Centres agree with sklearn to ~1e-12 otherwise.
 #include "grx_common.h"
 
+#include <cmath>
 #include <cstdlib>
 
-int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t ld, double *out, int64_t out_ld,
-                              void *workspace, hipStream_t st);
-extern "C" size_t grx_sort_workspace_bytes(int64_t n, int ncols);
+int grx_internal_sort_pairs(int64_t n, const double *col, double *out, uint32_t *perm, void *workspace, hipStream_t st);
+size_t grx_internal_sort_pairs_workspace_bytes(int64_t n);
 
 namespace {
 
-constexpr int KM_TILE = 1024;              // values per tile of the cumulative sum (256 threads x 4)
-constexpr int KM_MAX_TRIALS = 16;          // 2 + int(log(k)) <= 13 for k <= 65536
-constexpr int KM_MAX_K = 8192;              // the E step ranks the centres by counting: O(k^2) per iteration
+typedef __int128 i128;
+typedef unsigned long long u64;
+typedef long long i64;
+
+constexpr int KM_TILE = 1024;                 // values per tile of the prefix sums of the sorted values (256 threads x 4)
+constexpr int KM_MAX_BLOCKS = 2048;           // index blocks of the cumulative sum (two per thread of the prep scan)
+constexpr int KM_MIN_BLOCK_SHIFT = 6;
+constexpr int KM_MAX_TRIALS = 16;             // 2 + int(log(k)) <= 11 for k <= 8192
+constexpr int KM_MAX_K = 8192;                // the E step ranks the centres by counting: O(k^2) per iteration
+constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup step of the range kernels (256 x 8)
+constexpr int KM_RANGE_GRID = 2048;           // workgroups of the gain kernel
+constexpr int KM_UPDATE_GRID = 1024;          // ... of the update kernel (each flushes its block sums once)
+constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
 
 __device__ __forceinline__ double km_sqdist(double c, double csq, double x)
 {
@@ -44,14 +75,94 @@ __device__ __forceinline__ double km_sqdist(double c, double csq, double x)
     return d > 0.0 ? d : 0.0;
 }
 
-struct KmState {                 // device scalars shared by the kernels of one run
-    double mean, tol, pot;
+struct KmLimb { double cA, cB, cC, sA, sB, sC; };
+
+// per-seed records exist twice (index = seed number & 1): the prep workgroups of seed c + 1 read seed c's while they
+// write their own
+struct KmSeedRec {
     double cand_x[KM_MAX_TRIALS];
-    int64_t cand_id[KM_MAX_TRIALS];
-    double best_x;
-    int64_t best_id;
-    unsigned bar_count, bar_gen;   // grid barrier of the persistent seeding kernel
+    i64 cand_id[KM_MAX_TRIALS], cand_lo[KM_MAX_TRIALS], cand_hi[KM_MAX_TRIALS];   // candidate index; range of sorted positions
+    i64 gain[3][KM_MAX_TRIALS];  // limb sums of (d - min(d, dist to candidate)) over the candidate's range
+    u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
 };
+
+struct KmState {                 // device scalars shared by the kernels of one run
+    double mean, tol, vmin, vmax;
+    double amax;                 // bound on |x - mean|
+    double c0;                   // the first seed (centred)
+    KmLimb limb;
+    int faults, scale_e;
+    KmSeedRec rec[2];
+};
+
+// ---- exact sums: three limbs per distance ----------------------------------------------------------------------
+// a = d rounded to a multiple of 2^(E-32), b = (d - a) rounded to 2^(E-64), c = (d - a - b) rounded to 2^(E-96);
+// d - a and d - a - b are exact.  0 <= a / 2^(E-32) <= 2^32, |b|, |c| <= 2^31 units: sums of up to 2^20 limbs are
+// exact in fp64, sums of up to 2^30 as int64.  value(d) := a + b + c.
+__device__ __forceinline__ void km_split(const KmLimb &L, double d, double &a, double &b, double &c)
+{
+    a = __dadd_rn(__dadd_rn(d, L.cA), -L.cA);
+    const double r1 = __dadd_rn(d, -a);
+    b = __dadd_rn(__dadd_rn(r1, L.cB), -L.cB);
+    const double r2 = __dadd_rn(r1, -b);
+    c = __dadd_rn(__dadd_rn(r2, L.cC), -L.cC);
+}
+
+__device__ __forceinline__ i128 km_join(i64 a, i64 b, i64 c) { return ((i128)a << 64) + ((i128)b << 32) + (i128)c; }
+
+__device__ __forceinline__ i128 km_quanta(const KmLimb &L, double d)
+{
+    double a, b, c;
+    km_split(L, d, a, b, c);
+    return km_join(__double2ll_rn(a * L.sA), __double2ll_rn(b * L.sB), __double2ll_rn(c * L.sC));
+}
+
+__device__ __forceinline__ i128 km_make128(u64 lo, u64 hi) { return (i128)(((unsigned __int128)hi << 64) | lo); }
+
+__device__ __forceinline__ double km_to_double(i128 v)          // v >= 0
+{
+    return (double)(u64)(v >> 64) * 18446744073709551616.0 + (double)(u64)v;
+}
+
+__device__ __forceinline__ i128 km_ceil128(double r)            // smallest integer >= r, 0 <= r < 2^127
+{
+    if (!(r > 0.0)) return 0;
+    const u64 bits = (u64)__double_as_longlong(r);
+    const int e = (int)((bits >> 52) & 0x7FF);
+    const u64 mant = (bits & ((1ull << 52) - 1)) | (e ? (1ull << 52) : 0ull);
+    const int sh = (e ? e : 1) - 1075;                          // r = mant * 2^sh
+    if (sh >= 0) return (i128)mant << sh;
+    if (sh <= -64) return 1;
+    const u64 q = mant >> (-sh), rem = mant & ((1ull << (-sh)) - 1);
+    return (i128)(q + (rem ? 1 : 0));
+}
+
+__device__ __forceinline__ i128 km_shfl_up128(i128 v, int off)
+{
+    return km_make128(__shfl_up((u64)v, off, 64), __shfl_up((u64)(v >> 64), off, 64));
+}
+
+__device__ __forceinline__ i128 km_wave_scan128(i128 v, int lane)      // inclusive
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const i128 y = km_shfl_up128(v, off);
+        if (lane >= off) v += y;
+    }
+    return v;
+}
+
+__device__ __forceinline__ i64 km_wave_sum_i64(i64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void km_atomic_add_i64(i64 *p, i64 v)
+{
+    if (v) atomicAdd(reinterpret_cast<u64 *>(p), (u64)v);
+}
 
 // fixed-shape workgroup sum (256 threads): wave butterflies, then the four wave totals in order
 __device__ __forceinline__ double km_block_sum(double v, double *red)
@@ -63,356 +174,545 @@ __device__ __forceinline__ double km_block_sum(double v, double *red)
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// the same sum for one of several 256-thread sub-blocks of a larger workgroup (lt = thread id inside the sub-block,
-// red = the sub-block's four slots): identical tree, so a sub-block of the persistent kernel produces the bits a
-// 256-thread workgroup of the per-seed kernels does
-__device__ __forceinline__ double km_subblock_sum(double v, double *red, int lt)
-{
-    v = grx_group_sum<64>(v);
-    __syncthreads();
-    if ((lt & 63) == 0) red[lt >> 6] = v;
-    __syncthreads();
-    return ((red[0] + red[1]) + red[2]) + red[3];
-}
-
 // ---- moments ---------------------------------------------------------------------------------------
+// part[b] = workgroup sum; pass 0 (square == 0) also part[nb + b] = min, part[2 nb + b] = max
 __global__ __launch_bounds__(256) void km_sum_kernel(const double *__restrict__ v, int64_t m,
                                                      const KmState *__restrict__ st, int square,
                                                      double *__restrict__ part)
 {
-    __shared__ double red[4];
+    __shared__ double red[4], rmin[4], rmax[4];
     const double shift = square ? st->mean : 0.0;
-    double s = 0.0;
+    double s = 0.0, lo = v[0], hi = v[0];
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
-        const double x = v[i] - shift;
+        const double raw = v[i];
+        const double x = raw - shift;
         s += square ? x * x : x;
+        lo = raw < lo ? raw : lo;
+        hi = raw > hi ? raw : hi;
     }
     s = km_block_sum(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (!square) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = lo; rmax[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) { lo = rmin[w] < lo ? rmin[w] : lo; hi = rmax[w] > hi ? rmax[w] : hi; }
+            part[gridDim.x + blockIdx.x] = lo;
+            part[2 * gridDim.x + blockIdx.x] = hi;
+        }
+    }
 }
 
-__global__ __launch_bounds__(64) void km_moment_final_kernel(const double *__restrict__ part, int nb, int64_t m, int which,
-                                                             double rel_tol, KmState *st)
-{
-    if (threadIdx.x != 0) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[b];
-    if (which == 0) st->mean = s / (double)m;
-    else st->tol = (s / (double)m) * rel_tol;                  // _tolerance: mean(var(X, axis=0)) * tol
-}
-
-// x = v - mean; d = squared distance to the first seed; tile sums of d
-__global__ __launch_bounds__(256) void km_init_kernel(const double *__restrict__ v, int64_t m, int64_t first,
-                                                      const KmState *__restrict__ st, double *__restrict__ x,
-                                                      double *__restrict__ d, double *__restrict__ tsum,
-                                                      double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id)
+// which == 0: mean, min, max.  which == 1: tolerance, and the scale of the exact sums from the first seed.
+__global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__restrict__ part, int nb, int64_t m, int which,
+                                                              double rel_tol, const double *__restrict__ v, int64_t first,
+                                                              KmState *st)
 {
     __shared__ double red[4];
-    const double mean = st->mean;
-    const double c = v[first] - mean, csq = __dmul_rn(c, c);
-    const int64_t base = (int64_t)blockIdx.x * KM_TILE;
     double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += part[b];
+    s = km_block_sum(s, red);
+    if (threadIdx.x != 0) return;
+    if (which == 0) {
+        double lo = part[nb], hi = part[2 * nb];
+        for (int b = 1; b < nb; ++b) { lo = part[nb + b] < lo ? part[nb + b] : lo; hi = part[2 * nb + b] > hi ? part[2 * nb + b] : hi; }
+        st->mean = s / (double)m;
+        st->vmin = lo;
+        st->vmax = hi;
+        return;
+    }
+    st->tol = (s / (double)m) * rel_tol;                       // _tolerance: mean(var(X, axis=0)) * tol
+    const double mean = st->mean;
+    const double xl = st->vmin - mean, xh = st->vmax - mean, c0 = v[first] - mean;
+    st->c0 = c0;
+    st->amax = fabs(xl) > fabs(xh) ? fabs(xl) : fabs(xh);
+    const double reach = fabs(xl - c0) > fabs(xh - c0) ? fabs(xl - c0) : fabs(xh - c0);
+    const double bound = reach * reach;                        // no closest distance is ever larger (up to rounding: + 2 below)
+    int E = (bound > 0.0 && bound < 1.0e300) ? ilogb(bound) + 2 : (bound > 0.0 ? KM_E_MAX + 1 : KM_E_MIN);
+    int faults = 0;
+    if (E < KM_E_MIN) E = KM_E_MIN;                            // (values below 1e-135: distances lose their low bits)
+    if (E > KM_E_MAX) { E = KM_E_MAX; faults = 2; }            // values beyond 1e144: not representable
+    st->scale_e = E;
+    st->limb.cA = ldexp(1.5, 52 + E - 32);
+    st->limb.cB = ldexp(1.5, 52 + E - 64);
+    st->limb.cC = ldexp(1.5, 52 + E - 96);
+    st->limb.sA = ldexp(1.0, 32 - E);
+    st->limb.sB = ldexp(1.0, 64 - E);
+    st->limb.sC = ldexp(1.0, 96 - E);
+    st->faults = faults;
+}
+
+// index order: x = v - mean; per block of 2^block_shift indices the exact sum of the squared distances to the first
+// seed (a workgroup of 1024 indices touches at most 17 blocks: collected in LDS, then added with integer atomics)
+__global__ __launch_bounds__(256) void km_init_kernel(const double *__restrict__ v, int64_t m, int64_t first,
+                                                      KmState *st, double *__restrict__ x, i64 *__restrict__ bacc,
+                                                      int block_shift, double *__restrict__ seeds_x,
+                                                      int64_t *__restrict__ seeds_id, double *__restrict__ sorted)
+{
+    __shared__ u64 s_acc[3][(KM_TILE >> KM_MIN_BLOCK_SHIFT) + 1];
+    const double mean = st->mean;
+    const KmLimb L = st->limb;
+    const double c = st->c0, csq = __dmul_rn(c, c);
+    const int64_t base = (int64_t)blockIdx.x * KM_TILE;
+    const int64_t b0 = base >> block_shift;
+    if (threadIdx.x < 3 * ((KM_TILE >> KM_MIN_BLOCK_SHIFT) + 1)) (&s_acc[0][0])[threadIdx.x] = 0;
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < KM_TILE / 256; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
         if (i < m) {
             const double xi = v[i] - mean;
             x[i] = xi;
-            const double di = km_sqdist(c, csq, xi);
-            d[i] = di;
-            s += di;
+            double a, b, cc;
+            km_split(L, km_sqdist(c, csq, xi), a, b, cc);
+            const int slot = (int)((i >> block_shift) - b0);
+            atomicAdd(&s_acc[0][slot], (u64)__double2ll_rn(a * L.sA));
+            atomicAdd(&s_acc[1][slot], (u64)__double2ll_rn(b * L.sB));
+            atomicAdd(&s_acc[2][slot], (u64)__double2ll_rn(cc * L.sC));
         }
     }
-    s = km_block_sum(s, red);
-    if (threadIdx.x == 0) tsum[blockIdx.x] = s;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { seeds_x[0] = c; seeds_id[0] = first; }
-}
-
-// ---- k-means++ : one further seed = pick -> potentials -> choose -> update ---------------------------
-// pick: inclusive scan of the tile sums (potential = last), then per trial r = uniform * potential and the first
-// index whose cumulative sum reaches r: binary search over the tile prefixes, sequential additions inside the tile
-__device__ __forceinline__ void km_pick_body(const double *__restrict__ x, const double *__restrict__ d,
-                                             int64_t m, double *__restrict__ tsum, int64_t ntiles,
-                                             const double *__restrict__ uniform, int n_trials, int first_call,
-                                             KmState *st, double *s_scan, double *s_pot_p)
-{
-    double &s_pot = *s_pot_p;
-    {
-        // inclusive prefixes of the tile sums in place: a contiguous chunk of tiles per thread, the chunk totals
-        // scanned across the workgroup
-        const int64_t chunk = (ntiles + 1023) / 1024;
-        const int64_t t0 = (int64_t)threadIdx.x * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
-        double local = 0.0;
-        for (int64_t t = t0; t < t1; ++t) local += tsum[t];
-        s_scan[threadIdx.x] = local;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const double add = (threadIdx.x >= (unsigned)off) ? s_scan[threadIdx.x - off] : 0.0;
-            __syncthreads();
-            s_scan[threadIdx.x] += add;
-            __syncthreads();
-        }
-        double run = s_scan[threadIdx.x] - local;
-        for (int64_t t = t0; t < t1; ++t) { run += tsum[t]; tsum[t] = run; }
-        if (threadIdx.x == 0) {
-            // sklearn carries candidates_pot[best] as the potential; the first time it is closest_dist_sq @ weights
-            s_pot = first_call ? s_scan[1023] : st->pot;
-            if (first_call) st->pot = s_scan[1023];
-        }
-        __threadfence_block();
-        __syncthreads();
+    __syncthreads();
+    if (threadIdx.x < 3 * ((KM_TILE >> KM_MIN_BLOCK_SHIFT) + 1)) {
+        const int limb = threadIdx.x / ((KM_TILE >> KM_MIN_BLOCK_SHIFT) + 1), slot = threadIdx.x % ((KM_TILE >> KM_MIN_BLOCK_SHIFT) + 1);
+        if (s_acc[limb][slot]) km_atomic_add_i64(bacc + 4 * (b0 + slot) + limb, (i64)s_acc[limb][slot]);
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_trials) return;
-    const double r = uniform[wave] * s_pot;
-    // first tile whose inclusive prefix reaches r
-    int64_t lo = 0, hi = ntiles - 1;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tsum[mid] < r) lo = mid + 1; else hi = mid; }
-    const int64_t tile = lo;
-    const int64_t base = tile * KM_TILE;
-    // inside the tile: running cumulative sum 64 values at a time (wave scan), first position that reaches r
-    double carry = tile ? tsum[tile - 1] : 0.0;
-    int64_t idx = base + KM_TILE - 1;
-    bool found = false;
-    for (int j0 = 0; j0 < KM_TILE && !found; j0 += 64) {
-        const int64_t i = base + j0 + lane;
-        double inc = (i < m) ? d[i] : 0.0;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double y = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += y;
-        }
-        const double acc = carry + inc;
-        const uint64_t hit = __ballot(acc >= r);
-        if (hit) {
-            idx = base + j0 + (__ffsll((long long)hit) - 1);
-            found = true;
-        }
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) {
-        if (idx > m - 1) idx = m - 1;                           // np.clip(candidate_ids, None, n - 1)
-        st->cand_id[wave] = idx;
-        st->cand_x[wave] = x[idx];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seeds_x[0] = c;
+        seeds_id[0] = first;
+        sorted[0] = c;
     }
 }
 
-__global__ __launch_bounds__(1024) void km_pick_kernel(const double *__restrict__ x, const double *__restrict__ d,
-                                                       int64_t m, double *__restrict__ tsum, int64_t ntiles,
-                                                       const double *__restrict__ uniform, int n_trials, int first_call,
-                                                       KmState *st)
+// sorted order: closest distances to the first seed, and the inverse permutation
+__global__ __launch_bounds__(256) void km_sorted_init_kernel(const double *__restrict__ xs, const uint32_t *__restrict__ perm,
+                                                             int64_t m, const KmState *__restrict__ st,
+                                                             double *__restrict__ ds, uint32_t *__restrict__ rank)
 {
-    __shared__ double s_scan[1024];
-    __shared__ double s_pot;
-    km_pick_body(x, d, m, tsum, ntiles, uniform, n_trials, first_call, st, s_scan, &s_pot);
+    const double c = st->c0, csq = __dmul_rn(c, c);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < m; p += stride) {
+        ds[p] = km_sqdist(c, csq, xs[p]);
+        rank[perm[p]] = (uint32_t)p;
+    }
 }
 
-// potentials of the candidates: sum over all values of min(d, squared distance to the candidate).  One 256-thread
-// (sub-)block vb of nb: thread lt adds the values vb * 256 + lt, + nb * 256, ... in order, then the block tree.
-__device__ __forceinline__ void km_pots_block(const double *__restrict__ x, const double *__restrict__ d, int64_t m,
-                                              int n_trials, const KmState *__restrict__ st, double *__restrict__ ppart,
-                                              int vb, int nb, int lt, double *red, bool valid)
+// ---- k-means++ : one further seed = prep -> gain -> update --------------------------------------------------------
+// argmin of the candidates' potentials (= potential - gain), np.argmin's first minimum.  Exact ties are COMMON on
+// small inputs -- two isolated candidates that each capture only themselves and each other -- and sklearn's BLAS sums
+// return bit-equal potentials for them: potentials within 1e-12 of the minimum count as tied, the first wins.
+__device__ int km_best(const KmSeedRec *rec, int n_trials)
 {
-    double c[KM_MAX_TRIALS], csq[KM_MAX_TRIALS], s[KM_MAX_TRIALS];
+    const i128 pot = km_make128(rec->pot_lo, rec->pot_hi);
+    double pd[KM_MAX_TRIALS];
+    double lowest = 0.0;
 #pragma unroll
     for (int j = 0; j < KM_MAX_TRIALS; ++j) {
-        c[j] = j < n_trials ? st->cand_x[j] : 0.0;
-        csq[j] = __dmul_rn(c[j], c[j]);
-        s[j] = 0.0;
+        pd[j] = 0.0;
+        if (j < n_trials) {
+            pd[j] = km_to_double(pot - km_join(rec->gain[0][j], rec->gain[1][j], rec->gain[2][j]));
+            lowest = (j == 0 || pd[j] < lowest) ? pd[j] : lowest;
+        }
     }
-    const int64_t stride = (int64_t)nb * 256;
-    for (int64_t i = valid ? (int64_t)vb * 256 + lt : m; i < m; i += stride) {
-        const double xi = x[i], di = d[i];
+    int best = n_trials - 1;
 #pragma unroll
-        for (int j = 0; j < KM_MAX_TRIALS; ++j) {
-            if (j < n_trials) {
-                const double dj = km_sqdist(c[j], csq[j], xi);
-                s[j] += dj < di ? dj : di;
+    for (int j = KM_MAX_TRIALS - 1; j >= 0; --j)
+        if (j < n_trials && !(pd[j] > lowest + 1e-12 * lowest)) best = j;
+    return best;
+}
+
+// Two searches in one wavefront over an ascending array a[0, n): lanes 0-31 find the first index with a >= tlo
+// (0 when !has_lo), lanes 32-63 the first index with a > thi (n when !has_hi); 32 probes per step.
+__device__ __forceinline__ void km_dual_search(const double *__restrict__ a, int64_t n, double tlo, double thi, bool has_lo,
+                                               bool has_hi, int64_t &out_lo, int64_t &out_hi)
+{
+    const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+    const double t = half ? thi : tlo;
+    int64_t lo = 0, hi = n;                                     // the answer is in [lo, hi]
+    if (!(half ? has_hi : has_lo)) lo = hi = half ? n : 0;
+    for (;;) {
+        const int64_t len = hi - lo;
+        if (__ballot(len > 0) == 0) break;
+        const int64_t stride = (len + 31) >> 5;
+        const int64_t idx = lo + (int64_t)l * stride;
+        bool pred = false;
+        if (len > 0 && idx < hi) {
+            const double val = a[idx];
+            pred = half ? (val <= t) : (val < t);
+        }
+        const uint64_t bal = __ballot(pred);
+        const int cnt = __popc((unsigned)(half ? (bal >> 32) : (bal & 0xFFFFFFFFull)));
+        if (len > 0) {
+            if (cnt == 0) {
+                hi = lo;
+            } else {
+                const int64_t nlo = lo + (int64_t)(cnt - 1) * stride + 1;
+                int64_t nhi = lo + (int64_t)cnt * stride;
+                if (nhi > hi) nhi = hi;
+                lo = nlo;
+                hi = nhi;
             }
         }
     }
+    out_lo = __shfl(lo, 0, 64);
+    out_hi = __shfl(lo, 32, 64);
+}
+
+// prep of seed `seed_no`: ONE WORKGROUP PER TRIAL (all of them repeat the cheap common part).
+//  A (choose_prev): the winner among the previous seed's candidates becomes seed seed_no - 1; workgroup 0 records it and
+//    writes the sorted list of seeds with it inserted into the other buffer.
+//  B (do_pick): inclusive prefix of the index-block sums = sklearn's cumulative sum at block ends; total = the potential.
+//    The trial's r = uniform * potential; the first index whose cumulative sum reaches r (np.searchsorted, left): block
+//    by binary search, then the workgroup walks the block's indices (distances gathered through rank).
+//  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
+//    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
+//    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
+//    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
+__global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
+                                                       const uint32_t *__restrict__ rank, int64_t m,
+                                                       const i64 *__restrict__ bacc, int nblocks, int block_shift,
+                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
+                                                       int choose_prev, int do_pick, int full_range, KmState *st,
+                                                       double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
+                                                       double *__restrict__ sorted2, int sorted_ld)
+{
+    __shared__ u64 s_inc_lo[KM_MAX_BLOCKS], s_inc_hi[KM_MAX_BLOCKS];
+    __shared__ u64 s_wt_lo[16], s_wt_hi[16];
+    __shared__ u64 s_expect[2];
+    __shared__ int64_t s_idx;
+    __shared__ int s_best, s_first;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int trial = blockIdx.x;
+    KmSeedRec *cur = &st->rec[seed_no & 1];
+    const KmSeedRec *prev = &st->rec[(seed_no - 1) & 1];
+    const int n_old = choose_prev ? seed_no - 1 : seed_no;      // seeds in the sorted list: it lives in buffer (count & 1)
+    const double *sorted_old = sorted2 + (size_t)(n_old & 1) * sorted_ld;
+    double *sorted_new = sorted2 + (size_t)((n_old + 1) & 1) * sorted_ld;
+    double newest = 0.0;                                        // the seed chosen here, not yet in sorted_old
+    if (choose_prev) {
+        if (tid == 0) {
+            const int best = km_best(prev, n_trials);
+            s_best = best;
+            const i128 after = km_make128(prev->pot_lo, prev->pot_hi) -
+                               km_join(prev->gain[0][best], prev->gain[1][best], prev->gain[2][best]);
+            s_expect[0] = (u64)after;
+            s_expect[1] = (u64)(after >> 64);
+        }
+        __syncthreads();
+        const int best = s_best;
+        newest = prev->cand_x[best];
+        if (trial == 0) {
+            int pos = 0;                                        // seeds <= newest: it goes behind them
+            for (int i0 = 0; i0 < n_old; i0 += 1024) pos += __syncthreads_count(i0 + tid < n_old && sorted_old[i0 + tid] <= newest);
+            for (int i = tid; i < n_old; i += 1024) sorted_new[i < pos ? i : i + 1] = sorted_old[i];
+            if (tid == 0) {
+                sorted_new[pos] = newest;
+                seeds_x[seed_no - 1] = newest;
+                seeds_id[seed_no - 1] = prev->cand_id[best];
+            }
+        }
+    }
+    if (!do_pick) return;
+    // ---- B: prefix of the block sums
+    i128 e0 = 0, e1 = 0;
+    if (2 * tid < nblocks) e0 = km_join(bacc[8 * tid], bacc[8 * tid + 1], bacc[8 * tid + 2]);
+    if (2 * tid + 1 < nblocks) e1 = km_join(bacc[8 * tid + 4], bacc[8 * tid + 5], bacc[8 * tid + 6]);
+    const i128 loc = e0 + e1;
+    const i128 inc = km_wave_scan128(loc, lane);
+    if (lane == 63) { s_wt_lo[wave] = (u64)inc; s_wt_hi[wave] = (u64)(inc >> 64); }
+    __syncthreads();
+    i128 before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const i128 wt = km_make128(s_wt_lo[w], s_wt_hi[w]);
+        if (w < wave) before += wt;
+        total += wt;
+    }
+    {
+        const i128 i0 = before + inc - loc + e0, i1 = i0 + e1;
+        s_inc_lo[2 * tid] = (u64)i0; s_inc_hi[2 * tid] = (u64)(i0 >> 64);
+        s_inc_lo[2 * tid + 1] = (u64)i1; s_inc_hi[2 * tid + 1] = (u64)(i1 >> 64);
+    }
+    if (tid == 0) { s_first = 1024; s_idx = -1; }
+    __syncthreads();
+    if (trial == 0) {
+        if (tid == 0) {
+            if (choose_prev && seed_no >= 2 && ((u64)total != s_expect[0] || (u64)(total >> 64) != s_expect[1])) atomicOr(&st->faults, 1);
+            cur->pot_lo = (u64)total;
+            cur->pot_hi = (u64)(total >> 64);
+        }
+        if (tid < 3 * KM_MAX_TRIALS) cur->gain[tid / KM_MAX_TRIALS][tid % KM_MAX_TRIALS] = 0;
+    }
+    const KmLimb L = st->limb;
+    const double r = uniform[trial] * km_to_double(total);
+    const i128 R = km_ceil128(r);
+    int64_t idx = m - 1;                                        // np.clip(candidate_ids, None, n - 1)
+    if (R <= total) {                                           // (uniform over the workgroup)
+        int slo = 0, shi = nblocks - 1;
+        while (slo < shi) {
+            const int mid = (slo + shi) >> 1;
+            if (km_make128(s_inc_lo[mid], s_inc_hi[mid]) < R) slo = mid + 1; else shi = mid;
+        }
+        const i128 carry = slo ? km_make128(s_inc_lo[slo - 1], s_inc_hi[slo - 1]) : (i128)0;
+        // walk the block: thread t owns `per` consecutive indices
+        const int64_t bsize = (int64_t)1 << block_shift;
+        const int64_t per = bsize >= 1024 ? bsize >> 10 : 1;
+        const int64_t i0 = ((int64_t)slo << block_shift) + (int64_t)tid * per;
+        const int64_t bend = (((int64_t)slo + 1) << block_shift) < m ? (((int64_t)slo + 1) << block_shift) : m;
+        const int64_t i1 = (tid * per < bsize) ? (i0 + per < bend ? i0 + per : bend) : i0;
+        i128 lsum = 0;
+        for (int64_t ib = i0; ib < i1; ib += 16) {              // ranks first, then the distances they point at
+            uint32_t rk[16];
+            double dv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rk[s] = rank[ib + s < i1 ? ib + s : i1 - 1];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dv[s] = ds[rk[s]];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) lsum += (ib + s < i1) ? km_quanta(L, dv[s]) : (i128)0;
+        }
+        const i128 linc = km_wave_scan128(lsum, lane);
+        __syncthreads();                                        // (s_wt is read above by every thread)
+        if (lane == 63) { s_wt_lo[wave] = (u64)linc; s_wt_hi[wave] = (u64)(linc >> 64); }
+        __syncthreads();
+        i128 wbefore = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+            if (w < wave) wbefore += km_make128(s_wt_lo[w], s_wt_hi[w]);
+        const i128 mine = carry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
+        if (mine + lsum >= R) atomicMin(&s_first, tid);
+        __syncthreads();
+        const int owner = s_first;
+        if (owner == 1024) {
+            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = bend - 1; }
+        } else if (tid == owner) {
+            i128 run = mine;
+            int64_t hit = i1 - 1;
+            bool found = false;
+            for (int64_t ib = i0; ib < i1 && !found; ib += 16) {
+                uint32_t rk[16];
+                double dv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) rk[s] = rank[ib + s < i1 ? ib + s : i1 - 1];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) dv[s] = ds[rk[s]];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (!found && ib + s < i1) {
+                        run += km_quanta(L, dv[s]);
+                        if (run >= R) { hit = ib + s; found = true; }
+                    }
+                }
+            }
+            s_idx = hit;
+        }
+        __syncthreads();
+        idx = s_idx;
+        if (idx > m - 1) idx = m - 1;
+    }
+    if (wave != 0) return;
+    const double cx = xs[rank[idx]];
+    // ---- C: neighbours among the seeds, range of sorted positions
+    int64_t pl, pr;
+    km_dual_search(sorted_old, n_old, cx, cx, true, true, pl, pr);  // pl seeds < cx, pr seeds <= cx
+    bool has_l = pl > 0, has_r = pr < n_old;
+    double sl = has_l ? sorted_old[pl - 1] : 0.0, sr = has_r ? sorted_old[pr] : 0.0;
+    if (choose_prev) {
+        if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
+        if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
+    }
+    const double amax = st->amax;
+    const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
+    const double tlo = has_l ? 0.5 * (sl + cx) - (err / (cx - sl) + slack) : 0.0;
+    const double thi = has_r ? 0.5 * (cx + sr) + (err / (sr - cx) + slack) : 0.0;
+    int64_t lo = 0, hi = m;
+    if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
+    if (lane == 0) {
+        cur->cand_x[trial] = cx;
+        cur->cand_id[trial] = idx;
+        cur->cand_lo[trial] = lo;
+        cur->cand_hi[trial] = hi;
+    }
+}
+
+// union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
+struct KmIntervals {
+    int n;
+    int64_t lo[KM_MAX_TRIALS], hi[KM_MAX_TRIALS], chunk0[KM_MAX_TRIALS + 1];
+};
+
+__device__ void km_merge_intervals(const KmSeedRec *rec, int n_trials, KmIntervals *out)
+{
+    int64_t l[KM_MAX_TRIALS], h[KM_MAX_TRIALS];
+    int n = 0;
     for (int j = 0; j < n_trials; ++j) {
-        const double tot = km_subblock_sum(s[j], red, lt);
-        if (lt == 0 && valid) ppart[(size_t)j * nb + vb] = tot;
+        const int64_t a = rec->cand_lo[j], b = rec->cand_hi[j];
+        if (b <= a) continue;
+        int q = n++;
+        while (q > 0 && l[q - 1] > a) { l[q] = l[q - 1]; h[q] = h[q - 1]; --q; }
+        l[q] = a; h[q] = b;
     }
+    int o = 0;
+    for (int j = 0; j < n; ++j) {
+        if (o > 0 && l[j] <= h[o - 1]) { if (h[j] > h[o - 1]) h[o - 1] = h[j]; }
+        else { l[o] = l[j]; h[o] = h[j]; ++o; }
+    }
+    int64_t chunks = 0;
+    for (int j = 0; j < o; ++j) {
+        out->lo[j] = l[j];
+        out->hi[j] = h[j];
+        out->chunk0[j] = chunks;
+        chunks += (h[j] - l[j] + KM_CHUNK - 1) / KM_CHUNK;
+    }
+    out->chunk0[o] = chunks;
+    out->n = o;
 }
 
-__global__ __launch_bounds__(256) void km_pots_kernel(const double *__restrict__ x, const double *__restrict__ d, int64_t m,
-                                                      int n_trials, const KmState *__restrict__ st,
-                                                      double *__restrict__ ppart)
+// gain: for every candidate the exact sum over its range of d - min(d, distance to the candidate).  One pass over the
+// union of the ranges; a value is tested against the candidates whose range holds it.
+template <int NT>
+__global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
+                                                      KmState *st, int seed_no, int n_trials)
 {
-    __shared__ double red[4];
-    km_pots_block(x, d, m, n_trials, st, ppart, blockIdx.x, gridDim.x, threadIdx.x, red, true);
-}
-
-// one wavefront per candidate: lane-strided partial sums (eight loads in flight), fixed butterfly -- a single
-// thread walking the thousands of block partials of its candidate was a 0.1 ms latency chain per seed
-__device__ __forceinline__ void km_choose_body(const double *__restrict__ ppart, int nb, int n_trials, int seed_no,
-                                               KmState *st, double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
-                                               double *pots)
-{
-    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (j < n_trials) {
-        const double *src = ppart + (size_t)j * nb;
-        double s = 0.0;
-        for (int b0 = lane; b0 < nb; b0 += 64 * 8) {
-            double v[8];
+    __shared__ KmIntervals s_iv;
+    __shared__ i64 s_red[3][NT][4];
+    KmSeedRec *rec = &st->rec[seed_no & 1];
+    if (threadIdx.x == 0) km_merge_intervals(rec, n_trials, &s_iv);
+    __syncthreads();
+    const int n_iv = s_iv.n;
+    const int64_t total_chunks = s_iv.chunk0[n_iv];
+    if ((int64_t)blockIdx.x >= total_chunks) return;
+    const KmLimb L = st->limb;
+    double c[NT], csq[NT], ga[NT], gb[NT], gc[NT];
+    int64_t lo[NT], hi[NT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[b0 + 64 * q < nb ? b0 + 64 * q : nb - 1];
-            __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NT; ++j) {
+        c[j] = j < n_trials ? rec->cand_x[j] : 0.0;
+        csq[j] = __dmul_rn(c[j], c[j]);
+        lo[j] = j < n_trials ? rec->cand_lo[j] : 0;
+        hi[j] = j < n_trials ? rec->cand_hi[j] : 0;
+        ga[j] = gb[j] = gc[j] = 0.0;
+    }
+    int iv = 0;
+    for (int64_t ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
+        while (iv + 1 < n_iv && s_iv.chunk0[iv + 1] <= ch) ++iv;
+        const int64_t p0 = s_iv.lo[iv] + (ch - s_iv.chunk0[iv]) * KM_CHUNK;
+        const int64_t iv_end = s_iv.hi[iv];
+        const int64_t p1 = p0 + KM_CHUNK < iv_end ? p0 + KM_CHUNK : iv_end;
+        double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += b0 + 64 * q < nb ? v[q] : 0.0;
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            const int64_t p = p0 + u * 256 + threadIdx.x;
+            const int64_t q = p < p1 ? p : p1 - 1;
+            xv[u] = xs[q];
+            dv[u] = ds[q];
         }
-        s = grx_group_sum<64>(s);
-        if (lane == 0) pots[j] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // np.argmin: first minimum.  Exact ties are COMMON on small inputs -- two isolated candidates that each
-        // capture only themselves and each other give the same potential, the same numbers summed in swapped
-        // positions -- and BLAS returns bit-equal sums for them where another summation order may not: potentials
-        // within 1e-12 of the minimum count as tied, the first of them wins
-        double lowest = pots[0];
-        for (int q = 1; q < n_trials; ++q) lowest = pots[q] < lowest ? pots[q] : lowest;
-        int best = 0;
-        while (best < n_trials - 1 && pots[best] > lowest + 1e-12 * lowest) ++best;
-        st->pot = pots[best];
-        st->best_x = st->cand_x[best];
-        st->best_id = st->cand_id[best];
-        seeds_x[seed_no] = st->cand_x[best];
-        seeds_id[seed_no] = st->cand_id[best];
-    }
-}
-
-__global__ __launch_bounds__(64 * KM_MAX_TRIALS) void km_choose_kernel(const double *__restrict__ ppart, int nb,
-                                                                       int n_trials, int seed_no, KmState *st,
-                                                                       double *__restrict__ seeds_x,
-                                                                       int64_t *__restrict__ seeds_id)
-{
-    __shared__ double pots[KM_MAX_TRIALS];
-    km_choose_body(ppart, nb, n_trials, seed_no, st, seeds_x, seeds_id, pots);
-}
-
-// d = min(d, squared distance to the chosen seed); tile sums for the next cumulative sum.  One 256-thread
-// (sub-)block per tile of KM_TILE values.
-__device__ __forceinline__ void km_update_tile(const double *__restrict__ x, double *__restrict__ d, int64_t m,
-                                               const KmState *__restrict__ st, double *__restrict__ tsum, int64_t tile,
-                                               int lt, double *red, bool valid)
-{
-    const double c = st->best_x, csq = __dmul_rn(c, c);
-    const int64_t base = tile * KM_TILE;
-    double s = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t i = base + j * 256 + lt;
-        if (valid && i < m) {
-            const double dj = km_sqdist(c, csq, x[i]);
-            const double di = d[i];
-            const double nd = dj < di ? dj : di;
-            if (dj < di) d[i] = nd;                           // late seeds move few points: most lines stay clean
-            s += nd;
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            const int64_t p = p0 + u * 256 + threadIdx.x;
+            if (p >= p1) continue;
+            const double x = xv[u], d = dv[u];
+            if (!(d > 0.0)) continue;                          // nothing to gain
+            double a, b, cc;
+            km_split(L, d, a, b, cc);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j < n_trials && p >= lo[j] && p < hi[j]) {
+                    const double dj = km_sqdist(c[j], csq[j], x);
+                    if (dj < d) {
+                        double aj, bj, cj;
+                        km_split(L, dj, aj, bj, cj);
+                        ga[j] += a - aj; gb[j] += b - bj; gc[j] += cc - cj;     // exact: < 2^20 terms per thread
+                    }
+                }
+            }
         }
     }
-    s = km_subblock_sum(s, red, lt);
-    if (lt == 0 && valid) tsum[tile] = s;
-}
-
-__global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ x, double *__restrict__ d, int64_t m,
-                                                        const KmState *__restrict__ st, double *__restrict__ tsum)
-{
-    __shared__ double red[4];
-    km_update_tile(x, d, m, st, tsum, blockIdx.x, threadIdx.x, red, true);
-}
-
-// ---- the whole k-means++ seeding in ONE cooperative launch --------------------------------------------------------
-// Per further seed the four steps above depend on each other through grid-wide results (the cumulative sum of every
-// tile, the potentials over all values): as separate launches that is 4 (k - 1) launches per encode -- 2 044 for the
-// 512 levels of a wide table.  Here every workgroup stays resident (hipLaunchCooperativeKernel) and the steps are
-// separated by grid barriers; the serial steps (pick, choose) are run by the LAST workgroup to arrive, before it
-// releases the others: two barriers per seed.  A workgroup is four 256-thread sub-blocks that take the role of the
-// 256-thread workgroups of the per-seed kernels (same index sets, same trees), so the seeds are bit-identical.
-__device__ __forceinline__ bool km_grid_arrive(KmState *st, unsigned nwg, unsigned *s_flag, unsigned *gen_out)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(&st->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();                                      // this workgroup's results first
-        const unsigned prev = __hip_atomic_fetch_add(&st->bar_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_flag[0] = prev == nwg - 1;
-        s_flag[1] = gen;
-        if (prev == nwg - 1) __threadfence();                 // ... and everybody else's before the serial step reads them
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (j < n_trials) {
+            const i64 ua = km_wave_sum_i64(__double2ll_rn(ga[j] * L.sA));
+            const i64 ub = km_wave_sum_i64(__double2ll_rn(gb[j] * L.sB));
+            const i64 uc = km_wave_sum_i64(__double2ll_rn(gc[j] * L.sC));
+            if (lane == 0) { s_red[0][j][wave] = ua; s_red[1][j][wave] = ub; s_red[2][j][wave] = uc; }
+        }
     }
     __syncthreads();
-    *gen_out = s_flag[1];
-    return s_flag[0] != 0;
+    if (threadIdx.x < 3 * NT) {
+        const int limb = threadIdx.x / NT, j = threadIdx.x % NT;
+        if (j < n_trials)
+            km_atomic_add_i64(&rec->gain[limb][j], s_red[limb][j][0] + s_red[limb][j][1] + s_red[limb][j][2] + s_red[limb][j][3]);
+    }
 }
 
-__device__ __forceinline__ void km_grid_release(KmState *st)
+// update: d = min(d, distance to the chosen seed) over the winner's range.  What leaves the closest distances leaves
+// the sums of the INDEX blocks they belong to: collected per workgroup in LDS (integer limbs, any order), then added
+// to the block sums with integer atomics -- a straight atomic per value runs at 23 G atomics/s on MI355X
+// (tools/microbench/atomic_scatter.hip: 3.9 ms for the three limbs of 30 M values against 0.11 ms for the pass itself).
+__global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ xs, double *__restrict__ ds,
+                                                        const uint32_t *__restrict__ perm, i64 *__restrict__ bacc,
+                                                        int nblocks, int block_shift, const KmState *__restrict__ st,
+                                                        int seed_no, int n_trials)
 {
+    __shared__ u64 s_acc[3 * KM_MAX_BLOCKS];
+    __shared__ int s_best;
+    const KmSeedRec *rec = &st->rec[seed_no & 1];
+    if (threadIdx.x == 0) s_best = km_best(rec, n_trials);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&st->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        __hip_atomic_fetch_add(&st->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__device__ __forceinline__ void km_grid_wait(KmState *st, unsigned gen)
-{
-    if (threadIdx.x == 0) {
-        while (__hip_atomic_load(&st->bar_gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen)
-            __builtin_amdgcn_s_sleep(2);
-        __threadfence();
+    const int best = s_best;
+    const int64_t lo = rec->cand_lo[best], hi = rec->cand_hi[best];
+    const int64_t chunks = (hi - lo + KM_CHUNK - 1) / KM_CHUNK;
+    if ((int64_t)blockIdx.x >= chunks) return;
+    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
+    __syncthreads();
+    const KmLimb L = st->limb;
+    const double c = rec->cand_x[best], csq = __dmul_rn(c, c);
+    for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const int64_t p0 = lo + ch * KM_CHUNK;
+        const int64_t p1 = p0 + KM_CHUNK < hi ? p0 + KM_CHUNK : hi;
+        double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
+        uint32_t iv[KM_CHUNK / 256];
+#pragma unroll
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            const int64_t p = p0 + u * 256 + threadIdx.x;
+            const int64_t q = p < p1 ? p : p1 - 1;
+            xv[u] = xs[q];
+            dv[u] = ds[q];
+            iv[u] = perm[q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            const int64_t p = p0 + u * 256 + threadIdx.x;
+            if (p >= p1) continue;
+            const double d = dv[u];
+            const double dj = km_sqdist(c, csq, xv[u]);
+            if (dj < d) {
+                ds[p] = dj;
+                double a, b, cc, aj, bj, cj;
+                km_split(L, d, a, b, cc);
+                km_split(L, dj, aj, bj, cj);
+                const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
+                          uc = -__double2ll_rn((cc - cj) * L.sC);
+                const int blk = (int)(iv[u] >> block_shift);
+                if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
+                if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
+                if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
+            }
+        }
     }
     __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void km_seed_kernel(const double *__restrict__ x, double *__restrict__ d, int64_t m,
-                                                       double *__restrict__ tsum, int64_t ntiles,
-                                                       const double *__restrict__ uniform, int n_trials, int k, int nb,
-                                                       KmState *st, double *__restrict__ ppart,
-                                                       double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id)
-{
-    __shared__ double s_scan[1024];
-    __shared__ double s_pot;
-    __shared__ double s_red[4][4];
-    __shared__ double s_pots[KM_MAX_TRIALS];
-    __shared__ unsigned s_flag[2];
-    const unsigned nwg = gridDim.x;
-    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
-    const int64_t vstride = (int64_t)nwg * 4;
-    unsigned gen;
-    // the first pick needs the tile sums of km_init_kernel (an earlier launch): workgroup 0 runs it, the others wait
-    if (km_grid_arrive(st, nwg, s_flag, &gen)) {
-        km_pick_body(x, d, m, tsum, ntiles, uniform, n_trials, 1, st, s_scan, &s_pot);
-        km_grid_release(st);
-    } else {
-        km_grid_wait(st, gen);
-    }
-    for (int c = 1; c < k; ++c) {
-        // potentials of this seed's candidates
-        for (int64_t v0 = (int64_t)blockIdx.x * 4; v0 < nb; v0 += vstride) {
-            const int64_t vb = v0 + sub;
-            km_pots_block(x, d, m, n_trials, st, ppart, (int)vb, nb, lt, s_red[sub], vb < nb);
-        }
-        if (km_grid_arrive(st, nwg, s_flag, &gen)) {
-            km_choose_body(ppart, nb, n_trials, c, st, seeds_x, seeds_id, s_pots);
-            km_grid_release(st);
-        } else {
-            km_grid_wait(st, gen);
-        }
-        if (c == k - 1) break;                                 // the distances to the last seed are never needed
-        for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < ntiles; t0 += vstride) {
-            const int64_t tile = t0 + sub;
-            km_update_tile(x, d, m, st, tsum, tile, lt, s_red[sub], tile < ntiles);
-        }
-        if (km_grid_arrive(st, nwg, s_flag, &gen)) {
-            km_pick_body(x, d, m, tsum, ntiles, uniform + (size_t)c * n_trials, n_trials, 0, st, s_scan, &s_pot);
-            km_grid_release(st);
-        } else {
-            km_grid_wait(st, gen);
-        }
+    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
+        const u64 v = s_acc[i];
+        if (v) atomicAdd(reinterpret_cast<u64 *>(bacc) + 4 * (i / 3) + i % 3, v);
     }
 }
 
@@ -431,11 +731,28 @@ __global__ __launch_bounds__(256) void km_tile_sums_kernel(const double *__restr
     if (threadIdx.x == 0) tsum[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(64) void km_scan_tiles_kernel(double *__restrict__ tsum, int64_t ntiles)
+// exclusive scan of the tile sums in place: a contiguous chunk of tiles per thread, the chunk totals scanned across
+// the workgroup (fixed shape)
+__global__ __launch_bounds__(1024) void km_scan_tiles_kernel(double *__restrict__ tsum, int64_t ntiles)
 {
-    if (threadIdx.x != 0) return;
+    __shared__ double s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = (ntiles + 1023) / 1024;
+    const int64_t t0 = (int64_t)threadIdx.x * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+    double local = 0.0;
+    for (int64_t t = t0; t < t1; ++t) local += tsum[t];
+    double inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
     double run = 0.0;
-    for (int64_t t = 0; t < ntiles; ++t) { const double v = tsum[t]; tsum[t] = run; run += v; }
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+    run += inc - local;
+    for (int64_t t = t0; t < t1; ++t) { const double v = tsum[t]; tsum[t] = run; run += v; }
 }
 
 __global__ __launch_bounds__(256) void km_prefix_kernel(const double *__restrict__ xs, int64_t m,
@@ -641,6 +958,7 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
         info[0] = n_iter;
         info[1] = nonempty;
         info[2] = distinct;
+        info[3] = k > 1 ? st->faults : 0;
     }
 }
 
@@ -683,8 +1001,10 @@ __global__ __launch_bounds__(256) void km_transpose_kernel(int64_t rows, int64_t
 struct KmPlan {
     int64_t ntiles;
     int nb;                                                    // workgroups of the strided reductions
-    size_t off_state, off_x, off_d, off_tsum, off_ppart, off_part, off_seedx, off_seedid, off_uniform, off_xs, off_P,
-        off_lloyd, off_sort, total;
+    int block_shift, nblocks;                                  // index blocks of the cumulative sum
+    size_t off_state, off_x, off_ds, off_bacc, off_tsum, off_part, off_seedx, off_seedid, off_sorted, off_uniform,
+        off_xs, off_perm, off_rank, off_P, off_lloyd, off_sort, total;
+    size_t sorted_ld;
 };
 
 KmPlan km_plan(int64_t m, int k)
@@ -693,21 +1013,28 @@ KmPlan km_plan(int64_t m, int k)
     p.ntiles = grx_ceil_div(m, KM_TILE);
     const int64_t want = grx_ceil_div(m, 256 * 8);
     p.nb = (int)(want > 2048 ? 2048 : (want < 1 ? 1 : want));
+    p.block_shift = KM_MIN_BLOCK_SHIFT;
+    while (grx_ceil_div(m, (int64_t)1 << p.block_shift) > KM_MAX_BLOCKS) ++p.block_shift;
+    p.nblocks = (int)grx_ceil_div(m, (int64_t)1 << p.block_shift);
+    p.sorted_ld = grx_align_up((size_t)(k + 1) * 8, 256) / 8;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += grx_align_up(bytes, 256); return at; };
     p.off_state = take(sizeof(KmState));
     p.off_x = take((size_t)m * 8);
-    p.off_d = take((size_t)m * 8);
+    p.off_ds = take((size_t)m * 8);
+    p.off_bacc = take((size_t)(KM_MAX_BLOCKS + 32) * 32);
     p.off_tsum = take((size_t)p.ntiles * 8);
-    p.off_ppart = take((size_t)KM_MAX_TRIALS * p.nb * 8);
-    p.off_part = take((size_t)p.nb * 8);
+    p.off_part = take((size_t)3 * p.nb * 8);
     p.off_seedx = take((size_t)k * 8);
     p.off_seedid = take((size_t)k * 8);
+    p.off_sorted = take(2 * p.sorted_ld * 8);
     p.off_uniform = take((size_t)(k > 1 ? k - 1 : 1) * KM_MAX_TRIALS * 8);
     p.off_xs = take((size_t)m * 8);
+    p.off_perm = take((size_t)m * 4);
+    p.off_rank = take((size_t)m * 4);
     p.off_P = take((size_t)(m + 1) * 8);
     p.off_lloyd = take((size_t)k * 8 * 16);
-    p.off_sort = take(grx_sort_workspace_bytes(m, 1));
+    p.off_sort = take(grx_internal_sort_pairs_workspace_bytes(m));
     p.total = o;
     return p;
 }
@@ -759,69 +1086,60 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     char *ws = reinterpret_cast<char *>(d_workspace);
     KmState *state = reinterpret_cast<KmState *>(ws + p.off_state);
     double *x = reinterpret_cast<double *>(ws + p.off_x);
-    double *d = reinterpret_cast<double *>(ws + p.off_d);
+    double *ds = reinterpret_cast<double *>(ws + p.off_ds);
+    i64 *bacc = reinterpret_cast<i64 *>(ws + p.off_bacc);
     double *tsum = reinterpret_cast<double *>(ws + p.off_tsum);
-    double *ppart = reinterpret_cast<double *>(ws + p.off_ppart);
     double *part = reinterpret_cast<double *>(ws + p.off_part);
     double *seeds_x = reinterpret_cast<double *>(ws + p.off_seedx);
     int64_t *seeds_id = reinterpret_cast<int64_t *>(ws + p.off_seedid);
+    double *sorted2 = reinterpret_cast<double *>(ws + p.off_sorted);
     double *d_uniform = reinterpret_cast<double *>(ws + p.off_uniform);
     double *xs = reinterpret_cast<double *>(ws + p.off_xs);
+    uint32_t *perm = reinterpret_cast<uint32_t *>(ws + p.off_perm);
+    uint32_t *rank = reinterpret_cast<uint32_t *>(ws + p.off_rank);
     double *P = reinterpret_cast<double *>(ws + p.off_P);
     GRX_PROF(GRX_K_QUANT, st);
     if (k > 1)
         GRX_CHECK_HIP(hipMemcpyAsync(d_uniform, h_uniform, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, st));
+    GRX_CHECK_HIP(hipMemsetAsync(bacc, 0, (size_t)(KM_MAX_BLOCKS + 32) * 32, st));
     // mean and tolerance (KMeans.fit: X -= X.mean(axis=0); tol = mean(var(X, axis=0)) * 1e-4)
     km_sum_kernel<<<p.nb, 256, 0, st>>>(d_values, m, state, 0, part);
-    km_moment_final_kernel<<<1, 64, 0, st>>>(part, p.nb, m, 0, rel_tol, state);
+    km_moment_final_kernel<<<1, 256, 0, st>>>(part, p.nb, m, 0, rel_tol, d_values, first_seed, state);
     km_sum_kernel<<<p.nb, 256, 0, st>>>(d_values, m, state, 1, part);
-    km_moment_final_kernel<<<1, 64, 0, st>>>(part, p.nb, m, 1, rel_tol, state);
-    km_init_kernel<<<(int)p.ntiles, 256, 0, st>>>(d_values, m, first_seed, state, x, d, tsum, seeds_x, seeds_id);
+    km_moment_final_kernel<<<1, 256, 0, st>>>(part, p.nb, m, 1, rel_tol, d_values, first_seed, state);
+    // (the sorted list of seeds with n entries lives in buffer n & 1: the first seed goes to buffer 1)
+    km_init_kernel<<<(int)p.ntiles, 256, 0, st>>>(d_values, m, first_seed, state, x, bacc, p.block_shift, seeds_x, seeds_id,
+                                                  sorted2 + p.sorted_ld);
     GRX_LAUNCH_CHECK();
+    // the values in ascending order with the index each came from (the Lloyd iterations need the order as well)
+    int rc = grx_internal_sort_pairs(m, x, xs, perm, ws + p.off_sort, st);
+    if (rc != GRX_OK) return rc;
+    const int64_t want = grx_ceil_div(m, 256 * 4);
+    const int stream_grid = (int)(want > 2048 ? 2048 : want);
     if (k > 1) {
-        // GRX_KMEANS_COOPERATIVE=1: one cooperative launch for all k - 1 further seeds instead of four launches per
-        // seed -- same bits (tests/test_gpu_encode.py), but MEASURED SLOWER on MI355X (1 M x 6 factor, 64 levels: 16.1
-        // against 6.3 ms): every grid barrier needs an agent-scope release / acquire so that the distances written
-        // on one XCD are seen on another, i.e. an L2 write-back + invalidate per workgroup per barrier, which costs
-        // more than the launch boundary it replaces (the same finding as the fused reduce + H update of the NMF,
-        // DESIGN.md section 3).  Kept as an option; the default is the per-seed sequence.
-        static const bool per_seed = [] { const char *e = std::getenv("GRX_KMEANS_COOPERATIVE"); return !(e && *e == '1'); }();
-        int resident = 0;
-        if (!per_seed) {
-            int per_cu = 0, dev = 0, cus = 0;
-            GRX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_seed_kernel, 1024, 0));
-            GRX_CHECK_HIP(hipGetDevice(&dev));
-            GRX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            resident = per_cu * cus;
+        // GRX_KMEANS_FULL_RANGE=1: every candidate's range is [0, m) -- sklearn's own O(m k) formulation in the same exact
+        // arithmetic; the ranges are supersets of what can change, so both give the same bits (tests/test_gpu_encode.py)
+        static const int full_range = [] { const char *e = std::getenv("GRX_KMEANS_FULL_RANGE"); return (e && *e == '1') ? 1 : 0; }();
+        km_sorted_init_kernel<<<stream_grid, 256, 0, st>>>(xs, perm, m, state, ds, rank);
+        const int64_t max_chunks = grx_ceil_div(m, KM_CHUNK);
+        const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
+        const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
+        for (int c = 1; c < k; ++c) {
+            km_prep_kernel<<<n_trials, 1024, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
+                                                      d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1, full_range,
+                                                      state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+            if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
+            else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
+            if (c < k - 1)                                         // the distances to the last seed are never needed
+                km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, state, c, n_trials);
         }
-        if (resident >= 1) {
-            const int64_t useful = grx_ceil_div(p.ntiles > p.nb ? p.ntiles : (int64_t)p.nb, 4);
-            int grid = (int)(useful < resident ? useful : resident);
-            if (grid < 1) grid = 1;
-            GRX_CHECK_HIP(hipMemsetAsync(&state->bar_count, 0, 2 * sizeof(unsigned), st));
-            int64_t m_arg = m, ntiles_arg = p.ntiles;
-            int trials_arg = n_trials, k_arg = k, nb_arg = p.nb;
-            const double *x_arg = x, *u_arg = d_uniform;
-            void *args[] = {&x_arg, &d, &m_arg, &tsum, &ntiles_arg, &u_arg, &trials_arg, &k_arg, &nb_arg, &state, &ppart,
-                            &seeds_x, &seeds_id};
-            GRX_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(km_seed_kernel), dim3(grid), dim3(1024),
-                                                     args, 0, st));
-        } else {
-            for (int c = 1; c < k; ++c) {
-                km_pick_kernel<<<1, 1024, 0, st>>>(x, d, m, tsum, p.ntiles, d_uniform + (size_t)(c - 1) * n_trials, n_trials,
-                                                   c == 1, state);
-                km_pots_kernel<<<p.nb, 256, 0, st>>>(x, d, m, n_trials, state, ppart);
-                km_choose_kernel<<<1, 64 * n_trials, 0, st>>>(ppart, p.nb, n_trials, c, state, seeds_x, seeds_id);
-                km_update_kernel<<<(int)p.ntiles, 256, 0, st>>>(x, d, m, state, tsum);
-            }
-        }
+        km_prep_kernel<<<1, 1024, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
+                                           full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values
-    int rc = grx_internal_sort_columns(m, 1, x, m, xs, m, ws + p.off_sort, st);
-    if (rc != GRX_OK) return rc;
     km_tile_sums_kernel<<<(int)p.ntiles, 256, 0, st>>>(xs, m, tsum);
-    km_scan_tiles_kernel<<<1, 64, 0, st>>>(tsum, p.ntiles);
+    km_scan_tiles_kernel<<<1, 1024, 0, st>>>(tsum, p.ntiles);
     km_prefix_kernel<<<(int)p.ntiles, 256, 0, st>>>(xs, m, tsum, P);
     KmLloydBufs B;
     double *lb = reinterpret_cast<double *>(ws + p.off_lloyd);
@@ -831,9 +1149,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     B.lo = B.hiS + k; B.hi = B.lo + k; B.plo = B.hi + k; B.phi = B.plo + k; B.rl = B.phi + k; B.rh = B.rl + k;
     B.ord = reinterpret_cast<int32_t *>(B.rh + k);
     km_lloyd_kernel<<<1, 1024, 0, st>>>(xs, P, m, k, max_iter, state, seeds_x, B, d_info);
-    const int64_t want = grx_ceil_div(m, 256 * 4);
-    km_assign_kernel<<<(int)(want > 2048 ? 2048 : want), 256, 0, st>>>(d_values, m, k, state, B.maxval, B.cfinal, B.ord,
-                                                                      d_quantized, d_centers);
+    km_assign_kernel<<<stream_grid, 256, 0, st>>>(d_values, m, k, state, B.maxval, B.cfinal, B.ord, d_quantized, d_centers);
     GRX_LAUNCH_CHECK();
     return GRX_OK;
 }

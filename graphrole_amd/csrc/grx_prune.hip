@@ -314,6 +314,110 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(
     }
 }
 
+// scatter_kernel with a 32-bit payload travelling with every key (grx_kmeans.hip: the index of the value, so that the
+// sort also yields the permutation).  Single column, no pass skipping.  pay_src == nullptr: the payload is the
+// position (pass 0).  Stable like scatter_kernel: equal keys keep their index order.
+template <bool FROM_F64, bool TO_F64>
+__global__ __launch_bounds__(SORT_THREADS) void scatter_pairs_kernel(
+    const void *__restrict__ src, void *__restrict__ dst, const uint32_t *__restrict__ pay_src,
+    uint32_t *__restrict__ pay_dst, int64_t n, int shift, int ntiles, const uint32_t *__restrict__ offsets,
+    const uint32_t *__restrict__ digit_tot)
+{
+    __shared__ uint32_t cnt[4][RADIX];
+    __shared__ uint32_t gdelta[RADIX];
+    __shared__ uint32_t wsum[8];
+    __shared__ uint64_t stage[SORT_TILE];
+    __shared__ uint32_t stage_pay[SORT_TILE];
+    const int tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t keys[SORT_ITEMS];
+    uint32_t pay[SORT_ITEMS];
+    uint32_t vm;
+    load_keys<FROM_F64>(src, n, (int64_t)tile * SORT_TILE, keys, vm);
+    {
+        const int64_t base = (int64_t)tile * SORT_TILE + (int64_t)wave * 64 * SORT_ITEMS + lane;
+        const int64_t last = n > 0 ? n - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const int64_t idx = base + (int64_t)i * 64;
+            pay[i] = pay_src ? pay_src[idx < n ? idx : last] : (uint32_t)idx;
+        }
+    }
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t rank[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool valid = (vm >> i) & 1u;
+        const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
+        uint64_t peers = __ballot(valid);
+        const uint32_t d0 = __shfl(d, peers ? __ffsll((long long)peers) - 1 : 0, 64);
+        if (__ballot(valid && d != d0) != 0) {
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const uint64_t m = __ballot(set);
+                peers &= set ? m : ~m;
+            }
+        }
+        uint32_t r = 0;
+        if (valid) {
+            const uint32_t before = cnt[wave][d];
+            const uint32_t in_group = (uint32_t)__popcll(peers & lt_mask);
+            r = before + in_group;
+            __builtin_amdgcn_wave_barrier();
+            if (in_group == 0) cnt[wave][d] = before + (uint32_t)__popcll(peers);
+        }
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = r;
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        const uint32_t total = c0 + c1 + c2 + c3;
+        const uint32_t gtot = digit_tot[d];
+        uint32_t inc = total, ginc = gtot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(inc, off, 64), gy = __shfl_up(ginc, off, 64);
+            if (lane >= off) { inc += y; ginc += gy; }
+        }
+        if (lane == 63) { wsum[wave] = inc; wsum[4 + wave] = ginc; }
+        __syncthreads();
+        uint32_t lp = inc - total, gbase = ginc - gtot;
+        for (int w = 0; w < wave; ++w) { lp += wsum[w]; gbase += wsum[4 + w]; }
+        const uint32_t g = offsets[(size_t)d * ntiles + tile] + gbase;
+        gdelta[d] = g - lp;
+        cnt[0][d] = lp;
+        cnt[1][d] = lp + c0;
+        cnt[2][d] = lp + c0 + c1;
+        cnt[3][d] = lp + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        if ((vm >> i) & 1u) {
+            const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFF;
+            const uint32_t at = cnt[wave][d] + rank[i];
+            stage[at] = keys[i];
+            stage_pay[at] = pay[i];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)tile * SORT_TILE;
+    const int nv = (int)(left < SORT_TILE ? left : SORT_TILE);
+    for (int j = threadIdx.x; j < nv; j += SORT_THREADS) {
+        const uint64_t key = stage[j];
+        const uint32_t pos = gdelta[(uint32_t)(key >> shift) & 0xFF] + (uint32_t)j;
+        if (TO_F64) reinterpret_cast<double *>(dst)[pos] = key_to_f64(key);
+        else reinterpret_cast<uint64_t *>(dst)[pos] = key;
+        pay_dst[pos] = stage_pay[j];
+    }
+}
+
 // One wavefront per column.  prune.py:33-54: repeat { size = max(int(frac*unbinned),1);
 // hi = value at sorted position done+size-1; extend to the end of hi's tie run }.
 __global__ __launch_bounds__(64) void bin_threshold_kernel(const double *__restrict__ sorted,
@@ -1919,6 +2023,53 @@ int grx_internal_sort_columns(int64_t n, int ncols, const double *cols, int64_t 
     char *ws = reinterpret_cast<char *>(workspace);
     return sort_columns(n, ncols, cols, ld, out, out_ld, reinterpret_cast<uint64_t *>(ws),
                         reinterpret_cast<uint32_t *>(ws + p.keys_bytes), st);
+}
+
+// one fp64 column -> ascending values in `out` and, in `perm`, the index each sorted position came from (stable).
+// workspace: grx_sort_pairs_workspace_bytes(n) = key buffer, payload buffer, counters
+int grx_internal_sort_pairs(int64_t n, const double *col, double *out, uint32_t *perm, void *workspace, hipStream_t st)
+{
+    if (n <= 0) return GRX_OK;
+    const SortPlan p = make_plan(n, 1);
+    char *ws = reinterpret_cast<char *>(workspace);
+    uint64_t *keysA = reinterpret_cast<uint64_t *>(ws);
+    uint32_t *payA = reinterpret_cast<uint32_t *>(ws + p.keys_bytes);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(ws + p.keys_bytes + grx_align_up((size_t)n * 4, 256));
+    uint32_t *tot = hist + grx_align_up((size_t)RADIX * (size_t)p.ntiles * 4, 256) / 4;
+    const dim3 grid(p.ntiles, 1);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        const void *src = pass == 0 ? (const void *)col : ((pass & 1) ? (const void *)keysA : (const void *)out);
+        void *dst = (pass & 1) ? (void *)out : (void *)keysA;
+        const uint32_t *psrc = pass == 0 ? nullptr : ((pass & 1) ? payA : perm);
+        uint32_t *pdst = (pass & 1) ? perm : payA;
+        {
+            GRX_PROF(GRX_K_SORT_COUNT, st);
+            if (pass == 0) tile_count_kernel<true><<<grid, SORT_THREADS, 0, st>>>(src, n, n, shift, p.ntiles, hist, SkipCtl{});
+            else tile_count_kernel<false><<<grid, SORT_THREADS, 0, st>>>(src, n, n, shift, p.ntiles, hist, SkipCtl{});
+        }
+        GRX_LAUNCH_CHECK();
+        {
+            GRX_PROF(GRX_K_SORT_SCAN, st);
+            scan_rows_kernel<<<dim3(RADIX, 1), 64, 0, st>>>(hist, p.ntiles, tot, SkipCtl{}, pass);
+        }
+        GRX_LAUNCH_CHECK();
+        {
+            GRX_PROF(GRX_K_SORT_SCATTER, st);
+            if (pass == 0) scatter_pairs_kernel<true, false><<<grid, SORT_THREADS, 0, st>>>(src, dst, psrc, pdst, n, shift, p.ntiles, hist, tot);
+            else if (pass == 7) scatter_pairs_kernel<false, true><<<grid, SORT_THREADS, 0, st>>>(src, dst, psrc, pdst, n, shift, p.ntiles, hist, tot);
+            else scatter_pairs_kernel<false, false><<<grid, SORT_THREADS, 0, st>>>(src, dst, psrc, pdst, n, shift, p.ntiles, hist, tot);
+        }
+        GRX_LAUNCH_CHECK();
+    }
+    return GRX_OK;
+}
+
+size_t grx_internal_sort_pairs_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 256;
+    const SortPlan p = make_plan(n, 1);
+    return p.keys_bytes + grx_align_up((size_t)n * 4, 256) + p.hist_bytes;
 }
 
 // raw 64-bit keys (graph ingest: (row, column) / (row, edge sequence) pairs), ascending; same workspace

@@ -961,13 +961,13 @@ def kmeans_draws(m: int, n_bins: int):
 
 def kmeans1d(values: torch.Tensor, n_bins: int, max_iter: int = 300, rel_tol: float = 1e-4):
     """encode() as the reference computes it: `values` flat fp64 device tensor IN THE REFERENCE'S FLATTEN ORDER ->
-    (quantised tensor, centres [n_bins] in seed order, info int32[3] = {n_iter_, non-empty clusters, distinct
-    output values})."""
+    (quantised tensor, centres [n_bins] in seed order, info int32[4] = {n_iter_, non-empty clusters, distinct
+    output values, seeding faults (0: see include/grx.h)})."""
     m = values.numel()
     first, uniform, trials = kmeans_draws(m, int(n_bins))
     out = torch.empty_like(values)
     centers = torch.empty(max(int(n_bins), 1), dtype=torch.float64, device=device())
-    info = zeros(3, dtype=torch.int32)
+    info = zeros(4, dtype=torch.int32)
     ws_bytes = _lib.load().grx_kmeans1d_workspace_bytes(m, int(n_bins))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device())
     _lib.call('grx_kmeans1d', m, _ptr(values), int(n_bins), first, _hptr(uniform), trials, int(max_iter), float(rel_tol),

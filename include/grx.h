@@ -32,8 +32,7 @@
 extern "C" {
 #endif
 
-#define GRX_VERSION 500          /* 0.5.0: grx_egonet_features takes a workspace (grx_egonet_workspace_bytes); grx_refex_run takes a
-                                    grow function (the arena is a chain of chunks); role kernels take any r */
+#define GRX_VERSION 600          /* 0.6.0: grx_kmeans1d reports into int32[4] (d_info[3] = consistency faults of the seeding) */
 #define GRX_MAX_BINS 128         /* upper bound on vertical-log bins (n < 2^63 gives < 70) */
 #define GRX_MAX_ROLES 32         /* NMF rank limit of the device kernels: 1 .. 16 fused fp64-MFMA passes; 17 .. 32
                                     a composed update (several times the traffic), then with n_roles + features <= 480 */
@@ -704,13 +703,18 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
  * data), Lloyd iterations with sklearn's stopping rule (labels unchanged, or total squared centre shift <=
  * 1e-4 * var), empty-cluster relocation, every entry replaced by its cluster centre.  Centres agree with sklearn's
  * to ~1e-12 (sums are reduced in another order); the model selection of RolX then picks the reference's cell.
+ * The seeding does not stream all m values per seed as sklearn's _kmeans_plusplus (:163-257) does: on the line a
+ * candidate changes closest distances only in a contiguous range of the sorted values, and all sums are exact
+ * fixed-point integers (csrc/grx_kmeans.hip) -- same seeds, O(m log k) instead of O(m k) work.
  *   d_values      fp64[m] in the order the reference flattens the matrix (row-major n x r for the node-role
  *                 factor: grx_transpose from the feature-major device layout)
  *   first_seed    RandomState(1).choice(m, p = uniform)            (sklearn _kmeans_plusplus, first centre)
  *   h_uniform     (k - 1) x n_trials doubles, n_trials = 2 + int(log(k)): RandomState.uniform(size=n_trials) per seed
  *   max_iter, rel_tol   sklearn defaults 300, 1e-4
- *   d_centers     fp64[k] in seed order;  d_info int32[3] = {Lloyd iterations (n_iter_), non-empty clusters,
- *                 distinct output values}.   k <= 8192 (GRX_ERR_UNSUPPORTED above), k <= m (GRX_ERR_INVALID).
+ *   d_centers     fp64[k] in seed order;  d_info int32[4] = {Lloyd iterations (n_iter_), non-empty clusters,
+ *                 distinct output values, seeding faults (0 unless an internal consistency check failed: bit 0 the
+ *                 block sums after an update differ from potential - gain, bit 1 values beyond 1e144, bits 2.. a
+ *                 cumulative-sum search left its block)}.   k <= 8192 (GRX_ERR_UNSUPPORTED above), k <= m (GRX_ERR_INVALID).
  * grx_transpose: out[c * ld_out + r] = in[r * ld_in + c].
  */
 size_t grx_kmeans1d_workspace_bytes(int64_t m, int k);

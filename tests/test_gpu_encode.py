@@ -197,6 +197,7 @@ def test_kmeans_quantizer_equals_sklearn(case):
         assert int(info[0]) == km.n_iter_, (name, int(info[0]), km.n_iter_)
     assert np.abs(q - ref).max() <= 1e-9 * scale, (name, np.abs(q - ref).max())
     assert int(info[2]) == len(np.unique(ref)) == len(np.unique(q))
+    assert int(info[3]) == 0                                     # the seeding's internal consistency checks
     if len(np.unique(data)) >= k:
         # centres in seed order, like cluster_centers_
         np.testing.assert_allclose(K.to_host(centres), km.cluster_centers_[:, 0], rtol=0, atol=1e-9 * scale)
@@ -219,19 +220,26 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from graphrole_amd import kernels as K
 out = {}
-for tag, m, k, seed in (('a', 50_000, 64, 0), ('b', 300_007, 256, 1), ('c', 4_099, 17, 2), ('d', 1_200_000, 512, 3)):
+for tag, m, k, seed in (('a', 50_000, 64, 0), ('b', 300_007, 256, 1), ('c', 4_099, 17, 2), ('d', 1_200_000, 512, 3),
+                        ('e', 200_000, 32, 4), ('f', 90_000, 1024, 5), ('g', 130, 100, 6)):
     rng = np.random.default_rng(seed)
     v = np.abs(rng.standard_normal(m)) * rng.choice([1e-3, 1.0, 40.0], size=m)
+    if tag == 'e':
+        v = np.round(v, 1)                                       # few distinct values: long runs of ties
+    if tag == 'f':
+        v = rng.lognormal(0.0, 4.0, size=m)                      # fourteen orders of magnitude
     q, centers, info = K.kmeans1d(K.to_device(v), k)
     out[tag + '_q'] = K.to_host(q); out[tag + '_c'] = K.to_host(centers); out[tag + '_i'] = K.to_host(info)
 np.savez(OUT, **out)
 '''
 
 
-def test_cooperative_seeding_equals_the_per_seed_launches(tmp_path):
-    """The one-launch k-means++ seeding (km_seed_kernel: resident workgroups, grid barriers; GRX_KMEANS_COOPERATIVE=1,
-    measured slower and therefore not the default) against the four launches per seed: same index sets and summation
-    trees -> identical bits."""
+def test_interval_seeding_equals_the_full_pass(tmp_path):
+    """The one-dimensional k-means++ (csrc/grx_kmeans.hip): a candidate's potential and the update only visit the range
+    of sorted values between the midpoints to the neighbouring seeds (widened by a rounding bound).  With
+    GRX_KMEANS_FULL_RANGE=1 every range is [0, m) -- sklearn's own formulation, every value tested for every candidate --
+    in the same exact integer arithmetic: the ranges are supersets of what can change, so seeds, centres and quantised
+    values are identical bits; and the internal consistency checks report nothing in either mode."""
     import os
     import subprocess
     import sys
@@ -241,10 +249,24 @@ def test_cooperative_seeding_equals_the_per_seed_launches(tmp_path):
     for mode in ('0', '1'):
         out = tmp_path / f'km{mode}.npz'
         code = 'ROOT = %r\nOUT = %r\n' % (root, str(out)) + textwrap.dedent(_AB_DRIVER)
-        env = dict(os.environ, GRX_KMEANS_COOPERATIVE=mode)
-        res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+        env = dict(os.environ, GRX_KMEANS_FULL_RANGE=mode)
+        res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
         results.append(np.load(out))
     a, b = results
     for key in a.files:
         assert np.array_equal(a[key], b[key]), key
+        if key.endswith('_i'):
+            assert int(a[key][3]) == 0, (key, a[key])
+
+
+def test_kmeans_runs_are_bitwise_repeatable():
+    """All sums of the seeding are integers: no result depends on the order of an atomic or a reduction."""
+    from graphrole_amd import kernels as K
+    rng = np.random.default_rng(11)
+    v = K.to_device(np.abs(rng.standard_normal(700_001)) * rng.choice([1e-3, 1.0, 40.0], size=700_001))
+    first = [K.to_host(t) for t in K.kmeans1d(v, 128)]
+    for _ in range(3):
+        again = [K.to_host(t) for t in K.kmeans1d(v, 128)]
+        for x, y in zip(first, again):
+            assert np.array_equal(x, y)
