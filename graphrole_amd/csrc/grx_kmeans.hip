@@ -47,6 +47,11 @@
 #include <cmath>
 #include <cstdlib>
 
+// Built with -ffp-contract=off (csrc/Makefile): every product and sum below is rounded on its own, as numpy rounds
+// them.  hipcc's default (-ffp-contract=fast) fuses a * b + c differently from one kernel to the next -- HIP's
+// __dmul_rn / __dadd_rn are plain * and + and do not prevent it -- and the seeding needs the SAME distance bits
+// wherever a distance is evaluated (the consistency check of km_prep_kernel caught exactly that).
+
 int grx_internal_sort_pairs(int64_t n, const double *col, double *out, uint32_t *perm, void *workspace, hipStream_t st);
 size_t grx_internal_sort_pairs_workspace_bytes(int64_t n);
 
@@ -62,7 +67,7 @@ constexpr int KM_MIN_BLOCK_SHIFT = 6;
 constexpr int KM_MAX_TRIALS = 16;             // 2 + int(log(k)) <= 11 for k <= 8192
 constexpr int KM_MAX_K = 8192;                // the E step ranks the centres by counting: O(k^2) per iteration
 constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup step of the range kernels (256 x 8)
-constexpr int KM_RANGE_GRID = 2048;           // workgroups of the gain kernel
+constexpr int KM_RANGE_GRID = 1024;           // workgroups of the gain kernel
 constexpr int KM_UPDATE_GRID = 1024;          // ... of the update kernel (each flushes its block sums once)
 constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
 
@@ -215,19 +220,29 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
                                                               double rel_tol, const double *__restrict__ v, int64_t first,
                                                               KmState *st)
 {
-    __shared__ double red[4];
+    __shared__ double red[4], rmin[4], rmax[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) s += part[b];
     s = km_block_sum(s, red);
-    if (threadIdx.x != 0) return;
     if (which == 0) {
         double lo = part[nb], hi = part[2 * nb];
-        for (int b = 1; b < nb; ++b) { lo = part[nb + b] < lo ? part[nb + b] : lo; hi = part[2 * nb + b] > hi ? part[2 * nb + b] : hi; }
+        for (int b = threadIdx.x; b < nb; b += 256) { lo = part[nb + b] < lo ? part[nb + b] : lo; hi = part[2 * nb + b] > hi ? part[2 * nb + b] : hi; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = lo; rmax[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        for (int w = 1; w < 4; ++w) { lo = rmin[w] < lo ? rmin[w] : lo; hi = rmax[w] > hi ? rmax[w] : hi; }
         st->mean = s / (double)m;
         st->vmin = lo;
         st->vmax = hi;
         return;
     }
+    if (threadIdx.x != 0) return;
     st->tol = (s / (double)m) * rel_tol;                       // _tolerance: mean(var(X, axis=0)) * tol
     const double mean = st->mean;
     const double xl = st->vmin - mean, xh = st->vmax - mean, c0 = v[first] - mean;
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict_
         const int64_t i0 = ((int64_t)slo << block_shift) + (int64_t)tid * per;
         const int64_t bend = (((int64_t)slo + 1) << block_shift) < m ? (((int64_t)slo + 1) << block_shift) : m;
         const int64_t i1 = (tid * per < bsize) ? (i0 + per < bend ? i0 + per : bend) : i0;
-        i128 lsum = 0;
+        double wa = 0.0, wb = 0.0, wc = 0.0;                     // limb sums of this thread's values: exact (<= 2^20 terms)
         for (int64_t ib = i0; ib < i1; ib += 16) {              // ranks first, then the distances they point at
             uint32_t rk[16];
             double dv[16];
@@ -475,8 +490,13 @@ __global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict_
 #pragma unroll
             for (int s = 0; s < 16; ++s) dv[s] = ds[rk[s]];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) lsum += (ib + s < i1) ? km_quanta(L, dv[s]) : (i128)0;
+            for (int s = 0; s < 16; ++s) {
+                double a, b, cc;
+                km_split(L, ib + s < i1 ? dv[s] : 0.0, a, b, cc);
+                wa += a; wb += b; wc += cc;
+            }
         }
+        const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
         const i128 linc = km_wave_scan128(lsum, lane);
         __syncthreads();                                        // (s_wt is read above by every thread)
         if (lane == 63) { s_wt_lo[wave] = (u64)linc; s_wt_hi[wave] = (u64)(linc >> 64); }
@@ -491,26 +511,21 @@ __global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict_
         const int owner = s_first;
         if (owner == 1024) {
             if (tid == 0) { atomicOr(&st->faults, 4); s_idx = bend - 1; }
-        } else if (tid == owner) {
-            i128 run = mine;
-            int64_t hit = i1 - 1;
-            bool found = false;
-            for (int64_t ib = i0; ib < i1 && !found; ib += 16) {
-                uint32_t rk[16];
-                double dv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) rk[s] = rank[ib + s < i1 ? ib + s : i1 - 1];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) dv[s] = ds[rk[s]];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (!found && ib + s < i1) {
-                        run += km_quanta(L, dv[s]);
-                        if (run >= R) { hit = ib + s; found = true; }
-                    }
-                }
+        } else if (wave == (owner >> 6)) {
+            // the owner's wavefront walks the owner's indices together: one value per lane, inclusive scan, first hit
+            const int ol = owner & 63;
+            const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
+            i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
+            int64_t hit = o1 - 1;
+            for (int64_t ib = o0; ib < o1; ib += 64) {
+                const int64_t i = ib + lane;
+                const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
+                const i128 qinc = km_wave_scan128(qv, lane);
+                const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
+                if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
+                run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
             }
-            s_idx = hit;
+            if (lane == 0) s_idx = hit;
         }
         __syncthreads();
         idx = s_idx;
@@ -547,12 +562,12 @@ struct KmIntervals {
     int64_t lo[KM_MAX_TRIALS], hi[KM_MAX_TRIALS], chunk0[KM_MAX_TRIALS + 1];
 };
 
-__device__ void km_merge_intervals(const KmSeedRec *rec, int n_trials, KmIntervals *out)
+__device__ void km_merge_intervals(const int64_t *cand_lo, const int64_t *cand_hi, int n_trials, KmIntervals *out)
 {
     int64_t l[KM_MAX_TRIALS], h[KM_MAX_TRIALS];
     int n = 0;
     for (int j = 0; j < n_trials; ++j) {
-        const int64_t a = rec->cand_lo[j], b = rec->cand_hi[j];
+        const int64_t a = cand_lo[j], b = cand_hi[j];
         if (b <= a) continue;
         int q = n++;
         while (q > 0 && l[q - 1] > a) { l[q] = l[q - 1]; h[q] = h[q - 1]; --q; }
@@ -582,8 +597,14 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
 {
     __shared__ KmIntervals s_iv;
     __shared__ i64 s_red[3][NT][4];
+    __shared__ int64_t s_rng[2][KM_MAX_TRIALS];
     KmSeedRec *rec = &st->rec[seed_no & 1];
-    if (threadIdx.x == 0) km_merge_intervals(rec, n_trials, &s_iv);
+    if (threadIdx.x < 2 * KM_MAX_TRIALS) {
+        const int j = threadIdx.x & (KM_MAX_TRIALS - 1);
+        s_rng[threadIdx.x / KM_MAX_TRIALS][j] = j < n_trials ? (threadIdx.x < KM_MAX_TRIALS ? rec->cand_lo[j] : rec->cand_hi[j]) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) km_merge_intervals(s_rng[0], s_rng[1], n_trials, &s_iv);
     __syncthreads();
     const int n_iv = s_iv.n;
     const int64_t total_chunks = s_iv.chunk0[n_iv];
