@@ -64,6 +64,7 @@ typedef long long i64;
 constexpr int KM_TILE = 1024;                 // values per tile of the prefix sums of the sorted values (256 threads x 4)
 constexpr int KM_MAX_BLOCKS = 2048;           // index blocks of the cumulative sum (two per thread of the prep scan)
 constexpr int KM_MIN_BLOCK_SHIFT = 6;
+constexpr int KM_SUB = 16;                    // sub-blocks of an index block: one workgroup each in km_prep_kernel
 constexpr int KM_MAX_TRIALS = 16;             // 2 + int(log(k)) <= 11 for k <= 8192
 constexpr int KM_MAX_K = 8192;                // the E step ranks the centres by counting: O(k^2) per iteration
 constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup step of the range kernels (256 x 8)
@@ -89,6 +90,12 @@ struct KmSeedRec {
     i64 cand_id[KM_MAX_TRIALS], cand_lo[KM_MAX_TRIALS], cand_hi[KM_MAX_TRIALS];   // candidate index; range of sorted positions
     i64 gain[3][KM_MAX_TRIALS];  // limb sums of (d - min(d, dist to candidate)) over the candidate's range
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
+    // the pick, km_prep_kernel -> km_pick_kernel: per trial the index block r falls in (-1: beyond the total), the
+    // cumulative sum before it, r itself, the sums of the block's sub-blocks; the seed chosen by this prep
+    int block[KM_MAX_TRIALS];
+    u64 carry_lo[KM_MAX_TRIALS], carry_hi[KM_MAX_TRIALS], r_lo[KM_MAX_TRIALS], r_hi[KM_MAX_TRIALS];
+    i64 sub[KM_MAX_TRIALS][KM_SUB][3];
+    double newest;
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -98,7 +105,15 @@ struct KmState {                 // device scalars shared by the kernels of one 
     KmLimb limb;
     int faults, scale_e;
     KmSeedRec rec[2];
+#ifdef KM_DBG_TIMING
+    long long dbg[16];
+#endif
 };
+#ifdef KM_DBG_TIMING
+#define KM_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
+#else
+#define KM_T(i) do { } while (0)
+#endif
 
 // ---- exact sums: three limbs per distance ----------------------------------------------------------------------
 // a = d rounded to a multiple of 2^(E-32), b = (d - a) rounded to 2^(E-64), c = (d - a - b) rounded to 2^(E-96);
@@ -379,138 +394,238 @@ __device__ __forceinline__ void km_dual_search(const double *__restrict__ a, int
     out_hi = __shfl(lo, 32, 64);
 }
 
-// prep of seed `seed_no`: ONE WORKGROUP PER TRIAL (all of them repeat the cheap common part).
-//  A (choose_prev): the winner among the previous seed's candidates becomes seed seed_no - 1; workgroup 0 records it and
-//    writes the sorted list of seeds with it inserted into the other buffer.
-//  B (do_pick): inclusive prefix of the index-block sums = sklearn's cumulative sum at block ends; total = the potential.
-//    The trial's r = uniform * potential; the first index whose cumulative sum reaches r (np.searchsorted, left): block
-//    by binary search, then the workgroup walks the block's indices (distances gathered through rank).
-//  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
-//    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
-//    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
-//    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
-__global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
-                                                       const uint32_t *__restrict__ rank, int64_t m,
-                                                       const i64 *__restrict__ bacc, int nblocks, int block_shift,
-                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
-                                                       int choose_prev, int do_pick, int full_range, KmState *st,
-                                                       double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
-                                                       double *__restrict__ sorted2, int sorted_ld)
+// argmin by one wavefront (lane j = candidate j): same rule as km_best
+__device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, int lane)
 {
-    __shared__ u64 s_inc_lo[KM_MAX_BLOCKS], s_inc_hi[KM_MAX_BLOCKS];
-    __shared__ u64 s_wt_lo[16], s_wt_hi[16];
-    __shared__ u64 s_expect[2];
-    __shared__ int64_t s_idx;
-    __shared__ int s_best, s_first;
+    double pd = 1.79769313486231570e308;
+    if (lane < n_trials)
+        pd = km_to_double(km_make128(rec->pot_lo, rec->pot_hi) - km_join(rec->gain[0][lane], rec->gain[1][lane], rec->gain[2][lane]));
+    double lowest = pd;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(lowest, off, 64);
+        lowest = o < lowest ? o : lowest;
+    }
+    const uint64_t tied = __ballot(lane < n_trials && !(pd > lowest + 1e-12 * lowest));
+    return __ffsll((long long)tied) - 1;
+}
+
+// The pick of seed `seed_no` is two launches: km_prep_kernel (KM_SUB workgroups per trial) and km_pick_kernel (one per
+// trial) -- one workgroup gathers ~330 scattered values per microsecond, so the walk of an index block (16 384 indices at
+// 30 M values) is spread over sixteen.
+// prep, every workgroup (the common part is cheap and repeated):
+//  A (choose_prev): the winner among the previous seed's candidates becomes seed seed_no - 1; the first workgroup records
+//    it and writes the sorted list of seeds with it inserted into the other buffer.
+//  B (do_pick): inclusive prefix of the index-block sums = sklearn's cumulative sum at block ends; total = the potential.
+//    The trial's r = uniform * potential lies in the first block whose cumulative sum reaches it (np.searchsorted, left);
+//    workgroup `sub` gathers the closest distances of its sixteenth of that block (through rank) and records their sum.
+__global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__ ds, const uint32_t *__restrict__ rank,
+                                                      int64_t m, const i64 *__restrict__ bacc, int nblocks, int block_shift,
+                                                      const double *__restrict__ uniform, int n_trials, int seed_no,
+                                                      int choose_prev, int do_pick, KmState *st, double *__restrict__ seeds_x,
+                                                      int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
+{
+    __shared__ u64 s_w_lo[4], s_w_hi[4], s_carry[2], s_expect[2];
+    __shared__ double s_red[4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_best;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int trial = blockIdx.x;
+    const int sub = blockIdx.x, trial = blockIdx.y;
+    const bool lead = sub == 0 && trial == 0;
     KmSeedRec *cur = &st->rec[seed_no & 1];
     const KmSeedRec *prev = &st->rec[(seed_no - 1) & 1];
     const int n_old = choose_prev ? seed_no - 1 : seed_no;      // seeds in the sorted list: it lives in buffer (count & 1)
     const double *sorted_old = sorted2 + (size_t)(n_old & 1) * sorted_ld;
     double *sorted_new = sorted2 + (size_t)((n_old + 1) & 1) * sorted_ld;
-    double newest = 0.0;                                        // the seed chosen here, not yet in sorted_old
+    KM_T(0);
     if (choose_prev) {
-        if (tid == 0) {
-            const int best = km_best(prev, n_trials);
-            s_best = best;
-            const i128 after = km_make128(prev->pot_lo, prev->pot_hi) -
-                               km_join(prev->gain[0][best], prev->gain[1][best], prev->gain[2][best]);
-            s_expect[0] = (u64)after;
-            s_expect[1] = (u64)(after >> 64);
+        if (wave == 0) {
+            const int best = km_best_wave(prev, n_trials, lane);
+            if (lane == 0) {
+                s_best = best;
+                const i128 after = km_make128(prev->pot_lo, prev->pot_hi) -
+                                   km_join(prev->gain[0][best], prev->gain[1][best], prev->gain[2][best]);
+                s_expect[0] = (u64)after;
+                s_expect[1] = (u64)(after >> 64);
+            }
         }
         __syncthreads();
-        const int best = s_best;
-        newest = prev->cand_x[best];
-        if (trial == 0) {
+        if (lead) {
+            const int best = s_best;
+            const double newest = prev->cand_x[best];
             int pos = 0;                                        // seeds <= newest: it goes behind them
-            for (int i0 = 0; i0 < n_old; i0 += 1024) pos += __syncthreads_count(i0 + tid < n_old && sorted_old[i0 + tid] <= newest);
-            for (int i = tid; i < n_old; i += 1024) sorted_new[i < pos ? i : i + 1] = sorted_old[i];
+            for (int i0 = 0; i0 < n_old; i0 += 256) pos += __syncthreads_count(i0 + tid < n_old && sorted_old[i0 + tid] <= newest);
+            for (int i = tid; i < n_old; i += 256) sorted_new[i < pos ? i : i + 1] = sorted_old[i];
             if (tid == 0) {
                 sorted_new[pos] = newest;
                 seeds_x[seed_no - 1] = newest;
                 seeds_id[seed_no - 1] = prev->cand_id[best];
+                cur->newest = newest;
             }
         }
     }
     if (!do_pick) return;
-    // ---- B: prefix of the block sums
-    i128 e0 = 0, e1 = 0;
-    if (2 * tid < nblocks) e0 = km_join(bacc[8 * tid], bacc[8 * tid + 1], bacc[8 * tid + 2]);
-    if (2 * tid + 1 < nblocks) e1 = km_join(bacc[8 * tid + 4], bacc[8 * tid + 5], bacc[8 * tid + 6]);
-    const i128 loc = e0 + e1;
-    const i128 inc = km_wave_scan128(loc, lane);
-    if (lane == 63) { s_wt_lo[wave] = (u64)inc; s_wt_hi[wave] = (u64)(inc >> 64); }
+    KM_T(1);
+    // ---- B: prefix of the block sums, eight consecutive blocks per thread
+    i128 inc8[KM_MAX_BLOCKS / 256];
+    i128 loc = 0;
+#pragma unroll
+    for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q) {
+        const int b = tid * (KM_MAX_BLOCKS / 256) + q;
+        if (b < nblocks) loc += km_join(bacc[4 * b], bacc[4 * b + 1], bacc[4 * b + 2]);
+        inc8[q] = loc;
+    }
+    const i128 winc = km_wave_scan128(loc, lane);
+    if (lane == 63) { s_w_lo[wave] = (u64)winc; s_w_hi[wave] = (u64)(winc >> 64); }
     __syncthreads();
     i128 before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const i128 wt = km_make128(s_wt_lo[w], s_wt_hi[w]);
+    for (int w = 0; w < 4; ++w) {
+        const i128 wt = km_make128(s_w_lo[w], s_w_hi[w]);
         if (w < wave) before += wt;
         total += wt;
     }
-    {
-        const i128 i0 = before + inc - loc + e0, i1 = i0 + e1;
-        s_inc_lo[2 * tid] = (u64)i0; s_inc_hi[2 * tid] = (u64)(i0 >> 64);
-        s_inc_lo[2 * tid + 1] = (u64)i1; s_inc_hi[2 * tid + 1] = (u64)(i1 >> 64);
-    }
-    if (tid == 0) { s_first = 1024; s_idx = -1; }
+    before += winc - loc;                                       // cumulative sum before this thread's first block
+    KM_T(2);
+    const double r = uniform[trial] * km_to_double(total);
+    const i128 R = km_ceil128(r);
+    // the block: number of blocks whose inclusive cumulative sum is < R (they are non-decreasing)
+    int below = 0;
+#pragma unroll
+    for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q)
+        below += (tid * (KM_MAX_BLOCKS / 256) + q < nblocks && before + inc8[q] < R) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+    if (lane == 0) s_cnt[wave] = below;
     __syncthreads();
-    if (trial == 0) {
+    const int blk = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const bool clipped = R > total || blk >= nblocks;           // np.clip(candidate_ids, None, n - 1)
+    if (blk == 0 && tid == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+#pragma unroll
+    for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q)
+        if (tid * (KM_MAX_BLOCKS / 256) + q == blk - 1) { const i128 cy = before + inc8[q]; s_carry[0] = (u64)cy; s_carry[1] = (u64)(cy >> 64); }
+    __syncthreads();
+    KM_T(3);
+    if (lead) {
         if (tid == 0) {
-            if (choose_prev && seed_no >= 2 && ((u64)total != s_expect[0] || (u64)(total >> 64) != s_expect[1])) atomicOr(&st->faults, 1);
+            if (choose_prev && ((u64)total != s_expect[0] || (u64)(total >> 64) != s_expect[1])) atomicOr(&st->faults, 1);
             cur->pot_lo = (u64)total;
             cur->pot_hi = (u64)(total >> 64);
         }
         if (tid < 3 * KM_MAX_TRIALS) cur->gain[tid / KM_MAX_TRIALS][tid % KM_MAX_TRIALS] = 0;
     }
+    if (sub == 0 && tid == 0) {
+        cur->block[trial] = clipped ? -1 : blk;
+        cur->carry_lo[trial] = s_carry[0];
+        cur->carry_hi[trial] = s_carry[1];
+        cur->r_lo[trial] = (u64)R;
+        cur->r_hi[trial] = (u64)(R >> 64);
+    }
+    if (clipped) return;
+    // ---- this workgroup's sixteenth of the block
     const KmLimb L = st->limb;
-    const double r = uniform[trial] * km_to_double(total);
-    const i128 R = km_ceil128(r);
-    int64_t idx = m - 1;                                        // np.clip(candidate_ids, None, n - 1)
-    if (R <= total) {                                           // (uniform over the workgroup)
-        int slo = 0, shi = nblocks - 1;
-        while (slo < shi) {
-            const int mid = (slo + shi) >> 1;
-            if (km_make128(s_inc_lo[mid], s_inc_hi[mid]) < R) slo = mid + 1; else shi = mid;
+    const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
+    const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
+    const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
+    const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sub * ssize;
+    const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
+    const int64_t i0 = s0 + (int64_t)tid * per;
+    const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
+    double wa = 0.0, wb = 0.0, wc = 0.0;                         // limb sums of this thread's values: exact
+    for (int64_t ib = i0; ib < i1; ib += 8) {                   // ranks first, then the distances they point at
+        uint32_t rk[8];
+        double dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double a, b, cc;
+            km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
+            wa += a; wb += b; wc += cc;
         }
-        const i128 carry = slo ? km_make128(s_inc_lo[slo - 1], s_inc_hi[slo - 1]) : (i128)0;
-        // walk the block: thread t owns `per` consecutive indices
-        const int64_t bsize = (int64_t)1 << block_shift;
-        const int64_t per = bsize >= 1024 ? bsize >> 10 : 1;
-        const int64_t i0 = ((int64_t)slo << block_shift) + (int64_t)tid * per;
-        const int64_t bend = (((int64_t)slo + 1) << block_shift) < m ? (((int64_t)slo + 1) << block_shift) : m;
-        const int64_t i1 = (tid * per < bsize) ? (i0 + per < bend ? i0 + per : bend) : i0;
-        double wa = 0.0, wb = 0.0, wc = 0.0;                     // limb sums of this thread's values: exact (<= 2^20 terms)
-        for (int64_t ib = i0; ib < i1; ib += 16) {              // ranks first, then the distances they point at
-            uint32_t rk[16];
-            double dv[16];
+    }
+    KM_T(4);
+    wa = km_block_sum(wa, s_red);
+    wb = km_block_sum(wb, s_red);
+    wc = km_block_sum(wc, s_red);
+    if (tid == 0) {
+        cur->sub[trial][sub][0] = __double2ll_rn(wa * L.sA);
+        cur->sub[trial][sub][1] = __double2ll_rn(wb * L.sB);
+        cur->sub[trial][sub][2] = __double2ll_rn(wc * L.sC);
+    }
+    KM_T(5);
+}
+
+// pick, one workgroup per trial: the sub-block whose cumulative sum reaches r (prefix of the sixteen sums), the index
+// inside it (its values gathered once more, they are in L2 now), then
+//  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
+//    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
+//    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
+//    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
+__global__ __launch_bounds__(256) void km_pick_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
+                                                      const uint32_t *__restrict__ rank, int64_t m, int block_shift,
+                                                      int n_trials, int seed_no, int choose_prev, int full_range, KmState *st,
+                                                      const double *__restrict__ sorted2, int sorted_ld)
+{
+    __shared__ u64 s_w_lo[4], s_w_hi[4];
+    __shared__ int64_t s_idx;
+    __shared__ int s_first;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int trial = blockIdx.x;
+    KmSeedRec *cur = &st->rec[seed_no & 1];
+    const int n_old = choose_prev ? seed_no - 1 : seed_no;
+    const double *sorted_old = sorted2 + (size_t)(n_old & 1) * sorted_ld;
+    const int blk = cur->block[trial];
+    int64_t idx = m - 1;
+    if (blk >= 0) {                                             // (uniform over the workgroup)
+        const KmLimb L = st->limb;
+        const i128 R = km_make128(cur->r_lo[trial], cur->r_hi[trial]);
+        const i128 carry = km_make128(cur->carry_lo[trial], cur->carry_hi[trial]);
+        // sub-block: every wavefront repeats the scan of the sixteen sums
+        const i128 sv = lane < KM_SUB ? km_join(cur->sub[trial][lane][0], cur->sub[trial][lane][1], cur->sub[trial][lane][2]) : (i128)0;
+        const i128 sinc = km_wave_scan128(sv, lane);
+        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
+        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
+        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
+        const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
+        const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
+        const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
+        const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sidx * ssize;
+        const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
+        const int64_t i0 = s0 + (int64_t)tid * per;
+        const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
+        double wa = 0.0, wb = 0.0, wc = 0.0;
+        for (int64_t ib = i0; ib < i1; ib += 8) {
+            uint32_t rk[8];
+            double dv[8];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) rk[s] = rank[ib + s < i1 ? ib + s : i1 - 1];
+            for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dv[s] = ds[rk[s]];
+            for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int q = 0; q < 8; ++q) {
                 double a, b, cc;
-                km_split(L, ib + s < i1 ? dv[s] : 0.0, a, b, cc);
+                km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
                 wa += a; wb += b; wc += cc;
             }
         }
         const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
         const i128 linc = km_wave_scan128(lsum, lane);
-        __syncthreads();                                        // (s_wt is read above by every thread)
-        if (lane == 63) { s_wt_lo[wave] = (u64)linc; s_wt_hi[wave] = (u64)(linc >> 64); }
+        if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
+        if (tid == 0) { s_first = 256; s_idx = -1; }
         __syncthreads();
         i128 wbefore = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w)
-            if (w < wave) wbefore += km_make128(s_wt_lo[w], s_wt_hi[w]);
-        const i128 mine = carry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
-        if (mine + lsum >= R) atomicMin(&s_first, tid);
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) wbefore += km_make128(s_w_lo[w], s_w_hi[w]);
+        const i128 mine = scarry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
+        if (reach != 0 && mine + lsum >= R) atomicMin(&s_first, tid);
         __syncthreads();
         const int owner = s_first;
-        if (owner == 1024) {
-            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = bend - 1; }
+        if (owner == 256) {
+            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
         } else if (wave == (owner >> 6)) {
             // the owner's wavefront walks the owner's indices together: one value per lane, inclusive scan, first hit
             const int ol = owner & 63;
@@ -539,6 +654,7 @@ __global__ __launch_bounds__(1024) void km_prep_kernel(const double *__restrict_
     bool has_l = pl > 0, has_r = pr < n_old;
     double sl = has_l ? sorted_old[pl - 1] : 0.0, sr = has_r ? sorted_old[pr] : 0.0;
     if (choose_prev) {
+        const double newest = cur->newest;                      // the seed chosen in km_prep_kernel, not in sorted_old
         if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
         if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
     }
@@ -980,6 +1096,9 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
         info[1] = nonempty;
         info[2] = distinct;
         info[3] = k > 1 ? st->faults : 0;
+#ifdef KM_DBG_TIMING
+        for (int q = 1; q < 9; ++q) printf("prep phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+#endif
     }
 }
 
@@ -1146,16 +1265,18 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
         for (int c = 1; c < k; ++c) {
-            km_prep_kernel<<<n_trials, 1024, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
-                                                      d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1, full_range,
-                                                      state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+            km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(ds, rank, m, bacc, p.nblocks, p.block_shift,
+                                                                   d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
+                                                                   state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+            km_pick_kernel<<<n_trials, 256, 0, st>>>(xs, ds, rank, m, p.block_shift, n_trials, c, c >= 2, full_range, state, sorted2,
+                                                     (int)p.sorted_ld);
             if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             if (c < k - 1)                                         // the distances to the last seed are never needed
                 km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, state, c, n_trials);
         }
-        km_prep_kernel<<<1, 1024, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
-                                           full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+        km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0, state,
+                                                   seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values

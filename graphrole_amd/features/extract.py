@@ -175,19 +175,17 @@ class RecursiveFeatureExtractor:
 
     def _agg_names(self) -> List[str]:
         names = [_agg_name(a) for a in self.aggs]
-        bad = [nm for a, nm in zip(self.aggs, names) if isinstance(a, str) and nm not in _SUPPORTED_AGGS]
-        if bad:
-            raise NotImplementedError(
-                f'aggregations {bad} have no device kernel (supported: {list(_SUPPORTED_AGGS)}); pass a callable to '
-                f'have pandas evaluate it on the host')
         if self._host_callables() and len(set(names)) != len(names):
             # pandas: SpecificationError('Function names must be unique if there is no new column names assigned')
             raise ValueError(f'Function names must be unique: {names}')
         return names
 
     def _host_callables(self) -> Dict[str, object]:
-        """name -> callable for the entries of ``aggs`` that have no device kernel"""
-        return {_agg_name(a): a for a in self.aggs if not _has_kernel(a) and not isinstance(a, str)}
+        """name -> entry for the entries of ``aggs`` that have no device kernel: callables, and any other aggregation
+        NAME pandas knows ('sem', 'skew', 'nunique', 'first', ...) -- the reference hands the list to DataFrame.agg
+        as it is (extract.py:26,47,111), so these are evaluated by pandas on the host over device-gathered neighbour
+        rows; a name pandas does not know fails there with pandas' own AttributeError, as in the reference."""
+        return {_agg_name(a): a for a in self.aggs if not _has_kernel(a)}
 
     # ------------------------------------------------------------------ public API
     def extract_features(self) -> DataFrameLike:

@@ -135,6 +135,10 @@ CALLABLE_CASES = {
     'ba300_second_mean': ('ba300', ['callable:second_largest', 'mean'], 3),
     'loops_dangling150_spread': ('loops_dangling150', ['callable:spread'], 3),
     'er300_spread_max': ('er300', ['callable:spread', 'max'], 3),
+    # aggregation NAMES pandas knows and the device has no kernel for (extract.py:26,47,111: any name goes to DataFrame.agg)
+    'ba300_sum_sem': ('ba300', ['sum', 'sem'], 3),
+    'karate_skew_nunique': ('karate', ['skew', 'nunique'], 3),
+    'loops_dangling150_sem_max': ('loops_dangling150', ['sem', 'max'], 3),
 }
 CALLABLES = {'spread': spread, 'second_largest': second_largest}
 

@@ -243,8 +243,10 @@ class TestExtractorLikeReference:
 
     def test_unsupported_aggregation_fails_loudly(self):
         from graphrole_amd import RecursiveFeatureExtractor
-        with pytest.raises(NotImplementedError, match='no device kernel'):
-            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['sum', 'nunique']).extract_features()
+        # a NAME pandas does not know: pandas' own error, as in the reference (the list goes to DataFrame.agg);
+        # names it knows but the device does not ('sem', 'nunique', ...) run on the host: tests/test_gpu_callable_aggs.py
+        with pytest.raises(AttributeError, match='not a valid function'):
+            RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=['sum', 'no_such_agg']).extract_features()
         # a CALLABLE without a kernel is evaluated by pandas on the host (tests/test_gpu_callable_aggs.py): the same
         # numbers as the kernel-backed 'sum' here, under the name pandas gives a lambda
         X = RecursiveFeatureExtractor(nx.Graph(self.edges), aggs=[lambda s: s.sum()]).extract_features()
