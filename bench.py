@@ -285,26 +285,52 @@ def cpu_baseline(G, args, X_features):
     """Oracle (plain-C port, single thread) on the same graph once, plus the reference-faithful legs of
     BASELINE.md baseline (1) on bounded samples."""
     from oracle import ckernels, refex, reference_path
-    og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=None, directed=False,
-                           num_edges=G.num_edges, adj_col=G.adj_col)
+    # the workload itself: weights, directions and attribute columns included (config 5 has all three)
+    og = refex.OracleGraph(labels=G.labels, row_ptr=G.row_ptr, col=G.col, w=G.w, directed=G.directed,
+                           num_edges=G.num_edges, t_row_ptr=getattr(G, 't_row_ptr', None), t_col=getattr(G, 't_col', None),
+                           t_w=getattr(G, 't_w', None), adj_col=G.adj_col)
+    if G.attributes:
+        og.attrs = {'attribute_' + k: np.asarray(v, dtype=np.float64) for k, v in G.attributes.items()}
     # ONE thread: the oracle's row-parallel loops (OpenMP, there for the full-size parity tests) and its threaded
     # binning are switched off for the timing -- `cores` below says 1 and means it
+    bin_threads = refex.BIN_THREADS
     ckernels.set_threads(1)
     refex.BIN_THREADS = 1
-    t0 = time.perf_counter()
-    res = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
-    dt = time.perf_counter() - t0
-    ckernels.set_threads(0)
+    try:
+        t0 = time.perf_counter()
+        res = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
+        dt = time.perf_counter() - t0
+    finally:
+        ckernels.set_threads(0)
+        refex.BIN_THREADS = bin_threads
     gens = res.generation_count
     out = {
         'value': G.nnz * gens / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
-        'sample': f'full workload once: oracle C port, gen-0 + {gens} generations + pruning in {dt:.1f} s'
-                  + (' (structure only: this leg runs the oracle on the undirected unweighted graph of the same '
-                     'rows, without the workload\'s weights, directions and attribute columns)'
-                     if (G.directed or G.weighted or G.attributes) else ''),
+        'sample': f'full workload once: oracle C port, gen-0 + {gens} generations + pruning in {dt:.1f} s',
         'seconds': dt, 'host_cpus': os.cpu_count(),
     }
     extra = {}
+    # the same run on every core of the host (OpenMP row loops of oracle/csrc/oracle_kernels.c, threaded binning):
+    # what a competent multi-core CPU implementation of this restatement does on this box
+    try:
+        cores = os.cpu_count() or 1
+        ckernels.set_threads(cores)
+        refex.BIN_THREADS = cores
+        t0 = time.perf_counter()
+        res_all = refex.extract_features(og, max_generations=MAX_GENERATIONS, fast=True)
+        dt_all = time.perf_counter() - t0
+        extra['cpu_baseline_all_cores'] = {
+            'value': G.nnz * res_all.generation_count / dt_all, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+            'sample': f'full workload once: oracle C port with OpenMP row loops ({cores} threads) and one binning thread per '
+                      f'column, gen-0 + {res_all.generation_count} generations + pruning in {dt_all:.1f} s',
+            'seconds': dt_all,
+        }
+        del res_all
+    except Exception as exc:                       # baseline legs must never kill the bench line
+        extra['cpu_baseline_all_cores'] = {'error': repr(exc)}
+    finally:
+        ckernels.set_threads(0)
+        refex.BIN_THREADS = bin_threads
     ref = {'unit': 'edges/s', 'cores': 1, 'kind': 'port',
            'what': 'reference-faithful CPU path (BASELINE.md baseline 1): the pandas / networkx / scipy / sklearn call '
                    'sequences of the reference (oracle/reference_path.py, pinned on the reference\'s golden tables by '
@@ -407,6 +433,17 @@ def api_wall_once(G, with_roles=True):
                                 'Python dict of n entries (the reference\'s return type); role_percentage = upload + '
                                 'grx_row_normalise + download + DataFrame'}
         del first, roles, share
+        # the reference's DEFAULT RoleExtractor(): MDL model selection over 2..8 roles x 1..8 bits, every cell an NMF fit
+        # + two encodes + the KL cost (graphrole/roles/extract.py:98-142), on the same table
+        np.random.seed(0)
+        t7 = time.perf_counter()
+        rsel = RoleExtractor()
+        rsel.extract_role_factors(X)
+        out['rolx_model_selection_s'] = time.perf_counter() - t7
+        out['rolx_model_selection'] = {'selected_roles': int(rsel.node_role_factor.shape[1]),
+                                       'cells': int(np.isfinite(rsel.model_selection_['error_costs']).sum())
+                                       if getattr(rsel, 'model_selection_', None) else None}
+        del rsel
     del X, rx, fe
     gc.collect()
     return out
@@ -420,6 +457,9 @@ def api_wall(G, args, reps=3, with_roles=True):
     med = dict(runs[order[reps // 2]])
     if with_roles and 'roles' not in med:
         med['roles'] = runs[-1].get('roles')
+    for key in ('rolx_model_selection_s', 'rolx_model_selection'):
+        if with_roles and key in runs[-1]:
+            med[key] = runs[-1][key]
     out = {}
     if not G.directed and not G.weighted:
         from graphrole_amd.graph.csr import CSRGraph
@@ -668,6 +708,27 @@ def main():
                                       'distinct_levels': int(info[2])}
             encode_info['what'] = ('encode() of the N x r node-role factor: kmeans = sklearn KMeans(random_state=1) reproduced '
                                    '(grx_kmeans1d), lloyd_max = grx_lloyd_max')
+        # RolX's real cost per call (roles/extract.py:59-93,144-161): NMF fit + encode(G) + encode(F) on the same device
+        # table the steps factorise, as RoleExtractor(n_roles=6).extract_role_factors runs them -- outside `value`
+        rolx_info = None
+        if rank == 0 and world == 1 and not light:
+            try:
+                n_bits = int(np.log2(N_ROLES * min(G.n, state['F'])))               # roles/extract.py:72
+                shape = (G.n, state['F'])
+                np.random.seed(0)
+                factor.encoded_factors_device(state['Xd'], shape, N_ROLES, n_bits, 'kmeans')
+                torch.cuda.synchronize()
+                reps_r = 3
+                t0 = time.perf_counter()
+                for _ in range(reps_r):
+                    factor.encoded_factors_device(state['Xd'], shape, N_ROLES, n_bits, 'kmeans')
+                torch.cuda.synchronize()
+                rolx_info = {'ms_per_call': (time.perf_counter() - t0) / reps_r * 1e3, 'n_roles': N_ROLES, 'n_bits': n_bits,
+                             'calls_timed': reps_r,
+                             'what': 'NMF fit (NNDSVDa + MU loop) + encode(G) + encode(F) with the reference\'s quantiser '
+                                     '(grx_kmeans1d), device time, the steps\' own feature table'}
+            except Exception as exc:
+                rolx_info = {'error': repr(exc)}
 
         # per-rank figures (N > 1): every rank's aggregation launch time and exchange time, gathered on rank 0
         per_rank = None
@@ -804,7 +865,7 @@ def main():
                           'generations': state['stats']},
                 'nmf': {'iters_per_s': timers['nmf_iters'] / t_nmf, 'ms_per_step': t_nmf / steps * 1e3,
                         'iterations_per_step': state['n_iter'], 'includes': 'NNDSVDa init + MU loop + convergence checks'},
-                'soak': soak, 'encode': encode_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
+                'soak': soak, 'encode': encode_info, 'rolx': rolx_info, 'roofline': roofline, 'roofline_nmf': roofline_nmf,
                 'kernel_ms_per_step': {k: v[0] for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
             }
             if per_rank is not None:
@@ -825,6 +886,8 @@ def main():
                 try:
                     line['api_wall_s'] = api_wall(G, args, reps=3)
                     line['api_wall_s']['when'] = 'after the soak loop and the rocprofv3 --pmc child processes'
+                    # the reference's default RoleExtractor() (n_roles=None): wall-clock of the whole MDL grid, cold call
+                    line['rolx_model_selection_s'] = line['api_wall_s'].get('rolx_model_selection_s')
                 except Exception as exc:
                     line['api_wall_s'] = {'error': repr(exc)}
                 line['api_wall_before_soak_s'] = api_before

@@ -68,9 +68,10 @@ constexpr int KM_SUB = 16;                    // sub-blocks of an index block: o
 constexpr int KM_MAX_TRIALS = 16;             // 2 + int(log(k)) <= 11 for k <= 8192
 constexpr int KM_MAX_K = 8192;                // the E step ranks the centres by counting: O(k^2) per iteration
 constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup step of the range kernels (256 x 8)
-constexpr int KM_RANGE_GRID = 1024;           // workgroups of the gain kernel
-constexpr int KM_UPDATE_GRID = 1024;          // ... of the update kernel (each flushes its block sums once)
+constexpr int KM_RANGE_GRID = 512;            // workgroups of the gain kernel
+constexpr int KM_UPDATE_GRID = 512;           // ... of the update kernel (each flushes its block sums once)
 constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
+constexpr int KM_SMALL_M = 4096;              // at most this many values: the seeding runs in one workgroup
 
 __device__ __forceinline__ double km_sqdist(double c, double csq, double x)
 {
@@ -90,12 +91,7 @@ struct KmSeedRec {
     i64 cand_id[KM_MAX_TRIALS], cand_lo[KM_MAX_TRIALS], cand_hi[KM_MAX_TRIALS];   // candidate index; range of sorted positions
     i64 gain[3][KM_MAX_TRIALS];  // limb sums of (d - min(d, dist to candidate)) over the candidate's range
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
-    // the pick, km_prep_kernel -> km_pick_kernel: per trial the index block r falls in (-1: beyond the total), the
-    // cumulative sum before it, r itself, the sums of the block's sub-blocks; the seed chosen by this prep
-    int block[KM_MAX_TRIALS];
-    u64 carry_lo[KM_MAX_TRIALS], carry_hi[KM_MAX_TRIALS], r_lo[KM_MAX_TRIALS], r_hi[KM_MAX_TRIALS];
-    i64 sub[KM_MAX_TRIALS][KM_SUB][3];
-    double newest;
+    i64 sub[KM_MAX_TRIALS][KM_SUB][3];   // km_prep_kernel: limb sums of the sub-blocks of the block each trial's r falls in
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -104,15 +100,20 @@ struct KmState {                 // device scalars shared by the kernels of one 
     double c0;                   // the first seed (centred)
     KmLimb limb;
     int faults, scale_e;
+    unsigned arrivals[KM_MAX_TRIALS];   // per trial: prep workgroups that have recorded their sub-block sum (monotonic)
     KmSeedRec rec[2];
 #ifdef KM_DBG_TIMING
-    long long dbg[16];
+    long long dbg[32];
 #endif
 };
 #ifdef KM_DBG_TIMING
-#define KM_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
+#define KM_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
+#define KM_TP(i) do { if (trial == 0 && threadIdx.x == 0) st->dbg[i] = wall_clock64(); } while (0)
+#define KM_TG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
 #else
 #define KM_T(i) do { } while (0)
+#define KM_TP(i) do { } while (0)
+#define KM_TG(i) do { } while (0)
 #endif
 
 // ---- exact sums: three limbs per distance ----------------------------------------------------------------------
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
     st->limb.sB = ldexp(1.0, 64 - E);
     st->limb.sC = ldexp(1.0, 96 - E);
     st->faults = faults;
+    for (int j = 0; j < KM_MAX_TRIALS; ++j) st->arrivals[j] = 0;
 }
 
 // index order: x = v - mean; per block of 2^block_shift indices the exact sum of the squared distances to the first
@@ -410,25 +412,184 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
     return __ffsll((long long)tied) - 1;
 }
 
-// The pick of seed `seed_no` is two launches: km_prep_kernel (KM_SUB workgroups per trial) and km_pick_kernel (one per
-// trial) -- one workgroup gathers ~330 scattered values per microsecond, so the walk of an index block (16 384 indices at
-// 30 M values) is spread over sixteen.
-// prep, every workgroup (the common part is cheap and repeated):
+// pick, by the LAST of a trial's sixteen prep workgroups to record its sum: the sub-block whose cumulative sum reaches r
+// (prefix of the sixteen sums), the index inside it (its values gathered once more), then
+//  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
+//    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
+//    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
+//    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
+__device__ void km_pick_body(const double *__restrict__ xs, const double *__restrict__ ds, const uint32_t *__restrict__ rank,
+                             int64_t m, int block_shift, int trial, int blk, i128 R, i128 carry, bool has_newest, double newest,
+                             int n_old, const double *__restrict__ sorted_old, int full_range, KmState *st, KmSeedRec *cur)
+{
+    __shared__ u64 s_w_lo[4], s_w_hi[4], s_mine[2];
+    __shared__ int64_t s_idx, s_o[2];
+    __shared__ double s_dv[8];
+    __shared__ uint32_t s_rk[8], s_hit_rank;
+    __shared__ int s_first;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int64_t idx = m - 1;
+    if (blk >= 0) {                                             // (uniform over the workgroup)
+        const KmLimb L = st->limb;
+        // sub-block: every wavefront repeats the scan of the sixteen sums (written by other workgroups of this launch:
+        // agent-scope atomic stores there, agent-scope atomic loads here)
+        i128 sv = 0;
+        if (lane < KM_SUB)
+            sv = km_join(__hip_atomic_load(&cur->sub[trial][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __hip_atomic_load(&cur->sub[trial][lane][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __hip_atomic_load(&cur->sub[trial][lane][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const i128 sinc = km_wave_scan128(sv, lane);
+        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
+        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
+        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
+        const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
+        const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
+        const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
+        const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sidx * ssize;
+        const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
+        const int64_t i0 = s0 + (int64_t)tid * per;
+        const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
+        double wa = 0.0, wb = 0.0, wc = 0.0;
+        uint32_t rk0[8];                                        // the first eight stay in registers for the final step
+        double dv0[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t i = i0 + q < i1 ? i0 + q : (i1 > 0 ? i1 - 1 : 0);
+            rk0[q] = rank[i < m ? i : m - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dv0[q] = ds[rk0[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double a, b, cc;
+            km_split(L, i0 + q < i1 ? dv0[q] : 0.0, a, b, cc);
+            wa += a; wb += b; wc += cc;
+        }
+        for (int64_t ib = i0 + 8; ib < i1; ib += 8) {           // (only when m is beyond 2^29)
+            uint32_t rk[8];
+            double dv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double a, b, cc;
+                km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
+                wa += a; wb += b; wc += cc;
+            }
+        }
+        const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
+        const i128 linc = km_wave_scan128(lsum, lane);
+        if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
+        if (tid == 0) { s_first = 256; s_idx = -1; s_hit_rank = 0xFFFFFFFFu; }
+        __syncthreads();
+        i128 wbefore = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) wbefore += km_make128(s_w_lo[w], s_w_hi[w]);
+        const i128 mine = scarry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
+        if (reach != 0 && mine + lsum >= R) atomicMin(&s_first, tid);
+        __syncthreads();
+        const int owner = s_first;
+        if (owner == 256) {
+            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
+            __syncthreads();
+        } else if (per <= 8) {
+            // the owner's (at most eight) values through LDS to wavefront 0: one value per lane, inclusive scan, first hit
+            if (tid == owner) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { s_dv[q] = dv0[q]; s_rk[q] = rk0[q]; }
+                s_mine[0] = (u64)mine; s_mine[1] = (u64)(mine >> 64);
+                s_o[0] = i0; s_o[1] = i1;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int64_t o0 = s_o[0], o1 = s_o[1];
+                const i128 qv = lane < o1 - o0 ? km_quanta(L, s_dv[lane < 8 ? lane : 0]) : (i128)0;
+                const i128 qinc = km_wave_scan128(qv, lane);
+                const uint64_t ok = __ballot(lane < o1 - o0 && km_make128(s_mine[0], s_mine[1]) + qinc >= R);
+                const int h = ok ? __ffsll((long long)ok) - 1 : (int)(o1 - o0) - 1;
+                if (lane == 0) { s_idx = o0 + h; s_hit_rank = s_rk[h]; }
+            }
+            __syncthreads();
+        } else {
+            if (wave == (owner >> 6)) {
+                // the owner's wavefront walks the owner's indices together
+                const int ol = owner & 63;
+                const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
+                i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
+                int64_t hit = o1 - 1;
+                for (int64_t ib = o0; ib < o1; ib += 64) {
+                    const int64_t i = ib + lane;
+                    const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
+                    const i128 qinc = km_wave_scan128(qv, lane);
+                    const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
+                    if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
+                    run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
+                }
+                if (lane == 0) s_idx = hit;
+            }
+            __syncthreads();
+        }
+        idx = s_idx;
+        if (idx > m - 1) idx = m - 1;
+    } else if (tid == 0) {
+        s_hit_rank = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    KM_TP(6);
+    const uint32_t hr = s_hit_rank;
+    const double cx = xs[hr != 0xFFFFFFFFu ? hr : rank[idx]];
+    // ---- C: neighbours among the seeds, range of sorted positions
+    int64_t pl, pr;
+    km_dual_search(sorted_old, n_old, cx, cx, true, true, pl, pr);  // pl seeds < cx, pr seeds <= cx
+    bool has_l = pl > 0, has_r = pr < n_old;
+    double sl = has_l ? sorted_old[pl - 1] : 0.0, sr = has_r ? sorted_old[pr] : 0.0;
+    if (has_newest) {                                           // the seed chosen by this launch, not in sorted_old
+        if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
+        if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
+    }
+    KM_TP(7);
+    const double amax = st->amax;
+    const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
+    const double tlo = has_l ? 0.5 * (sl + cx) - (err / (cx - sl) + slack) : 0.0;
+    const double thi = has_r ? 0.5 * (cx + sr) + (err / (sr - cx) + slack) : 0.0;
+    int64_t lo = 0, hi = m;
+    if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
+    KM_TP(8);
+    if (lane == 0) {
+        cur->cand_x[trial] = cx;
+        cur->cand_id[trial] = idx;
+        cur->cand_lo[trial] = lo;
+        cur->cand_hi[trial] = hi;
+    }
+}
+
+// The pick of seed `seed_no`: KM_SUB workgroups per trial -- one workgroup gathers ~330 scattered values per microsecond,
+// so the walk of an index block (16 384 indices at 30 M values) is spread over sixteen; the last of them to record its
+// sum (an arrival counter per trial, no waiting) finishes the trial (km_pick_body).
+// Every workgroup (the common part is cheap and repeated):
 //  A (choose_prev): the winner among the previous seed's candidates becomes seed seed_no - 1; the first workgroup records
 //    it and writes the sorted list of seeds with it inserted into the other buffer.
 //  B (do_pick): inclusive prefix of the index-block sums = sklearn's cumulative sum at block ends; total = the potential.
 //    The trial's r = uniform * potential lies in the first block whose cumulative sum reaches it (np.searchsorted, left);
 //    workgroup `sub` gathers the closest distances of its sixteenth of that block (through rank) and records their sum.
-__global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__ ds, const uint32_t *__restrict__ rank,
-                                                      int64_t m, const i64 *__restrict__ bacc, int nblocks, int block_shift,
+__global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
+                                                      const uint32_t *__restrict__ rank, int64_t m,
+                                                      const i64 *__restrict__ bacc, int nblocks, int block_shift,
                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
-                                                      int choose_prev, int do_pick, KmState *st, double *__restrict__ seeds_x,
-                                                      int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
+                                                      int choose_prev, int do_pick, int full_range, KmState *st,
+                                                      double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
+                                                      double *__restrict__ sorted2, int sorted_ld)
 {
+    __shared__ int s_last;
+    __shared__ double s_newest;
+    __shared__ i64 s_newid;
     __shared__ u64 s_w_lo[4], s_w_hi[4], s_carry[2], s_expect[2];
     __shared__ double s_red[4];
     __shared__ int s_cnt[4];
-    __shared__ int s_best;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int sub = blockIdx.x, trial = blockIdx.y;
     const bool lead = sub == 0 && trial == 0;
@@ -437,12 +598,38 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     const int n_old = choose_prev ? seed_no - 1 : seed_no;      // seeds in the sorted list: it lives in buffer (count & 1)
     const double *sorted_old = sorted2 + (size_t)(n_old & 1) * sorted_ld;
     double *sorted_new = sorted2 + (size_t)((n_old + 1) & 1) * sorted_ld;
+    // ---- B (first half, issued before the choice so that the two round trips to memory overlap): this thread's eight
+    // consecutive block sums
+    i128 inc8[KM_MAX_BLOCKS / 256];
+    i128 loc = 0;
+    if (do_pick) {
+        i64 raw[KM_MAX_BLOCKS / 256][3];
+#pragma unroll
+        for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q) {
+            const int b = tid * (KM_MAX_BLOCKS / 256) + q;
+            const int bb = b < nblocks ? b : nblocks - 1;
+            raw[q][0] = bacc[4 * bb]; raw[q][1] = bacc[4 * bb + 1]; raw[q][2] = bacc[4 * bb + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q) {
+            if (tid * (KM_MAX_BLOCKS / 256) + q < nblocks) loc += km_join(raw[q][0], raw[q][1], raw[q][2]);
+            inc8[q] = loc;
+        }
+    }
+    double newest = 0.0;                                        // the seed chosen here, not yet in sorted_old
     KM_T(0);
     if (choose_prev) {
         if (wave == 0) {
+            // (the candidate values ride along with the gains: one round trip to memory instead of two)
+            const bool on = lane < n_trials && lane < KM_MAX_TRIALS;
+            const double cx = on ? prev->cand_x[lane] : 0.0;
+            const i64 cid = on ? prev->cand_id[lane] : 0;
             const int best = km_best_wave(prev, n_trials, lane);
+            const double bx = __shfl(cx, best, 64);
+            const i64 bid = __shfl(cid, best, 64);
             if (lane == 0) {
-                s_best = best;
+                s_newest = bx;
+                s_newid = bid;
                 const i128 after = km_make128(prev->pot_lo, prev->pot_hi) -
                                    km_join(prev->gain[0][best], prev->gain[1][best], prev->gain[2][best]);
                 s_expect[0] = (u64)after;
@@ -450,31 +637,20 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
             }
         }
         __syncthreads();
+        newest = s_newest;
         if (lead) {
-            const int best = s_best;
-            const double newest = prev->cand_x[best];
             int pos = 0;                                        // seeds <= newest: it goes behind them
             for (int i0 = 0; i0 < n_old; i0 += 256) pos += __syncthreads_count(i0 + tid < n_old && sorted_old[i0 + tid] <= newest);
             for (int i = tid; i < n_old; i += 256) sorted_new[i < pos ? i : i + 1] = sorted_old[i];
             if (tid == 0) {
                 sorted_new[pos] = newest;
                 seeds_x[seed_no - 1] = newest;
-                seeds_id[seed_no - 1] = prev->cand_id[best];
-                cur->newest = newest;
+                seeds_id[seed_no - 1] = s_newid;
             }
         }
     }
     if (!do_pick) return;
     KM_T(1);
-    // ---- B: prefix of the block sums, eight consecutive blocks per thread
-    i128 inc8[KM_MAX_BLOCKS / 256];
-    i128 loc = 0;
-#pragma unroll
-    for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q) {
-        const int b = tid * (KM_MAX_BLOCKS / 256) + q;
-        if (b < nblocks) loc += km_join(bacc[4 * b], bacc[4 * b + 1], bacc[4 * b + 2]);
-        inc8[q] = loc;
-    }
     const i128 winc = km_wave_scan128(loc, lane);
     if (lane == 63) { s_w_lo[wave] = (u64)winc; s_w_hi[wave] = (u64)(winc >> 64); }
     __syncthreads();
@@ -514,14 +690,12 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
         }
         if (tid < 3 * KM_MAX_TRIALS) cur->gain[tid / KM_MAX_TRIALS][tid % KM_MAX_TRIALS] = 0;
     }
-    if (sub == 0 && tid == 0) {
-        cur->block[trial] = clipped ? -1 : blk;
-        cur->carry_lo[trial] = s_carry[0];
-        cur->carry_hi[trial] = s_carry[1];
-        cur->r_lo[trial] = (u64)R;
-        cur->r_hi[trial] = (u64)(R >> 64);
+    const i128 carry = km_make128(s_carry[0], s_carry[1]);
+    if (clipped) {                                              // the last index, whatever the block holds
+        if (sub == 0) km_pick_body(xs, ds, rank, m, block_shift, trial, -1, R, carry, choose_prev != 0, newest, n_old, sorted_old,
+                                   full_range, st, cur);
+        return;
     }
-    if (clipped) return;
     // ---- this workgroup's sixteenth of the block
     const KmLimb L = st->limb;
     const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
@@ -551,125 +725,17 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     wb = km_block_sum(wb, s_red);
     wc = km_block_sum(wc, s_red);
     if (tid == 0) {
-        cur->sub[trial][sub][0] = __double2ll_rn(wa * L.sA);
-        cur->sub[trial][sub][1] = __double2ll_rn(wb * L.sB);
-        cur->sub[trial][sub][2] = __double2ll_rn(wc * L.sC);
+        __hip_atomic_store(&cur->sub[trial][sub][0], __double2ll_rn(wa * L.sA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cur->sub[trial][sub][1], __double2ll_rn(wb * L.sB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cur->sub[trial][sub][2], __double2ll_rn(wc * L.sC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the sums have left before the arrival is counted
+        const unsigned ticket = __hip_atomic_fetch_add(&st->arrivals[trial], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket % KM_SUB) == KM_SUB - 1;
     }
+    __syncthreads();
     KM_T(5);
-}
-
-// pick, one workgroup per trial: the sub-block whose cumulative sum reaches r (prefix of the sixteen sums), the index
-// inside it (its values gathered once more, they are in L2 now), then
-//  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
-//    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
-//    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
-//    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
-__global__ __launch_bounds__(256) void km_pick_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
-                                                      const uint32_t *__restrict__ rank, int64_t m, int block_shift,
-                                                      int n_trials, int seed_no, int choose_prev, int full_range, KmState *st,
-                                                      const double *__restrict__ sorted2, int sorted_ld)
-{
-    __shared__ u64 s_w_lo[4], s_w_hi[4];
-    __shared__ int64_t s_idx;
-    __shared__ int s_first;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int trial = blockIdx.x;
-    KmSeedRec *cur = &st->rec[seed_no & 1];
-    const int n_old = choose_prev ? seed_no - 1 : seed_no;
-    const double *sorted_old = sorted2 + (size_t)(n_old & 1) * sorted_ld;
-    const int blk = cur->block[trial];
-    int64_t idx = m - 1;
-    if (blk >= 0) {                                             // (uniform over the workgroup)
-        const KmLimb L = st->limb;
-        const i128 R = km_make128(cur->r_lo[trial], cur->r_hi[trial]);
-        const i128 carry = km_make128(cur->carry_lo[trial], cur->carry_hi[trial]);
-        // sub-block: every wavefront repeats the scan of the sixteen sums
-        const i128 sv = lane < KM_SUB ? km_join(cur->sub[trial][lane][0], cur->sub[trial][lane][1], cur->sub[trial][lane][2]) : (i128)0;
-        const i128 sinc = km_wave_scan128(sv, lane);
-        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
-        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
-        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
-        const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
-        const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
-        const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
-        const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sidx * ssize;
-        const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
-        const int64_t i0 = s0 + (int64_t)tid * per;
-        const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
-        double wa = 0.0, wb = 0.0, wc = 0.0;
-        for (int64_t ib = i0; ib < i1; ib += 8) {
-            uint32_t rk[8];
-            double dv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double a, b, cc;
-                km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
-                wa += a; wb += b; wc += cc;
-            }
-        }
-        const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
-        const i128 linc = km_wave_scan128(lsum, lane);
-        if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
-        if (tid == 0) { s_first = 256; s_idx = -1; }
-        __syncthreads();
-        i128 wbefore = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            if (w < wave) wbefore += km_make128(s_w_lo[w], s_w_hi[w]);
-        const i128 mine = scarry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
-        if (reach != 0 && mine + lsum >= R) atomicMin(&s_first, tid);
-        __syncthreads();
-        const int owner = s_first;
-        if (owner == 256) {
-            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
-        } else if (wave == (owner >> 6)) {
-            // the owner's wavefront walks the owner's indices together: one value per lane, inclusive scan, first hit
-            const int ol = owner & 63;
-            const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
-            i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
-            int64_t hit = o1 - 1;
-            for (int64_t ib = o0; ib < o1; ib += 64) {
-                const int64_t i = ib + lane;
-                const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
-                const i128 qinc = km_wave_scan128(qv, lane);
-                const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
-                if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
-                run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
-            }
-            if (lane == 0) s_idx = hit;
-        }
-        __syncthreads();
-        idx = s_idx;
-        if (idx > m - 1) idx = m - 1;
-    }
-    if (wave != 0) return;
-    const double cx = xs[rank[idx]];
-    // ---- C: neighbours among the seeds, range of sorted positions
-    int64_t pl, pr;
-    km_dual_search(sorted_old, n_old, cx, cx, true, true, pl, pr);  // pl seeds < cx, pr seeds <= cx
-    bool has_l = pl > 0, has_r = pr < n_old;
-    double sl = has_l ? sorted_old[pl - 1] : 0.0, sr = has_r ? sorted_old[pr] : 0.0;
-    if (choose_prev) {
-        const double newest = cur->newest;                      // the seed chosen in km_prep_kernel, not in sorted_old
-        if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
-        if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
-    }
-    const double amax = st->amax;
-    const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
-    const double tlo = has_l ? 0.5 * (sl + cx) - (err / (cx - sl) + slack) : 0.0;
-    const double thi = has_r ? 0.5 * (cx + sr) + (err / (sr - cx) + slack) : 0.0;
-    int64_t lo = 0, hi = m;
-    if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
-    if (lane == 0) {
-        cur->cand_x[trial] = cx;
-        cur->cand_id[trial] = idx;
-        cur->cand_lo[trial] = lo;
-        cur->cand_hi[trial] = hi;
-    }
+    if (!s_last) return;
+    km_pick_body(xs, ds, rank, m, block_shift, trial, blk, R, carry, choose_prev != 0, newest, n_old, sorted_old, full_range, st, cur);
 }
 
 // union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
@@ -678,31 +744,48 @@ struct KmIntervals {
     int64_t lo[KM_MAX_TRIALS], hi[KM_MAX_TRIALS], chunk0[KM_MAX_TRIALS + 1];
 };
 
-__device__ void km_merge_intervals(const int64_t *cand_lo, const int64_t *cand_hi, int n_trials, KmIntervals *out)
+// by ONE wavefront: lane j < n_trials brings range j.  Bitonic sort of the sixteen (lo, hi) by lo, running maximum of
+// hi, a range that starts beyond it opens a new interval -- a single lane doing this through LDS took 4 us per launch.
+__device__ __forceinline__ void km_merge_intervals_wave(int64_t lo, int64_t hi, int n_trials, int lane, KmIntervals *out)
 {
-    int64_t l[KM_MAX_TRIALS], h[KM_MAX_TRIALS];
-    int n = 0;
-    for (int j = 0; j < n_trials; ++j) {
-        const int64_t a = cand_lo[j], b = cand_hi[j];
-        if (b <= a) continue;
-        int q = n++;
-        while (q > 0 && l[q - 1] > a) { l[q] = l[q - 1]; h[q] = h[q - 1]; --q; }
-        l[q] = a; h[q] = b;
+    const int64_t none = 0x7FFFFFFFFFFFFFFFll;
+    if (lane >= n_trials || lane >= KM_MAX_TRIALS || hi <= lo) lo = hi = none;
+#pragma unroll
+    for (int k = 2; k <= KM_MAX_TRIALS; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int64_t olo = __shfl_xor(lo, j, 64), ohi = __shfl_xor(hi, j, 64);
+            const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+            if (take_min ? (olo < lo) : (olo > lo)) { lo = olo; hi = ohi; }
+        }
     }
-    int o = 0;
-    for (int j = 0; j < n; ++j) {
-        if (o > 0 && l[j] <= h[o - 1]) { if (h[j] > h[o - 1]) h[o - 1] = h[j]; }
-        else { l[o] = l[j]; h[o] = h[j]; ++o; }
+    const bool valid = lane < KM_MAX_TRIALS && lo != none;
+    int64_t pmax = valid ? hi : (int64_t)0x8000000000000000ll;
+#pragma unroll
+    for (int off = 1; off < KM_MAX_TRIALS; off <<= 1) {
+        const int64_t o = __shfl_up(pmax, off, 64);
+        if (lane >= off && o > pmax) pmax = o;
     }
+    const int64_t before = __shfl_up(pmax, 1, 64);
+    const bool start = valid && (lane == 0 || lo > before);
+    const uint64_t starts = __ballot(start), valids = __ballot(valid);
+    const int n = __popcll(starts);
+    const int gid = __popcll(starts & ((2ull << lane) - 1)) - 1;
+    const bool last = valid && (((starts >> (lane + 1)) & 1ull) || !((valids >> (lane + 1)) & 1ull));
+    if (start) out->lo[gid] = lo;
+    if (last) out->hi[gid] = pmax;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     int64_t chunks = 0;
-    for (int j = 0; j < o; ++j) {
-        out->lo[j] = l[j];
-        out->hi[j] = h[j];
-        out->chunk0[j] = chunks;
-        chunks += (h[j] - l[j] + KM_CHUNK - 1) / KM_CHUNK;
+    if (lane < n) chunks = (out->hi[lane] - out->lo[lane] + KM_CHUNK - 1) / KM_CHUNK;
+    int64_t inc = chunks;
+#pragma unroll
+    for (int off = 1; off < KM_MAX_TRIALS; off <<= 1) {
+        const int64_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
     }
-    out->chunk0[o] = chunks;
-    out->n = o;
+    if (lane < n) out->chunk0[lane] = inc - chunks;
+    if (lane == (n > 0 ? n - 1 : 0)) { out->chunk0[n] = n > 0 ? inc : 0; out->n = n; }
 }
 
 // gain: for every candidate the exact sum over its range of d - min(d, distance to the candidate).  One pass over the
@@ -712,25 +795,32 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
                                                       KmState *st, int seed_no, int n_trials)
 {
     __shared__ KmIntervals s_iv;
-    __shared__ i64 s_red[3][NT][4];
     __shared__ int64_t s_rng[2][KM_MAX_TRIALS];
+    __shared__ double s_cx[KM_MAX_TRIALS];
+    __shared__ u64 s_g[3][NT];
     KmSeedRec *rec = &st->rec[seed_no & 1];
-    if (threadIdx.x < 2 * KM_MAX_TRIALS) {
-        const int j = threadIdx.x & (KM_MAX_TRIALS - 1);
-        s_rng[threadIdx.x / KM_MAX_TRIALS][j] = j < n_trials ? (threadIdx.x < KM_MAX_TRIALS ? rec->cand_lo[j] : rec->cand_hi[j]) : 0;
+    const KmLimb L = st->limb;
+    if (threadIdx.x < 64) {                                     // everything this launch needs, in one round trip
+        const int j = threadIdx.x;
+        const bool on = j < n_trials && j < KM_MAX_TRIALS;
+        const int64_t lo_j = on ? rec->cand_lo[j] : 0, hi_j = on ? rec->cand_hi[j] : 0;
+        const double cx_j = on ? rec->cand_x[j] : 0.0;
+        if (j < KM_MAX_TRIALS) { s_rng[0][j] = lo_j; s_rng[1][j] = hi_j; s_cx[j] = cx_j; }
+        if (j < 3 * NT) (&s_g[0][0])[j] = 0;
+        KM_TG(10);
+        km_merge_intervals_wave(lo_j, hi_j, n_trials, j, &s_iv);
     }
+    KM_TG(11);
     __syncthreads();
-    if (threadIdx.x == 0) km_merge_intervals(s_rng[0], s_rng[1], n_trials, &s_iv);
-    __syncthreads();
+    KM_TG(12);
     const int n_iv = s_iv.n;
     const int64_t total_chunks = s_iv.chunk0[n_iv];
     if ((int64_t)blockIdx.x >= total_chunks) return;
-    const KmLimb L = st->limb;
     double c[NT], csq[NT], ga[NT], gb[NT], gc[NT];
     int64_t lo[NT], hi[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        c[j] = j < n_trials ? rec->cand_x[j] : 0.0;
+        c[j] = s_cx[j];
         csq[j] = __dmul_rn(c[j], c[j]);
         lo[j] = j < n_trials ? rec->cand_lo[j] : 0;
         hi[j] = j < n_trials ? rec->cand_hi[j] : 0;
@@ -772,22 +862,28 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
             }
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    KM_TG(13);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        if (j < n_trials) {
+        // (a chunk lies in the ranges of one or two candidates: the others' sums are zero in the whole wavefront)
+        if (j < n_trials && __ballot(ga[j] != 0.0 || gb[j] != 0.0 || gc[j] != 0.0) != 0) {
             const i64 ua = km_wave_sum_i64(__double2ll_rn(ga[j] * L.sA));
             const i64 ub = km_wave_sum_i64(__double2ll_rn(gb[j] * L.sB));
             const i64 uc = km_wave_sum_i64(__double2ll_rn(gc[j] * L.sC));
-            if (lane == 0) { s_red[0][j][wave] = ua; s_red[1][j][wave] = ub; s_red[2][j][wave] = uc; }
+            if (lane == 0) {
+                if (ua) atomicAdd(&s_g[0][j], (u64)ua);
+                if (ub) atomicAdd(&s_g[1][j], (u64)ub);
+                if (uc) atomicAdd(&s_g[2][j], (u64)uc);
+            }
         }
     }
     __syncthreads();
     if (threadIdx.x < 3 * NT) {
         const int limb = threadIdx.x / NT, j = threadIdx.x % NT;
-        if (j < n_trials)
-            km_atomic_add_i64(&rec->gain[limb][j], s_red[limb][j][0] + s_red[limb][j][1] + s_red[limb][j][2] + s_red[limb][j][3]);
+        if (j < n_trials) km_atomic_add_i64(&rec->gain[limb][j], (i64)s_g[limb][j]);
     }
+    KM_TG(14);
 }
 
 // update: d = min(d, distance to the chosen seed) over the winner's range.  What leaves the closest distances leaves
@@ -800,18 +896,28 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
                                                         int seed_no, int n_trials)
 {
     __shared__ u64 s_acc[3 * KM_MAX_BLOCKS];
-    __shared__ int s_best;
+    __shared__ int64_t s_lo, s_hi;
+    __shared__ double s_c;
     const KmSeedRec *rec = &st->rec[seed_no & 1];
-    if (threadIdx.x == 0) s_best = km_best(rec, n_trials);
+    const KmLimb L = st->limb;
+    if (threadIdx.x < 64) {
+        // (every candidate's range and value ride along with the gains: one round trip to memory, not two)
+        const int lane = threadIdx.x;
+        const bool on = lane < n_trials && lane < KM_MAX_TRIALS;
+        const int64_t lo_j = on ? rec->cand_lo[lane] : 0, hi_j = on ? rec->cand_hi[lane] : 0;
+        const double cx_j = on ? rec->cand_x[lane] : 0.0;
+        const int best = km_best_wave(rec, n_trials, lane);
+        const int64_t blo = __shfl(lo_j, best, 64), bhi = __shfl(hi_j, best, 64);
+        const double bc = __shfl(cx_j, best, 64);
+        if (lane == 0) { s_lo = blo; s_hi = bhi; s_c = bc; }
+    }
     __syncthreads();
-    const int best = s_best;
-    const int64_t lo = rec->cand_lo[best], hi = rec->cand_hi[best];
+    const int64_t lo = s_lo, hi = s_hi;
     const int64_t chunks = (hi - lo + KM_CHUNK - 1) / KM_CHUNK;
     if ((int64_t)blockIdx.x >= chunks) return;
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
     __syncthreads();
-    const KmLimb L = st->limb;
-    const double c = rec->cand_x[best], csq = __dmul_rn(c, c);
+    const double c = s_c, csq = __dmul_rn(c, c);
     for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
         const int64_t p0 = lo + ch * KM_CHUNK;
         const int64_t p1 = p0 + KM_CHUNK < hi ? p0 + KM_CHUNK : hi;
@@ -850,6 +956,149 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
         const u64 v = s_acc[i];
         if (v) atomicAdd(reinterpret_cast<u64 *>(bacc) + 4 * (i / 3) + i % 3, v);
+    }
+}
+
+// ---- few values (m <= 4096: the r x F factor of RolX, small graphs): the whole seeding in ONE workgroup -----------------
+// The same procedure in the same exact arithmetic -- cumulative sum in index order, candidates by searchsorted, gains,
+// first minimum with the 1e-12 tie rule, update -- with the values in registers (VPT consecutive indices per thread) and
+// six workgroup barriers per seed instead of three launches (which cost ~45 us per seed whatever m is: 63 seeds of a
+// 120-entry factor took 2.3 ms).  Every candidate's range is the whole input.
+template <int VPT, int NT>
+__global__ __launch_bounds__(1024) void km_seed_small_kernel(const double *__restrict__ v, int m, int64_t first,
+                                                             const double *__restrict__ uniform, int n_trials, int k,
+                                                             const KmState *__restrict__ st, double *__restrict__ seeds_x,
+                                                             int64_t *__restrict__ seeds_id)
+{
+    __shared__ double s_x[1024 * VPT];
+    __shared__ u64 s_w_lo[16], s_w_hi[16];
+    __shared__ u64 s_gain[3][KM_MAX_TRIALS];
+    __shared__ int s_cand[KM_MAX_TRIALS];
+    __shared__ double s_cx[KM_MAX_TRIALS];
+    __shared__ int s_best;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const KmLimb L = st->limb;
+    const double mean = st->mean, c0 = st->c0, c0sq = __dmul_rn(c0, c0);
+    double x[VPT], d[VPT];
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+        const int i = tid * VPT + q;
+        x[q] = i < m ? v[i] - mean : 0.0;
+        s_x[i] = x[q];
+        d[q] = i < m ? km_sqdist(c0, c0sq, x[q]) : 0.0;
+    }
+    if (tid == 0) { seeds_x[0] = c0; seeds_id[0] = first; }
+    const int nwaves = (int)(blockDim.x >> 6);                  // (launched with just enough wavefronts for m values)
+    double u = (lane < n_trials && k > 1) ? uniform[lane] : 0.0;   // lane j: the uniform of trial j
+    for (int c = 1; c < k; ++c) {
+        // cumulative sum of the closest distances in index order
+        i128 inc[VPT];
+        i128 lsum = 0;
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            lsum += (tid * VPT + q < m) ? km_quanta(L, d[q]) : (i128)0;
+            inc[q] = lsum;
+        }
+        const i128 winc = km_wave_scan128(lsum, lane);
+        if (lane == 63) { s_w_lo[wave] = (u64)winc; s_w_hi[wave] = (u64)(winc >> 64); }
+        if (tid < KM_MAX_TRIALS) s_cand[tid] = 0x7FFFFFFF;
+        if (tid < 3 * KM_MAX_TRIALS) (&s_gain[0][0])[tid] = 0;
+        __syncthreads();
+        i128 mine = winc - lsum, total = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const i128 wt = km_make128(s_w_lo[w], s_w_hi[w]);
+            if (w < wave) mine += wt;
+            total += wt;
+        }
+        const double potd = km_to_double(total);
+        // candidates: first index whose cumulative sum reaches uniform * potential (lane j works out trial j's target)
+        const i128 Rl = km_ceil128(u * potd);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < n_trials) {
+                const i128 R = km_make128(__shfl((u64)Rl, j, 64), __shfl((u64)(Rl >> 64), j, 64));
+                if (mine < R && mine + lsum >= R) {             // (at most one thread per trial)
+                    int hit = VPT - 1;
+#pragma unroll
+                    for (int q = VPT - 1; q >= 0; --q)
+                        if (mine + inc[q] >= R) hit = q;
+                    atomicMin(&s_cand[j], tid * VPT + hit);
+                } else if (R == 0 && tid == 0) {
+                    atomicMin(&s_cand[j], 0);
+                }
+            }
+        }
+        // (the next seed's uniforms while this one is worked on)
+        const double un = (lane < n_trials && c + 1 < k) ? uniform[(size_t)c * n_trials + lane] : 0.0;
+        __syncthreads();
+        if (tid < n_trials) {
+            const int idx = s_cand[tid] < m - 1 ? s_cand[tid] : m - 1;      // np.clip(candidate_ids, None, n - 1)
+            s_cand[tid] = idx;
+            s_cx[tid] = s_x[idx];
+        }
+        __syncthreads();
+        // gains
+        double cj[NT], ga[NT], gb[NT], gc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { cj[j] = j < n_trials ? s_cx[j] : 0.0; ga[j] = gb[j] = gc[j] = 0.0; }
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            if (tid * VPT + q < m && d[q] > 0.0) {
+                double a, b, cc;
+                km_split(L, d[q], a, b, cc);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (j < n_trials) {
+                        const double dj = km_sqdist(cj[j], __dmul_rn(cj[j], cj[j]), x[q]);
+                        if (dj < d[q]) {
+                            double aj, bj, cc2;
+                            km_split(L, dj, aj, bj, cc2);
+                            ga[j] += a - aj; gb[j] += b - bj; gc[j] += cc - cc2;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < n_trials && __ballot(ga[j] != 0.0 || gb[j] != 0.0 || gc[j] != 0.0) != 0) {
+                const i64 ua = km_wave_sum_i64(__double2ll_rn(ga[j] * L.sA));
+                const i64 ub = km_wave_sum_i64(__double2ll_rn(gb[j] * L.sB));
+                const i64 uc = km_wave_sum_i64(__double2ll_rn(gc[j] * L.sC));
+                if (lane == 0) {
+                    if (ua) atomicAdd(&s_gain[0][j], (u64)ua);
+                    if (ub) atomicAdd(&s_gain[1][j], (u64)ub);
+                    if (uc) atomicAdd(&s_gain[2][j], (u64)uc);
+                }
+            }
+        }
+        __syncthreads();
+        // first minimum of potential - gain, potentials within 1e-12 tied (km_best)
+        if (wave == 0) {
+            double pd = 1.79769313486231570e308;
+            if (lane < n_trials) pd = km_to_double(total - km_join((i64)s_gain[0][lane], (i64)s_gain[1][lane], (i64)s_gain[2][lane]));
+            double lowest = pd;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(lowest, off, 64);
+                lowest = o < lowest ? o : lowest;
+            }
+            const uint64_t tied = __ballot(lane < n_trials && !(pd > lowest + 1e-12 * lowest));
+            const int best = __ffsll((long long)tied) - 1;
+            if (lane == 0) {
+                s_best = best;
+                seeds_x[c] = s_cx[best];
+                seeds_id[c] = s_cand[best];
+            }
+        }
+        __syncthreads();
+        const double cb = s_cx[s_best], cbsq = __dmul_rn(cb, cb);
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const double dj = km_sqdist(cb, cbsq, x[q]);
+            d[q] = dj < d[q] ? dj : d[q];
+        }
+        u = un;
     }
 }
 
@@ -1098,6 +1347,7 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
         info[3] = k > 1 ? st->faults : 0;
 #ifdef KM_DBG_TIMING
         for (int q = 1; q < 9; ++q) printf("prep phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+        for (int q = 11; q < 15; ++q) printf("gain phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
 #endif
     }
 }
@@ -1256,27 +1506,41 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     if (rc != GRX_OK) return rc;
     const int64_t want = grx_ceil_div(m, 256 * 4);
     const int stream_grid = (int)(want > 2048 ? 2048 : want);
-    if (k > 1) {
-        // GRX_KMEANS_FULL_RANGE=1: every candidate's range is [0, m) -- sklearn's own O(m k) formulation in the same exact
-        // arithmetic; the ranges are supersets of what can change, so both give the same bits (tests/test_gpu_encode.py)
-        static const int full_range = [] { const char *e = std::getenv("GRX_KMEANS_FULL_RANGE"); return (e && *e == '1') ? 1 : 0; }();
+    // GRX_KMEANS_FULL_RANGE=1: every candidate's range is [0, m) -- sklearn's own O(m k) formulation in the same exact
+    // arithmetic; the ranges are supersets of what can change, so both give the same bits (tests/test_gpu_encode.py).
+    // GRX_KMEANS_SMALL=0: few values take the many-launch path as well (the same test: same bits again).
+    static const int full_range = [] { const char *e = std::getenv("GRX_KMEANS_FULL_RANGE"); return (e && *e == '1') ? 1 : 0; }();
+    static const int small_ok = [] { const char *e = std::getenv("GRX_KMEANS_SMALL"); return (e && *e == '0') ? 0 : 1; }();
+    if (k > 1 && m <= KM_SMALL_M && small_ok) {
+        const int vpt = m <= 1024 ? 1 : KM_SMALL_M / 1024;
+        const int threads = (int)grx_align_up((size_t)grx_ceil_div(m, vpt), 64);
+        if (vpt == 1 && n_trials <= 8)
+            km_seed_small_kernel<1, 8><<<1, threads, 0, st>>>(d_values, (int)m, first_seed, d_uniform, n_trials, k, state, seeds_x, seeds_id);
+        else if (vpt == 1)
+            km_seed_small_kernel<1, KM_MAX_TRIALS><<<1, threads, 0, st>>>(d_values, (int)m, first_seed, d_uniform, n_trials, k, state,
+                                                                          seeds_x, seeds_id);
+        else if (n_trials <= 8)
+            km_seed_small_kernel<KM_SMALL_M / 1024, 8><<<1, threads, 0, st>>>(d_values, (int)m, first_seed, d_uniform, n_trials, k, state,
+                                                                              seeds_x, seeds_id);
+        else
+            km_seed_small_kernel<KM_SMALL_M / 1024, KM_MAX_TRIALS><<<1, threads, 0, st>>>(d_values, (int)m, first_seed, d_uniform, n_trials,
+                                                                                          k, state, seeds_x, seeds_id);
+    } else if (k > 1) {
         km_sorted_init_kernel<<<stream_grid, 256, 0, st>>>(xs, perm, m, state, ds, rank);
         const int64_t max_chunks = grx_ceil_div(m, KM_CHUNK);
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
         for (int c = 1; c < k; ++c) {
-            km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(ds, rank, m, bacc, p.nblocks, p.block_shift,
+            km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
-                                                                   state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
-            km_pick_kernel<<<n_trials, 256, 0, st>>>(xs, ds, rank, m, p.block_shift, n_trials, c, c >= 2, full_range, state, sorted2,
-                                                     (int)p.sorted_ld);
+                                                                   full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
             if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             if (c < k - 1)                                         // the distances to the last seed are never needed
                 km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, state, c, n_trials);
         }
-        km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0, state,
-                                                   seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+        km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
+                                                   full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values

@@ -221,7 +221,8 @@ import numpy as np, torch
 from graphrole_amd import kernels as K
 out = {}
 for tag, m, k, seed in (('a', 50_000, 64, 0), ('b', 300_007, 256, 1), ('c', 4_099, 17, 2), ('d', 1_200_000, 512, 3),
-                        ('e', 200_000, 32, 4), ('f', 90_000, 1024, 5), ('g', 130, 100, 6)):
+                        ('e', 200_000, 32, 4), ('f', 90_000, 1024, 5), ('g', 130, 100, 6), ('h', 3_000, 64, 7),
+                        ('i', 900, 512, 8), ('j', 4_096, 700, 9)):
     rng = np.random.default_rng(seed)
     v = np.abs(rng.standard_normal(m)) * rng.choice([1e-3, 1.0, 40.0], size=m)
     if tag == 'e':
@@ -239,25 +240,28 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     of sorted values between the midpoints to the neighbouring seeds (widened by a rounding bound).  With
     GRX_KMEANS_FULL_RANGE=1 every range is [0, m) -- sklearn's own formulation, every value tested for every candidate --
     in the same exact integer arithmetic: the ranges are supersets of what can change, so seeds, centres and quantised
-    values are identical bits; and the internal consistency checks report nothing in either mode."""
+    values are identical bits; and the internal consistency checks report nothing in either mode.  Likewise the
+    one-workgroup seeding of few values (m <= 4096, km_seed_small_kernel) against the many-launch path (GRX_KMEANS_SMALL=0)."""
     import os
     import subprocess
     import sys
     import textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = []
-    for mode in ('0', '1'):
-        out = tmp_path / f'km{mode}.npz'
+    # default; every range [0, m); few values (m <= 4096) through the many-launch path instead of the one-workgroup kernel
+    for tag, extra in (('default', {}), ('full', {'GRX_KMEANS_FULL_RANGE': '1'}), ('nosmall', {'GRX_KMEANS_SMALL': '0'})):
+        out = tmp_path / f'km_{tag}.npz'
         code = 'ROOT = %r\nOUT = %r\n' % (root, str(out)) + textwrap.dedent(_AB_DRIVER)
-        env = dict(os.environ, GRX_KMEANS_FULL_RANGE=mode)
+        env = dict(os.environ, **extra)
         res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
         results.append(np.load(out))
-    a, b = results
-    for key in a.files:
-        assert np.array_equal(a[key], b[key]), key
-        if key.endswith('_i'):
-            assert int(a[key][3]) == 0, (key, a[key])
+    a = results[0]
+    for b in results[1:]:
+        for key in a.files:
+            assert np.array_equal(a[key], b[key]), key
+            if key.endswith('_i'):
+                assert int(a[key][3]) == 0 and int(b[key][3]) == 0, (key, a[key], b[key])
 
 
 def test_kmeans_runs_are_bitwise_repeatable():
