@@ -566,6 +566,13 @@ def main():
         if args.agg_lanes:
             dev_graph.plan().set_lanes(args.agg_lanes)
         plan = fe._shard()
+        # the NMF passes cost the same for every row: its row shards are EQUAL ROW COUNTS, as RoleExtractor._plan cuts
+        # them (roles/extract.py), not the nnz-balanced ranges of ReFeX (whose last rank holds 15 x the rows of the
+        # first on the power-law graph: profiles/r06_projected_scaling_*.json)
+        nmf_plan = None
+        if plan is not None:
+            from graphrole_amd import parallel
+            nmf_plan = parallel.maybe_plan(np.zeros(G.n + 1, dtype=np.int64), True)
         rng = np.random.RandomState(0)
 
         def barrier():
@@ -585,7 +592,7 @@ def main():
             t1 = time.perf_counter()
             Xd = K.gather_columns(cols, G.n)
             omega = rng.normal(size=(len(names), N_ROLES + 10))
-            nmf_state, n_iter = factor.nmf_device(Xd, G.n, N_ROLES, omega, plan=plan)
+            nmf_state, n_iter = factor.nmf_device(Xd, G.n, N_ROLES, omega, plan=nmf_plan)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             timers['refex'] += t1 - t0

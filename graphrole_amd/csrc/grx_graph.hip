@@ -2110,7 +2110,7 @@ int grx_egonet_features(int64_t n, int64_t nnz, const int64_t *d_row_ptr, const 
     GRX_REQUIRE(n < ((int64_t)1 << 31), "grx_egonet_features: more than 2^31 - 1 nodes");
     hipStream_t st = grx_stream(stream);
     const int64_t nrows = row_end - row_begin;
-    constexpr int64_t HUB = 512;             // members handled by a 512-thread workgroup from this out-degree on
+    constexpr int64_t HUB = 512;             // out-degree from which a row goes to the workgroup kernel (egonet_big_kernel, 256 threads, split into parts)
     // workspace: row slots | counters (256 bytes) | rows of the wide group kernel, the wavefront and the workgroup kernel
     const size_t rows_cap = (size_t)(n + 64);
     EgoSlot *slots = reinterpret_cast<EgoSlot *>(d_workspace);

@@ -1328,6 +1328,14 @@ constexpr int SEL_MAX_IDS = 512;                           // marked buckets wit
 constexpr int SEL_SORT_CAP = 8192;                         // keys of a segment the segment sort holds in LDS
 constexpr uint16_t SEL_MARK_SORTED = 0x8000;               // mark bit: the segment is in ascending order
 constexpr uint16_t SEL_MARK_TIES = 0xFFFF;                 // mark: a certified block of ties, nothing collected
+constexpr uint16_t SEL_THR_EXACT = 0x8000;                 // thr_bucket bit: keys of the bucket need the exact compare
+// columns from this height on keep their bucket ids (see sel_assign_kernel); GRX_BIN_BID_MIN_N overrides (tests: 0)
+inline int64_t sel_bid_min_n()
+{
+    static const int64_t v = [] { const char *e = std::getenv("GRX_BIN_BID_MIN_N"); return e ? (int64_t)std::atoll(e) : (int64_t)2500000; }();
+    return v;
+}
+__host__ __device__ inline int64_t sel_bid_stride(int64_t n) { return (n + 3) & ~(int64_t)3; }   // 8-byte aligned columns
 constexpr int SEL_HIST_ITEMS = 32;                         // keys per thread of the histogram pass
 constexpr int SEL_HIST_TILE = 256 * SEL_HIST_ITEMS;        // 8192 keys per workgroup
 // The bucket map of a column: a LINEAR map of the sampled key range onto 4096 cells, refined by a look-up table built
@@ -1496,11 +1504,12 @@ __global__ __launch_bounds__(1024) void sel_map_kernel(const double *__restrict_
     }
 }
 
+template <bool STORE_BID>
 __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
                                                        const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
                                                        const uint16_t *__restrict__ tie_of_bucket,
                                                        const uint64_t *__restrict__ tie_value, uint8_t *__restrict__ tie_broken,
-                                                       uint32_t *__restrict__ hist, ColFlags flags)
+                                                       uint32_t *__restrict__ hist, uint16_t *__restrict__ bid, ColFlags flags)
 {
     __shared__ uint32_t h[SEL_NB];
     __shared__ uint32_t lut[SEL_NB];
@@ -1533,6 +1542,8 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
             const bool valid = base + (int64_t)(i0 + j) * 256 + threadIdx.x < n;
             const uint64_t key = value_key(raw[j], i64);
             const int b = sel_bucket(m, lut, key);
+            if (STORE_BID && valid)                               // for the two passes below (2 bytes per key instead of 8)
+                bid[(size_t)col * sel_bid_stride(n) + base + (int64_t)(i0 + j) * 256 + threadIdx.x] = (uint16_t)b;
             const int tid = valid ? (int)tieb[b] : 0;
             if (tid && tiev[tid] != key) tie_broken[(size_t)col * SEL_NB + b] = 1;     // not a block of ties after all
             // heavy ties put a whole wavefront into one bucket: one atomic for all of it
@@ -1717,7 +1728,10 @@ __global__ __launch_bounds__(512) void sel_sort_kernel(const uint32_t *__restric
     }
 }
 
+// FROM_BID: the bucket of a key is read from the ids the histogram pass stored; the key itself only when its bucket is marked
+template <bool FROM_BID>
 __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                          const uint16_t *__restrict__ bid,
                                                           const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
                                                           const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
@@ -1735,17 +1749,20 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     const int col = blockIdx.y;
     const bool i64 = col_is_i64(flags, col);
     const SelMap m = maps[col];
-    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; lut[b] = luts[(size_t)col * SEL_NB + b]; }
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; lut[b] = FROM_BID ? 0u : luts[(size_t)col * SEL_NB + b]; }
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
     const int64_t last = n - 1;
     double raw[SORT_ITEMS];
+    uint16_t bv[SORT_ITEMS];
+    const uint16_t *bx = FROM_BID ? bid + (size_t)col * sel_bid_stride(n) : nullptr;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
-        raw[i] = x[idx < n ? idx : last];
+        if (FROM_BID) { bv[i] = bx[idx < n ? idx : last]; raw[i] = 0.0; }
+        else { raw[i] = x[idx < n ? idx : last]; bv[i] = 0; }
     }
     __builtin_amdgcn_sched_barrier(0);
     uint64_t *dst = coll + (size_t)col * n;
@@ -1756,10 +1773,12 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     bool any = false;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
-        const bool valid = base + (int64_t)i * 256 + threadIdx.x < n;
-        keys[i] = value_key(raw[i], i64);
-        const int b = sel_bucket(m, lut, keys[i]);
+        const int64_t idx = base + (int64_t)i * 256 + threadIdx.x;
+        const bool valid = idx < n;
+        keys[i] = FROM_BID ? 0ull : value_key(raw[i], i64);
+        const int b = FROM_BID ? (int)bv[i] : sel_bucket(m, lut, keys[i]);
         const int mk = valid ? (int)M[b] : 0;
+        if (FROM_BID && mk > 0) keys[i] = value_key(x[idx], i64);
         id[i] = mk - 1;
         rank[i] = -1;
         if (mk > 0 && mk < SEL_MAX_IDS) {
@@ -1863,8 +1882,8 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
                                                         const uint32_t *__restrict__ seg_off, const uint64_t *__restrict__ coll,
                                                         const unsigned long long *__restrict__ bmin,
                                                         const unsigned long long *__restrict__ bmax,
-                                                        uint64_t *__restrict__ thr, int32_t *__restrict__ nbins,
-                                                        int32_t *__restrict__ fault)
+                                                        uint64_t *__restrict__ thr, uint16_t *__restrict__ thr_bucket,
+                                                        int32_t *__restrict__ nbins, int32_t *__restrict__ fault)
 {
     __shared__ uint32_t C[SEL_NB];
     __shared__ uint32_t SO[SEL_NB];
@@ -1946,11 +1965,98 @@ __global__ __launch_bounds__(256) void sel_walk2_kernel(int64_t n, double frac,
         } else {
             sel_segment_select(seg, len, q, mn, mx, &tk, &le, s_hist, s_wsum, s_pick);
         }
-        if (threadIdx.x == 0) t[nb] = tk;
+        if (threadIdx.x == 0) {
+            t[nb] = tk;
+            // bucket of the threshold; bit 15: the bucket holds other keys too, so its keys are compared with the thresholds
+            if (thr_bucket) thr_bucket[(size_t)col * GRX_MAX_BINS + nb] = (uint16_t)(j | (mn != mx ? SEL_THR_EXACT : 0));
+        }
         ++nb;
         done = before + le;
     }
     if (threadIdx.x == 0) nbins[col] = (done < n) ? -nb : nb;
+}
+
+// Labels from the stored bucket ids (columns of sel_bid_min_n() = 2.5 M rows and more: round 3 measured the three streaming
+// passes of config 5 at 7.3 -> 6.3 ms with it, and the 1 M-row columns of BASELINE's headline graph 0.05 ms SLOWER --
+// hence the switch on the height).  The bucket map is monotone, so every key of a bucket WITHOUT a threshold lies
+// between the same two thresholds -- its bin is the number of thresholds in earlier buckets -- and so does every key
+// of a bucket that is one block of ties.  Only the keys of the buckets that hold a threshold among other keys (~20 of
+// 4096) are read and compared.  2 + 1 bytes per key instead of 8 + 1.
+__global__ __launch_bounds__(256) void sel_assign_kernel(const double *__restrict__ cols, int64_t ld, int64_t n,
+                                                         const uint16_t *__restrict__ bid,
+                                                         const uint64_t *__restrict__ thr,
+                                                         const uint16_t *__restrict__ thr_bucket,
+                                                         const int32_t *__restrict__ nbins,
+                                                         uint8_t *__restrict__ bins, int64_t ld_bins, ColFlags flags,
+                                                         const int32_t *__restrict__ fault, int32_t *__restrict__ status)
+{
+    __shared__ uint64_t t[GRX_MAX_BINS];
+    __shared__ uint16_t tb[GRX_MAX_BINS];
+    __shared__ uint8_t lut[SEL_NB];                              // bin of the bucket | 0x80: compare exactly
+    const int col = blockIdx.y;
+    const bool i64 = col_is_i64(flags, col);
+    int nb = nbins[col];
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) {         // (as bin_assign_kernel)
+        if (col == 0 && fault && *fault != 0) status[0] = 1;
+        if (nb < 0) status[1] = 1;
+    }
+    const bool saturated = nb < 0;                               // more than GRX_MAX_BINS bins: the walk stopped early
+    if (saturated) nb = GRX_MAX_BINS;
+    if (threadIdx.x < GRX_MAX_BINS) {
+        t[threadIdx.x] = (threadIdx.x < nb) ? thr[(size_t)col * GRX_MAX_BINS + threadIdx.x] : 0ull;
+        tb[threadIdx.x] = (threadIdx.x < nb) ? thr_bucket[(size_t)col * GRX_MAX_BINS + threadIdx.x] : (uint16_t)0x7FFF;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SEL_NB; b += 256) {
+        int lo = 0, hi = nb;                                     // thresholds in earlier buckets (ascending with the index)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((tb[mid] & 0x7FFF) < b) lo = mid + 1; else hi = mid;
+        }
+        bool exact = saturated;
+        for (int k = lo; k < nb && (tb[k] & 0x7FFF) == b; ++k) exact |= (tb[k] & SEL_THR_EXACT) != 0;
+        lut[b] = (uint8_t)(lo | (exact ? 0x80 : 0));
+    }
+    __syncthreads();
+    const double *x = cols + (size_t)col * ld;
+    const uint16_t *bx = bid + (size_t)col * sel_bid_stride(n);
+    uint8_t *o = bins + (size_t)col * ld_bins;
+    const bool word_stores = (reinterpret_cast<uintptr_t>(o) & 3) == 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
+        // four consecutive keys per thread: one 8-byte load of bucket ids, one 4-byte store of labels
+        uint16_t b4[4];
+        if (i0 + 3 < n) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(bx + i0);
+            b4[0] = (uint16_t)(raw.x & 0xFFFF); b4[1] = (uint16_t)(raw.x >> 16);
+            b4[2] = (uint16_t)(raw.y & 0xFFFF); b4[3] = (uint16_t)(raw.y >> 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = i0 + j < n ? bx[i0 + j] : (uint16_t)0;
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t lab = lut[b4[j]];
+            if ((lab & 0x80) && i0 + j < n) {
+                const uint64_t v = value_key(x[i0 + j], i64);
+                int lo = 0, hi = nb;                             // first threshold >= v
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (t[mid] < v) lo = mid + 1; else hi = mid;
+                }
+                lab = (uint32_t)lo;
+            }
+            packed |= (lab & 0xFF) << (8 * j);
+        }
+        if (i0 + 3 < n && word_stores) {
+            *reinterpret_cast<uint32_t *>(o + i0) = packed;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < n) o[i0 + j] = (uint8_t)(packed >> (8 * j));
+        }
+    }
 }
 
 struct SortPlan {
@@ -2092,7 +2198,7 @@ size_t grx_sort_workspace_bytes(int64_t n, int ncols)
 }
 
 namespace {
-struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, idlist, nids, coll, thr, nbins, fault, total; };
+struct SelLayout { size_t maps, luts, tieb, tiev, hist, cum, seg_off, cursor, bmax, tbroken, bmin, mark, idlist, nids, coll, bid, thr, thrb, nbins, fault, total; };
 SelLayout sel_layout(int64_t n, int ncols)
 {
     SelLayout L;
@@ -2113,7 +2219,9 @@ SelLayout sel_layout(int64_t n, int ncols)
     L.idlist = take((size_t)ncols * SEL_MAX_IDS * 2);
     L.nids = take((size_t)ncols * 4);
     L.coll = take((size_t)ncols * (size_t)n * 8);
+    L.bid = take(n >= sel_bid_min_n() ? (size_t)ncols * (size_t)sel_bid_stride(n) * 2 : 0);
     L.thr = take((size_t)ncols * GRX_MAX_BINS * 8);
+    L.thrb = take((size_t)ncols * GRX_MAX_BINS * 2);
     L.nbins = take((size_t)ncols * 4);
     L.fault = take(4);
     L.total = o;
@@ -2223,6 +2331,10 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         int32_t *nids = reinterpret_cast<int32_t *>(ws + L.nids);
         uint64_t *coll = reinterpret_cast<uint64_t *>(ws + L.coll);
         uint64_t *thr = reinterpret_cast<uint64_t *>(ws + L.thr);
+        uint16_t *bid = reinterpret_cast<uint16_t *>(ws + L.bid);
+        uint16_t *thrb = reinterpret_cast<uint16_t *>(ws + L.thrb);
+        // tall columns keep their bucket ids: passes 2 and 3 read 2 bytes per key instead of 8
+        const bool use_bid = n >= sel_bid_min_n();
         int32_t *nb_ws = reinterpret_cast<int32_t *>(ws + L.nbins);
         int32_t *fault = reinterpret_cast<int32_t *>(ws + L.fault);
         unsigned long long *bmin = reinterpret_cast<unsigned long long *>(ws + L.bmin);
@@ -2233,7 +2345,9 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         }
         {
             GRX_PROF(GRX_K_SEL_HIST, st);
-            sel_hist_kernel<<<dim3((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, flags);
+            const dim3 hgrid((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols);
+            if (use_bid) sel_hist_kernel<true><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, bid, flags);
+            else sel_hist_kernel<false><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, nullptr, flags);
         }
         {
             GRX_PROF(GRX_K_SEL_WALK1, st);
@@ -2241,7 +2355,8 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         }
         {
             GRX_PROF(GRX_K_SEL_COLLECT, st);
-            sel_collect_kernel<<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            if (use_bid) sel_collect_kernel<true><<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, bid, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            else sel_collect_kernel<false><<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, nullptr, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
         }
         {
             GRX_PROF(GRX_K_SEL_SEGSORT, st);
@@ -2249,14 +2364,15 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         }
         {
             GRX_PROF(GRX_K_SEL_WALK2, st);
-            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, nb_ws, fault);
+            sel_walk2_kernel<<<ncols, 256, 0, st>>>(n, frac, cum, mark, seg_off, coll, bmin, bmax, thr, use_bid ? thrb : nullptr, nb_ws, fault);
         }
         GRX_LAUNCH_CHECK();
         const int64_t want = grx_ceil_div(n, 256 * 4);
         const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
         {
             GRX_PROF(GRX_K_BIN_ASSIGN, st);
-            bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags, fault, status);
+            if (use_bid) sel_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, bid, thr, thrb, nb_ws, d_bins, ld_bins, flags, fault, status);
+            else bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags, fault, status);
         }
         GRX_LAUNCH_CHECK();
         if (d_nbins)

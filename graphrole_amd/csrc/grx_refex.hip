@@ -225,11 +225,13 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
     const int64_t rb = comm ? h_bounds[me] : 0, re = comm ? h_bounds[me + 1] : n;
     Arena arena(d_arena, d_arena ? arena_bytes : 0, grow, grow_user);
     // Every allocation below is sized from RANK-INDEPENDENT upper bounds (ceil(count / P) owned columns, the largest
-    // nnz slice of the partition): every rank asks for the same sizes at the same points, so with a grow function no
-    // rank ever fails alone, and without one -- with the equal capacity the caller agrees on -- every rank's arena
-    // overflows at the same allocation or not at all -- so the `if (!arena.overflow)` guards around the exchanges
-    // below take the same branch on every rank and a too-small arena is a joint GRX_ERR_WORKSPACE, never a rank
-    // that restarts while its peers wait inside a collective.
+    // nnz slice of the partition): every rank asks for the same sizes at the same points.  WITHOUT a grow function --
+    // and with arenas of one capacity on every rank -- every rank's arena overflows at the same allocation or not at
+    // all, so the `if (!arena.overflow)` guards around the exchanges below take the same branch on every rank and a
+    // too-small arena is a joint GRX_ERR_WORKSPACE.  WITH a grow function an overflow means that THIS rank's grow()
+    // failed (the device is out of memory): that is not agreed between the ranks -- the peers wait inside the next
+    // exchange until the transport's own timeout ends the job.  A joint error would cost one more latency-sized
+    // collective per generation on every run; an out-of-memory rank ends the job either way (include/grx.h says so).
     int64_t nnz_rows = 0;                                    // adjacency entries of the longest row slice (median workspace)
     if (has[GRX_AGG_MEDIAN]) {
         std::vector<int64_t> ends(P + 1, 0);

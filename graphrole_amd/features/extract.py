@@ -57,10 +57,8 @@ def _kernel_functions() -> dict:
             fn = getattr(owner, name, None)
             if callable(fn) and getattr(fn, '__name__', None) == name:
                 table[id(fn)] = name
-    for alias, name in (('amin', 'min'), ('amax', 'max')):
-        fn = getattr(np, alias, None)
-        if callable(fn):
-            table.setdefault(id(fn), name)
+    # (np.amin / np.amax carry their own __name__ -- the label pandas puts in the result -- and therefore run on the host
+    # like any other callable: the kernels are selected by the names above)
     return table
 
 

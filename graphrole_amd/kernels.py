@@ -755,8 +755,10 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
             refex_run.trace.append(('grow %d bytes' % nbytes, _time.perf_counter() - _t0))
             return chunk.data_ptr()
         except Exception:                       # out of device memory: the library reports GRX_ERR_WORKSPACE
+            grow_failed.append(int(nbytes))
             return None
 
+    grow_failed: list = []                     # a failed grow is an exhausted ARENA, whatever the byte counts below say
     grow_cb = _lib.GROW_FN(_grow)
     max_columns = 256
     refex_run.attempts = 0                     # diagnostics: how often the library was entered (column table grown)
@@ -774,7 +776,10 @@ def refex_run(csr: DeviceCSR, gen0_cols: Sequence[torch.Tensor], gen0_names: Seq
                                _stream())
         refex_run.trace.append(('grx_refex_run rc=%d chunks=%d needed=%d' % (rc, len(chunks), needed.value),
                                 _time.perf_counter() - _t0))
-        if rc == -3 and needed.value <= sum(c.numel() for c in chunks):
+        # GRX_ERR_WORKSPACE is returned for a full column table AND for an exhausted arena.  The table is the cause only
+        # when no grow failed (a reused spare chunk can be larger than what the library asked for, so the byte counts alone
+        # do not tell) -- and the table is not grown without bound: 256 -> 65 536 columns is far beyond any feature set
+        if rc == -3 and not grow_failed and needed.value <= sum(c.numel() for c in chunks) and max_columns < 65536:
             max_columns *= 4                            # GRX_ERR_WORKSPACE from the column table, not from the arena
             spare[:0] = chunks[1:]
             chunks = chunks[:1]

@@ -325,17 +325,6 @@ class ShardPlan:
         from graphrole_amd import kernels as K
         return (K.to_host(t) if t.is_cuda else t.numpy()).reshape(a.shape)
 
-    def agree_min(self, value: int) -> int:
-        """Smallest `value` over the ranks.  Used for the arena capacity of the sharded generation loop.  ALWAYS a
-        collective (one 8-byte all-reduce per run): a rank must not decide on its own to skip it -- arenas kept from
-        earlier runs may differ in size between ranks, and a rank that skipped while its peers reduce would enter the
-        exchanges of grx_refex_run one collective ahead of them."""
-        if self._solo:
-            return int(value)
-        t = torch.tensor([-float(value)], dtype=torch.float64, device=self._small_device())
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return int(-float(t.cpu()[0]))
-
     def all_gather_host(self, a: np.ndarray) -> np.ndarray:
         """[world, *a.shape]: the small host array of every rank."""
         a = np.ascontiguousarray(a, dtype=np.float64)

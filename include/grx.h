@@ -457,7 +457,10 @@ typedef struct {
  * that stay valid as long as the caller uses the returned columns, or NULL.  With it the run never fails for want of
  * room (round 5: a first size is a guess, and a wrong guess used to cost a whole second run); columns may then lie
  * in any chunk -- d_col is an absolute pointer either way.  Without it a too-small arena is GRX_ERR_WORKSPACE and
- * *arena_needed a lower bound of what the run takes. */
+ * *arena_needed a lower bound of what the run takes.  GRX_ERR_WORKSPACE is also what a full column table returns
+ * (max_columns): a caller that grows tells the two apart by whether its grow ever returned NULL.
+ * Sharded (comm != NULL): a grow that returns NULL on ONE rank (that device is out of memory) is not agreed with the
+ * peers -- they wait in the next exchange until the transport's timeout ends the job. */
 typedef void *(*grx_grow_fn)(size_t bytes, void *user);
 /* Columns the loop hands to one call of the binning (workspace = grx_log_bin_workspace_bytes(n, this), at most about 4 GiB for
  * wide blocks of long columns; all of them for small graphs): what a caller's first arena size should assume. */
@@ -728,7 +731,8 @@ int grx_transpose(int64_t rows, int64_t cols, const double *d_in, int64_t ld_in,
 /* ------------------------------------------------------------------ RolX roles ---------- */
 /*
  * The two row passes over the fitted node-role factor.  d_G: fp64 n x r row-major (the layout of the reference's
- * node_role_factor.values), 1 <= r <= GRX_MAX_ROLES.
+ * node_role_factor.values), any r >= 1 (the limit of the NMF kernels, GRX_MAX_ROLES, does not apply: a caller may
+ * assign a wider frame).
  *   grx_role_argmax    replaces RoleExtractor.roles (graphrole/roles/extract.py:38-47, DataFrame.idxmax(axis=1)):
  *                      d_first_max int32[n] = column of the FIRST maximum of every row (quantised factors are full
  *                      of exact ties), NaN entries skipped, -1 for a row of NaNs only.

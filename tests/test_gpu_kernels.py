@@ -3,6 +3,8 @@
 the golden vectors produced by the reference.  Integer / index results are compared bit-exactly;
 fp64 sums within RTOL (re-association of fp64 additions only -- stated in DESIGN.md).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -938,3 +940,20 @@ def test_pack_rows_every_width(K, f, n):
     assert got.shape == (n, ldr) and ldr >= f
     assert np.array_equal(got[:, :f], X.T)
     assert np.all(got[:, f:] == 0.0)
+
+
+def test_log_bin_stored_bucket_id_path_equals_the_default():
+    """Columns of 2.5 M rows and more keep the bucket ids of the histogram pass so that the collect and label passes read
+    2 bytes per key instead of 8 (csrc/grx_prune.hip sel_assign_kernel).  GRX_BIN_BID_MIN_N=0 sends EVERY column that
+    way: the whole binning / Chebyshev part of this file -- the reference's known answers, the goldens' per-generation
+    bins, the adversarial and random cases against the oracle -- must pass unchanged (bins are integers: equal, not close)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRX_BIN_BID_MIN_N='0')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-m', 'gpu', '-x',
+                          '-k', '(log_bin or chebyshev) and not stored_bucket_id', '-p', 'no:cacheprovider'],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout
+

@@ -19,11 +19,12 @@ from tests import graphs, util
 pytestmark = pytest.mark.gpu
 
 RTOL = util.WEIGHTED_RTOL        # one tolerance for weighted graphs, defined once (tests/util.py)
+RTOL_FIXTURES = util.WEIGHTED_RTOL_FIXTURES     # the reference-generated fixtures hold the tighter bound
 
 
 def _check_values(actual, expected, weighted):
     if weighted:
-        np.testing.assert_allclose(actual, expected, rtol=RTOL, atol=0)
+        np.testing.assert_allclose(actual, expected, rtol=RTOL_FIXTURES, atol=0)
     else:
         assert np.array_equal(actual, expected), f'{int((actual != expected).sum())} entries differ'
 
@@ -103,7 +104,7 @@ def test_generation_trace_matches_reference(name):
     feats = fe.graph.get_neighborhood_features()
     assert list(feats.columns) == g.js('gen0_names')
     assert list(feats.index) == labels
-    np.testing.assert_allclose(feats.values.astype(float), g['gen0_values'], rtol=RTOL)
+    np.testing.assert_allclose(feats.values.astype(float), g['gen0_values'], rtol=RTOL_FIXTURES)
     fe._update(feats)
     assert list(fe._features.columns) == g.js('g0_working_after')
     for gen in range(1, int(g['n_generations_recorded'])):

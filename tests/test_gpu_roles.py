@@ -38,8 +38,7 @@ def test_kernels_on_wide_reference_factors():
         assert np.array_equal(share, z[f'{key}_role_percentage'], equal_nan=True), key
 
 
-@pytest.mark.parametrize('n,r', [(1, 1), (129, 1), (70001, 2), (127, 3), (70001, 5), (128, 7), (70001, 8), (129, 9),
-                                 (70001, 16), (1, 17), (70001, 24), (129, 31), (70001, 32),
+@pytest.mark.parametrize('n,r', [(n, r) for r in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 24, 31, 32) for n in (1, 127, 128, 129, 70001)] + [
                                  # wider than any fitted factor (a frame the caller assigned): fewer rows per LDS tile,
                                  # numpy's pairwise recursion beyond 128 values, rows that do not fit LDS at all
                                  (5000, 33), (3001, 59), (3001, 60), (2000, 128), (2000, 129), (700, 300), (300, 1000),

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #: THE tolerance of weighted graphs (README): the reference adds edge weights in the iteration order
 #: of Python sets, the device in CSR order -- the tables agree to this relative error, everything else is bit-exact
 WEIGHTED_RTOL = 1e-11
+#: ... and the tighter bound that holds on the reference-generated fixtures (<= 2 000 nodes, rows of <= a few hundred
+#: terms): the loosening to 1e-11 is for hubs that add ~10^5 weights (5 M / 100 M graph), not for these
+WEIGHTED_RTOL_FIXTURES = 1e-12
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 REFEX_CASES = ['karate', 'karate_weighted', 'er300', 'ba300', 'dw200_attrs', 'loops_dangling150',
