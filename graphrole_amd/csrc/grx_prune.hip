@@ -1509,7 +1509,8 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
                                                        const SelMap *__restrict__ maps, const uint32_t *__restrict__ luts,
                                                        const uint16_t *__restrict__ tie_of_bucket,
                                                        const uint64_t *__restrict__ tie_value, uint8_t *__restrict__ tie_broken,
-                                                       uint32_t *__restrict__ hist, uint16_t *__restrict__ bid, ColFlags flags)
+                                                       uint32_t *__restrict__ hist, uint16_t *__restrict__ bid, ColFlags flags,
+                                                       int tiles_per_wg)
 {
     __shared__ uint32_t h[SEL_NB];
     __shared__ uint32_t lut[SEL_NB];
@@ -1526,9 +1527,13 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
     for (int k = threadIdx.x; k <= SEL_MAX_TIES; k += 256) tiev[k] = tie_value[(size_t)col * (SEL_MAX_TIES + 1) + k];
     __syncthreads();
     const double *x = cols + (size_t)col * ld;
-    const int64_t base = (int64_t)blockIdx.x * SEL_HIST_TILE;
     const int64_t last = n - 1;
     const int lane = threadIdx.x & 63;
+    // (tall columns: several tiles per workgroup -- the tables above and the 4096 counters flushed below are a fixed
+    // cost per workgroup, about as much LDS and atomic traffic as one tile of keys)
+    for (int tile = 0; tile < tiles_per_wg; ++tile) {
+    const int64_t base = ((int64_t)blockIdx.x * tiles_per_wg + tile) * SEL_HIST_TILE;
+    if (base >= n) break;
     for (int i0 = 0; i0 < SEL_HIST_ITEMS; i0 += 8) {
         double raw[8];
 #pragma unroll
@@ -1556,6 +1561,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double *__restrict_
                 atomicAdd(&h[b], 1u);
             }
         }
+    }
     }
     __syncthreads();
     uint32_t *out = hist + (size_t)col * SEL_NB;
@@ -1736,7 +1742,8 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
                                                           const uint16_t *__restrict__ mark,
                                                           const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ cursor,
                                                           uint64_t *__restrict__ coll, unsigned long long *__restrict__ bmin,
-                                                          unsigned long long *__restrict__ bmax, ColFlags flags)
+                                                          unsigned long long *__restrict__ bmax, ColFlags flags,
+                                                          int tiles_per_wg)
 {
     // per marked bucket (compact id): how many keys of this tile, their smallest and largest, the bucket itself
     __shared__ uint32_t cnt[SEL_MAX_IDS];
@@ -1750,11 +1757,15 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
     const bool i64 = col_is_i64(flags, col);
     const SelMap m = maps[col];
     for (int b = threadIdx.x; b < SEL_NB; b += 256) { M[b] = mark[(size_t)col * SEL_NB + b]; lut[b] = FROM_BID ? 0u : luts[(size_t)col * SEL_NB + b]; }
+    const double *x = cols + (size_t)col * ld;
+    const int64_t last = n - 1;
+    // (tall columns: several tiles per workgroup, the 4096 marks are loaded once)
+    for (int tile = 0; tile < tiles_per_wg; ++tile) {
+    const int64_t base = ((int64_t)blockIdx.x * tiles_per_wg + tile) * SORT_TILE;
+    if (base >= n) break;
+    __syncthreads();                                            // (the previous tile's slots are no longer read)
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) { cnt[k] = 0; lo_id[k] = ~0ull; hi_id[k] = 0ull; }
     __syncthreads();
-    const double *x = cols + (size_t)col * ld;
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-    const int64_t last = n - 1;
     double raw[SORT_ITEMS];
     uint16_t bv[SORT_ITEMS];
     const uint16_t *bx = FROM_BID ? bid + (size_t)col * sel_bid_stride(n) : nullptr;
@@ -1796,7 +1807,7 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
             atomicMax(&bmax[cell], (unsigned long long)keys[i]);
         }
     }
-    if (__syncthreads_or(any) == 0) return;                     // nothing of this tile has an LDS slot
+    if (__syncthreads_or(any) == 0) continue;                   // nothing of this tile has an LDS slot
     for (int k = threadIdx.x; k < SEL_MAX_IDS; k += 256) {
         if (cnt[k]) {
             const int b = bucket_of_id[k];
@@ -1810,6 +1821,7 @@ __global__ __launch_bounds__(256) void sel_collect_kernel(const double *__restri
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i)
         if (rank[i] >= 0) dst[basev[id[i]] + (uint32_t)rank[i]] = keys[i];
+    }
 }
 
 // the q-th smallest (0-based) key of an unordered segment whose smallest / largest keys are mn / mx, and the number of
@@ -2345,9 +2357,10 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         }
         {
             GRX_PROF(GRX_K_SEL_HIST, st);
-            const dim3 hgrid((unsigned)grx_ceil_div(n, SEL_HIST_TILE), ncols);
-            if (use_bid) sel_hist_kernel<true><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, bid, flags);
-            else sel_hist_kernel<false><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, nullptr, flags);
+            const int hist_tiles = use_bid ? 4 : 1;
+            const dim3 hgrid((unsigned)grx_ceil_div(n, (int64_t)SEL_HIST_TILE * hist_tiles), ncols);
+            if (use_bid) sel_hist_kernel<true><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, bid, flags, hist_tiles);
+            else sel_hist_kernel<false><<<hgrid, 256, 0, st>>>(d_cols, ld, n, maps, luts, tieb, tiev, tbroken, hist, nullptr, flags, hist_tiles);
         }
         {
             GRX_PROF(GRX_K_SEL_WALK1, st);
@@ -2355,8 +2368,10 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         }
         {
             GRX_PROF(GRX_K_SEL_COLLECT, st);
-            if (use_bid) sel_collect_kernel<true><<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, bid, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
-            else sel_collect_kernel<false><<<dim3(p.ntiles, ncols), 256, 0, st>>>(d_cols, ld, n, nullptr, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags);
+            const int coll_tiles = use_bid ? 8 : 1;
+            const dim3 cgrid((unsigned)grx_ceil_div(p.ntiles, coll_tiles), ncols);
+            if (use_bid) sel_collect_kernel<true><<<cgrid, 256, 0, st>>>(d_cols, ld, n, bid, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags, coll_tiles);
+            else sel_collect_kernel<false><<<cgrid, 256, 0, st>>>(d_cols, ld, n, nullptr, maps, luts, mark, seg_off, cursor, coll, bmin, bmax, flags, coll_tiles);
         }
         {
             GRX_PROF(GRX_K_SEL_SEGSORT, st);
@@ -2371,7 +2386,11 @@ int grx_internal_vertical_log_bin(int64_t n, int ncols, const double *d_cols, in
         const dim3 grid((unsigned)(want > 2048 ? 2048 : want), ncols);
         {
             GRX_PROF(GRX_K_BIN_ASSIGN, st);
-            if (use_bid) sel_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, bid, thr, thrb, nb_ws, d_bins, ld_bins, flags, fault, status);
+            // (sel_assign builds a 4096-entry bucket -> label table per workgroup: sixteen strides of keys per workgroup,
+            // not two and a half, or the table costs more than the pass -- measured 2.6 ms against 1.8 at config 5)
+            const int64_t want_a = grx_ceil_div(n, 256 * 4 * 16);
+            const dim3 agrid((unsigned)(want_a > 2048 ? 2048 : want_a), ncols);
+            if (use_bid) sel_assign_kernel<<<agrid, 256, 0, st>>>(d_cols, ld, n, bid, thr, thrb, nb_ws, d_bins, ld_bins, flags, fault, status);
             else bin_assign_kernel<<<grid, 256, 0, st>>>(d_cols, ld, n, thr, nb_ws, d_bins, ld_bins, flags, fault, status);
         }
         GRX_LAUNCH_CHECK();
