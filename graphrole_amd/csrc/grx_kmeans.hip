@@ -746,45 +746,59 @@ struct KmIntervals {
 
 // by ONE wavefront: lane j < n_trials brings range j.  Bitonic sort of the sixteen (lo, hi) by lo, running maximum of
 // hi, a range that starts beyond it opens a new interval -- a single lane doing this through LDS took 4 us per launch.
-__device__ __forceinline__ void km_merge_intervals_wave(int64_t lo, int64_t hi, int n_trials, int lane, KmIntervals *out)
+template <int NT>
+__device__ __forceinline__ void km_merge_intervals_wave(int64_t lo64, int64_t hi64, int n_trials, int lane, KmIntervals *out)
 {
-    const int64_t none = 0x7FFFFFFFFFFFFFFFll;
-    if (lane >= n_trials || lane >= KM_MAX_TRIALS || hi <= lo) lo = hi = none;
+    // positions are < 2^31 (grx_kmeans1d requires m < 2^31): 32-bit shuffles, and a sorting network of NT lanes only
+    const int none = 0x7FFFFFFF;
+    int lo = (int)lo64, hi = (int)hi64;
+    if (lane >= n_trials || lane >= NT || hi <= lo) lo = hi = none;
 #pragma unroll
-    for (int k = 2; k <= KM_MAX_TRIALS; k <<= 1) {
+    for (int k = 2; k <= NT; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const int64_t olo = __shfl_xor(lo, j, 64), ohi = __shfl_xor(hi, j, 64);
+            const int olo = __shfl_xor(lo, j, 64), ohi = __shfl_xor(hi, j, 64);
             const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
             if (take_min ? (olo < lo) : (olo > lo)) { lo = olo; hi = ohi; }
         }
     }
-    const bool valid = lane < KM_MAX_TRIALS && lo != none;
-    int64_t pmax = valid ? hi : (int64_t)0x8000000000000000ll;
+    const bool valid = lane < NT && lo != none;
+    int pmax = valid ? hi : (int)0x80000000;
 #pragma unroll
-    for (int off = 1; off < KM_MAX_TRIALS; off <<= 1) {
-        const int64_t o = __shfl_up(pmax, off, 64);
+    for (int off = 1; off < NT; off <<= 1) {
+        const int o = __shfl_up(pmax, off, 64);
         if (lane >= off && o > pmax) pmax = o;
     }
-    const int64_t before = __shfl_up(pmax, 1, 64);
+    const int before = __shfl_up(pmax, 1, 64);
     const bool start = valid && (lane == 0 || lo > before);
     const uint64_t starts = __ballot(start), valids = __ballot(valid);
     const int n = __popcll(starts);
     const int gid = __popcll(starts & ((2ull << lane) - 1)) - 1;
     const bool last = valid && (((starts >> (lane + 1)) & 1ull) || !((valids >> (lane + 1)) & 1ull));
-    if (start) out->lo[gid] = lo;
-    if (last) out->hi[gid] = pmax;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int64_t chunks = 0;
-    if (lane < n) chunks = (out->hi[lane] - out->lo[lane] + KM_CHUNK - 1) / KM_CHUNK;
-    int64_t inc = chunks;
+    // interval g: its first range's lo, the running maximum at its last range; both to lane g by ballots and shuffles
+    int glo = 0, ghi = 0;
+    {
+        // the lane that starts group `lane` / ends it: the (lane + 1)-th set bit of starts / of lasts
+        const uint64_t lasts = __ballot(last);
+        uint64_t sbits = starts, lbits = lasts;
+        int s_lane = 0, l_lane = 0;
+        for (int q = 0; q <= lane && q < n; ++q) {
+            s_lane = __ffsll((long long)sbits) - 1; sbits &= sbits - 1;
+            l_lane = __ffsll((long long)lbits) - 1; lbits &= lbits - 1;
+        }
+        glo = __shfl(lo, s_lane, 64);
+        ghi = __shfl(pmax, l_lane, 64);
+    }
+    (void)gid;
+    int chunks = 0;
+    if (lane < n) chunks = (ghi - glo + KM_CHUNK - 1) / KM_CHUNK;
+    int inc = chunks;
 #pragma unroll
-    for (int off = 1; off < KM_MAX_TRIALS; off <<= 1) {
-        const int64_t o = __shfl_up(inc, off, 64);
+    for (int off = 1; off < NT; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
         if (lane >= off) inc += o;
     }
-    if (lane < n) out->chunk0[lane] = inc - chunks;
+    if (lane < n) { out->lo[lane] = glo; out->hi[lane] = ghi; out->chunk0[lane] = inc - chunks; }
     if (lane == (n > 0 ? n - 1 : 0)) { out->chunk0[n] = n > 0 ? inc : 0; out->n = n; }
 }
 
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
         if (j < KM_MAX_TRIALS) { s_rng[0][j] = lo_j; s_rng[1][j] = hi_j; s_cx[j] = cx_j; }
         if (j < 3 * NT) (&s_g[0][0])[j] = 0;
         KM_TG(10);
-        km_merge_intervals_wave(lo_j, hi_j, n_trials, j, &s_iv);
+        km_merge_intervals_wave<NT>(lo_j, hi_j, n_trials, j, &s_iv);
     }
     KM_TG(11);
     __syncthreads();
@@ -915,8 +929,14 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     const int64_t lo = s_lo, hi = s_hi;
     const int64_t chunks = (hi - lo + KM_CHUNK - 1) / KM_CHUNK;
     if ((int64_t)blockIdx.x >= chunks) return;
-    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
-    __syncthreads();
+    // (straight atomics to the block sums for workgroups with a single chunk -- no clearing and scanning of 3 * nblocks
+    // LDS words -- were measured SLOWER: 30 M values / 512 levels 32.5 -> 37.0 ms; a chunk's 2048 values share blocks
+    // often enough for the LDS stage to save global atomics, which run at 23 G/s whatever their addresses)
+    const bool direct = false;
+    if (!direct) {
+        for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
+        __syncthreads();
+    }
     const double c = s_c, csq = __dmul_rn(c, c);
     for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
         const int64_t p0 = lo + ch * KM_CHUNK;
@@ -946,12 +966,19 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
                 const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
                           uc = -__double2ll_rn((cc - cj) * L.sC);
                 const int blk = (int)(iv[u] >> block_shift);
-                if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
-                if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
-                if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
+                if (direct) {
+                    km_atomic_add_i64(bacc + 4 * (int64_t)blk, ua);
+                    km_atomic_add_i64(bacc + 4 * (int64_t)blk + 1, ub);
+                    km_atomic_add_i64(bacc + 4 * (int64_t)blk + 2, uc);
+                } else {
+                    if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
+                    if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
+                    if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
+                }
             }
         }
     }
+    if (direct) return;
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
         const u64 v = s_acc[i];

@@ -572,6 +572,14 @@ __global__ __launch_bounds__(256, (HAS_T && KT <= 5) ? 2 : 1) void gram_full_mfm
 #pragma unroll
                 for (int g = 0; g < 4; ++g) yp[(16 * jt + lq + 4 * g) * GF_LD + li] = y[jt][g];
             __syncthreads();
+            // the four partial tiles summed ONCE (fixed order) into the first: read four times per operand below, the
+            // planes made this kernel LDS-bound -- 128 ds_reads per lane and sub-tile against 55 MFMAs per wave
+            // (profiles/r06_gram.txt)
+            for (int e = t; e < 16 * KT * 16; e += 256) {
+                const int a = (e >> 4) * GF_LD + (e & 15);
+                ypart[a] = (ypart[a] + ypart[YPLANE + a]) + (ypart[2 * YPLANE + a] + ypart[3 * YPLANE + a]);
+            }
+            __syncthreads();
         }
         // this wave's pairs: pair number pp (order (0,0),(0,1),...,(0,KT-1),(1,1),...) belongs to wave pp & 3
 #pragma unroll
@@ -581,8 +589,7 @@ __global__ __launch_bounds__(256, (HAS_T && KT <= 5) ? 2 : 1) void gram_full_mfm
 #pragma unroll
             for (int m = 0; m < KT; ++m) {
                 const int a = (16 * m + li) * GF_LD + i;
-                if (HAS_T) op[m] = (ypart[a] + ypart[YPLANE + a]) + (ypart[2 * YPLANE + a] + ypart[3 * YPLANE + a]);
-                else op[m] = xT[a];
+                op[m] = HAS_T ? ypart[a] : xT[a];
             }
             switch (wave) {
             case 0: gram_full_step<KT, 0>(op, acc); break;
