@@ -41,6 +41,20 @@ import torch.distributed as dist
 _NP_DTYPES = {0: np.float64, 1: np.int32, 2: np.int64, 3: np.uint8}            # grx_dtype
 
 
+def row_cuts(row_ptr: np.ndarray, world: int) -> np.ndarray:
+    """int64[world + 1]: contiguous row ranges with equal shares of nnz + n (the work of a neighbour aggregation: one
+    gather per adjacency entry, one output row per node).  The partition of every ShardPlan; tools/project_scaling.py
+    times every rank's share of it on one GPU."""
+    n = len(row_ptr) - 1
+    work = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n + 1, dtype=np.int64)
+    total = int(work[-1]) if n else 0
+    cuts = [0]
+    for p in range(1, world):
+        cuts.append(int(np.searchsorted(work, total * p / world, side='left')))
+    cuts.append(n)
+    return np.maximum.accumulate(np.array(cuts, dtype=np.int64))
+
+
 class ShardPlan:
 
     def __init__(self, row_ptr: np.ndarray, group=None) -> None:
@@ -51,13 +65,7 @@ class ShardPlan:
         self.world = dist.get_world_size(group)
         n = len(row_ptr) - 1
         self.n = n
-        work = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n + 1, dtype=np.int64)
-        total = int(work[-1]) if n else 0
-        cuts = [0]
-        for p in range(1, self.world):
-            cuts.append(int(np.searchsorted(work, total * p / self.world, side='left')))
-        cuts.append(n)
-        self.bounds = np.maximum.accumulate(np.array(cuts, dtype=np.int64))
+        self.bounds = row_cuts(row_ptr, self.world)
         self.row_begin = int(self.bounds[self.rank])
         self.row_end = int(self.bounds[self.rank + 1])
         self.max_rows = int(np.diff(self.bounds).max()) if n else 0

@@ -62,12 +62,9 @@ def build(workload):
 
 
 def cuts_work(row_ptr, world):
-    """ShardPlan.__init__ (graphrole_amd/parallel.py:54-60): balanced by nnz + n."""
-    n = len(row_ptr) - 1
-    work = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n + 1, dtype=np.int64)
-    total = int(work[-1]) if n else 0
-    cuts = [0] + [int(np.searchsorted(work, total * p / world, side='left')) for p in range(1, world)] + [n]
-    return np.maximum.accumulate(np.array(cuts, dtype=np.int64))
+    """the partition of every ShardPlan (graphrole_amd/parallel.py row_cuts): balanced by nnz + n"""
+    from graphrole_amd.parallel import row_cuts
+    return row_cuts(np.asarray(row_ptr), world)
 
 
 def timed(fn, reps=5, inner=5):
