@@ -92,6 +92,7 @@ struct KmSeedRec {
     i64 gain[3][KM_MAX_TRIALS];  // limb sums of (d - min(d, dist to candidate)) over the candidate's range
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
     i64 sub[KM_MAX_TRIALS][KM_SUB][3];   // km_prep_kernel: limb sums of the sub-blocks of the block each trial's r falls in
+    double gain_d[KM_MAX_TRIALS];        // gains from the sorted-block sums (km_pick_body), when no gain pass runs
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -322,17 +323,43 @@ __global__ __launch_bounds__(256) void km_init_kernel(const double *__restrict__
     }
 }
 
-// sorted order: closest distances to the first seed, and the inverse permutation
+// sorted order, one workgroup per block of KM_CHUNK positions: closest distances to the first seed, the inverse
+// permutation, and what the gains are later computed from without a pass over the values (km_pick_body): the block's sum
+// of closest distances (kept current by km_update_kernel) and its static moments about a reference value mu inside the
+// block -- sum(x - mu), sum((x - mu)^2) -- from which sum((x - c)^2) over the block follows for any c
+struct KmSorted {
+    double sd;         // sum of the closest distances of the block (fixed-shape tree: reproducible)
+    double mu, s1, s2;
+};
+
 __global__ __launch_bounds__(256) void km_sorted_init_kernel(const double *__restrict__ xs, const uint32_t *__restrict__ perm,
                                                              int64_t m, const KmState *__restrict__ st,
-                                                             double *__restrict__ ds, uint32_t *__restrict__ rank)
+                                                             double *__restrict__ ds, uint32_t *__restrict__ rank,
+                                                             KmSorted *__restrict__ sb)
 {
+    __shared__ double red[4];
     const double c = st->c0, csq = __dmul_rn(c, c);
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < m; p += stride) {
-        ds[p] = km_sqdist(c, csq, xs[p]);
-        rank[perm[p]] = (uint32_t)p;
+    const int64_t p0 = (int64_t)blockIdx.x * KM_CHUNK;
+    const int64_t p1 = p0 + KM_CHUNK < m ? p0 + KM_CHUNK : m;
+    const double mu = xs[p0 + (p1 - p0) / 2];
+    double sd = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < KM_CHUNK / 256; ++u) {
+        const int64_t p = p0 + u * 256 + threadIdx.x;
+        if (p < p1) {
+            const double x = xs[p];
+            const double d = km_sqdist(c, csq, x);
+            ds[p] = d;
+            rank[perm[p]] = (uint32_t)p;
+            sd += d;
+            s1 += x - mu;
+            s2 += (x - mu) * (x - mu);
+        }
     }
+    sd = km_block_sum(sd, red);
+    s1 = km_block_sum(s1, red);
+    s2 = km_block_sum(s2, red);
+    if (threadIdx.x == 0) { KmSorted o; o.sd = sd; o.mu = mu; o.s1 = s1; o.s2 = s2; sb[blockIdx.x] = o; }
 }
 
 // ---- k-means++ : one further seed = prep -> gain -> update --------------------------------------------------------
@@ -397,11 +424,14 @@ __device__ __forceinline__ void km_dual_search(const double *__restrict__ a, int
 }
 
 // argmin by one wavefront (lane j = candidate j): same rule as km_best
-__device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, int lane)
+__device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, int lane, int closed)
 {
     double pd = 1.79769313486231570e308;
-    if (lane < n_trials)
-        pd = km_to_double(km_make128(rec->pot_lo, rec->pot_hi) - km_join(rec->gain[0][lane], rec->gain[1][lane], rec->gain[2][lane]));
+    if (lane < n_trials) {
+        const i128 pot = km_make128(rec->pot_lo, rec->pot_hi);
+        pd = closed ? km_to_double(pot) - rec->gain_d[lane]
+                    : km_to_double(pot - km_join(rec->gain[0][lane], rec->gain[1][lane], rec->gain[2][lane]));
+    }
     double lowest = pd;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -420,9 +450,12 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
 //    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
 __device__ void km_pick_body(const double *__restrict__ xs, const double *__restrict__ ds, const uint32_t *__restrict__ rank,
                              int64_t m, int block_shift, int trial, int blk, i128 R, i128 carry, bool has_newest, double newest,
-                             int n_old, const double *__restrict__ sorted_old, int full_range, KmState *st, KmSeedRec *cur)
+                             int n_old, const double *__restrict__ sorted_old, int full_range, int closed,
+                             const KmSorted *__restrict__ sb, KmState *st, KmSeedRec *cur)
 {
     __shared__ u64 s_w_lo[4], s_w_hi[4], s_mine[2];
+    __shared__ int64_t s_bounds[4];
+    __shared__ double s_cx, s_gred[4];
     __shared__ int64_t s_idx, s_o[2];
     __shared__ double s_dv[8];
     __shared__ uint32_t s_rk[8], s_hit_rank;
@@ -538,7 +571,7 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
         s_hit_rank = 0xFFFFFFFFu;
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
     KM_TP(6);
     const uint32_t hr = s_hit_rank;
     const double cx = xs[hr != 0xFFFFFFFFu ? hr : rank[idx]];
@@ -554,16 +587,86 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
     KM_TP(7);
     const double amax = st->amax;
     const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
-    const double tlo = has_l ? 0.5 * (sl + cx) - (err / (cx - sl) + slack) : 0.0;
-    const double thi = has_r ? 0.5 * (cx + sr) + (err / (sr - cx) + slack) : 0.0;
+    const double wl = has_l ? err / (cx - sl) + slack : 0.0, wr = has_r ? err / (sr - cx) + slack : 0.0;
+    const double tlo = has_l ? 0.5 * (sl + cx) - wl : 0.0;
+    const double thi = has_r ? 0.5 * (cx + sr) + wr : 0.0;
     int64_t lo = 0, hi = m;
     if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
+    // the values that CERTAINLY get closer (same bound, inward): [ilo, ihi).  The two bands between the bounds hold a
+    // handful of values: looked for next to lo / hi first
+    int64_t ilo = lo, ihi = hi;
+    if (closed) {
+        const double t_in_lo = 0.5 * (sl + cx) + wl, t_in_hi = 0.5 * (cx + sr) - wr;
+        bool far = false;
+        if (has_l) {
+            const int64_t q = lo + lane;
+            const uint64_t in = __ballot(q >= hi || xs[q < hi ? q : hi - 1] > t_in_lo);
+            if (in) ilo = lo + __ffsll((long long)in) - 1; else far = true;
+        }
+        if (has_r) {
+            const int64_t q = hi - 1 - lane;
+            const uint64_t in = __ballot(q < lo || xs[q >= lo ? q : lo] < t_in_hi);
+            if (in) ihi = hi - (__ffsll((long long)in) - 1); else far = true;
+        }
+        if (far) {                                              // a wide band (neighbouring seeds a rounding error apart)
+            int64_t a, b;
+            km_dual_search(xs, m, t_in_hi, t_in_lo, has_r, has_l, a, b);   // a: first >= t_in_hi, b: first > t_in_lo
+            if (has_l) ilo = b < lo ? lo : b;
+            if (has_r) ihi = a > hi ? hi : a;
+        }
+        if (ilo > ihi) ilo = ihi;
+    }
     KM_TP(8);
     if (lane == 0) {
         cur->cand_x[trial] = cx;
         cur->cand_id[trial] = idx;
         cur->cand_lo[trial] = lo;
         cur->cand_hi[trial] = hi;
+        s_bounds[0] = lo; s_bounds[1] = hi; s_bounds[2] = ilo; s_bounds[3] = ihi;
+        s_cx = cx;
+    }
+    }
+    if (!closed) return;
+    __syncthreads();
+    // ---- D: the candidate's gain = sum over its range of d - min(d, dist) WITHOUT a pass over the range: blocks of
+    // KM_CHUNK sorted positions that lie inside [ilo, ihi) contribute sum(d) - sum((x - c)^2) from the block sums of the
+    // closest distances and the static block moments; the two ragged ends (and everything when the range is short) are
+    // evaluated value by value with the expression the update uses.  fp64, fixed order: the potentials only feed the
+    // argmin with its 1e-12 tie rule (sklearn's own are BLAS sums).
+    {
+        const int64_t lo = s_bounds[0], hi = s_bounds[1], ilo = s_bounds[2], ihi = s_bounds[3];
+        const double c = s_cx, csq = __dmul_rn(c, c);
+        int64_t bl = (ilo + KM_CHUNK - 1) / KM_CHUNK, bh = ihi / KM_CHUNK;
+        if (bl >= bh) { bl = 0; bh = 0; }
+        const int64_t e0 = bl < bh ? bl * KM_CHUNK : hi;         // [lo, e0) and [e1, hi) value by value
+        const int64_t e1 = bl < bh ? bh * KM_CHUNK : hi;
+        double g = 0.0;
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const int64_t a = side ? e1 : lo, b = side ? hi : e0;
+            for (int64_t base = a; base < b; base += 8 * 256) {
+                double xv[8], dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t p = base + u * 256 + tid;
+                    const int64_t q = p < b ? p : b - 1;
+                    xv[u] = xs[q];
+                    dv[u] = ds[q];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double dj = km_sqdist(c, csq, xv[u]);
+                    g += (base + u * 256 + tid < b && dj < dv[u]) ? dv[u] - dj : 0.0;
+                }
+            }
+        }
+        for (int64_t B = bl + tid; B < bh; B += 256) {
+            const KmSorted o = sb[B];
+            const double t = o.mu - c;
+            g += o.sd - (o.s2 + 2.0 * t * o.s1 + (double)KM_CHUNK * t * t);
+        }
+        g = km_block_sum(g, s_gred);
+        if (tid == 0) cur->gain_d[trial] = g * st->limb.sC;   // in the quanta of the exact sums (a power of two)
     }
 }
 
@@ -580,15 +683,15 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                                       const uint32_t *__restrict__ rank, int64_t m,
                                                       const i64 *__restrict__ bacc, int nblocks, int block_shift,
                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
-                                                      int choose_prev, int do_pick, int full_range, KmState *st,
-                                                      double *__restrict__ seeds_x, int64_t *__restrict__ seeds_id,
-                                                      double *__restrict__ sorted2, int sorted_ld)
+                                                      int choose_prev, int do_pick, int full_range, int closed,
+                                                      const KmSorted *__restrict__ sb, KmState *st, double *__restrict__ seeds_x,
+                                                      int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
     __shared__ int s_last;
     __shared__ double s_newest;
     __shared__ i64 s_newid;
     __shared__ u64 s_w_lo[4], s_w_hi[4], s_carry[2], s_expect[2];
-    __shared__ double s_red[4];
+    __shared__ double s_red[4], s_expect_d;
     __shared__ int s_cnt[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int sub = blockIdx.x, trial = blockIdx.y;
@@ -624,7 +727,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
             const bool on = lane < n_trials && lane < KM_MAX_TRIALS;
             const double cx = on ? prev->cand_x[lane] : 0.0;
             const i64 cid = on ? prev->cand_id[lane] : 0;
-            const int best = km_best_wave(prev, n_trials, lane);
+            const int best = km_best_wave(prev, n_trials, lane, closed);
             const double bx = __shfl(cx, best, 64);
             const i64 bid = __shfl(cid, best, 64);
             if (lane == 0) {
@@ -634,6 +737,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                    km_join(prev->gain[0][best], prev->gain[1][best], prev->gain[2][best]);
                 s_expect[0] = (u64)after;
                 s_expect[1] = (u64)(after >> 64);
+                s_expect_d = km_to_double(km_make128(prev->pot_lo, prev->pot_hi)) - prev->gain_d[best];
             }
         }
         __syncthreads();
@@ -684,7 +788,13 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     KM_T(3);
     if (lead) {
         if (tid == 0) {
-            if (choose_prev && ((u64)total != s_expect[0] || (u64)(total >> 64) != s_expect[1])) atomicOr(&st->faults, 1);
+            // the block sums after the update = the potential the winner's gain promised: to the last bit with the
+            // exact gains of the gain pass, to rounding with the closed-form ones
+            if (choose_prev && !closed && ((u64)total != s_expect[0] || (u64)(total >> 64) != s_expect[1])) atomicOr(&st->faults, 1);
+            if (choose_prev && closed) {
+                const double got = km_to_double(total), prev_pot = km_to_double(km_make128(prev->pot_lo, prev->pot_hi));
+                if (!(fabs(got - s_expect_d) <= 1e-9 * prev_pot)) atomicOr(&st->faults, 8);
+            }
             cur->pot_lo = (u64)total;
             cur->pot_hi = (u64)(total >> 64);
         }
@@ -693,7 +803,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     const i128 carry = km_make128(s_carry[0], s_carry[1]);
     if (clipped) {                                              // the last index, whatever the block holds
         if (sub == 0) km_pick_body(xs, ds, rank, m, block_shift, trial, -1, R, carry, choose_prev != 0, newest, n_old, sorted_old,
-                                   full_range, st, cur);
+                                   full_range, closed, sb, st, cur);
         return;
     }
     // ---- this workgroup's sixteenth of the block
@@ -735,7 +845,8 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     __syncthreads();
     KM_T(5);
     if (!s_last) return;
-    km_pick_body(xs, ds, rank, m, block_shift, trial, blk, R, carry, choose_prev != 0, newest, n_old, sorted_old, full_range, st, cur);
+    km_pick_body(xs, ds, rank, m, block_shift, trial, blk, R, carry, choose_prev != 0, newest, n_old, sorted_old, full_range, closed,
+                 sb, st, cur);
 }
 
 // union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
@@ -906,12 +1017,12 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
 // (tools/microbench/atomic_scatter.hip: 3.9 ms for the three limbs of 30 M values against 0.11 ms for the pass itself).
 __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ xs, double *__restrict__ ds,
                                                         const uint32_t *__restrict__ perm, i64 *__restrict__ bacc,
-                                                        int nblocks, int block_shift, const KmState *__restrict__ st,
-                                                        int seed_no, int n_trials)
+                                                        int nblocks, int block_shift, int64_t m, KmSorted *__restrict__ sb,
+                                                        const KmState *__restrict__ st, int seed_no, int n_trials, int closed)
 {
     __shared__ u64 s_acc[3 * KM_MAX_BLOCKS];
     __shared__ int64_t s_lo, s_hi;
-    __shared__ double s_c;
+    __shared__ double s_c, s_red[4];
     const KmSeedRec *rec = &st->rec[seed_no & 1];
     const KmLimb L = st->limb;
     if (threadIdx.x < 64) {
@@ -920,27 +1031,26 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
         const bool on = lane < n_trials && lane < KM_MAX_TRIALS;
         const int64_t lo_j = on ? rec->cand_lo[lane] : 0, hi_j = on ? rec->cand_hi[lane] : 0;
         const double cx_j = on ? rec->cand_x[lane] : 0.0;
-        const int best = km_best_wave(rec, n_trials, lane);
+        const int best = km_best_wave(rec, n_trials, lane, closed);
         const int64_t blo = __shfl(lo_j, best, 64), bhi = __shfl(hi_j, best, 64);
         const double bc = __shfl(cx_j, best, 64);
         if (lane == 0) { s_lo = blo; s_hi = bhi; s_c = bc; }
     }
     __syncthreads();
     const int64_t lo = s_lo, hi = s_hi;
-    const int64_t chunks = (hi - lo + KM_CHUNK - 1) / KM_CHUNK;
+    // one chunk = one block of KM_CHUNK sorted positions (whole: its sum of closest distances is rewritten)
+    const int64_t first = lo / KM_CHUNK;
+    const int64_t chunks = hi > lo ? (hi - 1) / KM_CHUNK - first + 1 : 0;
     if ((int64_t)blockIdx.x >= chunks) return;
     // (straight atomics to the block sums for workgroups with a single chunk -- no clearing and scanning of 3 * nblocks
     // LDS words -- were measured SLOWER: 30 M values / 512 levels 32.5 -> 37.0 ms; a chunk's 2048 values share blocks
     // often enough for the LDS stage to save global atomics, which run at 23 G/s whatever their addresses)
-    const bool direct = false;
-    if (!direct) {
-        for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
-        __syncthreads();
-    }
+    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
+    __syncthreads();
     const double c = s_c, csq = __dmul_rn(c, c);
     for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const int64_t p0 = lo + ch * KM_CHUNK;
-        const int64_t p1 = p0 + KM_CHUNK < hi ? p0 + KM_CHUNK : hi;
+        const int64_t p0 = (first + ch) * KM_CHUNK;
+        const int64_t p1 = p0 + KM_CHUNK < m ? p0 + KM_CHUNK : m;
         double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
         uint32_t iv[KM_CHUNK / 256];
 #pragma unroll
@@ -952,33 +1062,32 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
             iv[u] = perm[q];
         }
         __builtin_amdgcn_sched_barrier(0);
+        double left = 0.0;                                      // what stays: the block's new sum
 #pragma unroll
         for (int u = 0; u < KM_CHUNK / 256; ++u) {
             const int64_t p = p0 + u * 256 + threadIdx.x;
             if (p >= p1) continue;
             const double d = dv[u];
             const double dj = km_sqdist(c, csq, xv[u]);
-            if (dj < d) {
+            if (p >= lo && p < hi && dj < d) {
                 ds[p] = dj;
+                left += dj;
                 double a, b, cc, aj, bj, cj;
                 km_split(L, d, a, b, cc);
                 km_split(L, dj, aj, bj, cj);
                 const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
                           uc = -__double2ll_rn((cc - cj) * L.sC);
                 const int blk = (int)(iv[u] >> block_shift);
-                if (direct) {
-                    km_atomic_add_i64(bacc + 4 * (int64_t)blk, ua);
-                    km_atomic_add_i64(bacc + 4 * (int64_t)blk + 1, ub);
-                    km_atomic_add_i64(bacc + 4 * (int64_t)blk + 2, uc);
-                } else {
-                    if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
-                    if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
-                    if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
-                }
+                if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
+                if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
+                if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
+            } else {
+                left += d;
             }
         }
+        left = km_block_sum(left, s_red);
+        if (threadIdx.x == 0) sb[first + ch].sd = left;
     }
-    if (direct) return;
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
         const u64 v = s_acc[i];
@@ -1420,7 +1529,7 @@ struct KmPlan {
     int nb;                                                    // workgroups of the strided reductions
     int block_shift, nblocks;                                  // index blocks of the cumulative sum
     size_t off_state, off_x, off_ds, off_bacc, off_tsum, off_part, off_seedx, off_seedid, off_sorted, off_uniform,
-        off_xs, off_perm, off_rank, off_P, off_lloyd, off_sort, total;
+        off_xs, off_perm, off_rank, off_sb, off_P, off_lloyd, off_sort, total;
     size_t sorted_ld;
 };
 
@@ -1449,6 +1558,7 @@ KmPlan km_plan(int64_t m, int k)
     p.off_xs = take((size_t)m * 8);
     p.off_perm = take((size_t)m * 4);
     p.off_rank = take((size_t)m * 4);
+    p.off_sb = take((size_t)grx_ceil_div(m, KM_CHUNK) * sizeof(KmSorted));
     p.off_P = take((size_t)(m + 1) * 8);
     p.off_lloyd = take((size_t)k * 8 * 16);
     p.off_sort = take(grx_internal_sort_pairs_workspace_bytes(m));
@@ -1514,6 +1624,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     double *xs = reinterpret_cast<double *>(ws + p.off_xs);
     uint32_t *perm = reinterpret_cast<uint32_t *>(ws + p.off_perm);
     uint32_t *rank = reinterpret_cast<uint32_t *>(ws + p.off_rank);
+    KmSorted *sb = reinterpret_cast<KmSorted *>(ws + p.off_sb);
     double *P = reinterpret_cast<double *>(ws + p.off_P);
     GRX_PROF(GRX_K_QUANT, st);
     if (k > 1)
@@ -1553,21 +1664,30 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
             km_seed_small_kernel<KM_SMALL_M / 1024, KM_MAX_TRIALS><<<1, threads, 0, st>>>(d_values, (int)m, first_seed, d_uniform, n_trials,
                                                                                           k, state, seeds_x, seeds_id);
     } else if (k > 1) {
-        km_sorted_init_kernel<<<stream_grid, 256, 0, st>>>(xs, perm, m, state, ds, rank);
+        // GRX_KMEANS_GAIN_PASS=1 (and the full ranges): every candidate's gain by a pass over its range in exact integer
+        // arithmetic (km_gain_kernel) instead of the closed form over sorted blocks inside the pick (km_pick_body, D):
+        // same seeds unless two potentials agree to 1e-12 (tests/test_gpu_encode.py compares the modes)
+        static const int gain_pass = [] { const char *e = std::getenv("GRX_KMEANS_GAIN_PASS"); return (e && *e == '1') ? 1 : 0; }();
+        const int closed = (full_range || gain_pass) ? 0 : 1;
         const int64_t max_chunks = grx_ceil_div(m, KM_CHUNK);
+        km_sorted_init_kernel<<<(int)max_chunks, 256, 0, st>>>(xs, perm, m, state, ds, rank, sb);
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
         for (int c = 1; c < k; ++c) {
             km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
-                                                                   full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
-            if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
-            else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
+                                                                   full_range, closed, sb, state, seeds_x, seeds_id, sorted2,
+                                                                   (int)p.sorted_ld);
+            if (!closed) {
+                if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
+                else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
+            }
             if (c < k - 1)                                         // the distances to the last seed are never needed
-                km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, state, c, n_trials);
+                km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, m, sb, state, c,
+                                                              n_trials, closed);
         }
         km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
-                                                   full_range, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+                                                   full_range, closed, sb, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values

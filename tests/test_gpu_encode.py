@@ -241,7 +241,10 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     GRX_KMEANS_FULL_RANGE=1 every range is [0, m) -- sklearn's own formulation, every value tested for every candidate --
     in the same exact integer arithmetic: the ranges are supersets of what can change, so seeds, centres and quantised
     values are identical bits; and the internal consistency checks report nothing in either mode.  Likewise the
-    one-workgroup seeding of few values (m <= 4096, km_seed_small_kernel) against the many-launch path (GRX_KMEANS_SMALL=0)."""
+    one-workgroup seeding of few values (m <= 4096, km_seed_small_kernel) against the many-launch path (GRX_KMEANS_SMALL=0),
+    and the default evaluation of the candidates' potentials from sums over blocks of sorted values (closed form, fp64)
+    against the pass over each range in integer arithmetic (GRX_KMEANS_GAIN_PASS=1): the two can only choose differently
+    where two potentials agree to 1e-12, which none of these inputs has."""
     import os
     import subprocess
     import sys
@@ -249,7 +252,9 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = []
     # default; every range [0, m); few values (m <= 4096) through the many-launch path instead of the one-workgroup kernel
-    for tag, extra in (('default', {}), ('full', {'GRX_KMEANS_FULL_RANGE': '1'}), ('nosmall', {'GRX_KMEANS_SMALL': '0'})):
+    for tag, extra in (('default', {}), ('full', {'GRX_KMEANS_FULL_RANGE': '1'}), ('nosmall', {'GRX_KMEANS_SMALL': '0'}),
+                       ('gainpass', {'GRX_KMEANS_GAIN_PASS': '1'}), ('gainpass_nosmall', {'GRX_KMEANS_GAIN_PASS': '1',
+                                                                                          'GRX_KMEANS_SMALL': '0'})):
         out = tmp_path / f'km_{tag}.npz'
         code = 'ROOT = %r\nOUT = %r\n' % (root, str(out)) + textwrap.dedent(_AB_DRIVER)
         env = dict(os.environ, **extra)
