@@ -71,6 +71,8 @@ constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup 
 constexpr int KM_RANGE_GRID = 512;            // workgroups of the gain kernel
 constexpr int KM_UPDATE_GRID = 512;           // ... of the update kernel (each flushes its block sums once)
 constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
+constexpr int KM_TOP2 = 1024;            // LDS level of the search over the sorted values
+constexpr int KM_SEEDS_LDS = 2048;       // sorted seeds the pick keeps in LDS (more: searched in memory)
 constexpr int KM_SMALL_M = 4096;              // at most this many values: the seeding runs in one workgroup
 
 __device__ __forceinline__ double km_sqdist(double c, double csq, double x)
@@ -109,8 +111,8 @@ struct KmState {                 // device scalars shared by the kernels of one 
 };
 #ifdef KM_DBG_TIMING
 #define KM_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
-#define KM_TP(i) do { if (trial == 0 && threadIdx.x == 0) st->dbg[i] = wall_clock64(); } while (0)
-#define KM_TG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) st->dbg[i] = wall_clock64(); } while (0)
+#define KM_TP(i) do { if (trial == 0 && threadIdx.x == 0 && st->dbg[0] != 0 && st->dbg[i] == 0) st->dbg[i] = wall_clock64(); } while (0)
+#define KM_TG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING) const_cast<KmState *>(st)->dbg[i] = wall_clock64(); } while (0)
 #else
 #define KM_T(i) do { } while (0)
 #define KM_TP(i) do { } while (0)
@@ -280,6 +282,9 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
     st->limb.sC = ldexp(1.0, 96 - E);
     st->faults = faults;
     for (int j = 0; j < KM_MAX_TRIALS; ++j) st->arrivals[j] = 0;
+#ifdef KM_DBG_TIMING
+    for (int j = 0; j < 32; ++j) st->dbg[j] = 0;
+#endif
 }
 
 // index order: x = v - mean; per block of 2^block_shift indices the exact sum of the squared distances to the first
@@ -332,16 +337,30 @@ struct KmSorted {
     double mu, s1, s2;
 };
 
+// the search for a value's position among the sorted values, from the top: xtop2 (every s2-th block start, at most KM_TOP2
+// entries: in LDS for the whole launch) -> xtop (the first value of every block, one load per lane) -> the block itself
+// (eight values per thread of the workgroup).  Two round trips to memory where a 32-ary search over xs takes five.
+struct KmTop {
+    double *xtop, *xtop2;
+    int64_t nsb;       // blocks of KM_CHUNK sorted positions
+    int s2, n2;        // xtop2[j] = xtop[j * s2], j < n2
+};
+
 __global__ __launch_bounds__(256) void km_sorted_init_kernel(const double *__restrict__ xs, const uint32_t *__restrict__ perm,
                                                              int64_t m, const KmState *__restrict__ st,
                                                              double *__restrict__ ds, uint32_t *__restrict__ rank,
-                                                             KmSorted *__restrict__ sb)
+                                                             KmSorted *__restrict__ sb, KmTop top)
 {
     __shared__ double red[4];
     const double c = st->c0, csq = __dmul_rn(c, c);
     const int64_t p0 = (int64_t)blockIdx.x * KM_CHUNK;
     const int64_t p1 = p0 + KM_CHUNK < m ? p0 + KM_CHUNK : m;
     const double mu = xs[p0 + (p1 - p0) / 2];
+    if (threadIdx.x == 0) {
+        const double x0 = xs[p0];
+        top.xtop[blockIdx.x] = x0;
+        if (blockIdx.x % top.s2 == 0) top.xtop2[blockIdx.x / top.s2] = x0;
+    }
     double sd = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int u = 0; u < KM_CHUNK / 256; ++u) {
@@ -450,12 +469,14 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
 //    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
 __device__ void km_pick_body(const double *__restrict__ xs, const double *__restrict__ ds, const uint32_t *__restrict__ rank,
                              int64_t m, int block_shift, int trial, int blk, i128 R, i128 carry, bool has_newest, double newest,
-                             int n_old, const double *__restrict__ sorted_old, int full_range, int closed,
-                             const KmSorted *__restrict__ sb, KmState *st, KmSeedRec *cur)
+                             int n_old, const double *__restrict__ sorted_old, int full_range, int closed, int slow_pick,
+                             const KmSorted *__restrict__ sb, KmTop top, const double *s_top2, const double *s_seeds,
+                             KmState *st, KmSeedRec *cur)
 {
-    __shared__ u64 s_w_lo[4], s_w_hi[4], s_mine[2];
-    __shared__ int64_t s_bounds[4];
-    __shared__ double s_cx, s_gred[4];
+    __shared__ u64 s_w_lo[4], s_w_hi[4], s_mine[2], s_cnt4[4];
+    __shared__ int64_t s_bounds[6];
+    __shared__ double s_f[5], s_gred[4];
+    __shared__ int s_flags;
     __shared__ int64_t s_idx, s_o[2];
     __shared__ double s_dv[8];
     __shared__ uint32_t s_rk[8], s_hit_rank;
@@ -571,71 +592,181 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
         s_hit_rank = 0xFFFFFFFFu;
     }
     __syncthreads();
+    // ---- C: neighbours among the seeds (wavefront 0)
     if (wave == 0) {
-    KM_TP(6);
-    const uint32_t hr = s_hit_rank;
-    const double cx = xs[hr != 0xFFFFFFFFu ? hr : rank[idx]];
-    // ---- C: neighbours among the seeds, range of sorted positions
-    int64_t pl, pr;
-    km_dual_search(sorted_old, n_old, cx, cx, true, true, pl, pr);  // pl seeds < cx, pr seeds <= cx
-    bool has_l = pl > 0, has_r = pr < n_old;
-    double sl = has_l ? sorted_old[pl - 1] : 0.0, sr = has_r ? sorted_old[pr] : 0.0;
-    if (has_newest) {                                           // the seed chosen by this launch, not in sorted_old
-        if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
-        if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
+        KM_TP(6);
+        const uint32_t hr = s_hit_rank;
+        const double cx = xs[hr != 0xFFFFFFFFu ? hr : rank[idx]];
+        int64_t pl, pr;                                         // pl seeds < cx, pr seeds <= cx
+        double sl = 0.0, sr = 0.0;
+        if (s_seeds) {                                          // the sorted seeds are in LDS
+            int nl = 0, nr = 0;
+            for (int i = lane; i < n_old; i += 64) { const double v = s_seeds[i]; nl += v < cx ? 1 : 0; nr += v <= cx ? 1 : 0; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off, 64); nr += __shfl_xor(nr, off, 64); }
+            pl = nl; pr = nr;
+            if (pl > 0) sl = s_seeds[pl - 1];
+            if (pr < n_old) sr = s_seeds[pr];
+        } else {
+            km_dual_search(sorted_old, n_old, cx, cx, true, true, pl, pr);
+            if (pl > 0) sl = sorted_old[pl - 1];
+            if (pr < n_old) sr = sorted_old[pr];
+        }
+        bool has_l = pl > 0, has_r = pr < n_old;
+        if (has_newest) {                                       // the seed chosen by this launch, not in sorted_old
+            if (newest < cx && (!has_l || newest > sl)) { sl = newest; has_l = true; }
+            if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
+        }
+        KM_TP(7);
+        const double amax = st->amax;
+        const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
+        const double wl = has_l ? err / (cx - sl) + slack : 0.0, wr = has_r ? err / (sr - cx) + slack : 0.0;
+        // range [lo, hi): first value >= tlo .. first value > thi.  The values that CERTAINLY get closer (the same bound,
+        // inward): first value > til .. first value >= tih
+        const double inf = __builtin_inf();
+        const bool open_l = !has_l || full_range, open_r = !has_r || full_range;
+        const double tlo = open_l ? -inf : 0.5 * (sl + cx) - wl, til = has_l ? 0.5 * (sl + cx) + wl : -inf;
+        const double thi = open_r ? inf : 0.5 * (cx + sr) + wr, tih = has_r ? 0.5 * (cx + sr) - wr : inf;
+        int64_t Blo = 0, Bhi = 0;
+        if (closed && !slow_pick) {
+            // blocks of sorted positions that hold lo and hi: the last block that starts below tlo (at or below thi)
+            int n2l = 0, n2h = 0;
+            for (int i = lane; i < top.n2; i += 64) { const double v = s_top2[i]; n2l += v < tlo ? 1 : 0; n2h += v <= thi ? 1 : 0; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { n2l += __shfl_xor(n2l, off, 64); n2h += __shfl_xor(n2h, off, 64); }
+            const int64_t jl = n2l > 0 ? n2l - 1 : 0, jh = n2h > 0 ? n2h - 1 : 0;
+            const int64_t l0 = jl * top.s2, h0 = jh * top.s2;
+            const int64_t l1 = l0 + top.s2 < top.nsb ? l0 + top.s2 : top.nsb, h1 = h0 + top.s2 < top.nsb ? h0 + top.s2 : top.nsb;
+            int cl = 0, chh = 0;
+            for (int64_t o = lane; o < top.s2; o += 64) {
+                const double vl = top.xtop[l0 + o < l1 ? l0 + o : l1 - 1], vh = top.xtop[h0 + o < h1 ? h0 + o : h1 - 1];
+                cl += (l0 + o < l1 && vl < tlo) ? 1 : 0;
+                chh += (h0 + o < h1 && vh <= thi) ? 1 : 0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { cl += __shfl_xor(cl, off, 64); chh += __shfl_xor(chh, off, 64); }
+            const int64_t nbl = n2l > 0 ? l0 + cl : 0, nbh = n2h > 0 ? h0 + chh : 0;
+            Blo = nbl > 0 ? nbl - 1 : 0;
+            Bhi = nbh > 0 ? nbh - 1 : 0;
+        }
+        KM_TP(8);
+        if (lane == 0) {
+            s_f[0] = cx; s_f[1] = tlo; s_f[2] = til; s_f[3] = tih; s_f[4] = thi;
+            s_bounds[4] = Blo; s_bounds[5] = Bhi;
+            s_flags = (has_l ? 1 : 0) | (has_r ? 2 : 0);
+        }
     }
-    KM_TP(7);
-    const double amax = st->amax;
-    const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
-    const double wl = has_l ? err / (cx - sl) + slack : 0.0, wr = has_r ? err / (sr - cx) + slack : 0.0;
-    const double tlo = has_l ? 0.5 * (sl + cx) - wl : 0.0;
-    const double thi = has_r ? 0.5 * (cx + sr) + wr : 0.0;
-    int64_t lo = 0, hi = m;
-    if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
-    // the values that CERTAINLY get closer (same bound, inward): [ilo, ihi).  The two bands between the bounds hold a
-    // handful of values: looked for next to lo / hi first
-    int64_t ilo = lo, ihi = hi;
-    if (closed) {
-        const double t_in_lo = 0.5 * (sl + cx) + wl, t_in_hi = 0.5 * (cx + sr) - wr;
-        bool far = false;
-        if (has_l) {
-            const int64_t q = lo + lane;
-            const uint64_t in = __ballot(q >= hi || xs[q < hi ? q : hi - 1] > t_in_lo);
-            if (in) ilo = lo + __ffsll((long long)in) - 1; else far = true;
+    __syncthreads();
+    const double c = s_f[0], csq = __dmul_rn(c, c);
+    bool slow = !closed || slow_pick;
+    if (!slow) {
+        // ---- D (the usual way): lo and hi inside their blocks, and the candidate's gain = sum over its range of
+        // d - min(d, dist) WITHOUT a pass over the range: the blocks of KM_CHUNK sorted positions strictly between the two
+        // contribute sum(d) - sum((x - c)^2) from the block sums of the closest distances and the static block moments;
+        // the two end blocks, already here for the counting, value by value with the expression the update uses.
+        // fp64, fixed order: the potentials only feed the argmin with its 1e-12 tie rule (sklearn's own are BLAS sums).
+        const double tlo = s_f[1], til = s_f[2], tih = s_f[3], thi = s_f[4];
+        const int64_t Blo = s_bounds[4], Bhi = s_bounds[5];
+        const bool same = Blo == Bhi;
+        const int64_t a0 = Blo * KM_CHUNK, a1 = a0 + KM_CHUNK < m ? a0 + KM_CHUNK : m;
+        const int64_t b0 = Bhi * KM_CHUNK, b1 = b0 + KM_CHUNK < m ? b0 + KM_CHUNK : m;
+        double xa[KM_CHUNK / 256], da[KM_CHUNK / 256], xb[KM_CHUNK / 256], db[KM_CHUNK / 256];
+#pragma unroll
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            const int64_t p = a0 + u * 256 + tid, q = p < a1 ? p : a1 - 1;
+            xa[u] = xs[q];
+            da[u] = ds[q];
         }
-        if (has_r) {
-            const int64_t q = hi - 1 - lane;
-            const uint64_t in = __ballot(q < lo || xs[q >= lo ? q : lo] < t_in_hi);
-            if (in) ihi = hi - (__ffsll((long long)in) - 1); else far = true;
+        if (!same) {
+#pragma unroll
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = b0 + u * 256 + tid, q = p < b1 ? p : b1 - 1;
+                xb[u] = xs[q];
+                db[u] = ds[q];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KM_CHUNK / 256; ++u) { xb[u] = xa[u]; db[u] = da[u]; }
         }
-        if (far) {                                              // a wide band (neighbouring seeds a rounding error apart)
+        const int64_t Bf = Blo + 1 + tid;                       // this thread's first block in between
+        KmSorted mid = sb[Bf < Bhi ? Bf : Blo];
+        u64 cnt = 0;                                            // four counts of at most KM_CHUNK, 16 bits each
+#pragma unroll
+        for (int u = 0; u < KM_CHUNK / 256; ++u) {
+            if (a0 + u * 256 + tid < a1) cnt += (xa[u] < tlo ? 1ull : 0ull) + (xa[u] <= til ? 1ull << 16 : 0ull);
+            if (b0 + u * 256 + tid < b1) cnt += (xb[u] < tih ? 1ull << 32 : 0ull) + (xb[u] <= thi ? 1ull << 48 : 0ull);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) s_cnt4[wave] = cnt;
+        __syncthreads();
+        cnt = s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];
+        const int64_t lo = a0 + (int64_t)(cnt & 0xFFFF), ilo = a0 + (int64_t)((cnt >> 16) & 0xFFFF);
+        const int64_t ihi = b0 + (int64_t)((cnt >> 32) & 0xFFFF), hi = b0 + (int64_t)(cnt >> 48);
+        // blocks in between are only summed in closed form when all their values certainly get closer: always, unless the
+        // band where that is undecided reaches out of an end block (neighbouring seeds a rounding error apart)
+        if (Bhi > Blo + 1 && (ilo > a1 - 1 || ihi <= b0)) {
+            slow = true;
+        } else {
+            double g = 0.0;
+#pragma unroll
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = a0 + u * 256 + tid;
+                const double dj = km_sqdist(c, csq, xa[u]);
+                g += (p >= lo && p < hi && p < a1 && dj < da[u]) ? da[u] - dj : 0.0;
+            }
+            if (!same) {
+#pragma unroll
+                for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                    const int64_t p = b0 + u * 256 + tid;
+                    const double dj = km_sqdist(c, csq, xb[u]);
+                    g += (p < hi && p < b1 && dj < db[u]) ? db[u] - dj : 0.0;
+                }
+            }
+            for (int64_t B = Bf; B < Bhi; B += 256) {
+                if (B != Bf) mid = sb[B];
+                const double t = mid.mu - c;
+                g += mid.sd - (mid.s2 + 2.0 * t * mid.s1 + (double)KM_CHUNK * t * t);
+            }
+            g = km_block_sum(g, s_gred);
+            KM_TP(9);
+            if (tid == 0) {
+                cur->cand_x[trial] = c;
+                cur->cand_id[trial] = idx;
+                cur->cand_lo[trial] = lo;
+                cur->cand_hi[trial] = hi;
+                cur->gain_d[trial] = g * st->limb.sC;           // in the quanta of the exact sums (a power of two)
+            }
+            return;
+        }
+    }
+    // ---- the general way (and the comparison modes): positions by searches over all the sorted values
+    if (wave == 0) {
+        const double tlo = s_f[1], til = s_f[2], tih = s_f[3], thi = s_f[4];
+        const bool has_l = s_flags & 1, has_r = s_flags & 2;
+        int64_t lo = 0, hi = m;
+        if (!full_range) km_dual_search(xs, m, tlo, thi, has_l, has_r, lo, hi);
+        int64_t ilo = lo, ihi = hi;
+        if (closed) {
             int64_t a, b;
-            km_dual_search(xs, m, t_in_hi, t_in_lo, has_r, has_l, a, b);   // a: first >= t_in_hi, b: first > t_in_lo
+            km_dual_search(xs, m, tih, til, has_r, has_l, a, b);    // a: first value >= tih, b: first value > til
             if (has_l) ilo = b < lo ? lo : b;
             if (has_r) ihi = a > hi ? hi : a;
+            if (ilo > ihi) ilo = ihi;
         }
-        if (ilo > ihi) ilo = ihi;
-    }
-    KM_TP(8);
-    if (lane == 0) {
-        cur->cand_x[trial] = cx;
-        cur->cand_id[trial] = idx;
-        cur->cand_lo[trial] = lo;
-        cur->cand_hi[trial] = hi;
-        s_bounds[0] = lo; s_bounds[1] = hi; s_bounds[2] = ilo; s_bounds[3] = ihi;
-        s_cx = cx;
-    }
+        if (lane == 0) {
+            cur->cand_x[trial] = c;
+            cur->cand_id[trial] = idx;
+            cur->cand_lo[trial] = lo;
+            cur->cand_hi[trial] = hi;
+            s_bounds[0] = lo; s_bounds[1] = hi; s_bounds[2] = ilo; s_bounds[3] = ihi;
+        }
     }
     if (!closed) return;
     __syncthreads();
-    // ---- D: the candidate's gain = sum over its range of d - min(d, dist) WITHOUT a pass over the range: blocks of
-    // KM_CHUNK sorted positions that lie inside [ilo, ihi) contribute sum(d) - sum((x - c)^2) from the block sums of the
-    // closest distances and the static block moments; the two ragged ends (and everything when the range is short) are
-    // evaluated value by value with the expression the update uses.  fp64, fixed order: the potentials only feed the
-    // argmin with its 1e-12 tie rule (sklearn's own are BLAS sums).
     {
+        // blocks inside [ilo, ihi) in closed form, the ragged ends value by value
         const int64_t lo = s_bounds[0], hi = s_bounds[1], ilo = s_bounds[2], ihi = s_bounds[3];
-        const double c = s_cx, csq = __dmul_rn(c, c);
         int64_t bl = (ilo + KM_CHUNK - 1) / KM_CHUNK, bh = ihi / KM_CHUNK;
         if (bl >= bh) { bl = 0; bh = 0; }
         const int64_t e0 = bl < bh ? bl * KM_CHUNK : hi;         // [lo, e0) and [e1, hi) value by value
@@ -666,7 +797,7 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
             g += o.sd - (o.s2 + 2.0 * t * o.s1 + (double)KM_CHUNK * t * t);
         }
         g = km_block_sum(g, s_gred);
-        if (tid == 0) cur->gain_d[trial] = g * st->limb.sC;   // in the quanta of the exact sums (a power of two)
+        if (tid == 0) cur->gain_d[trial] = g * st->limb.sC;
     }
 }
 
@@ -683,11 +814,12 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                                       const uint32_t *__restrict__ rank, int64_t m,
                                                       const i64 *__restrict__ bacc, int nblocks, int block_shift,
                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
-                                                      int choose_prev, int do_pick, int full_range, int closed,
-                                                      const KmSorted *__restrict__ sb, KmState *st, double *__restrict__ seeds_x,
+                                                      int choose_prev, int do_pick, int full_range, int closed, int slow_pick,
+                                                      const KmSorted *__restrict__ sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
                                                       int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
     __shared__ int s_last;
+    __shared__ double s_top2[KM_TOP2], s_seeds[KM_SEEDS_LDS];
     __shared__ double s_newest;
     __shared__ i64 s_newid;
     __shared__ u64 s_w_lo[4], s_w_hi[4], s_carry[2], s_expect[2];
@@ -705,7 +837,13 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     // consecutive block sums
     i128 inc8[KM_MAX_BLOCKS / 256];
     i128 loc = 0;
+    const bool seeds_in_lds = n_old <= KM_SEEDS_LDS;
     if (do_pick) {
+        // (what the end of the pick searches, into LDS now: used after several barriers)
+        if (closed && !slow_pick)
+            for (int i = tid; i < top.n2; i += 256) s_top2[i] = top.xtop2[i];
+        if (seeds_in_lds)
+            for (int i = tid; i < n_old; i += 256) s_seeds[i] = sorted_old[i];
         i64 raw[KM_MAX_BLOCKS / 256][3];
 #pragma unroll
         for (int q = 0; q < KM_MAX_BLOCKS / 256; ++q) {
@@ -803,7 +941,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     const i128 carry = km_make128(s_carry[0], s_carry[1]);
     if (clipped) {                                              // the last index, whatever the block holds
         if (sub == 0) km_pick_body(xs, ds, rank, m, block_shift, trial, -1, R, carry, choose_prev != 0, newest, n_old, sorted_old,
-                                   full_range, closed, sb, st, cur);
+                                   full_range, closed, slow_pick, sb, top, s_top2, seeds_in_lds ? s_seeds : nullptr, st, cur);
         return;
     }
     // ---- this workgroup's sixteenth of the block
@@ -846,7 +984,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     KM_T(5);
     if (!s_last) return;
     km_pick_body(xs, ds, rank, m, block_shift, trial, blk, R, carry, choose_prev != 0, newest, n_old, sorted_old, full_range, closed,
-                 sb, st, cur);
+                 slow_pick, sb, top, s_top2, seeds_in_lds ? s_seeds : nullptr, st, cur);
 }
 
 // union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
@@ -1024,6 +1162,7 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     __shared__ int64_t s_lo, s_hi;
     __shared__ double s_c, s_red[4];
     const KmSeedRec *rec = &st->rec[seed_no & 1];
+    KM_TG(15);
     const KmLimb L = st->limb;
     if (threadIdx.x < 64) {
         // (every candidate's range and value ride along with the gains: one round trip to memory, not two)
@@ -1036,6 +1175,7 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
         const double bc = __shfl(cx_j, best, 64);
         if (lane == 0) { s_lo = blo; s_hi = bhi; s_c = bc; }
     }
+    KM_TG(16);
     __syncthreads();
     const int64_t lo = s_lo, hi = s_hi;
     // one chunk = one block of KM_CHUNK sorted positions (whole: its sum of closest distances is rewritten)
@@ -1047,6 +1187,7 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     // often enough for the LDS stage to save global atomics, which run at 23 G/s whatever their addresses)
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
     __syncthreads();
+    KM_TG(17);
     const double c = s_c, csq = __dmul_rn(c, c);
     for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
         const int64_t p0 = (first + ch) * KM_CHUNK;
@@ -1089,10 +1230,12 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
         if (threadIdx.x == 0) sb[first + ch].sd = left;
     }
     __syncthreads();
+    KM_TG(18);
     for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
         const u64 v = s_acc[i];
         if (v) atomicAdd(reinterpret_cast<u64 *>(bacc) + 4 * (i / 3) + i % 3, v);
     }
+    KM_TG(19);
 }
 
 // ---- few values (m <= 4096: the r x F factor of RolX, small graphs): the whole seeding in ONE workgroup -----------------
@@ -1482,8 +1625,9 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
         info[2] = distinct;
         info[3] = k > 1 ? st->faults : 0;
 #ifdef KM_DBG_TIMING
-        for (int q = 1; q < 9; ++q) printf("prep phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
-        for (int q = 11; q < 15; ++q) printf("gain phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+        for (int q = 1; q < 10; ++q) printf("prep phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+        printf("prep end -> update start: %lld ns\n", (st->dbg[15] - st->dbg[9]) * 10);
+        for (int q = 16; q < 20; ++q) printf("update phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
 #endif
     }
 }
@@ -1529,7 +1673,7 @@ struct KmPlan {
     int nb;                                                    // workgroups of the strided reductions
     int block_shift, nblocks;                                  // index blocks of the cumulative sum
     size_t off_state, off_x, off_ds, off_bacc, off_tsum, off_part, off_seedx, off_seedid, off_sorted, off_uniform,
-        off_xs, off_perm, off_rank, off_sb, off_P, off_lloyd, off_sort, total;
+        off_xs, off_perm, off_rank, off_sb, off_top, off_top2, off_P, off_lloyd, off_sort, total;
     size_t sorted_ld;
 };
 
@@ -1559,6 +1703,8 @@ KmPlan km_plan(int64_t m, int k)
     p.off_perm = take((size_t)m * 4);
     p.off_rank = take((size_t)m * 4);
     p.off_sb = take((size_t)grx_ceil_div(m, KM_CHUNK) * sizeof(KmSorted));
+    p.off_top = take((size_t)grx_ceil_div(m, KM_CHUNK) * 8);
+    p.off_top2 = take((size_t)KM_TOP2 * 8);
     p.off_P = take((size_t)(m + 1) * 8);
     p.off_lloyd = take((size_t)k * 8 * 16);
     p.off_sort = take(grx_internal_sort_pairs_workspace_bytes(m));
@@ -1669,15 +1815,24 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         // same seeds unless two potentials agree to 1e-12 (tests/test_gpu_encode.py compares the modes)
         static const int gain_pass = [] { const char *e = std::getenv("GRX_KMEANS_GAIN_PASS"); return (e && *e == '1') ? 1 : 0; }();
         const int closed = (full_range || gain_pass) ? 0 : 1;
+        // GRX_KMEANS_SLOW_PICK=1: the positions of every range by searches over all the sorted values (what the pick falls
+        // back to when a range's undecided band leaves its end blocks) -- same positions, the same test again
+        static const int slow_pick = [] { const char *e = std::getenv("GRX_KMEANS_SLOW_PICK"); return (e && *e == '1') ? 1 : 0; }();
         const int64_t max_chunks = grx_ceil_div(m, KM_CHUNK);
-        km_sorted_init_kernel<<<(int)max_chunks, 256, 0, st>>>(xs, perm, m, state, ds, rank, sb);
+        KmTop top;
+        top.xtop = reinterpret_cast<double *>(ws + p.off_top);
+        top.xtop2 = reinterpret_cast<double *>(ws + p.off_top2);
+        top.nsb = max_chunks;
+        top.s2 = (int)grx_ceil_div(max_chunks, KM_TOP2);
+        top.n2 = (int)grx_ceil_div(max_chunks, top.s2);
+        km_sorted_init_kernel<<<(int)max_chunks, 256, 0, st>>>(xs, perm, m, state, ds, rank, sb, top);
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
         for (int c = 1; c < k; ++c) {
             km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
-                                                                   full_range, closed, sb, state, seeds_x, seeds_id, sorted2,
-                                                                   (int)p.sorted_ld);
+                                                                   full_range, closed, slow_pick, sb, top, state, seeds_x, seeds_id,
+                                                                   sorted2, (int)p.sorted_ld);
             if (!closed) {
                 if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
                 else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
@@ -1687,7 +1842,8 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                                                               n_trials, closed);
         }
         km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
-                                                   full_range, closed, sb, state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
+                                                   full_range, closed, slow_pick, sb, top, state, seeds_x, seeds_id, sorted2,
+                                                   (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();
     // Lloyd on the sorted values

@@ -222,7 +222,7 @@ from graphrole_amd import kernels as K
 out = {}
 for tag, m, k, seed in (('a', 50_000, 64, 0), ('b', 300_007, 256, 1), ('c', 4_099, 17, 2), ('d', 1_200_000, 512, 3),
                         ('e', 200_000, 32, 4), ('f', 90_000, 1024, 5), ('g', 130, 100, 6), ('h', 3_000, 64, 7),
-                        ('i', 900, 512, 8), ('j', 4_096, 700, 9)):
+                        ('i', 900, 512, 8), ('j', 4_096, 700, 9), ('k', 20_000, 2_500, 10), ('l', 2_100_000, 40, 11)):
     rng = np.random.default_rng(seed)
     v = np.abs(rng.standard_normal(m)) * rng.choice([1e-3, 1.0, 40.0], size=m)
     if tag == 'e':
@@ -253,6 +253,7 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     results = []
     # default; every range [0, m); few values (m <= 4096) through the many-launch path instead of the one-workgroup kernel
     for tag, extra in (('default', {}), ('full', {'GRX_KMEANS_FULL_RANGE': '1'}), ('nosmall', {'GRX_KMEANS_SMALL': '0'}),
+                       ('slowpick', {'GRX_KMEANS_SLOW_PICK': '1', 'GRX_KMEANS_SMALL': '0'}),
                        ('gainpass', {'GRX_KMEANS_GAIN_PASS': '1'}), ('gainpass_nosmall', {'GRX_KMEANS_GAIN_PASS': '1',
                                                                                           'GRX_KMEANS_SMALL': '0'})):
         out = tmp_path / f'km_{tag}.npz'
