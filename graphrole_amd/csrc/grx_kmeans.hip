@@ -71,6 +71,7 @@ constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup 
 constexpr int KM_RANGE_GRID = 512;            // workgroups of the gain kernel
 constexpr int KM_UPDATE_GRID = 512;           // ... of the update kernel (each flushes its block sums once)
 constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
+constexpr int KM_SPIN_LIMIT = 1 << 18;   // reads of a trial's sums before the pick gives up (a fraction of a second)
 constexpr int KM_TOP2 = 1024;            // LDS level of the search over the sorted values
 constexpr int KM_SEEDS_LDS = 2048;       // sorted seeds the pick keeps in LDS (more: searched in memory)
 constexpr int KM_SMALL_M = 4096;              // at most this many values: the seeding runs in one workgroup
@@ -94,7 +95,7 @@ struct KmSeedRec {
     i64 gain[3][KM_MAX_TRIALS];  // limb sums of (d - min(d, dist to candidate)) over the candidate's range
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
     i64 sub[KM_MAX_TRIALS][KM_SUB][3];   // km_prep_kernel: limb sums of the sub-blocks of the block each trial's r falls in
-    double gain_d[KM_MAX_TRIALS];        // gains from the sorted-block sums (km_pick_body), when no gain pass runs
+    double gain_d[KM_MAX_TRIALS];        // gains from the sorted-block sums (km_pick_tail), when no gain pass runs
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -103,7 +104,6 @@ struct KmState {                 // device scalars shared by the kernels of one 
     double c0;                   // the first seed (centred)
     KmLimb limb;
     int faults, scale_e;
-    unsigned arrivals[KM_MAX_TRIALS];   // per trial: prep workgroups that have recorded their sub-block sum (monotonic)
     KmSeedRec rec[2];
 #ifdef KM_DBG_TIMING
     long long dbg[32];
@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
         st->vmax = hi;
         return;
     }
+    // (a sub-block sum is valid when it carries its seed's number, never 0)
+    for (int i = threadIdx.x; i < 2 * KM_MAX_TRIALS * KM_SUB * 3; i += 256) (&st->rec[i / (KM_MAX_TRIALS * KM_SUB * 3)].sub[0][0][0])[i % (KM_MAX_TRIALS * KM_SUB * 3)] = 0;
     if (threadIdx.x != 0) return;
     st->tol = (s / (double)m) * rel_tol;                       // _tolerance: mean(var(X, axis=0)) * tol
     const double mean = st->mean;
@@ -281,7 +283,6 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
     st->limb.sB = ldexp(1.0, 64 - E);
     st->limb.sC = ldexp(1.0, 96 - E);
     st->faults = faults;
-    for (int j = 0; j < KM_MAX_TRIALS; ++j) st->arrivals[j] = 0;
 #ifdef KM_DBG_TIMING
     for (int j = 0; j < 32; ++j) st->dbg[j] = 0;
 #endif
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void km_init_kernel(const double *__restrict__
 }
 
 // sorted order, one workgroup per block of KM_CHUNK positions: closest distances to the first seed, the inverse
-// permutation, and what the gains are later computed from without a pass over the values (km_pick_body): the block's sum
+// permutation, and what the gains are later computed from without a pass over the values (km_pick_tail): the block's sum
 // of closest distances (kept current by km_update_kernel) and its static moments about a reference value mu inside the
 // block -- sum(x - mu), sum((x - mu)^2) -- from which sum((x - c)^2) over the block follows for any c
 struct KmSorted {
@@ -461,142 +462,28 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
     return __ffsll((long long)tied) - 1;
 }
 
-// pick, by the LAST of a trial's sixteen prep workgroups to record its sum: the sub-block whose cumulative sum reaches r
-// (prefix of the sixteen sums), the index inside it (its values gathered once more), then
+// The end of a trial's pick, by the workgroup that holds the chosen index idx (hit_rank = its sorted position when the
+// workgroup already knows it, 0xFFFFFFFF otherwise):
 //  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
 //    only get closer to c than it is to its closest seed if (x - c)^2 - err < (x - s_R)^2 + err, err the rounding error
 //    of the two evaluations of km_sqdist (<= 11 * 2^-53 * max|x|^2 each: three products and two sums of terms <= 4 max|x|^2),
 //    i.e. x < (c + s_R) / 2 + err / (s_R - c);  same on the left.  The range is widened by three times that.
-__device__ void km_pick_body(const double *__restrict__ xs, const double *__restrict__ ds, const uint32_t *__restrict__ rank,
-                             int64_t m, int block_shift, int trial, int blk, i128 R, i128 carry, bool has_newest, double newest,
+//  D: the candidate's gain.
+__device__ void km_pick_tail(const double *__restrict__ xs, const double *__restrict__ ds, const uint32_t *__restrict__ rank,
+                             int64_t m, int trial, int64_t idx, uint32_t hit_rank, bool has_newest, double newest,
                              int n_old, const double *__restrict__ sorted_old, int full_range, int closed, int slow_pick,
                              const KmSorted *__restrict__ sb, KmTop top, const double *s_top2, const double *s_seeds,
-                             KmState *st, KmSeedRec *cur)
+                             double amax, double quanta_per_unit, KmState *st, KmSeedRec *cur)
 {
-    __shared__ u64 s_w_lo[4], s_w_hi[4], s_mine[2], s_cnt4[4];
+    __shared__ u64 s_cnt4[4];
     __shared__ int64_t s_bounds[6];
     __shared__ double s_f[5], s_gred[4];
     __shared__ int s_flags;
-    __shared__ int64_t s_idx, s_o[2];
-    __shared__ double s_dv[8];
-    __shared__ uint32_t s_rk[8], s_hit_rank;
-    __shared__ int s_first;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int64_t idx = m - 1;
-    if (blk >= 0) {                                             // (uniform over the workgroup)
-        const KmLimb L = st->limb;
-        // sub-block: every wavefront repeats the scan of the sixteen sums (written by other workgroups of this launch:
-        // agent-scope atomic stores there, agent-scope atomic loads here)
-        i128 sv = 0;
-        if (lane < KM_SUB)
-            sv = km_join(__hip_atomic_load(&cur->sub[trial][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                         __hip_atomic_load(&cur->sub[trial][lane][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                         __hip_atomic_load(&cur->sub[trial][lane][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const i128 sinc = km_wave_scan128(sv, lane);
-        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
-        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
-        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
-        const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
-        const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
-        const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
-        const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sidx * ssize;
-        const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
-        const int64_t i0 = s0 + (int64_t)tid * per;
-        const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
-        double wa = 0.0, wb = 0.0, wc = 0.0;
-        uint32_t rk0[8];                                        // the first eight stay in registers for the final step
-        double dv0[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t i = i0 + q < i1 ? i0 + q : (i1 > 0 ? i1 - 1 : 0);
-            rk0[q] = rank[i < m ? i : m - 1];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dv0[q] = ds[rk0[q]];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double a, b, cc;
-            km_split(L, i0 + q < i1 ? dv0[q] : 0.0, a, b, cc);
-            wa += a; wb += b; wc += cc;
-        }
-        for (int64_t ib = i0 + 8; ib < i1; ib += 8) {           // (only when m is beyond 2^29)
-            uint32_t rk[8];
-            double dv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double a, b, cc;
-                km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
-                wa += a; wb += b; wc += cc;
-            }
-        }
-        const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
-        const i128 linc = km_wave_scan128(lsum, lane);
-        if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
-        if (tid == 0) { s_first = 256; s_idx = -1; s_hit_rank = 0xFFFFFFFFu; }
-        __syncthreads();
-        i128 wbefore = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            if (w < wave) wbefore += km_make128(s_w_lo[w], s_w_hi[w]);
-        const i128 mine = scarry + wbefore + linc - lsum;          // cumulative sum before this thread's first index
-        if (reach != 0 && mine + lsum >= R) atomicMin(&s_first, tid);
-        __syncthreads();
-        const int owner = s_first;
-        if (owner == 256) {
-            if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
-            __syncthreads();
-        } else if (per <= 8) {
-            // the owner's (at most eight) values through LDS to wavefront 0: one value per lane, inclusive scan, first hit
-            if (tid == owner) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { s_dv[q] = dv0[q]; s_rk[q] = rk0[q]; }
-                s_mine[0] = (u64)mine; s_mine[1] = (u64)(mine >> 64);
-                s_o[0] = i0; s_o[1] = i1;
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const int64_t o0 = s_o[0], o1 = s_o[1];
-                const i128 qv = lane < o1 - o0 ? km_quanta(L, s_dv[lane < 8 ? lane : 0]) : (i128)0;
-                const i128 qinc = km_wave_scan128(qv, lane);
-                const uint64_t ok = __ballot(lane < o1 - o0 && km_make128(s_mine[0], s_mine[1]) + qinc >= R);
-                const int h = ok ? __ffsll((long long)ok) - 1 : (int)(o1 - o0) - 1;
-                if (lane == 0) { s_idx = o0 + h; s_hit_rank = s_rk[h]; }
-            }
-            __syncthreads();
-        } else {
-            if (wave == (owner >> 6)) {
-                // the owner's wavefront walks the owner's indices together
-                const int ol = owner & 63;
-                const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
-                i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
-                int64_t hit = o1 - 1;
-                for (int64_t ib = o0; ib < o1; ib += 64) {
-                    const int64_t i = ib + lane;
-                    const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
-                    const i128 qinc = km_wave_scan128(qv, lane);
-                    const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
-                    if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
-                    run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
-                }
-                if (lane == 0) s_idx = hit;
-            }
-            __syncthreads();
-        }
-        idx = s_idx;
-        if (idx > m - 1) idx = m - 1;
-    } else if (tid == 0) {
-        s_hit_rank = 0xFFFFFFFFu;
-    }
-    __syncthreads();
     // ---- C: neighbours among the seeds (wavefront 0)
     if (wave == 0) {
         KM_TP(6);
-        const uint32_t hr = s_hit_rank;
-        const double cx = xs[hr != 0xFFFFFFFFu ? hr : rank[idx]];
+        const double cx = xs[hit_rank != 0xFFFFFFFFu ? hit_rank : rank[idx]];
         int64_t pl, pr;                                         // pl seeds < cx, pr seeds <= cx
         double sl = 0.0, sr = 0.0;
         if (s_seeds) {                                          // the sorted seeds are in LDS
@@ -618,7 +505,6 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
             if (newest > cx && (!has_r || newest < sr)) { sr = newest; has_r = true; }
         }
         KM_TP(7);
-        const double amax = st->amax;
         const double err = 64.0 * 1.1102230246251565e-16 * amax * amax, slack = 8.0 * 2.220446049250313e-16 * amax;
         const double wl = has_l ? err / (cx - sl) + slack : 0.0, wr = has_r ? err / (sr - cx) + slack : 0.0;
         // range [lo, hi): first value >= tlo .. first value > thi.  The values that CERTAINLY get closer (the same bound,
@@ -690,52 +576,51 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
         }
         const int64_t Bf = Blo + 1 + tid;                       // this thread's first block in between
         KmSorted mid = sb[Bf < Bhi ? Bf : Blo];
-        u64 cnt = 0;                                            // four counts of at most KM_CHUNK, 16 bits each
+        // four counts of at most KM_CHUNK (16 bits each) and the end blocks' part of the gain -- a value at position p is
+        // in [lo, hi) exactly when tlo <= x <= thi -- in one reduction
+        u64 cnt = 0;
+        double g = 0.0;
 #pragma unroll
         for (int u = 0; u < KM_CHUNK / 256; ++u) {
-            if (a0 + u * 256 + tid < a1) cnt += (xa[u] < tlo ? 1ull : 0ull) + (xa[u] <= til ? 1ull << 16 : 0ull);
-            if (b0 + u * 256 + tid < b1) cnt += (xb[u] < tih ? 1ull << 32 : 0ull) + (xb[u] <= thi ? 1ull << 48 : 0ull);
+            if (a0 + u * 256 + tid < a1) {
+                cnt += (xa[u] < tlo ? 1ull : 0ull) + (xa[u] <= til ? 1ull << 16 : 0ull);
+                const double dj = km_sqdist(c, csq, xa[u]);
+                g += (xa[u] >= tlo && xa[u] <= thi && dj < da[u]) ? da[u] - dj : 0.0;
+            }
+            if (b0 + u * 256 + tid < b1) {
+                cnt += (xb[u] < tih ? 1ull << 32 : 0ull) + (xb[u] <= thi ? 1ull << 48 : 0ull);
+                if (!same) {
+                    const double dj = km_sqdist(c, csq, xb[u]);
+                    g += (xb[u] <= thi && dj < db[u]) ? db[u] - dj : 0.0;
+                }
+            }
+        }
+        for (int64_t B = Bf; B < Bhi; B += 256) {              // (dropped below when the band leaves an end block)
+            if (B != Bf) mid = sb[B];
+            const double t = mid.mu - c;
+            g += mid.sd - (mid.s2 + 2.0 * t * mid.s1 + (double)KM_CHUNK * t * t);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (lane == 0) s_cnt4[wave] = cnt;
+        for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_xor(cnt, off, 64); g += __shfl_xor(g, off, 64); }
+        if (lane == 0) { s_cnt4[wave] = cnt; s_gred[wave] = g; }
         __syncthreads();
         cnt = s_cnt4[0] + s_cnt4[1] + s_cnt4[2] + s_cnt4[3];
+        g = ((s_gred[0] + s_gred[1]) + s_gred[2]) + s_gred[3];
         const int64_t lo = a0 + (int64_t)(cnt & 0xFFFF), ilo = a0 + (int64_t)((cnt >> 16) & 0xFFFF);
         const int64_t ihi = b0 + (int64_t)((cnt >> 32) & 0xFFFF), hi = b0 + (int64_t)(cnt >> 48);
         // blocks in between are only summed in closed form when all their values certainly get closer: always, unless the
         // band where that is undecided reaches out of an end block (neighbouring seeds a rounding error apart)
         if (Bhi > Blo + 1 && (ilo > a1 - 1 || ihi <= b0)) {
             slow = true;
+            __syncthreads();                                    // (s_gred is used again)
         } else {
-            double g = 0.0;
-#pragma unroll
-            for (int u = 0; u < KM_CHUNK / 256; ++u) {
-                const int64_t p = a0 + u * 256 + tid;
-                const double dj = km_sqdist(c, csq, xa[u]);
-                g += (p >= lo && p < hi && p < a1 && dj < da[u]) ? da[u] - dj : 0.0;
-            }
-            if (!same) {
-#pragma unroll
-                for (int u = 0; u < KM_CHUNK / 256; ++u) {
-                    const int64_t p = b0 + u * 256 + tid;
-                    const double dj = km_sqdist(c, csq, xb[u]);
-                    g += (p < hi && p < b1 && dj < db[u]) ? db[u] - dj : 0.0;
-                }
-            }
-            for (int64_t B = Bf; B < Bhi; B += 256) {
-                if (B != Bf) mid = sb[B];
-                const double t = mid.mu - c;
-                g += mid.sd - (mid.s2 + 2.0 * t * mid.s1 + (double)KM_CHUNK * t * t);
-            }
-            g = km_block_sum(g, s_gred);
             KM_TP(9);
             if (tid == 0) {
                 cur->cand_x[trial] = c;
                 cur->cand_id[trial] = idx;
                 cur->cand_lo[trial] = lo;
                 cur->cand_hi[trial] = hi;
-                cur->gain_d[trial] = g * st->limb.sC;           // in the quanta of the exact sums (a power of two)
+                cur->gain_d[trial] = g * quanta_per_unit;       // in the quanta of the exact sums (a power of two)
             }
             return;
         }
@@ -797,13 +682,16 @@ __device__ void km_pick_body(const double *__restrict__ xs, const double *__rest
             g += o.sd - (o.s2 + 2.0 * t * o.s1 + (double)KM_CHUNK * t * t);
         }
         g = km_block_sum(g, s_gred);
-        if (tid == 0) cur->gain_d[trial] = g * st->limb.sC;
+        if (tid == 0) cur->gain_d[trial] = g * quanta_per_unit;
     }
 }
 
 // The pick of seed `seed_no`: KM_SUB workgroups per trial -- one workgroup gathers ~330 scattered values per microsecond,
-// so the walk of an index block (16 384 indices at 30 M values) is spread over sixteen; the last of them to record its
-// sum (an arrival counter per trial, no waiting) finishes the trial (km_pick_body).
+// so the walk of an index block (16 384 indices at 30 M values) is spread over sixteen.  Each publishes the sum of its
+// sixteenth tagged with the seed's number and reads the sixteen sums of its trial until all carry the tag (the 16 x n_trials
+// workgroups of a launch are far fewer than the GPU holds at once: nobody waits for a workgroup that cannot start; the
+// wait is bounded all the same and reports a fault).  The one whose sixteenth holds the trial's r continues with the
+// values it gathered still in registers (km_pick_tail); the others leave.
 // Every workgroup (the common part is cheap and repeated):
 //  A (choose_prev): the winner among the previous seed's candidates becomes seed seed_no - 1; the first workgroup records
 //    it and writes the sorted list of seeds with it inserted into the other buffer.
@@ -818,12 +706,16 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                                       const KmSorted *__restrict__ sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
                                                       int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
-    __shared__ int s_last;
     __shared__ double s_top2[KM_TOP2], s_seeds[KM_SEEDS_LDS];
+    __shared__ u64 s_mine[2];
+    __shared__ int64_t s_idx, s_o[2];
+    __shared__ double s_dv[8];
+    __shared__ uint32_t s_rk[8], s_hit_rank;
+    __shared__ int s_first, s_sidx, s_reach;
     __shared__ double s_newest;
     __shared__ i64 s_newid;
     __shared__ u64 s_w_lo[4], s_w_hi[4], s_carry[2], s_expect[2];
-    __shared__ double s_red[4], s_expect_d;
+    __shared__ double s_expect_d;
     __shared__ int s_cnt[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int sub = blockIdx.x, trial = blockIdx.y;
@@ -838,6 +730,10 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     i128 inc8[KM_MAX_BLOCKS / 256];
     i128 loc = 0;
     const bool seeds_in_lds = n_old <= KM_SEEDS_LDS;
+    // (scalars of the later steps: loaded now, not in the middle of the chain)
+    const double u_trial = do_pick ? uniform[trial] : 0.0;
+    const KmLimb L = st->limb;
+    const double amax = st->amax;
     if (do_pick) {
         // (what the end of the pick searches, into LDS now: used after several barriers)
         if (closed && !slow_pick)
@@ -905,7 +801,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     }
     before += winc - loc;                                       // cumulative sum before this thread's first block
     KM_T(2);
-    const double r = uniform[trial] * km_to_double(total);
+    const double r = u_trial * km_to_double(total);
     const i128 R = km_ceil128(r);
     // the block: number of blocks whose inclusive cumulative sum is < R (they are non-decreasing)
     int below = 0;
@@ -939,13 +835,13 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
         if (tid < 3 * KM_MAX_TRIALS) cur->gain[tid / KM_MAX_TRIALS][tid % KM_MAX_TRIALS] = 0;
     }
     const i128 carry = km_make128(s_carry[0], s_carry[1]);
+    const double *seeds_lds = seeds_in_lds ? s_seeds : nullptr;
     if (clipped) {                                              // the last index, whatever the block holds
-        if (sub == 0) km_pick_body(xs, ds, rank, m, block_shift, trial, -1, R, carry, choose_prev != 0, newest, n_old, sorted_old,
-                                   full_range, closed, slow_pick, sb, top, s_top2, seeds_in_lds ? s_seeds : nullptr, st, cur);
+        if (sub == 0) km_pick_tail(xs, ds, rank, m, trial, m - 1, 0xFFFFFFFFu, choose_prev != 0, newest, n_old, sorted_old, full_range,
+                                   closed, slow_pick, sb, top, s_top2, seeds_lds, amax, L.sC, st, cur);
         return;
     }
     // ---- this workgroup's sixteenth of the block
-    const KmLimb L = st->limb;
     const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
     const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
     const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
@@ -954,7 +850,22 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     const int64_t i0 = s0 + (int64_t)tid * per;
     const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
     double wa = 0.0, wb = 0.0, wc = 0.0;                         // limb sums of this thread's values: exact
-    for (int64_t ib = i0; ib < i1; ib += 8) {                   // ranks first, then the distances they point at
+    uint32_t rk0[8];                                            // the first eight stay in registers for the last step
+    double dv0[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                               // ranks first, then the distances they point at
+        const int64_t i = i0 + q < i1 ? i0 + q : (i1 > 0 ? i1 - 1 : 0);
+        rk0[q] = rank[i < m ? i : m - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dv0[q] = ds[rk0[q]];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        double a, b, cc;
+        km_split(L, i0 + q < i1 ? dv0[q] : 0.0, a, b, cc);
+        wa += a; wb += b; wc += cc;
+    }
+    for (int64_t ib = i0 + 8; ib < i1; ib += 8) {               // (only when m is beyond 2^29)
         uint32_t rk[8];
         double dv[8];
 #pragma unroll
@@ -969,22 +880,102 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
         }
     }
     KM_T(4);
-    wa = km_block_sum(wa, s_red);
-    wb = km_block_sum(wb, s_red);
-    wc = km_block_sum(wc, s_red);
-    if (tid == 0) {
-        __hip_atomic_store(&cur->sub[trial][sub][0], __double2ll_rn(wa * L.sA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&cur->sub[trial][sub][1], __double2ll_rn(wb * L.sB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&cur->sub[trial][sub][2], __double2ll_rn(wc * L.sC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the sums have left before the arrival is counted
-        const unsigned ticket = __hip_atomic_fetch_add(&st->arrivals[trial], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket % KM_SUB) == KM_SUB - 1;
+    // prefix over the threads (wavefront scan, then the four wavefront totals), total of the workgroup
+    const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
+    const i128 linc = km_wave_scan128(lsum, lane);
+    if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
+    if (tid == 0) { s_first = 256; s_idx = -1; s_hit_rank = 0xFFFFFFFFu; }
+    __syncthreads();
+    i128 wbefore = 0, wtotal = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const i128 wt = km_make128(s_w_lo[w], s_w_hi[w]);
+        if (w < wave) wbefore += wt;
+        wtotal += wt;
+    }
+    // publish: three words of 48 bits under the seed's number (a sum is below 2^112 quanta)
+    const u64 mask48 = (1ull << 48) - 1, tag = (u64)(seed_no & 0xFFFF);
+    if (wave == 0) {
+        u64 *words = reinterpret_cast<u64 *>(&cur->sub[trial][0][0]);
+        if (lane == 0) {
+            __hip_atomic_store(words + 3 * sub, ((u64)wtotal & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + 3 * sub + 1, ((u64)(wtotal >> 48) & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + 3 * sub + 2, ((u64)(wtotal >> 96) & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the sixteen sums of the trial: lane e reads word e until every word carries the tag
+        const int e = lane < 3 * KM_SUB ? lane : 0;
+        u64 w = 0;
+        int spins = 0;
+        for (;;) {
+            w = __hip_atomic_load(words + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot((w >> 48) != tag) == 0) break;
+            if (++spins >= KM_SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const u64 pay = w & mask48;
+        const int src = lane < KM_SUB ? 3 * lane : 0;
+        const u64 p0 = __shfl(pay, src, 64), p1 = __shfl(pay, src + 1, 64), p2 = __shfl(pay, src + 2, 64);
+        const i128 sv = lane < KM_SUB ? (i128)p0 + ((i128)p1 << 48) + ((i128)p2 << 96) : (i128)0;
+        const i128 sinc = km_wave_scan128(sv, lane);
+        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
+        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
+        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
+        if (lane == 0) {
+            if (spins >= KM_SPIN_LIMIT) { atomicOr(&st->faults, 16); s_sidx = -1; }
+            else s_sidx = sidx;
+            s_reach = reach != 0;
+            s_carry[0] = (u64)scarry; s_carry[1] = (u64)(scarry >> 64);
+        }
     }
     __syncthreads();
     KM_T(5);
-    if (!s_last) return;
-    km_pick_body(xs, ds, rank, m, block_shift, trial, blk, R, carry, choose_prev != 0, newest, n_old, sorted_old, full_range, closed,
-                 slow_pick, sb, top, s_top2, seeds_in_lds ? s_seeds : nullptr, st, cur);
+    if (sub != s_sidx) return;
+    // ---- this workgroup's sixteenth holds the index: the thread, then the value
+    KM_TP(5);
+    const i128 mine = km_make128(s_carry[0], s_carry[1]) + wbefore + linc - lsum;   // cumulative sum before this thread's first index
+    if (s_reach && mine + lsum >= R) atomicMin(&s_first, tid);
+    __syncthreads();
+    const int owner = s_first;
+    if (owner == 256) {
+        if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
+    } else if (per <= 8) {
+        // the owner's (at most eight) values through LDS to wavefront 0: one value per lane, inclusive scan, first hit
+        if (tid == owner) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s_dv[q] = dv0[q]; s_rk[q] = rk0[q]; }
+            s_mine[0] = (u64)mine; s_mine[1] = (u64)(mine >> 64);
+            s_o[0] = i0; s_o[1] = i1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int64_t o0 = s_o[0], o1 = s_o[1];
+            const i128 qv = lane < o1 - o0 ? km_quanta(L, s_dv[lane < 8 ? lane : 0]) : (i128)0;
+            const i128 qinc = km_wave_scan128(qv, lane);
+            const uint64_t ok = __ballot(lane < o1 - o0 && km_make128(s_mine[0], s_mine[1]) + qinc >= R);
+            const int h = ok ? __ffsll((long long)ok) - 1 : (int)(o1 - o0) - 1;
+            if (lane == 0) { s_idx = o0 + h; s_hit_rank = s_rk[h]; }
+        }
+    } else if (wave == (owner >> 6)) {
+        // the owner's wavefront walks the owner's indices together
+        const int ol = owner & 63;
+        const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
+        i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
+        int64_t hit = o1 - 1;
+        for (int64_t ib = o0; ib < o1; ib += 64) {
+            const int64_t i = ib + lane;
+            const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
+            const i128 qinc = km_wave_scan128(qv, lane);
+            const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
+            if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
+            run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
+        }
+        if (lane == 0) s_idx = hit;
+    }
+    __syncthreads();
+    int64_t idx = s_idx;
+    if (idx > m - 1) idx = m - 1;
+    km_pick_tail(xs, ds, rank, m, trial, idx, s_hit_rank, choose_prev != 0, newest, n_old, sorted_old, full_range, closed, slow_pick,
+                 sb, top, s_top2, seeds_lds, amax, L.sC, st, cur);
 }
 
 // union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
@@ -1811,7 +1802,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                                                                                           k, state, seeds_x, seeds_id);
     } else if (k > 1) {
         // GRX_KMEANS_GAIN_PASS=1 (and the full ranges): every candidate's gain by a pass over its range in exact integer
-        // arithmetic (km_gain_kernel) instead of the closed form over sorted blocks inside the pick (km_pick_body, D):
+        // arithmetic (km_gain_kernel) instead of the closed form over sorted blocks inside the pick (km_pick_tail, D):
         // same seeds unless two potentials agree to 1e-12 (tests/test_gpu_encode.py compares the modes)
         static const int gain_pass = [] { const char *e = std::getenv("GRX_KMEANS_GAIN_PASS"); return (e && *e == '1') ? 1 : 0; }();
         const int closed = (full_range || gain_pass) ? 0 : 1;
