@@ -1155,6 +1155,9 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     const KmSeedRec *rec = &st->rec[seed_no & 1];
     KM_TG(15);
     const KmLimb L = st->limb;
+    // (wavefronts 1-3 clear the LDS sums while wavefront 0 waits for the candidates' records)
+    if (threadIdx.x >= 64)
+        for (int i = threadIdx.x - 64; i < 3 * nblocks; i += 192) s_acc[i] = 0;
     if (threadIdx.x < 64) {
         // (every candidate's range and value ride along with the gains: one round trip to memory, not two)
         const int lane = threadIdx.x;
@@ -1176,8 +1179,6 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     // (straight atomics to the block sums for workgroups with a single chunk -- no clearing and scanning of 3 * nblocks
     // LDS words -- were measured SLOWER: 30 M values / 512 levels 32.5 -> 37.0 ms; a chunk's 2048 values share blocks
     // often enough for the LDS stage to save global atomics, which run at 23 G/s whatever their addresses)
-    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) s_acc[i] = 0;
-    __syncthreads();
     KM_TG(17);
     const double c = s_c, csq = __dmul_rn(c, c);
     for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
@@ -1818,7 +1819,8 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         top.n2 = (int)grx_ceil_div(max_chunks, top.s2);
         km_sorted_init_kernel<<<(int)max_chunks, 256, 0, st>>>(xs, perm, m, state, ds, rank, sb, top);
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
-        const int update_grid = (int)(max_chunks < KM_UPDATE_GRID ? max_chunks : KM_UPDATE_GRID);
+        static const int update_grid_max = [] { const char *e = std::getenv("GRX_KMEANS_UPDATE_GRID"); return e ? atoi(e) : KM_UPDATE_GRID; }();
+        const int update_grid = (int)(max_chunks < update_grid_max ? max_chunks : update_grid_max);
         for (int c = 1; c < k; ++c) {
             km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
