@@ -71,6 +71,7 @@ constexpr int KM_CHUNK = 2048;                // sorted positions per workgroup 
 constexpr int KM_RANGE_GRID = 512;            // workgroups of the gain kernel
 constexpr int KM_UPDATE_GRID = 512;           // ... of the update kernel (each flushes its block sums once)
 constexpr int KM_E_MIN = -900, KM_E_MAX = 960;
+constexpr int KM_UPDATE_THREADS = 1024;  // km_update_kernel: four chunks in flight per workgroup
 constexpr int KM_SPIN_LIMIT = 1 << 18;   // reads of a trial's sums before the pick gives up (a fraction of a second)
 constexpr int KM_TOP2 = 1024;            // LDS level of the search over the sorted values
 constexpr int KM_SEEDS_LDS = 2048;       // sorted seeds the pick keeps in LDS (more: searched in memory)
@@ -755,6 +756,9 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     }
     double newest = 0.0;                                        // the seed chosen here, not yet in sorted_old
     KM_T(0);
+#ifdef KM_DBG_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && seed_no == KM_DBG_TIMING + 1) st->dbg[20] = wall_clock64();
+#endif
     if (choose_prev) {
         if (wave == 0) {
             // (the candidate values ride along with the gains: one round trip to memory instead of two)
@@ -1144,20 +1148,25 @@ __global__ __launch_bounds__(256) void km_gain_kernel(const double *__restrict__
 // the sums of the INDEX blocks they belong to: collected per workgroup in LDS (integer limbs, any order), then added
 // to the block sums with integer atomics -- a straight atomic per value runs at 23 G atomics/s on MI355X
 // (tools/microbench/atomic_scatter.hip: 3.9 ms for the three limbs of 30 M values against 0.11 ms for the pass itself).
-__global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict__ xs, double *__restrict__ ds,
+__global__ __launch_bounds__(KM_UPDATE_THREADS) void km_update_kernel(const double *__restrict__ xs, double *__restrict__ ds,
                                                         const uint32_t *__restrict__ perm, i64 *__restrict__ bacc,
                                                         int nblocks, int block_shift, int64_t m, KmSorted *__restrict__ sb,
                                                         const KmState *__restrict__ st, int seed_no, int n_trials, int closed)
 {
+    // KM_UPDATE_THREADS / 256 groups of 256 threads, one chunk each at a time, ONE set of LDS sums: what a workgroup adds to
+    // the index-block sums at the end is up to 3 * nblocks atomics whatever it processed (a chunk's 2048 values already
+    // touch two thirds of 2048 blocks), so more chunks in flight per workgroup, not more workgroups
+    constexpr int GROUPS = KM_UPDATE_THREADS / 256;
     __shared__ u64 s_acc[3 * KM_MAX_BLOCKS];
     __shared__ int64_t s_lo, s_hi;
-    __shared__ double s_c, s_red[4];
+    __shared__ double s_c, s_red[2][GROUPS * 4];
     const KmSeedRec *rec = &st->rec[seed_no & 1];
+    const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
     KM_TG(15);
     const KmLimb L = st->limb;
-    // (wavefronts 1-3 clear the LDS sums while wavefront 0 waits for the candidates' records)
+    // (the other wavefronts clear the LDS sums while wavefront 0 waits for the candidates' records)
     if (threadIdx.x >= 64)
-        for (int i = threadIdx.x - 64; i < 3 * nblocks; i += 192) s_acc[i] = 0;
+        for (int i = threadIdx.x - 64; i < 3 * nblocks; i += KM_UPDATE_THREADS - 64) s_acc[i] = 0;
     if (threadIdx.x < 64) {
         // (every candidate's range and value ride along with the gains: one round trip to memory, not two)
         const int lane = threadIdx.x;
@@ -1175,55 +1184,68 @@ __global__ __launch_bounds__(256) void km_update_kernel(const double *__restrict
     // one chunk = one block of KM_CHUNK sorted positions (whole: its sum of closest distances is rewritten)
     const int64_t first = lo / KM_CHUNK;
     const int64_t chunks = hi > lo ? (hi - 1) / KM_CHUNK - first + 1 : 0;
-    if ((int64_t)blockIdx.x >= chunks) return;
+    int64_t share = (chunks + GROUPS - 1) / GROUPS;             // workgroups that take part
+    if (share > (int64_t)gridDim.x) share = gridDim.x;
+    if ((int64_t)blockIdx.x >= share) return;
     // (straight atomics to the block sums for workgroups with a single chunk -- no clearing and scanning of 3 * nblocks
     // LDS words -- were measured SLOWER: 30 M values / 512 levels 32.5 -> 37.0 ms; a chunk's 2048 values share blocks
     // often enough for the LDS stage to save global atomics, which run at 23 G/s whatever their addresses)
     KM_TG(17);
     const double c = s_c, csq = __dmul_rn(c, c);
-    for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const int64_t p0 = (first + ch) * KM_CHUNK;
+    const int64_t rounds = (chunks + share * GROUPS - 1) / (share * GROUPS);
+    for (int64_t it = 0; it < rounds; ++it) {
+        const int64_t ch = (it * share + blockIdx.x) * GROUPS + grp;
+        const bool active = ch < chunks;
+        const int64_t p0 = (first + (active ? ch : 0)) * KM_CHUNK;
         const int64_t p1 = p0 + KM_CHUNK < m ? p0 + KM_CHUNK : m;
-        double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
-        uint32_t iv[KM_CHUNK / 256];
-#pragma unroll
-        for (int u = 0; u < KM_CHUNK / 256; ++u) {
-            const int64_t p = p0 + u * 256 + threadIdx.x;
-            const int64_t q = p < p1 ? p : p1 - 1;
-            xv[u] = xs[q];
-            dv[u] = ds[q];
-            iv[u] = perm[q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
         double left = 0.0;                                      // what stays: the block's new sum
+        if (active) {
+            double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
+            uint32_t iv[KM_CHUNK / 256];
 #pragma unroll
-        for (int u = 0; u < KM_CHUNK / 256; ++u) {
-            const int64_t p = p0 + u * 256 + threadIdx.x;
-            if (p >= p1) continue;
-            const double d = dv[u];
-            const double dj = km_sqdist(c, csq, xv[u]);
-            if (p >= lo && p < hi && dj < d) {
-                ds[p] = dj;
-                left += dj;
-                double a, b, cc, aj, bj, cj;
-                km_split(L, d, a, b, cc);
-                km_split(L, dj, aj, bj, cj);
-                const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
-                          uc = -__double2ll_rn((cc - cj) * L.sC);
-                const int blk = (int)(iv[u] >> block_shift);
-                if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
-                if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
-                if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
-            } else {
-                left += d;
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = p0 + u * 256 + t;
+                const int64_t q = p < p1 ? p : p1 - 1;
+                xv[u] = xs[q];
+                dv[u] = ds[q];
+                iv[u] = perm[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = p0 + u * 256 + t;
+                if (p >= p1) continue;
+                const double d = dv[u];
+                const double dj = km_sqdist(c, csq, xv[u]);
+                if (p >= lo && p < hi && dj < d) {
+                    ds[p] = dj;
+                    left += dj;
+                    double a, b, cc, aj, bj, cj;
+                    km_split(L, d, a, b, cc);
+                    km_split(L, dj, aj, bj, cj);
+                    const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
+                              uc = -__double2ll_rn((cc - cj) * L.sC);
+                    const int blk = (int)(iv[u] >> block_shift);
+                    if (ua) atomicAdd(&s_acc[3 * blk], (u64)ua);
+                    if (ub) atomicAdd(&s_acc[3 * blk + 1], (u64)ub);
+                    if (uc) atomicAdd(&s_acc[3 * blk + 2], (u64)uc);
+                } else {
+                    left += d;
+                }
             }
         }
-        left = km_block_sum(left, s_red);
-        if (threadIdx.x == 0) sb[first + ch].sd = left;
+        // the group's sum in a fixed shape: wavefront butterflies, then its four wavefront totals in order
+        left = grx_group_sum<64>(left);
+        if ((threadIdx.x & 63) == 0) s_red[it & 1][threadIdx.x >> 6] = left;
+        __syncthreads();
+        if (t == 0 && active) {
+            const double *r4 = &s_red[it & 1][grp * 4];
+            sb[first + ch].sd = ((r4[0] + r4[1]) + r4[2]) + r4[3];
+        }
     }
     __syncthreads();
     KM_TG(18);
-    for (int i = threadIdx.x; i < 3 * nblocks; i += 256) {
+    for (int i = threadIdx.x; i < 3 * nblocks; i += KM_UPDATE_THREADS) {
         const u64 v = s_acc[i];
         if (v) atomicAdd(reinterpret_cast<u64 *>(bacc) + 4 * (i / 3) + i % 3, v);
     }
@@ -1619,7 +1641,8 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
 #ifdef KM_DBG_TIMING
         for (int q = 1; q < 10; ++q) printf("prep phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
         printf("prep end -> update start: %lld ns\n", (st->dbg[15] - st->dbg[9]) * 10);
-        for (int q = 16; q < 20; ++q) printf("update phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+        for (int q = 16; q < 21; ++q) printf("update phase %d: %lld ns\n", q, (st->dbg[q] - st->dbg[q - 1]) * 10);
+        printf("seed to seed: %lld ns\n", (st->dbg[20] - st->dbg[0]) * 10);
 #endif
     }
 }
@@ -1831,8 +1854,8 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                 else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             }
             if (c < k - 1)                                         // the distances to the last seed are never needed
-                km_update_kernel<<<update_grid, 256, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, m, sb, state, c,
-                                                              n_trials, closed);
+                km_update_kernel<<<update_grid, KM_UPDATE_THREADS, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, m, sb, state,
+                                                                            c, n_trials, closed);
         }
         km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
                                                    full_range, closed, slow_pick, sb, top, state, seeds_x, seeds_id, sorted2,
