@@ -97,6 +97,7 @@ struct KmSeedRec {
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
     i64 sub[KM_MAX_TRIALS][KM_SUB][3];   // km_prep_kernel: limb sums of the sub-blocks of the block each trial's r falls in
     double gain_d[KM_MAX_TRIALS];        // gains from the sorted-block sums (km_pick_tail), when no gain pass runs
+    u64 done[KM_MAX_TRIALS];             // = seed number once the trial's candidate is recorded (update inside the pick kernel)
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void km_moment_final_kernel(const double *__re
         return;
     }
     // (a sub-block sum is valid when it carries its seed's number, never 0)
-    for (int i = threadIdx.x; i < 2 * KM_MAX_TRIALS * KM_SUB * 3; i += 256) (&st->rec[i / (KM_MAX_TRIALS * KM_SUB * 3)].sub[0][0][0])[i % (KM_MAX_TRIALS * KM_SUB * 3)] = 0;
+    for (int i = threadIdx.x; i < (int)(2 * sizeof(KmSeedRec) / 8); i += 256) reinterpret_cast<u64 *>(&st->rec[0])[i] = 0;
     if (threadIdx.x != 0) return;
     st->tol = (s / (double)m) * rel_tol;                       // _tolerance: mean(var(X, axis=0)) * tol
     const double mean = st->mean;
@@ -444,7 +445,20 @@ __device__ __forceinline__ void km_dual_search(const double *__restrict__ a, int
     out_hi = __shfl(lo, 32, 64);
 }
 
-// argmin by one wavefront (lane j = candidate j): same rule as km_best
+// argmin by one wavefront (lane j = candidate j, pd its potential; lanes >= n_trials are ignored): same rule as km_best
+__device__ __forceinline__ int km_best_of(double pd, int n_trials, int lane)
+{
+    if (lane >= n_trials) pd = 1.79769313486231570e308;
+    double lowest = pd;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(lowest, off, 64);
+        lowest = o < lowest ? o : lowest;
+    }
+    const uint64_t tied = __ballot(lane < n_trials && !(pd > lowest + 1e-12 * lowest));
+    return __ffsll((long long)tied) - 1;
+}
+
 __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, int lane, int closed)
 {
     double pd = 1.79769313486231570e308;
@@ -463,6 +477,28 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
     return __ffsll((long long)tied) - 1;
 }
 
+// a trial's candidate into the seed's record.  merge_tag != 0: workgroups of THIS launch read it (the update inside the
+// pick kernel): stores that go to memory, and the trial's tag once they have left
+__device__ __forceinline__ void km_publish(KmSeedRec *cur, int trial, double c, int64_t idx, int64_t lo, int64_t hi, double gain,
+                                           u64 merge_tag)
+{
+    if (!merge_tag) {
+        cur->cand_x[trial] = c;
+        cur->cand_id[trial] = idx;
+        cur->cand_lo[trial] = lo;
+        cur->cand_hi[trial] = hi;
+        cur->gain_d[trial] = gain;
+        return;
+    }
+    __hip_atomic_store(&cur->cand_x[trial], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&cur->cand_id[trial], (i64)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&cur->cand_lo[trial], (i64)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&cur->cand_hi[trial], (i64)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&cur->gain_d[trial], gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&cur->done[trial], merge_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The end of a trial's pick, by the workgroup that holds the chosen index idx (hit_rank = its sorted position when the
 // workgroup already knows it, 0xFFFFFFFF otherwise):
 //  C: the candidate's neighbours s_L < c < s_R among the seeds and its range of sorted positions.  A value x > c can
@@ -474,7 +510,7 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
                              int64_t m, int trial, int64_t idx, uint32_t hit_rank, bool has_newest, double newest,
                              int n_old, const double *__restrict__ sorted_old, int full_range, int closed, int slow_pick,
                              const KmSorted *__restrict__ sb, KmTop top, const double *s_top2, const double *s_seeds,
-                             double amax, double quanta_per_unit, KmState *st, KmSeedRec *cur)
+                             double amax, double quanta_per_unit, u64 merge_tag, KmState *st, KmSeedRec *cur)
 {
     __shared__ u64 s_cnt4[4];
     __shared__ int64_t s_bounds[6];
@@ -616,13 +652,8 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
             __syncthreads();                                    // (s_gred is used again)
         } else {
             KM_TP(9);
-            if (tid == 0) {
-                cur->cand_x[trial] = c;
-                cur->cand_id[trial] = idx;
-                cur->cand_lo[trial] = lo;
-                cur->cand_hi[trial] = hi;
-                cur->gain_d[trial] = g * quanta_per_unit;       // in the quanta of the exact sums (a power of two)
-            }
+            // (the gain in the quanta of the exact sums: a power of two)
+            if (tid == 0) km_publish(cur, trial, c, idx, lo, hi, g * quanta_per_unit, merge_tag);
             return;
         }
     }
@@ -641,10 +672,7 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
             if (ilo > ihi) ilo = ihi;
         }
         if (lane == 0) {
-            cur->cand_x[trial] = c;
-            cur->cand_id[trial] = idx;
-            cur->cand_lo[trial] = lo;
-            cur->cand_hi[trial] = hi;
+            if (!closed) km_publish(cur, trial, c, idx, lo, hi, 0.0, 0);
             s_bounds[0] = lo; s_bounds[1] = hi; s_bounds[2] = ilo; s_bounds[3] = ihi;
         }
     }
@@ -683,7 +711,7 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
             g += o.sd - (o.s2 + 2.0 * t * o.s1 + (double)KM_CHUNK * t * t);
         }
         g = km_block_sum(g, s_gred);
-        if (tid == 0) cur->gain_d[trial] = g * quanta_per_unit;
+        if (tid == 0) km_publish(cur, trial, c, idx, lo, hi, g * quanta_per_unit, merge_tag);
     }
 }
 
@@ -699,15 +727,22 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
 //  B (do_pick): inclusive prefix of the index-block sums = sklearn's cumulative sum at block ends; total = the potential.
 //    The trial's r = uniform * potential lies in the first block whose cumulative sum reaches it (np.searchsorted, left);
 //    workgroup `sub` gathers the closest distances of its sixteenth of that block (through rank) and records their sum.
-__global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__ xs, const double *__restrict__ ds,
-                                                      const uint32_t *__restrict__ rank, int64_t m,
-                                                      const i64 *__restrict__ bacc, int nblocks, int block_shift,
+//  C (merge): the update of the closest distances with the seed chosen among this launch's candidates, by all the
+//    workgroups once every trial is recorded -- for the seeds whose ranges are short enough for 16 x n_trials workgroups
+//    (the host decides by the seed's number); km_update_kernel otherwise.
+__global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__ xs, double *ds,
+                                                      const uint32_t *__restrict__ rank, const uint32_t *__restrict__ perm, int64_t m,
+                                                      i64 *bacc, int nblocks, int block_shift,
                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
-                                                      int choose_prev, int do_pick, int full_range, int closed, int slow_pick,
-                                                      const KmSorted *__restrict__ sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
+                                                      int choose_prev, int do_pick, int full_range, int closed, int slow_pick, int merge,
+                                                      KmSorted *sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
                                                       int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
-    __shared__ double s_top2[KM_TOP2], s_seeds[KM_SEEDS_LDS];
+    // (the LDS of the searches -- top level of the sorted values, sorted seeds -- later holds the update's block sums)
+    __shared__ u64 s_big[3 * KM_MAX_BLOCKS];
+    double *s_top2 = reinterpret_cast<double *>(s_big), *s_seeds = s_top2 + KM_TOP2;
+    __shared__ int64_t s_ulo, s_uhi;
+    __shared__ double s_uc, s_ured[4];
     __shared__ u64 s_mine[2];
     __shared__ int64_t s_idx, s_o[2];
     __shared__ double s_dv[8];
@@ -840,146 +875,231 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     }
     const i128 carry = km_make128(s_carry[0], s_carry[1]);
     const double *seeds_lds = seeds_in_lds ? s_seeds : nullptr;
+    const u64 merge_tag = merge ? (u64)seed_no : 0;
     if (clipped) {                                              // the last index, whatever the block holds
         if (sub == 0) km_pick_tail(xs, ds, rank, m, trial, m - 1, 0xFFFFFFFFu, choose_prev != 0, newest, n_old, sorted_old, full_range,
-                                   closed, slow_pick, sb, top, s_top2, seeds_lds, amax, L.sC, st, cur);
-        return;
-    }
-    // ---- this workgroup's sixteenth of the block
-    const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
-    const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
-    const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
-    const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sub * ssize;
-    const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
-    const int64_t i0 = s0 + (int64_t)tid * per;
-    const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
-    double wa = 0.0, wb = 0.0, wc = 0.0;                         // limb sums of this thread's values: exact
-    uint32_t rk0[8];                                            // the first eight stay in registers for the last step
-    double dv0[8];
+                                   closed, slow_pick, sb, top, s_top2, seeds_lds, amax, L.sC, merge_tag, st, cur);
+    } else {
+        // ---- this workgroup's sixteenth of the block
+        const int64_t bsize = (int64_t)1 << block_shift, ssize = bsize / KM_SUB;
+        const int64_t per = ssize >= 256 ? ssize >> 8 : 1;
+        const int64_t bend = (((int64_t)blk + 1) << block_shift) < m ? (((int64_t)blk + 1) << block_shift) : m;
+        const int64_t s0 = ((int64_t)blk << block_shift) + (int64_t)sub * ssize;
+        const int64_t s1 = s0 + ssize < bend ? s0 + ssize : bend;
+        const int64_t i0 = s0 + (int64_t)tid * per;
+        const int64_t i1 = i0 + per < s1 ? i0 + per : s1;
+        double wa = 0.0, wb = 0.0, wc = 0.0;                     // limb sums of this thread's values: exact
+        uint32_t rk0[8];                                        // the first eight stay in registers for the last step
+        double dv0[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                               // ranks first, then the distances they point at
-        const int64_t i = i0 + q < i1 ? i0 + q : (i1 > 0 ? i1 - 1 : 0);
-        rk0[q] = rank[i < m ? i : m - 1];
-    }
+        for (int q = 0; q < 8; ++q) {                           // ranks first, then the distances they point at
+            const int64_t i = i0 + q < i1 ? i0 + q : (i1 > 0 ? i1 - 1 : 0);
+            rk0[q] = rank[i < m ? i : m - 1];
+        }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dv0[q] = ds[rk0[q]];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        double a, b, cc;
-        km_split(L, i0 + q < i1 ? dv0[q] : 0.0, a, b, cc);
-        wa += a; wb += b; wc += cc;
-    }
-    for (int64_t ib = i0 + 8; ib < i1; ib += 8) {               // (only when m is beyond 2^29)
-        uint32_t rk[8];
-        double dv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
+        for (int q = 0; q < 8; ++q) dv0[q] = ds[rk0[q]];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             double a, b, cc;
-            km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
+            km_split(L, i0 + q < i1 ? dv0[q] : 0.0, a, b, cc);
             wa += a; wb += b; wc += cc;
         }
-    }
-    KM_T(4);
-    // prefix over the threads (wavefront scan, then the four wavefront totals), total of the workgroup
-    const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
-    const i128 linc = km_wave_scan128(lsum, lane);
-    if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
-    if (tid == 0) { s_first = 256; s_idx = -1; s_hit_rank = 0xFFFFFFFFu; }
-    __syncthreads();
-    i128 wbefore = 0, wtotal = 0;
+        for (int64_t ib = i0 + 8; ib < i1; ib += 8) {           // (only when m is beyond 2^29)
+            uint32_t rk[8];
+            double dv[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const i128 wt = km_make128(s_w_lo[w], s_w_hi[w]);
-        if (w < wave) wbefore += wt;
-        wtotal += wt;
-    }
-    // publish: three words of 48 bits under the seed's number (a sum is below 2^112 quanta)
-    const u64 mask48 = (1ull << 48) - 1, tag = (u64)(seed_no & 0xFFFF);
-    if (wave == 0) {
-        u64 *words = reinterpret_cast<u64 *>(&cur->sub[trial][0][0]);
-        if (lane == 0) {
-            __hip_atomic_store(words + 3 * sub, ((u64)wtotal & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(words + 3 * sub + 1, ((u64)(wtotal >> 48) & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(words + 3 * sub + 2, ((u64)(wtotal >> 96) & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 8; ++q) rk[q] = rank[ib + q < i1 ? ib + q : i1 - 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dv[q] = ds[rk[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double a, b, cc;
+                km_split(L, ib + q < i1 ? dv[q] : 0.0, a, b, cc);
+                wa += a; wb += b; wc += cc;
+            }
         }
-        // the sixteen sums of the trial: lane e reads word e until every word carries the tag
-        const int e = lane < 3 * KM_SUB ? lane : 0;
-        u64 w = 0;
+        KM_T(4);
+        // prefix over the threads (wavefront scan, then the four wavefront totals), total of the workgroup
+        const i128 lsum = km_join(__double2ll_rn(wa * L.sA), __double2ll_rn(wb * L.sB), __double2ll_rn(wc * L.sC));
+        const i128 linc = km_wave_scan128(lsum, lane);
+        if (lane == 63) { s_w_lo[wave] = (u64)linc; s_w_hi[wave] = (u64)(linc >> 64); }
+        if (tid == 0) { s_first = 256; s_idx = -1; s_hit_rank = 0xFFFFFFFFu; }
+        __syncthreads();
+        i128 wbefore = 0, wtotal = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const i128 wt = km_make128(s_w_lo[w], s_w_hi[w]);
+            if (w < wave) wbefore += wt;
+            wtotal += wt;
+        }
+        // publish: three words of 48 bits under the seed's number (a sum is below 2^112 quanta)
+        const u64 mask48 = (1ull << 48) - 1, tag = (u64)(seed_no & 0xFFFF);
+        if (wave == 0) {
+            u64 *words = reinterpret_cast<u64 *>(&cur->sub[trial][0][0]);
+            if (lane == 0) {
+                __hip_atomic_store(words + 3 * sub, ((u64)wtotal & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(words + 3 * sub + 1, ((u64)(wtotal >> 48) & mask48) | (tag << 48), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(words + 3 * sub + 2, ((u64)(wtotal >> 96) & mask48) | (tag << 48), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the sixteen sums of the trial: lane e reads word e until every word carries the tag
+            const int e = lane < 3 * KM_SUB ? lane : 0;
+            u64 w = 0;
+            int spins = 0;
+            for (;;) {
+                w = __hip_atomic_load(words + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__ballot((w >> 48) != tag) == 0) break;
+                if (++spins >= KM_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const u64 pay = w & mask48;
+            const int src = lane < KM_SUB ? 3 * lane : 0;
+            const u64 p0 = __shfl(pay, src, 64), p1 = __shfl(pay, src + 1, 64), p2 = __shfl(pay, src + 2, 64);
+            const i128 sv = lane < KM_SUB ? (i128)p0 + ((i128)p1 << 48) + ((i128)p2 << 96) : (i128)0;
+            const i128 sinc = km_wave_scan128(sv, lane);
+            const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
+            const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
+            const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
+            if (lane == 0) {
+                if (spins >= KM_SPIN_LIMIT) { atomicOr(&st->faults, 16); s_sidx = -1; }
+                else s_sidx = sidx;
+                s_reach = reach != 0;
+                s_carry[0] = (u64)scarry; s_carry[1] = (u64)(scarry >> 64);
+            }
+        }
+        __syncthreads();
+        KM_T(5);
+        if (sub == s_sidx) {
+            // ---- this workgroup's sixteenth holds the index: the thread, then the value
+            KM_TP(5);
+            const i128 mine = km_make128(s_carry[0], s_carry[1]) + wbefore + linc - lsum;   // cumulative sum before this thread's first index
+            if (s_reach && mine + lsum >= R) atomicMin(&s_first, tid);
+            __syncthreads();
+            const int owner = s_first;
+            if (owner == 256) {
+                if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
+            } else if (per <= 8) {
+                // the owner's (at most eight) values through LDS to wavefront 0: one value per lane, inclusive scan, first hit
+                if (tid == owner) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s_dv[q] = dv0[q]; s_rk[q] = rk0[q]; }
+                    s_mine[0] = (u64)mine; s_mine[1] = (u64)(mine >> 64);
+                    s_o[0] = i0; s_o[1] = i1;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const int64_t o0 = s_o[0], o1 = s_o[1];
+                    const i128 qv = lane < o1 - o0 ? km_quanta(L, s_dv[lane < 8 ? lane : 0]) : (i128)0;
+                    const i128 qinc = km_wave_scan128(qv, lane);
+                    const uint64_t ok = __ballot(lane < o1 - o0 && km_make128(s_mine[0], s_mine[1]) + qinc >= R);
+                    const int h = ok ? __ffsll((long long)ok) - 1 : (int)(o1 - o0) - 1;
+                    if (lane == 0) { s_idx = o0 + h; s_hit_rank = s_rk[h]; }
+                }
+            } else if (wave == (owner >> 6)) {
+                // the owner's wavefront walks the owner's indices together
+                const int ol = owner & 63;
+                const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
+                i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
+                int64_t hit = o1 - 1;
+                for (int64_t ib = o0; ib < o1; ib += 64) {
+                    const int64_t i = ib + lane;
+                    const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
+                    const i128 qinc = km_wave_scan128(qv, lane);
+                    const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
+                    if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
+                    run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
+                }
+                if (lane == 0) s_idx = hit;
+            }
+            __syncthreads();
+            int64_t idx = s_idx;
+            if (idx > m - 1) idx = m - 1;
+            km_pick_tail(xs, ds, rank, m, trial, idx, s_hit_rank, choose_prev != 0, newest, n_old, sorted_old, full_range, closed,
+                         slow_pick, sb, top, s_top2, seeds_lds, amax, L.sC, merge_tag, st, cur);
+        }
+    }
+    if (!merge) return;
+    // ---- C: every workgroup of the launch takes part in the update once all trials are recorded
+    __syncthreads();                                            // (the searches are over: their LDS is free)
+    u64 *s_acc = s_big;
+    for (int i = tid; i < 3 * nblocks; i += 256) s_acc[i] = 0;
+    if (wave == 0) {
+        const int e = lane < n_trials ? lane : 0;
         int spins = 0;
         for (;;) {
-            w = __hip_atomic_load(words + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot((w >> 48) != tag) == 0) break;
+            const u64 w = __hip_atomic_load(&cur->done[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(w != merge_tag) == 0) break;
             if (++spins >= KM_SPIN_LIMIT) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        const u64 pay = w & mask48;
-        const int src = lane < KM_SUB ? 3 * lane : 0;
-        const u64 p0 = __shfl(pay, src, 64), p1 = __shfl(pay, src + 1, 64), p2 = __shfl(pay, src + 2, 64);
-        const i128 sv = lane < KM_SUB ? (i128)p0 + ((i128)p1 << 48) + ((i128)p2 << 96) : (i128)0;
-        const i128 sinc = km_wave_scan128(sv, lane);
-        const uint64_t reach = __ballot(lane < KM_SUB && carry + sinc >= R);
-        const int sidx = reach ? __ffsll((long long)reach) - 1 : KM_SUB - 1;
-        const i128 scarry = carry + km_make128(__shfl((u64)(sinc - sv), sidx, 64), __shfl((u64)((sinc - sv) >> 64), sidx, 64));
+        const double g_j = __hip_atomic_load(&cur->gain_d[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const i64 lo_j = __hip_atomic_load(&cur->cand_lo[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const i64 hi_j = __hip_atomic_load(&cur->cand_hi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double cx_j = __hip_atomic_load(&cur->cand_x[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int best = km_best_of(km_to_double(total) - g_j, n_trials, lane);
+        const i64 blo = __shfl(lo_j, best, 64), bhi = __shfl(hi_j, best, 64);
+        const double bc = __shfl(cx_j, best, 64);
         if (lane == 0) {
-            if (spins >= KM_SPIN_LIMIT) { atomicOr(&st->faults, 16); s_sidx = -1; }
-            else s_sidx = sidx;
-            s_reach = reach != 0;
-            s_carry[0] = (u64)scarry; s_carry[1] = (u64)(scarry >> 64);
+            const bool ok = spins < KM_SPIN_LIMIT;
+            if (!ok) atomicOr(&st->faults, 16);
+            s_ulo = ok ? blo : 0; s_uhi = ok ? bhi : 0; s_uc = bc;
         }
     }
     __syncthreads();
-    KM_T(5);
-    if (sub != s_sidx) return;
-    // ---- this workgroup's sixteenth holds the index: the thread, then the value
-    KM_TP(5);
-    const i128 mine = km_make128(s_carry[0], s_carry[1]) + wbefore + linc - lsum;   // cumulative sum before this thread's first index
-    if (s_reach && mine + lsum >= R) atomicMin(&s_first, tid);
-    __syncthreads();
-    const int owner = s_first;
-    if (owner == 256) {
-        if (tid == 0) { atomicOr(&st->faults, 4); s_idx = s1 - 1; }
-    } else if (per <= 8) {
-        // the owner's (at most eight) values through LDS to wavefront 0: one value per lane, inclusive scan, first hit
-        if (tid == owner) {
+    {
+        const int64_t lo = s_ulo, hi = s_uhi;
+        const double c = s_uc, csq = __dmul_rn(c, c);
+        const int64_t first = lo / KM_CHUNK;
+        const int64_t chunks = hi > lo ? (hi - 1) / KM_CHUNK - first + 1 : 0;
+        const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
+        if (wg >= chunks) return;
+        for (int64_t ch = wg; ch < chunks; ch += nwg) {
+            const int64_t p0 = (first + ch) * KM_CHUNK;
+            const int64_t p1 = p0 + KM_CHUNK < m ? p0 + KM_CHUNK : m;
+            double xv[KM_CHUNK / 256], dv[KM_CHUNK / 256];
+            uint32_t iv[KM_CHUNK / 256];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { s_dv[q] = dv0[q]; s_rk[q] = rk0[q]; }
-            s_mine[0] = (u64)mine; s_mine[1] = (u64)(mine >> 64);
-            s_o[0] = i0; s_o[1] = i1;
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = p0 + u * 256 + tid;
+                const int64_t q = p < p1 ? p : p1 - 1;
+                xv[u] = xs[q];
+                dv[u] = ds[q];
+                iv[u] = perm[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double left = 0.0;                                  // what stays: the block's new sum
+#pragma unroll
+            for (int u = 0; u < KM_CHUNK / 256; ++u) {
+                const int64_t p = p0 + u * 256 + tid;
+                if (p >= p1) continue;
+                const double d = dv[u];
+                const double dj = km_sqdist(c, csq, xv[u]);
+                if (p >= lo && p < hi && dj < d) {
+                    ds[p] = dj;
+                    left += dj;
+                    double a, b, cc, aj, bj, cj;
+                    km_split(L, d, a, b, cc);
+                    km_split(L, dj, aj, bj, cj);
+                    const i64 ua = -__double2ll_rn((a - aj) * L.sA), ub = -__double2ll_rn((b - bj) * L.sB),
+                              uc = -__double2ll_rn((cc - cj) * L.sC);
+                    const int ib = (int)(iv[u] >> block_shift);
+                    if (ua) atomicAdd(&s_acc[3 * ib], (u64)ua);
+                    if (ub) atomicAdd(&s_acc[3 * ib + 1], (u64)ub);
+                    if (uc) atomicAdd(&s_acc[3 * ib + 2], (u64)uc);
+                } else {
+                    left += d;
+                }
+            }
+            left = km_block_sum(left, s_ured);                  // (the same shape as km_update_kernel's)
+            if (tid == 0) sb[first + ch].sd = left;
         }
         __syncthreads();
-        if (wave == 0) {
-            const int64_t o0 = s_o[0], o1 = s_o[1];
-            const i128 qv = lane < o1 - o0 ? km_quanta(L, s_dv[lane < 8 ? lane : 0]) : (i128)0;
-            const i128 qinc = km_wave_scan128(qv, lane);
-            const uint64_t ok = __ballot(lane < o1 - o0 && km_make128(s_mine[0], s_mine[1]) + qinc >= R);
-            const int h = ok ? __ffsll((long long)ok) - 1 : (int)(o1 - o0) - 1;
-            if (lane == 0) { s_idx = o0 + h; s_hit_rank = s_rk[h]; }
+        for (int i = tid; i < 3 * nblocks; i += 256) {
+            const u64 v = s_acc[i];
+            if (v) atomicAdd(reinterpret_cast<u64 *>(bacc) + 4 * (i / 3) + i % 3, v);
         }
-    } else if (wave == (owner >> 6)) {
-        // the owner's wavefront walks the owner's indices together
-        const int ol = owner & 63;
-        const int64_t o0 = __shfl(i0, ol, 64), o1 = __shfl(i1, ol, 64);
-        i128 run = km_make128(__shfl((u64)mine, ol, 64), __shfl((u64)(mine >> 64), ol, 64));
-        int64_t hit = o1 - 1;
-        for (int64_t ib = o0; ib < o1; ib += 64) {
-            const int64_t i = ib + lane;
-            const i128 qv = i < o1 ? km_quanta(L, ds[rank[i]]) : (i128)0;
-            const i128 qinc = km_wave_scan128(qv, lane);
-            const uint64_t ok = __ballot(i < o1 && run + qinc >= R);
-            if (ok) { hit = ib + __ffsll((long long)ok) - 1; break; }
-            run += km_make128(__shfl((u64)qinc, 63, 64), __shfl((u64)(qinc >> 64), 63, 64));
-        }
-        if (lane == 0) s_idx = hit;
     }
-    __syncthreads();
-    int64_t idx = s_idx;
-    if (idx > m - 1) idx = m - 1;
-    km_pick_tail(xs, ds, rank, m, trial, idx, s_hit_rank, choose_prev != 0, newest, n_old, sorted_old, full_range, closed, slow_pick,
-                 sb, top, s_top2, seeds_lds, amax, L.sC, st, cur);
 }
 
 // union of the candidates' ranges as disjoint intervals in ascending order, and their prefix in chunks of KM_CHUNK
@@ -1844,21 +1964,27 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         static const int update_grid_max = [] { const char *e = std::getenv("GRX_KMEANS_UPDATE_GRID"); return e ? atoi(e) : KM_UPDATE_GRID; }();
         const int update_grid = (int)(max_chunks < update_grid_max ? max_chunks : update_grid_max);
+        // The update with seed c inside its pick kernel (GRX_KMEANS_MERGE=0: never) once the ranges are short: a range
+        // holds about m / c values, the launch has 16 * n_trials workgroups, and up to GRX_KMEANS_MERGE chunks (default 2)
+        // per workgroup still beat km_update_kernel's launch
+        static const double merge_chunks = [] { const char *e = std::getenv("GRX_KMEANS_MERGE"); return e ? atof(e) : 2.0; }();
+        const double merge_from = merge_chunks > 0.0 ? (double)m / ((double)KM_CHUNK * merge_chunks * KM_SUB * n_trials) : 1e300;
         for (int c = 1; c < k; ++c) {
-            km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift,
+            const int merge = (closed && c < k - 1 && (double)c >= merge_from) ? 1 : 0;
+            km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, perm, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
-                                                                   full_range, closed, slow_pick, sb, top, state, seeds_x, seeds_id,
-                                                                   sorted2, (int)p.sorted_ld);
+                                                                   full_range, closed, slow_pick, merge, sb, top, state, seeds_x,
+                                                                   seeds_id, sorted2, (int)p.sorted_ld);
             if (!closed) {
                 if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
                 else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
             }
-            if (c < k - 1)                                         // the distances to the last seed are never needed
+            if (c < k - 1 && !merge)                               // the distances to the last seed are never needed
                 km_update_kernel<<<update_grid, KM_UPDATE_THREADS, 0, st>>>(xs, ds, perm, bacc, p.nblocks, p.block_shift, m, sb, state,
                                                                             c, n_trials, closed);
         }
-        km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1, 0,
-                                                   full_range, closed, slow_pick, sb, top, state, seeds_x, seeds_id, sorted2,
+        km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, perm, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1,
+                                                   0, full_range, closed, slow_pick, 0, sb, top, state, seeds_x, seeds_id, sorted2,
                                                    (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();

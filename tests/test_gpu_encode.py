@@ -244,7 +244,8 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     one-workgroup seeding of few values (m <= 4096, km_seed_small_kernel) against the many-launch path (GRX_KMEANS_SMALL=0),
     and the default evaluation of the candidates' potentials from sums over blocks of sorted values (closed form, fp64)
     against the pass over each range in integer arithmetic (GRX_KMEANS_GAIN_PASS=1): the two can only choose differently
-    where two potentials agree to 1e-12, which none of these inputs has."""
+    where two potentials agree to 1e-12, which none of these inputs has.  And the update inside the pick kernel (late
+    seeds) against km_update_kernel for every seed (GRX_KMEANS_MERGE=0) and against the merged update for every seed."""
     import os
     import subprocess
     import sys
@@ -254,6 +255,8 @@ def test_interval_seeding_equals_the_full_pass(tmp_path):
     # default; every range [0, m); few values (m <= 4096) through the many-launch path instead of the one-workgroup kernel
     for tag, extra in (('default', {}), ('full', {'GRX_KMEANS_FULL_RANGE': '1'}), ('nosmall', {'GRX_KMEANS_SMALL': '0'}),
                        ('slowpick', {'GRX_KMEANS_SLOW_PICK': '1', 'GRX_KMEANS_SMALL': '0'}),
+                       ('nomerge', {'GRX_KMEANS_MERGE': '0', 'GRX_KMEANS_SMALL': '0'}),
+                       ('merge_all', {'GRX_KMEANS_MERGE': '1e9', 'GRX_KMEANS_SMALL': '0'}),
                        ('gainpass', {'GRX_KMEANS_GAIN_PASS': '1'}), ('gainpass_nosmall', {'GRX_KMEANS_GAIN_PASS': '1',
                                                                                           'GRX_KMEANS_SMALL': '0'})):
         out = tmp_path / f'km_{tag}.npz'
