@@ -62,7 +62,10 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 constexpr int KM_TILE = 1024;                 // values per tile of the prefix sums of the sorted values (256 threads x 4)
-constexpr int KM_MAX_BLOCKS = 2048;           // index blocks of the cumulative sum (two per thread of the prep scan)
+#ifndef KM_MAX_BLOCKS_V
+#define KM_MAX_BLOCKS_V 1024
+#endif
+constexpr int KM_MAX_BLOCKS = KM_MAX_BLOCKS_V;           // index blocks of the cumulative sum (four per thread of the prep scan)
 constexpr int KM_MIN_BLOCK_SHIFT = 6;
 constexpr int KM_SUB = 16;                    // sub-blocks of an index block: one workgroup each in km_prep_kernel
 constexpr int KM_MAX_TRIALS = 16;             // 2 + int(log(k)) <= 11 for k <= 8192
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                                       int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
     // (the LDS of the searches -- top level of the sorted values, sorted seeds -- later holds the update's block sums)
-    __shared__ u64 s_big[3 * KM_MAX_BLOCKS];
+    __shared__ u64 s_big[3 * KM_MAX_BLOCKS > KM_TOP2 + KM_SEEDS_LDS ? 3 * KM_MAX_BLOCKS : KM_TOP2 + KM_SEEDS_LDS];
     double *s_top2 = reinterpret_cast<double *>(s_big), *s_seeds = s_top2 + KM_TOP2;
     __shared__ int64_t s_ulo, s_uhi;
     __shared__ double s_uc, s_ured[4];
