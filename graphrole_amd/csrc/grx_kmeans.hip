@@ -100,7 +100,8 @@ struct KmSeedRec {
     u64 pot_lo, pot_hi;          // potential before this seed = sum of the closest distances, in quanta of 2^(E-96)
     i64 sub[KM_MAX_TRIALS][KM_SUB][3];   // km_prep_kernel: limb sums of the sub-blocks of the block each trial's r falls in
     double gain_d[KM_MAX_TRIALS];        // gains from the sorted-block sums (km_pick_tail), when no gain pass runs
-    u64 done[KM_MAX_TRIALS];             // = seed number once the trial's candidate is recorded (update inside the pick kernel)
+    u64 pub[KM_MAX_TRIALS][6];           // the trial's range, value and gain for the update inside the pick kernel: 32 or 48 bits
+                                         // per word under the seed's number (bits 48..63)
 };
 
 struct KmState {                 // device scalars shared by the kernels of one run
@@ -480,26 +481,26 @@ __device__ __forceinline__ int km_best_wave(const KmSeedRec *rec, int n_trials, 
     return __ffsll((long long)tied) - 1;
 }
 
-// a trial's candidate into the seed's record.  merge_tag != 0: workgroups of THIS launch read it (the update inside the
-// pick kernel): stores that go to memory, and the trial's tag once they have left
+// a trial's candidate into the seed's record.  merge_tag != 0: workgroups of THIS launch read it as well (the update
+// inside the pick kernel), from words that go straight to memory
 __device__ __forceinline__ void km_publish(KmSeedRec *cur, int trial, double c, int64_t idx, int64_t lo, int64_t hi, double gain,
                                            u64 merge_tag)
 {
-    if (!merge_tag) {
-        cur->cand_x[trial] = c;
-        cur->cand_id[trial] = idx;
-        cur->cand_lo[trial] = lo;
-        cur->cand_hi[trial] = hi;
-        cur->gain_d[trial] = gain;
-        return;
-    }
-    __hip_atomic_store(&cur->cand_x[trial], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&cur->cand_id[trial], (i64)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&cur->cand_lo[trial], (i64)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&cur->cand_hi[trial], (i64)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&cur->gain_d[trial], gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&cur->done[trial], merge_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cur->cand_x[trial] = c;
+    cur->cand_id[trial] = idx;
+    cur->cand_lo[trial] = lo;
+    cur->cand_hi[trial] = hi;
+    cur->gain_d[trial] = gain;
+    if (!merge_tag) return;
+    // every word validates itself: no order among the stores, no second read for whoever waits
+    const u64 cb = (u64)__double_as_longlong(c), gb = (u64)__double_as_longlong(gain), t = merge_tag << 48;
+    u64 *w = cur->pub[trial];
+    __hip_atomic_store(w + 0, (u64)lo | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // positions are below 2^31
+    __hip_atomic_store(w + 1, (u64)hi | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, (cb & 0xFFFFFFFFull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 3, (cb >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 4, (gb & 0xFFFFFFFFull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 5, (gb >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The end of a trial's pick, by the workgroup that holds the chosen index idx (hit_rank = its sorted position when the
@@ -1028,18 +1029,28 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     u64 *s_acc = s_big;
     for (int i = tid; i < 3 * nblocks; i += 256) s_acc[i] = 0;
     if (wave == 0) {
-        const int e = lane < n_trials ? lane : 0;
+        // lane e reads words e and e + 64 of the 6 * n_trials published ones until all carry the seed's number
+        const u64 *words = &cur->pub[0][0];
+        const int nw = 6 * n_trials, e0 = lane < nw ? lane : 0, e1 = lane + 64 < nw ? lane + 64 : 0;
+        u64 r0 = 0, r1 = 0;
         int spins = 0;
         for (;;) {
-            const u64 w = __hip_atomic_load(&cur->done[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(w != merge_tag) == 0) break;
+            r0 = __hip_atomic_load(words + e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r1 = __hip_atomic_load(words + e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot((r0 >> 48) != merge_tag || (r1 >> 48) != merge_tag) == 0) break;
             if (++spins >= KM_SPIN_LIMIT) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        const double g_j = __hip_atomic_load(&cur->gain_d[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const i64 lo_j = __hip_atomic_load(&cur->cand_lo[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const i64 hi_j = __hip_atomic_load(&cur->cand_hi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double cx_j = __hip_atomic_load(&cur->cand_x[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 f[6];                                               // lane j: the six words of trial j
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int src = lane < n_trials ? 6 * lane + q : q;
+            const u64 a = __shfl(r0, src & 63, 64), b = __shfl(r1, src & 63, 64);
+            f[q] = (src < 64 ? a : b) & ((1ull << 48) - 1);
+        }
+        const i64 lo_j = (i64)f[0], hi_j = (i64)f[1];
+        const double cx_j = __longlong_as_double((long long)(f[2] | (f[3] << 32)));
+        const double g_j = __longlong_as_double((long long)(f[4] | (f[5] << 32)));
         const int best = km_best_of(km_to_double(total) - g_j, n_trials, lane);
         const i64 blo = __shfl(lo_j, best, 64), bhi = __shfl(hi_j, best, 64);
         const double bc = __shfl(cx_j, best, 64);

@@ -707,8 +707,11 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
  * 1e-4 * var), empty-cluster relocation, every entry replaced by its cluster centre.  Centres agree with sklearn's
  * to ~1e-12 (sums are reduced in another order); the model selection of RolX then picks the reference's cell.
  * The seeding does not stream all m values per seed as sklearn's _kmeans_plusplus (:163-257) does: on the line a
- * candidate changes closest distances only in a contiguous range of the sorted values, and all sums are exact
- * fixed-point integers (csrc/grx_kmeans.hip) -- same seeds, O(m log k) instead of O(m k) work.
+ * candidate changes closest distances only in a contiguous range of the sorted values, and the sums the candidate
+ * INDEX is drawn from (sklearn's cumulative sum in index order) are exact fixed-point integers (csrc/grx_kmeans.hip)
+ * -- same seeds, O(m log k) instead of O(m k) work.  The candidates' potentials, which only feed an argmin, come from
+ * fp64 sums over blocks of sorted values (first minimum, potentials within 1e-12 count as tied: sklearn's own are BLAS
+ * sums in another order).
  *   d_values      fp64[m] in the order the reference flattens the matrix (row-major n x r for the node-role
  *                 factor: grx_transpose from the feature-major device layout)
  *   first_seed    RandomState(1).choice(m, p = uniform)            (sklearn _kmeans_plusplus, first centre)
@@ -716,8 +719,15 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
  *   max_iter, rel_tol   sklearn defaults 300, 1e-4
  *   d_centers     fp64[k] in seed order;  d_info int32[4] = {Lloyd iterations (n_iter_), non-empty clusters,
  *                 distinct output values, seeding faults (0 unless an internal consistency check failed: bit 0 the
- *                 block sums after an update differ from potential - gain, bit 1 values beyond 1e144, bits 2.. a
- *                 cumulative-sum search left its block)}.   k <= 8192 (GRX_ERR_UNSUPPORTED above), k <= m (GRX_ERR_INVALID).
+ *                 block sums after an update differ from potential - gain (exact gains, GRX_KMEANS_GAIN_PASS=1), bit 1
+ *                 values beyond 1e144, bit 2 a cumulative-sum search left its block, bit 3 the potential after an
+ *                 update is further than 1e-9 from potential - gain (fp64 gains, the default), bit 4 a workgroup of
+ *                 the pick waited in vain for the others of its launch)}.
+ *                 k <= 8192 (GRX_ERR_UNSUPPORTED above), k <= m (GRX_ERR_INVALID).
+ * Environment (read once; for tests/test_gpu_encode.py, which runs every mode on the same inputs and compares bits):
+ * GRX_KMEANS_FULL_RANGE=1 every range [0, m); GRX_KMEANS_GAIN_PASS=1 gains by an integer pass over each range;
+ * GRX_KMEANS_SLOW_PICK=1 range positions by searches over all values; GRX_KMEANS_MERGE=0 the update always in its own
+ * kernel; GRX_KMEANS_SMALL=0 no one-workgroup seeding of m <= 4096.
  * grx_transpose: out[c * ld_out + r] = in[r * ld_in + c].
  */
 size_t grx_kmeans1d_workspace_bytes(int64_t m, int k);
