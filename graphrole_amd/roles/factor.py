@@ -362,6 +362,19 @@ def _quantize_flat(flat, n_bins: int, quantizer: str):
     return q, info
 
 
+class QuantizerFault(RuntimeError):
+    """grx_kmeans1d reported a failed internal consistency check (include/grx.h, d_info[3])."""
+
+
+def _checked_info(info, quantizer: str):
+    """Host copy of a quantiser's info; the k-means seeding checks itself as it goes (its potential after every update,
+    every search inside its block, every wait between workgroups): a non-zero report is an error, never a result."""
+    info = _kernels().to_host(info)
+    if quantizer == 'kmeans' and int(info[3]) != 0:
+        raise QuantizerFault(f'grx_kmeans1d: seeding fault bits {int(info[3]):#x} (include/grx.h: d_info[3])')
+    return info
+
+
 def encoded_factors_device(Xd, X, n_roles: int, n_bits: int, quantizer: str = 'kmeans', plan=None,
                            want_node_major: bool = False):
     """
@@ -386,7 +399,7 @@ def encoded_factors_device(Xd, X, n_roles: int, n_bits: int, quantizer: str = 'k
     Gq_flat, info_w = _quantize_flat(G_flat, n_bins, quantizer)
     Wq = Gq_flat.view(n, n_roles) if want_node_major else K.transpose(Gq_flat.view(n, n_roles), n, n_roles)
     Hq, info_h = _quantize_flat(state.H.reshape(-1), n_bins, quantizer)
-    info_w, info_h = K.to_host(info_w), K.to_host(info_h)
+    info_w, info_h = _checked_info(info_w, quantizer), _checked_info(info_h, quantizer)
     return state, Wq, Hq.view(n_roles, F), int(info_w[2]), int(info_h[2])
 
 
@@ -408,5 +421,6 @@ def encode(X: np.ndarray, n_bins: int, quantizer: str = 'kmeans') -> np.ndarray:
         # of RoleExtractor relies on it (roles/extract.py:127-129)
         raise TooFewSamples(f'n_samples={X.size} should be >= n_clusters={n_bins}.')
     flat = K.to_device(np.ascontiguousarray(X).reshape(-1))
-    quantized, _ = _quantize_flat(flat, int(n_bins), quantizer)
+    quantized, info = _quantize_flat(flat, int(n_bins), quantizer)
+    _checked_info(info, quantizer)
     return K.to_host(quantized).reshape(X.shape)

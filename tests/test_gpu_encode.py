@@ -283,3 +283,14 @@ def test_kmeans_runs_are_bitwise_repeatable():
         again = [K.to_host(t) for t in K.kmeans1d(v, 128)]
         for x, y in zip(first, again):
             assert np.array_equal(x, y)
+
+
+def test_a_seeding_fault_is_an_error_not_a_result():
+    """grx_kmeans1d checks itself while it seeds (include/grx.h, d_info[3]); the host code turns any report into an
+    exception.  The one report an input can provoke: values beyond 1e144, whose squared distances leave the fixed-point
+    range of the exact sums (sklearn's own distances overflow a little further up)."""
+    from graphrole_amd.roles import factor
+    x = np.array([[1.0, 2.0, 3.0e150], [4.0, 5.0, 6.0]])
+    with pytest.raises(factor.QuantizerFault):
+        factor.encode(x, 2)
+    assert factor.encode(x / 1e150, 2).shape == x.shape
