@@ -776,11 +776,29 @@ constexpr unsigned TRI_SAT = (1u << TRI_FIELD) - 1;
 // A wavefront takes 64 consecutive arcs per iteration: one LANE per arc reads the 8-byte table entry (a coalesced
 // 512-byte read), then one 16-lane GROUP per arc, four arcs at a time, receives the entries from the lanes that read
 // them, loads the lists and intersects them by the binary search above.
-__global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
+// The counters of the first TRI_HUBS vertices (rows are in degree-descending order: the hubs) are kept per workgroup in
+// LDS and added to T once at the end.  Every corner of every triangle is one atomic increment, and on a power-law graph
+// a few vertices take most of them (BA 1 M / 10 M: 12 275 of 180 k on vertex 0, 35 k on the first sixteen); atomics to
+// ONE address are served one after the other (~9 ns each): 0.15 of the kernel's 0.41 ms was that queue (measured by
+// dropping the atomics below an index: 0.41 -> 0.30 without vertex 0, 0.25 without the first sixteen).  With the LDS
+// counters 0.27 ms; workgroups of 512 / 1024 threads, which collect more per flush, were slower (0.28 / 0.30).
+constexpr int TRI_HUBS = 256;
+constexpr int TRI_THREADS = 256;
+
+__device__ __forceinline__ void tri_add(unsigned long long *__restrict__ T, unsigned long long *s_hub, int32_t idx, unsigned c)
+{
+    if (idx < TRI_HUBS) atomicAdd(&s_hub[idx], (unsigned long long)c);
+    else atomicAdd(&T[idx], (unsigned long long)c);
+}
+
+__global__ __launch_bounds__(TRI_THREADS) void triangle_count_arcs_kernel(
     const int64_t *__restrict__ o_row_ptr, const int32_t *__restrict__ o_col,
     const unsigned long long *__restrict__ o_arc, int64_t row_begin, int64_t row_end,
     unsigned long long *__restrict__ T)
 {
+    __shared__ unsigned long long s_hub[TRI_HUBS];
+    for (int i = threadIdx.x; i < TRI_HUBS; i += blockDim.x) s_hub[i] = 0;
+    __syncthreads();
     constexpr int G = TRI_AG;
     constexpr unsigned long long GMASK = (1ull << G) - 1;
     const int wlane = threadIdx.x & 63;
@@ -821,10 +839,10 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                         if (o_col[mid] < y) a = mid + 1; else e = mid;
                     }
                     const bool hit = have && a < ue && o_col[a] == y;
-                    if (hit) atomicAdd(&T[y], 1ull);
+                    if (hit) tri_add(T, s_hub, y, 1u);
                     c += (unsigned long long)__popcll(__ballot(hit));
                 }
-                if (c && wlane == 0) { atomicAdd(&T[v], c); atomicAdd(&T[lo], c); }
+                if (c && wlane == 0) { tri_add(T, s_hub, v, (unsigned)c); tri_add(T, s_hub, (int32_t)lo, (unsigned)c); }
             }
         }
         // ---- the group phase
@@ -890,7 +908,7 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                 unsigned c_arc = 0;
                 const unsigned long long b0 = __ballot(h[j]);
                 if (b0) {
-                    if (h[j]) atomicAdd(&T[y0[j]], 1ull);
+                    if (h[j]) tri_add(T, s_hub, y0[j], 1u);
                     c_arc = (unsigned)__popcll((b0 >> gshift) & GMASK);
                 }
                 if (__ballot((ulen[j] > G || vlen[j] > G) && ulen[j] > 0) != 0) {
@@ -902,7 +920,7 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                             const bool hh = tri_search16(y, a, group_byte);
                             const unsigned long long bh = __ballot(hh);
                             if (bh) {
-                                if (hh) atomicAdd(&T[y], 1ull);
+                                if (hh) tri_add(T, s_hub, y, 1u);
                                 c_arc += (unsigned)__popcll((bh >> gshift) & GMASK);
                             }
                         }
@@ -918,13 +936,16 @@ __global__ __launch_bounds__(256) void triangle_count_arcs_kernel(
                             const int64_t mid = (lo + hi) >> 1;
                             if (o_row_ptr[mid] <= k) lo = mid; else hi = mid;
                         }
-                        atomicAdd(&T[v], (unsigned long long)c_arc);
-                        atomicAdd(&T[lo], (unsigned long long)c_arc);
+                        tri_add(T, s_hub, v, c_arc);
+                        tri_add(T, s_hub, (int32_t)lo, c_arc);
                     }
                 }
             }
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TRI_HUBS; i += blockDim.x)
+        if (s_hub[i]) atomicAdd(&T[i], s_hub[i]);
 }
 
 // info[v] = (d'(v) << 1) | L(v)   (int32: the whole table is 4 B/node and stays L2-resident)
@@ -2174,10 +2195,12 @@ int grx_triangle_counts(int64_t n, const int64_t *d_o_row_ptr, const int32_t *d_
     GRX_REQUIRE(n >= 0 && row_begin >= 0 && row_begin <= row_end && row_end <= n, "grx_triangle_counts: bad row range");
     if (row_end == row_begin) return GRX_OK;
     GRX_REQUIRE(d_o_row_ptr && d_o_col && d_o_arc && d_T, "grx_triangle_counts: NULL pointer");
-    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);      // ~64 arcs per wavefront and sweep at 8 arcs per row
-    const int grid = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+    const int64_t want = grx_ceil_div((row_end - row_begin) * 8, TRI_THREADS);   // ~64 arcs per wavefront and sweep at 8 arcs per row
+    static const int rounds = [] { const char *e = std::getenv("GRX_TRI_ROUNDS"); return e ? atoi(e) : 4; }();
+    const int64_t cap = (int64_t)GRX_NUM_CU * (2048 / TRI_THREADS) * rounds;   // workgroups that fill the chip, times rounds
+    const int grid = (int)(want > cap ? cap : (want < 1 ? 1 : want));
     { GRX_PROF(GRX_K_TRIANGLES, grx_stream(stream));
-    triangle_count_arcs_kernel<<<grid, 256, 0, grx_stream(stream)>>>(
+    triangle_count_arcs_kernel<<<grid, TRI_THREADS, 0, grx_stream(stream)>>>(
         d_o_row_ptr, d_o_col, reinterpret_cast<const unsigned long long *>(d_o_arc), row_begin, row_end,
         reinterpret_cast<unsigned long long *>(d_T));
     }
