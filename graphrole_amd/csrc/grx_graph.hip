@@ -975,15 +975,16 @@ __device__ __forceinline__ void egonet_finish_row(int64_t v, long long sum_d, lo
 
 // G = 8 lanes per row; rows with more than hub_deg neighbours are left to the workgroup-per-row
 // variant below (integer sums: any order is exact).
-__global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
+__device__ __forceinline__ void egonet_rows_body(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
-    int64_t row_end, int64_t hub_deg, double *__restrict__ internal, double *__restrict__ external)
+    int64_t row_end, int64_t hub_deg, double *__restrict__ internal, double *__restrict__ external, int64_t block,
+    int64_t nblocks)
 {
     constexpr int G = 8;
     const int lane = threadIdx.x % G;
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    const int64_t group = (block * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = nblocks * blockDim.x / G;
     for (int64_t v = row_begin + group; v < row_end; v += ngroups) {
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
         if (e - b > hub_deg) continue;
@@ -1005,14 +1006,14 @@ __global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void egonet_from_triangles_hub_kernel(
+__device__ __forceinline__ void egonet_hubs_body(
     const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
     int64_t row_end, const int32_t *__restrict__ hub_rows, int64_t n_hubs,
-    double *__restrict__ internal, double *__restrict__ external)
+    double *__restrict__ internal, double *__restrict__ external, int64_t block, int64_t nblocks)
 {
     __shared__ long long red[2][4];
-    for (int64_t h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+    for (int64_t h = block; h < n_hubs; h += nblocks) {
         const int64_t v = hub_rows[h];
         if (v < row_begin || v >= row_end) continue;
         const int64_t b = row_ptr[v], e = row_ptr[v + 1];
@@ -1037,6 +1038,23 @@ __global__ __launch_bounds__(256) void egonet_from_triangles_hub_kernel(
                               red[1][0] + red[1][1] + red[1][2] + red[1][3], info, T, internal, external);
         __syncthreads();
     }
+}
+
+// ONE launch for both: the first hub_blocks workgroups take the hub rows (a workgroup per row: a chain of dependent
+// loads 40 deep for a 10 k-neighbour hub), the others the eight-lanes-per-row pass.  As two launches the hub kernel ran
+// alone on a few CUs AFTER the row pass (0.04 ms of a 0.155 ms phase at BA 1 M / 10 M); now the chains start first and
+// hide behind the row pass.
+__global__ __launch_bounds__(256) void egonet_from_triangles_kernel(
+    const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ info, const unsigned long long *__restrict__ T, int64_t row_begin,
+    int64_t row_end, int64_t hub_deg, const int32_t *__restrict__ hub_rows, int64_t n_hubs, int hub_blocks,
+    double *__restrict__ internal, double *__restrict__ external)
+{
+    if ((int)blockIdx.x < hub_blocks)
+        egonet_hubs_body(row_ptr, col, info, T, row_begin, row_end, hub_rows, n_hubs, internal, external, blockIdx.x, hub_blocks);
+    else
+        egonet_rows_body(row_ptr, col, info, T, row_begin, row_end, hub_deg, internal, external,
+                         (int64_t)blockIdx.x - hub_blocks, (int64_t)gridDim.x - hub_blocks);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2227,15 +2245,12 @@ int grx_egonet_unweighted(int64_t n, const int64_t *d_row_ptr, const int32_t *d_
         const int64_t want = grx_ceil_div((row_end - row_begin) * 8, 256);
         GRX_PROF(GRX_K_EGONET_FINISH, st);
         const int64_t hub_deg = (d_hub_rows && n_hub_rows > 0) ? hub_degree : ((int64_t)1 << 62);
-        egonet_from_triangles_kernel<<<(int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want), 256, 0, st>>>(
+        const bool hubs = d_hub_rows && n_hub_rows > 0;
+        const int hub_blocks = hubs ? (int)(n_hub_rows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hub_rows) : 0;
+        const int row_blocks = (int)(want > GRX_NUM_CU * 32 ? GRX_NUM_CU * 32 : want);
+        egonet_from_triangles_kernel<<<hub_blocks + row_blocks, 256, 0, st>>>(
             d_row_ptr, d_col, d_scratch, reinterpret_cast<const unsigned long long *>(d_T), row_begin, row_end,
-            hub_deg, d_internal, d_external);
-        if (d_hub_rows && n_hub_rows > 0) {
-            const int hgrid = (int)(n_hub_rows > GRX_NUM_CU * 8 ? GRX_NUM_CU * 8 : n_hub_rows);
-            egonet_from_triangles_hub_kernel<<<hgrid, 256, 0, st>>>(
-                d_row_ptr, d_col, d_scratch, reinterpret_cast<const unsigned long long *>(d_T), row_begin,
-                row_end, d_hub_rows, n_hub_rows, d_internal, d_external);
-        }
+            hub_deg, d_hub_rows, hubs ? n_hub_rows : 0, hub_blocks, d_internal, d_external);
     }
     GRX_LAUNCH_CHECK();
     return GRX_OK;
