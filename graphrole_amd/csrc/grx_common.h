@@ -58,6 +58,17 @@ constexpr int GRX_WAVE = 64;       // CDNA4 wavefront
 constexpr int GRX_NUM_CU = 256;    // MI355X
 
 static inline int64_t grx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Small device -> host read-backs the host's next launch depends on (distance matrix of the pruner, Gram matrices,
+// residuals), without the copy engine and without an interrupt: a one-workgroup kernel stores the bytes into the
+// caller's PINNED host buffer (hipHostMalloc: device-visible) and then a sequence number into a pinned flag; the host
+// spins on the flag in its own memory.  hipMemcpyAsync + hipStreamSynchronize takes 18 us, this 14
+// (tools/microbench/readback_latency.hip, profiles/r05_readback_latency.json); a step has nine such points.
+// grx_fetch_begin queues one copy (any number before a wait); grx_fetch_wait returns when all queued copies of the
+// calling thread are in host memory -- like hipStreamSynchronize it implies that everything queued on the stream before
+// them has finished.  More than 32 KB, sizes that are not multiples of 4, GRX_READBACK=memcpy: the copy engine.
+int grx_fetch_begin(void *h_dst_pinned, const void *d_src, size_t bytes, hipStream_t st);
+int grx_fetch_wait(hipStream_t st);
 static inline size_t grx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Fixed-shape butterfly: every lane ends with the same total, the addition tree depends only

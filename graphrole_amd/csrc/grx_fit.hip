@@ -34,7 +34,7 @@ int staging(size_t bytes, double **out)
         g_stage.ptr = nullptr;
         g_stage.bytes = 0;
         size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        GRX_CHECK_HIP(hipHostMalloc(&g_stage.ptr, want, hipHostMallocDefault));
+        GRX_CHECK_HIP(hipHostMalloc(&g_stage.ptr, want, hipHostMallocMapped));
         g_stage.bytes = want;
     }
     *out = reinterpret_cast<double *>(g_stage.ptr);
@@ -53,9 +53,8 @@ size_t staging_bytes(int F, int r)
 // device -> pinned host, then wait for the stream: the values are valid on return
 int fetch(double *h_dst, const double *d_src, size_t count, hipStream_t st)
 {
-    GRX_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, count * 8, hipMemcpyDeviceToHost, st));
-    GRX_CHECK_HIP(hipStreamSynchronize(st));
-    return GRX_OK;
+    const int rc = grx_fetch_begin(h_dst, d_src, count * 8, st);
+    return rc != GRX_OK ? rc : grx_fetch_wait(st);
 }
 
 struct FitLayout {
@@ -171,9 +170,9 @@ static int nmf_mu_impl(int64_t n, int F, int r, const double *d_X, int64_t ldx, 
         // exact, so it is only trusted for a relative squared residual above 1e-8 (its own rounding error
         // is then far under the 1e-4 stopping tolerance); otherwise the direct kernel runs.
         double err = -1.0;
-        if (!have_init) GRX_CHECK_HIP(hipMemcpyAsync(h_err_init, d_err_init, 8, hipMemcpyDeviceToHost, st));
+        if (!have_init) GRX_TRY(grx_fetch_begin(h_err_init, d_err_init, 8, st));
         if (x_sq_norm > 0.0) {
-            GRX_CHECK_HIP(hipMemcpyAsync(host, d_AB, (nA + nB) * 8, hipMemcpyDeviceToHost, st));
+            GRX_TRY(grx_fetch_begin(host, d_AB, (nA + nB) * 8, st));
             GRX_TRY(fetch(host + nA + nB, d_H, nA, st));
             const double *A = host, *B = host + nA, *H = host + nA + nB;
             double ah = 0.0;

@@ -112,7 +112,7 @@ int pinned(size_t bytes, void **out)
         g_pinned = nullptr;
         g_pinned_bytes = 0;
         const size_t want = bytes < (256u << 10) ? (256u << 10) : bytes;
-        GRX_CHECK_HIP(hipHostMalloc(&g_pinned, want, hipHostMallocDefault));
+        GRX_CHECK_HIP(hipHostMalloc(&g_pinned, want, hipHostMallocMapped));
         g_pinned_bytes = want;
     }
     *out = g_pinned;
@@ -328,8 +328,8 @@ int grx_refex_run(const grx_aggregate_plan *plan, int64_t n, const int64_t *d_ro
                 if (comm) GRX_TRY(grx_comm_all_reduce(comm, d_dist, (size_t)F * F + tail_words, GRX_I32, GRX_MAX, stream));
                 void *host = nullptr;
                 GRX_TRY(pinned(((size_t)F * F + tail_words) * 4, &host));
-                GRX_CHECK_HIP(hipMemcpyAsync(host, d_dist, ((size_t)F * F + tail_words) * 4, hipMemcpyDeviceToHost, st));
-                GRX_CHECK_HIP(hipStreamSynchronize(st));
+                GRX_TRY(grx_fetch_begin(host, d_dist, ((size_t)F * F + tail_words) * 4, st));
+                GRX_TRY(grx_fetch_wait(st));
                 if (tail_words > 2)
                     for (int j = 0; j < count; ++j) {
                         const int32_t b = reinterpret_cast<const int32_t *>(host)[(size_t)F * F + 2 + j];

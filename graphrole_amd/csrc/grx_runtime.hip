@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "grx_common.h"
+#include <cstdlib>
 
 static thread_local char g_err[1024] = "";
 
@@ -76,6 +77,96 @@ void grx_prof_end(int id, hipStream_t st)
 __global__ void grx_marker_kernel(int tag, int *sink)
 {
     if (sink && tag == 0x7fffffff) *sink = tag;
+}
+
+// ---- read-backs through mapped host memory (grx_common.h) ----------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void publish_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ host_dst, int words,
+                                                      volatile uint32_t *flag, uint32_t seq)
+{
+    for (int i = threadIdx.x; i < words; i += 256) host_dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *flag = seq; __threadfence_system(); }
+}
+
+struct FetchState {
+    uint32_t *h_flag = nullptr, *d_flag = nullptr;
+    uint32_t seq = 0;
+    bool flag_pending = false, sync_pending = false;
+    int mode = -1;                                              // 1: mapped flag, 0: copy engine
+    ~FetchState() { if (h_flag) (void)hipHostFree(h_flag); }
+};
+thread_local FetchState g_fetch;
+
+}  // namespace
+
+int grx_fetch_begin(void *h_dst_pinned, const void *d_src, size_t bytes, hipStream_t st)
+{
+    FetchState &f = g_fetch;
+    if (f.mode < 0) {
+        const char *e = std::getenv("GRX_READBACK");
+        f.mode = (e && e[0] == 'm') ? 0 : 1;                    // GRX_READBACK=memcpy
+        if (f.mode == 1) {
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                f.h_flag = reinterpret_cast<uint32_t *>(h);
+                f.d_flag = reinterpret_cast<uint32_t *>(d);
+                *f.h_flag = 0;
+            } else {
+                if (h) (void)hipHostFree(h);
+                (void)hipGetLastError();
+                f.mode = 0;
+            }
+        }
+    }
+    if (bytes == 0) return GRX_OK;
+    void *d_dst = nullptr;
+    if (f.mode == 1 && bytes <= (32u << 10) && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 &&
+        hipHostGetDevicePointer(&d_dst, h_dst_pinned, 0) == hipSuccess) {
+        ++f.seq;
+        if (f.seq == 0) f.seq = 1;
+        publish_kernel<<<1, 256, 0, st>>>(reinterpret_cast<const uint32_t *>(d_src), reinterpret_cast<uint32_t *>(d_dst),
+                                          (int)(bytes / 4), f.d_flag, f.seq);
+        GRX_LAUNCH_CHECK();
+        f.flag_pending = true;
+        return GRX_OK;
+    }
+    (void)hipGetLastError();                                     // (a buffer that is not device-visible: the copy engine)
+    GRX_CHECK_HIP(hipMemcpyAsync(h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, st));
+    f.sync_pending = true;
+    return GRX_OK;
+}
+
+int grx_fetch_wait(hipStream_t st)
+{
+    FetchState &f = g_fetch;
+    if (f.sync_pending) {                                       // a copy-engine copy is among them: wait for the stream
+        GRX_CHECK_HIP(hipStreamSynchronize(st));
+        f.sync_pending = f.flag_pending = false;
+        return GRX_OK;
+    }
+    if (!f.flag_pending) return GRX_OK;
+    f.flag_pending = false;
+    const uint32_t want = f.seq;
+    for (uint64_t spins = 1;; ++spins) {
+        if (__atomic_load_n(f.h_flag, __ATOMIC_ACQUIRE) == want) return GRX_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0) {
+            // every ~100 us: has the stream failed, or finished without the flag arriving?
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(f.h_flag, __ATOMIC_ACQUIRE) == want) return GRX_OK;
+                grx_set_error("grx_fetch_wait: the stream is idle and the read-back flag never arrived");
+                return GRX_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) {
+                grx_set_error("grx_fetch_wait: %s", hipGetErrorString(q));
+                return GRX_ERR_HIP;
+            }
+        }
+    }
 }
 
 extern "C" {
