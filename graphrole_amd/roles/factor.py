@@ -370,7 +370,7 @@ def _checked_info(info, quantizer: str):
     """Host copy of a quantiser's info; the k-means seeding checks itself as it goes (its potential after every update,
     every search inside its block, every wait between workgroups): a non-zero report is an error, never a result."""
     info = _kernels().to_host(info)
-    if quantizer == 'kmeans' and int(info[3]) != 0:
+    if quantizer == 'kmeans' and len(info) > 3 and int(info[3]) != 0:
         raise QuantizerFault(f'grx_kmeans1d: seeding fault bits {int(info[3]):#x} (include/grx.h: d_info[3])')
     return info
 
