@@ -23,24 +23,29 @@
 // closest distance of values between the two midpoints, a CONTIGUOUS RANGE of the sorted values.  So:
 //   * the values are sorted once together with their indices (perm: sorted position -> index, rank: its inverse);
 //     the closest distances live in SORTED order (ds);
-//   * potentials: potential(c) = potential - sum over c's range of (d - min(d, dist(c, x))) -- one pass over the
-//     union of the candidates' ranges (km_gain_kernel);  update: the winner's range only (km_update_kernel);
 //   * the range is a SUPERSET of the values the full pass would change: midpoints widened by a bound on the
-//     rounding error of the two fp distances (see km_prep_kernel), and inside it every value is tested with the very
+//     rounding error of the two fp distances (see km_pick_tail), and inside it every value is tested with the very
 //     expression the full pass uses -- GRX_KMEANS_FULL_RANGE=1 makes every range [0, m) and must give the same bits
 //     (tests/test_gpu_encode.py);
-//   * sums are EXACT: a distance is split into three fixed-point limbs (units 2^(E-32), 2^(E-64), 2^(E-96), E from
-//     the largest possible distance; the rest, < 2^-96 of it, is dropped -- a function of the value alone), limb sums
-//     are integers, integer addition is associative: per-tile (1024 indices) and per-super-tile (64 tiles) sums of
-//     the closest distances IN INDEX ORDER are kept by integer atomics from the range update, in any order, and the
-//     cumulative sum sklearn searches is their prefix;  gains likewise.  Nothing depends on the order of a reduction,
-//     so grids and chunking are free to change and every run gives the same bits;
-//   * per seed three launches, no host round trip: prep (one workgroup: winner of the previous seed, prefix of the
-//     super-tile sums, the n_trials candidates by searchsorted, their neighbours among the seeds, their ranges),
-//     gain (potentials), update (winner's range).
+//   * the sums a candidate INDEX is drawn from are EXACT: a distance is split into three fixed-point limbs (units
+//     2^(E-32), 2^(E-64), 2^(E-96), E from the largest possible distance; the rest, < 2^-96 of it, is dropped -- a
+//     function of the value alone), limb sums are integers, integer addition is associative: the sums of the closest
+//     distances per block of 2^s INDICES (at most 1024 blocks) are kept by integer atomics from the range update, in
+//     any order, and the cumulative sum sklearn searches is their prefix; inside the block a trial's r falls in, the
+//     distances are gathered through rank.  Nothing depends on the order of a reduction, so grids and chunking are
+//     free to change and every run gives the same bits;
+//   * the candidates' potentials only feed an argmin: potential(c) = potential - sum over c's range of
+//     (d - min(d, dist(c, x))) comes from fp64 sums over blocks of KM_CHUNK SORTED positions (sum of d per block,
+//     rewritten by every update, and static moments of the block's values: km_pick_tail, D) plus the two end blocks
+//     value by value -- no pass over the ranges.  GRX_KMEANS_GAIN_PASS=1: the pass, in exact integers (km_gain_kernel);
+//   * per seed one launch for most seeds, no host round trip: km_prep_kernel (winner of the previous seed, prefix of
+//     the block sums, the n_trials candidates -- sixteen workgroups per trial share the gather of a block and hand
+//     over through tagged words --, their neighbours among the seeds, their ranges, their gains, and once every
+//     trial is recorded the update of the winner's range by all workgroups); the first seeds, whose ranges are long,
+//     get their update from km_update_kernel.  m <= 4096: the whole seeding in one workgroup (km_seed_small_kernel).
 // What cannot be bit-identical to sklearn: it sums in floating point (cumsum, BLAS), relative 1e-13, so a uniform
 // draw that lands within that distance of a boundary of the cumulative sum picks a neighbouring index (probability
-// ~1e-6 per draw at 6 M values), and tied candidate potentials are recognised with a 1e-12 tolerance (km_best).
+// ~1e-6 per draw at 6 M values), and tied candidate potentials are recognised with a 1e-12 tolerance (km_best_of).
 // Centres agree with sklearn to ~1e-12 otherwise.
 #include "grx_common.h"
 
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void km_sorted_init_kernel(const double *__res
     if (threadIdx.x == 0) { KmSorted o; o.sd = sd; o.mu = mu; o.s1 = s1; o.s2 = s2; sb[blockIdx.x] = o; }
 }
 
-// ---- k-means++ : one further seed = prep -> gain -> update --------------------------------------------------------
+// ---- k-means++ : one further seed = km_prep_kernel (pick [+ update]) [-> km_gain_kernel] [-> km_update_kernel] --------
 // argmin of the candidates' potentials (= potential - gain), np.argmin's first minimum.  Exact ties are COMMON on
 // small inputs -- two isolated candidates that each capture only themselves and each other -- and sklearn's BLAS sums
 // return bit-equal potentials for them: potentials within 1e-12 of the minimum count as tied, the first wins.

@@ -616,3 +616,21 @@ def test_nmf_on_graded_tables_with_full_rank_request(shape, seed):
     We, He, it = rolx.nmf(X, r)
     assert n_iter == it
     assert _relmax(G, We) < 1e-7 and _relmax(H, He) < 1e-7, (_relmax(G, We), _relmax(H, He))
+
+
+def test_read_backs_through_the_copy_engine_give_the_same_results():
+    """The values the host decides on (distance matrix of the pruner, Gram matrices, residuals) reach it through mapped
+    host memory and a flag (csrc/grx_runtime.hip grx_fetch_begin / grx_fetch_wait); GRX_READBACK=memcpy sends them
+    through hipMemcpyAsync + hipStreamSynchronize as before round 6.  Same bytes either way: the golden NMF factors, the
+    stopping rule and the end-to-end run must pass unchanged, and so must the generation loop on the reference's tables."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRX_READBACK='memcpy')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_rolx.py'),
+                          os.path.join(root, 'tests', 'test_gpu_refex.py'), '-q', '-m', 'gpu', '-x', '-p', 'no:cacheprovider', '-k',
+                          'nmf_matches_reference_golden or stopping_rule or end_to_end or fixed_rank or golden or reference'],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout
