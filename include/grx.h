@@ -47,6 +47,15 @@ typedef enum {
     GRX_ERR_DEGENERATE = -5      /* numerically degenerate input (e.g. an all-zero feature matrix) */
 } grx_status;
 
+/* Environment switches, each read once per process; all of them select between formulations that the tests compare
+ * on the same inputs (same results), none changes what is computed:
+ *   GRX_READBACK=memcpy        the few KB grx_refex_run / grx_nmf_fit read back before they decide what to launch next
+ *                              go through hipMemcpyAsync + hipStreamSynchronize instead of mapped host memory and a flag
+ *   GRX_BIN_BID_MIN_N=<rows>   column height from which the binning keeps 12-bit bucket ids (default 2 500 000)
+ *   GRX_TRI_ROUNDS=<k>         workgroups of grx_triangle_counts = k x what fills the chip (default 4)
+ *   GRX_KMEANS_*               see grx_kmeans1d below
+ *   GRX_FORCE_COLLECTIVES=1    a one-rank communicator issues every exchange of the sharded path (bench.py)
+ */
 /* ------------------------------------------------------------------ runtime helpers ---- */
 int grx_version(void);
 const char *grx_last_error(void);
