@@ -242,6 +242,43 @@ def test_triangle_counts_long_oriented_lists(K):
         assert np.array_equal(o.arc.cpu().numpy()[:o_nnz], ref.arc.cpu().numpy()[:o_nnz])
 
 
+def test_triangle_counts_concentrated_on_hubs(K):
+    """Every corner of every triangle is an atomic increment of T[vertex], and atomics to one address queue up: the
+    counters of the first 256 vertices of the degree-descending order are collected per workgroup in LDS
+    (csrc/grx_graph.hip, triangle_count_arcs_kernel) and added once per workgroup.  Graphs that send almost every
+    increment to a handful of hubs, with counts known in closed form:
+      * h hubs joined to each other and to every one of m leaves (no leaf-leaf edges): a leaf closes C(h, 2) triangles,
+        a hub (h - 1) m + C(h - 1, 2) -- hub counters far beyond 2^16, leaves beyond index 256 untouched by LDS;
+      * a wheel: the hub closes m triangles, every rim vertex 2;
+    and source-row ranges (the sharded path) must add up to the whole."""
+    for h, m in ((2, 150_000), (5, 60_000), (40, 3_000)):
+        n = h + m
+        hubs = np.arange(h)
+        leaves = np.arange(h, n)
+        hs, hd = np.triu_indices(h, 1)
+        src = np.concatenate([hs, np.repeat(hubs, m)]).astype(np.int64)
+        dst = np.concatenate([hd, np.tile(leaves, h)]).astype(np.int64)
+        og = _oracle_graph(n, src, dst, None, False)
+        csr = _dev_csr(K, og)
+        T = K.triangle_counts(csr).cpu().numpy()[:n].astype(np.int64)
+        exp_hub = (h - 1) * m + (h - 1) * (h - 2) // 2
+        exp_leaf = h * (h - 1) // 2
+        # (rows stay in label order here: the hubs are rows 0 .. h - 1, and the rows of largest degree)
+        assert np.array_equal(T[:h], np.full(h, exp_hub)), (h, m)
+        assert np.array_equal(T[h:], np.full(m, exp_leaf)), (h, m)
+        cut = n // 3
+        Ta = K.triangle_counts(csr, 0, cut).cpu().numpy() + K.triangle_counts(csr, cut, None).cpu().numpy()
+        assert np.array_equal(Ta[:n].astype(np.int64), T)
+    m = 200_000                                                           # wheel: hub 0, rim 1 .. m
+    rim = np.arange(1, m + 1)
+    src = np.concatenate([np.zeros(m, dtype=np.int64), rim])
+    dst = np.concatenate([rim, np.roll(rim, -1)])
+    og = _oracle_graph(m + 1, src, dst, None, False)
+    csr = _dev_csr(K, og)
+    T = K.triangle_counts(csr).cpu().numpy()[:m + 1].astype(np.int64)
+    assert T[0] == m and np.array_equal(T[1:], np.full(m, 2))
+
+
 @pytest.mark.parametrize('name', ['karate', 'karate_weighted', 'dw200_attrs', 'loops_dangling150', 'directed120',
                                   'iface7', 'iface7_dw', 'path4', 'er2000', 'ba2000'])
 def test_gen0_vs_reference_golden(K, name):
