@@ -775,6 +775,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
     i128 inc8[KM_MAX_BLOCKS / 256];
     i128 loc = 0;
     const bool seeds_in_lds = n_old <= KM_SEEDS_LDS;
+    const int faults_before = st->faults;                       // (branched on below, when it has long arrived)
     // (scalars of the later steps: loaded now, not in the middle of the chain)
     const double u_trial = do_pick ? uniform[trial] : 0.0;
     const KmLimb L = st->limb;
@@ -835,7 +836,9 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
             }
         }
     }
-    if (!do_pick) return;
+    // a wait between workgroups has expired in an earlier launch of this run (fault bit 4): the run is lost and reported
+    // as such -- do not wait again, seed after seed
+    if (!do_pick || (faults_before & 16)) return;
     KM_T(1);
     const i128 winc = km_wave_scan128(loc, lane);
     if (lane == 63) { s_w_lo[wave] = (u64)winc; s_w_hi[wave] = (u64)(winc >> 64); }
