@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
                                                       i64 *bacc, int nblocks, int block_shift,
                                                       const double *__restrict__ uniform, int n_trials, int seed_no,
                                                       int choose_prev, int do_pick, int full_range, int closed, int slow_pick, int merge,
-                                                      KmSorted *sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
+                                                      int lose_a_sum, KmSorted *sb, KmTop top, KmState *st, double *__restrict__ seeds_x,
                                                       int64_t *__restrict__ seeds_id, double *__restrict__ sorted2, int sorted_ld)
 {
     // (the LDS of the searches -- top level of the sorted values, sorted seeds -- later holds the update's block sums)
@@ -948,7 +948,8 @@ __global__ __launch_bounds__(256) void km_prep_kernel(const double *__restrict__
         const u64 mask48 = (1ull << 48) - 1, tag = (u64)(seed_no & 0xFFFF);
         if (wave == 0) {
             u64 *words = reinterpret_cast<u64 *>(&cur->sub[trial][0][0]);
-            if (lane == 0) {
+            // (lose_a_sum: the test of the time-out -- one workgroup of the launch never publishes, GRX_KMEANS_LOSE_A_SUM)
+            if (lane == 0 && !(lose_a_sum && sub == 3 && trial == 0)) {
                 __hip_atomic_store(words + 3 * sub, ((u64)wtotal & mask48) | (tag << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(words + 3 * sub + 1, ((u64)(wtotal >> 48) & mask48) | (tag << 48), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -1991,12 +1992,15 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         // per workgroup still beat km_update_kernel's launch
         static const double merge_chunks = [] { const char *e = std::getenv("GRX_KMEANS_MERGE"); return e ? atof(e) : 2.0; }();
         const double merge_from = merge_chunks > 0.0 ? (double)m / ((double)KM_CHUNK * merge_chunks * KM_SUB * n_trials) : 1e300;
+        // GRX_KMEANS_LOSE_A_SUM=<seed>: at that seed one workgroup of the pick withholds its sum (tests: the others' wait
+        // must expire, the run must end at once with fault bit 4, nothing may hang)
+        static const int lose_at = [] { const char *e = std::getenv("GRX_KMEANS_LOSE_A_SUM"); return e ? atoi(e) : -1; }();
         for (int c = 1; c < k; ++c) {
             const int merge = (closed && c < k - 1 && (double)c >= merge_from) ? 1 : 0;
             km_prep_kernel<<<dim3(KM_SUB, n_trials), 256, 0, st>>>(xs, ds, rank, perm, m, bacc, p.nblocks, p.block_shift,
                                                                    d_uniform + (size_t)(c - 1) * n_trials, n_trials, c, c >= 2, 1,
-                                                                   full_range, closed, slow_pick, merge, sb, top, state, seeds_x,
-                                                                   seeds_id, sorted2, (int)p.sorted_ld);
+                                                                   full_range, closed, slow_pick, merge, c == lose_at ? 1 : 0, sb, top,
+                                                                   state, seeds_x, seeds_id, sorted2, (int)p.sorted_ld);
             if (!closed) {
                 if (n_trials <= 8) km_gain_kernel<8><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
                 else km_gain_kernel<KM_MAX_TRIALS><<<range_grid, 256, 0, st>>>(xs, ds, state, c, n_trials);
@@ -2006,7 +2010,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
                                                                             c, n_trials, closed);
         }
         km_prep_kernel<<<dim3(1, 1), 256, 0, st>>>(xs, ds, rank, perm, m, bacc, p.nblocks, p.block_shift, d_uniform, n_trials, k, 1,
-                                                   0, full_range, closed, slow_pick, 0, sb, top, state, seeds_x, seeds_id, sorted2,
+                                                   0, full_range, closed, slow_pick, 0, 0, sb, top, state, seeds_x, seeds_id, sorted2,
                                                    (int)p.sorted_ld);
     }
     GRX_LAUNCH_CHECK();

@@ -736,7 +736,8 @@ int grx_lloyd_max(int64_t m, const double *d_values, int n_bins, int max_iter, d
  * Environment (read once; for tests/test_gpu_encode.py, which runs every mode on the same inputs and compares bits):
  * GRX_KMEANS_FULL_RANGE=1 every range [0, m); GRX_KMEANS_GAIN_PASS=1 gains by an integer pass over each range;
  * GRX_KMEANS_SLOW_PICK=1 range positions by searches over all values; GRX_KMEANS_MERGE=0 the update always in its own
- * kernel; GRX_KMEANS_SMALL=0 no one-workgroup seeding of m <= 4096.
+ * kernel; GRX_KMEANS_SMALL=0 no one-workgroup seeding of m <= 4096; GRX_KMEANS_LOSE_A_SUM=<seed> (test of the bounded
+ * waits) one workgroup of that seed's launch withholds its sum: the run ends within a second with fault bit 4.
  * grx_transpose: out[c * ld_out + r] = in[r * ld_in + c].
  */
 size_t grx_kmeans1d_workspace_bytes(int64_t m, int k);

@@ -294,3 +294,47 @@ def test_a_seeding_fault_is_an_error_not_a_result():
     with pytest.raises(factor.QuantizerFault):
         factor.encode(x, 2)
     assert factor.encode(x / 1e150, 2).shape == x.shape
+
+
+def test_an_expired_wait_ends_the_run_at_once_and_is_reported(tmp_path):
+    """The workgroups of a pick launch wait for each other's sums (tagged words, csrc/grx_kmeans.hip).  The waits are
+    bounded; GRX_KMEANS_LOSE_A_SUM=<seed> makes one workgroup of that seed's launch withhold its sum: the others' wait
+    must expire (a fraction of a second), the remaining launches of the run must return at once, d_info[3] must carry
+    bit 4 and encode() must raise -- no hang, no result."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'ROOT = %r\n' % root + textwrap.dedent('''
+        import sys, time
+        sys.path.insert(0, ROOT)
+        import numpy as np, torch
+        from graphrole_amd import kernels as K
+        from graphrole_amd.roles import factor
+        v = np.abs(np.random.default_rng(0).standard_normal(300_000))
+        K.kmeans1d(K.to_device(v[:5000]), 8)          # (load the library, warm up: the small path is not affected)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q, c, info = K.kmeans1d(K.to_device(v), 200)
+        info = K.to_host(info)
+        dt = time.perf_counter() - t0
+        print('FAULTS', int(info[3]), 'SECONDS', round(dt, 2))
+        try:
+            factor.encode(v.reshape(-1, 3), 200)
+            print('RAISED no')
+        except factor.QuantizerFault as e:
+            print('RAISED yes')
+    ''')
+    t0 = time.perf_counter()
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=240,
+                         env=dict(os.environ, GRX_KMEANS_LOSE_A_SUM='7'))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = res.stdout
+    faults = int(out.split('FAULTS')[1].split()[0])
+    seconds = float(out.split('SECONDS')[1].split()[0])
+    assert faults & 16, out
+    assert seconds < 20.0, out
+    assert 'RAISED yes' in out, out
+    assert time.perf_counter() - t0 < 200
