@@ -1629,10 +1629,29 @@ __device__ __forceinline__ bool km_prefers_right(double x, double cl, int idl, d
     return fr < fl || (fr == fl && idr < idl);
 }
 
-// number of sorted values that go to centres at or left of `cl` when the next distinct centre is `cr`
-__device__ int64_t km_boundary(const double *__restrict__ xs, int64_t m, double cl, int idl, double cr, int idr)
+// The Lloyd kernel's view of the sorted values from the top (km_sorted_init's block starts): tops[j] = xs[j * step] for
+// j < n_tops in LDS (every block start when there are at most KM_LLOYD_TOPS of them, every s2-th otherwise), so that a
+// search for a boundary reads memory only inside [tops interval] -- 11 to 15 dependent loads instead of 23 to 25.
+constexpr int KM_LLOYD_TOPS = 4096;
+struct KmTopLds { const double *tops; int n_tops; int64_t step; };     // n_tops == 0: no index (few values)
+
+// first index with xs > b, like km_upper
+__device__ __forceinline__ int64_t km_upper_top(const double *__restrict__ xs, int64_t m, double b, const KmTopLds &T)
 {
-    int64_t h = km_upper(xs, m, 0.5 * (cl + cr));
+    if (T.n_tops == 0) return km_upper(xs, m, b);
+    int lo = 0, up = T.n_tops;                                  // tops <= b: the answer lies behind the last of them
+    while (lo < up) { const int mid = (lo + up) >> 1; if (T.tops[mid] <= b) lo = mid + 1; else up = mid; }
+    if (lo == 0) return 0;                                      // xs[0] > b
+    int64_t a = (int64_t)(lo - 1) * T.step + 1, e = (int64_t)lo * T.step < m ? (int64_t)lo * T.step : m;
+    while (a < e) { const int64_t mid = (a + e) >> 1; if (xs[mid] <= b) a = mid + 1; else e = mid; }
+    return a;
+}
+
+// number of sorted values that go to centres at or left of `cl` when the next distinct centre is `cr`
+__device__ int64_t km_boundary(const double *__restrict__ xs, int64_t m, double cl, int idl, double cr, int idr,
+                               const KmTopLds &T)
+{
+    int64_t h = km_upper_top(xs, m, 0.5 * (cl + cr), T);
     for (int guard = 0; guard < 8; ++guard) {
         if (h > 0 && km_prefers_right(xs[h - 1], cl, idl, cr, idr)) { h = km_lower(xs, m, xs[h - 1]); continue; }
         if (h < m && !km_prefers_right(xs[h], cl, idl, cr, idr)) { h = km_upper(xs, m, xs[h]); continue; }
@@ -1647,15 +1666,23 @@ struct KmLloydBufs {
     int64_t *hiS, *lo, *hi, *plo, *phi, *rl, *rh;
 };
 
-__device__ void km_e_step(const double *__restrict__ xs, int64_t m, int k, const KmLloydBufs &B)
+// (s_c: LDS room for k centres when k <= KM_LLOYD_C_LDS, else nullptr -- the ranking reads every centre k times)
+constexpr int KM_LLOYD_C_LDS = 2048;
+__device__ void km_e_step(const double *__restrict__ xs, int64_t m, int k, const KmLloydBufs &B, const KmTopLds &T, double *s_c)
 {
     const int t = threadIdx.x, nt = blockDim.x;
+    const double *cc = B.c;
+    if (s_c) {
+        for (int j = t; j < k; j += nt) s_c[j] = B.c[j];
+        __syncthreads();
+        cc = s_c;
+    }
     // sorted order of the centres (ties by centre id): rank by counting
     for (int j = t; j < k; j += nt) {
-        const double cj = B.c[j];
+        const double cj = cc[j];
         int rank = 0;
         for (int i = 0; i < k; ++i) {
-            const double ci = B.c[i];
+            const double ci = cc[i];
             rank += (ci < cj) || (ci == cj && i < j);
         }
         B.ord[rank] = j;
@@ -1663,12 +1690,12 @@ __device__ void km_e_step(const double *__restrict__ xs, int64_t m, int k, const
     __syncthreads();
     // hiS[p]: values assigned to sorted positions <= p.  Equal centres: the smallest id takes the values.
     for (int p = t; p < k; p += nt) {
-        const double cp = B.c[B.ord[p]];
+        const double cp = cc[B.ord[p]];
         int g = p;                                              // first member of p's group of equal centres
-        while (g > 0 && B.c[B.ord[g - 1]] == cp) --g;
+        while (g > 0 && cc[B.ord[g - 1]] == cp) --g;
         int nx = p + 1;                                         // next distinct centre
-        while (nx < k && B.c[B.ord[nx]] == cp) ++nx;
-        B.hiS[p] = (nx >= k) ? m : km_boundary(xs, m, cp, B.ord[g], B.c[B.ord[nx]], B.ord[nx]);
+        while (nx < k && cc[B.ord[nx]] == cp) ++nx;
+        B.hiS[p] = (nx >= k) ? m : km_boundary(xs, m, cp, B.ord[g], cc[B.ord[nx]], B.ord[nx], T);
     }
     __syncthreads();
     for (int p = t; p < k; p += nt) {
@@ -1676,7 +1703,7 @@ __device__ void km_e_step(const double *__restrict__ xs, int64_t m, int k, const
         const int64_t h = B.hiS[p];
         int64_t l;
         if (p == 0) l = 0;
-        else if (B.c[B.ord[p - 1]] == B.c[j]) l = h;            // not the first of its group: empty
+        else if (cc[B.ord[p - 1]] == cc[j]) l = h;            // not the first of its group: empty
         else l = B.hiS[p - 1];
         B.lo[j] = l;
         B.hi[j] = h;
@@ -1687,10 +1714,23 @@ __device__ void km_e_step(const double *__restrict__ xs, int64_t m, int k, const
 __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict__ xs, const double *__restrict__ P,
                                                         int64_t m, int k, int max_iter, const KmState *__restrict__ st,
                                                         const double *__restrict__ seeds_x, KmLloydBufs B,
-                                                        int32_t *__restrict__ info)
+                                                        int32_t *__restrict__ info, const double *__restrict__ xtop,
+                                                        int64_t nsb, const double *__restrict__ xtop2, int n2, int s2)
 {
     __shared__ double s_red[16];
+    __shared__ double s_tops[KM_LLOYD_TOPS], s_cbuf[KM_LLOYD_C_LDS];
     const int t = threadIdx.x, nt = blockDim.x;
+    // block starts of the sorted values (km_sorted_init_kernel) into LDS: all of them, or the coarser level
+    KmTopLds T;
+    T.tops = s_tops; T.n_tops = 0; T.step = 0;
+    if (xtop && nsb > 0 && nsb <= KM_LLOYD_TOPS) {
+        for (int i = t; i < (int)nsb; i += nt) s_tops[i] = xtop[i];
+        T.n_tops = (int)nsb; T.step = KM_CHUNK;
+    } else if (xtop2 && n2 > 0 && n2 <= KM_LLOYD_TOPS) {
+        for (int i = t; i < n2; i += nt) s_tops[i] = xtop2[i];
+        T.n_tops = n2; T.step = (int64_t)s2 * KM_CHUNK;
+    }
+    double *s_c = k <= KM_LLOYD_C_LDS ? s_cbuf : nullptr;
     for (int j = t; j < k; j += nt) { B.c[j] = seeds_x[j]; B.plo[j] = -1; B.phi[j] = -1; }
     __syncthreads();
     const double tol = st->tol;
@@ -1698,7 +1738,7 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
     bool strict = false;
     for (int it = 0; it < max_iter; ++it) {
         n_iter = it + 1;
-        km_e_step(xs, m, k, B);
+        km_e_step(xs, m, k, B, T, s_c);
         int n_empty_local = 0;
         for (int j = t; j < k; j += nt) {
             const int64_t l = B.lo[j], h = B.hi[j];
@@ -1757,7 +1797,7 @@ __global__ __launch_bounds__(1024) void km_lloyd_kernel(const double *__restrict
         if (!any_changed) { strict = true; break; }             // labels unchanged: strict convergence
         if (tot <= tol) break;
     }
-    if (!strict) km_e_step(xs, m, k, B);                        // a last E step so that labels match the centres
+    if (!strict) km_e_step(xs, m, k, B, T, s_c);                // a last E step so that labels match the centres
     // tables of the assignment pass: per sorted position the largest value it takes, and the output level
     const double mean = st->mean;
     for (int p = t; p < k; p += nt) {
@@ -1953,6 +1993,10 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     // GRX_KMEANS_SMALL=0: few values take the many-launch path as well (the same test: same bits again).
     static const int full_range = [] { const char *e = std::getenv("GRX_KMEANS_FULL_RANGE"); return (e && *e == '1') ? 1 : 0; }();
     static const int small_ok = [] { const char *e = std::getenv("GRX_KMEANS_SMALL"); return (e && *e == '0') ? 0 : 1; }();
+    // (block starts of the sorted values for the Lloyd kernel's searches: built by the many-launch seeding only)
+    const double *l_xtop = nullptr, *l_xtop2 = nullptr;
+    int64_t l_nsb = 0;
+    int l_n2 = 0, l_s2 = 0;
     if (k > 1 && m <= KM_SMALL_M && small_ok) {
         const int vpt = m <= 1024 ? 1 : KM_SMALL_M / 1024;
         const int threads = (int)grx_align_up((size_t)grx_ceil_div(m, vpt), 64);
@@ -1984,6 +2028,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
         top.s2 = (int)grx_ceil_div(max_chunks, KM_TOP2);
         top.n2 = (int)grx_ceil_div(max_chunks, top.s2);
         km_sorted_init_kernel<<<(int)max_chunks, 256, 0, st>>>(xs, perm, m, state, ds, rank, sb, top);
+        l_xtop = top.xtop; l_xtop2 = top.xtop2; l_nsb = top.nsb; l_n2 = top.n2; l_s2 = top.s2;
         const int range_grid = (int)(max_chunks < KM_RANGE_GRID ? max_chunks : KM_RANGE_GRID);
         static const int update_grid_max = [] { const char *e = std::getenv("GRX_KMEANS_UPDATE_GRID"); return e ? atoi(e) : KM_UPDATE_GRID; }();
         const int update_grid = (int)(max_chunks < update_grid_max ? max_chunks : update_grid_max);
@@ -2025,7 +2070,7 @@ int grx_kmeans1d(int64_t m, const double *d_values, int k, int64_t first_seed, c
     B.hiS = reinterpret_cast<int64_t *>(lb + 6 * (size_t)k);
     B.lo = B.hiS + k; B.hi = B.lo + k; B.plo = B.hi + k; B.phi = B.plo + k; B.rl = B.phi + k; B.rh = B.rl + k;
     B.ord = reinterpret_cast<int32_t *>(B.rh + k);
-    km_lloyd_kernel<<<1, 1024, 0, st>>>(xs, P, m, k, max_iter, state, seeds_x, B, d_info);
+    km_lloyd_kernel<<<1, 1024, 0, st>>>(xs, P, m, k, max_iter, state, seeds_x, B, d_info, l_xtop, l_nsb, l_xtop2, l_n2, l_s2);
     km_assign_kernel<<<stream_grid, 256, 0, st>>>(d_values, m, k, state, B.maxval, B.cfinal, B.ord, d_quantized, d_centers);
     GRX_LAUNCH_CHECK();
     return GRX_OK;
