@@ -725,7 +725,7 @@ __device__ void km_pick_tail(const double *__restrict__ xs, const double *__rest
 }
 
 // The pick of seed `seed_no`: KM_SUB workgroups per trial -- one workgroup gathers ~330 scattered values per microsecond,
-// so the walk of an index block (16 384 indices at 30 M values) is spread over sixteen.  Each publishes the sum of its
+// so the walk of an index block (32 768 indices at 30 M values) is spread over sixteen.  Each publishes the sum of its
 // sixteenth tagged with the seed's number and reads the sixteen sums of its trial until all carry the tag (the 16 x n_trials
 // workgroups of a launch are far fewer than the GPU holds at once: nobody waits for a workgroup that cannot start; the
 // wait is bounded all the same and reports a fault).  The one whose sixteenth holds the trial's r continues with the
